@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz from the REFERENCE.
+
+Runs only in the build container, where the upstream repository is mounted at
+/root/reference (np_bnn 0.1.23, imported unmodified; nothing of it is copied
+into this repository -- only its numeric outputs on seeded synthetic inputs
+are stored).  Usage:  python tests/golden/make_golden.py
+
+Groups:
+  G1 grid.npz        forward / categorical likelihood / accuracy statistics
+  G2 regression.npz  Gaussian likelihoods (fixed, vector, empirical sigma; predicted sigma)
+  G3 counts.npz      Poisson / negative-binomial / gamma plug-in likelihoods
+  G4 trace_*.npz     Metropolis-Hastings traces (per-proposal logLik', logPrior', accept)
+  G5 mc3.npz         MC3 (4 chains) swap sequence and final chain states
+  G6 masks.npz       create_mask block layouts
+"""
+import contextlib
+import io
+import os
+import re
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+import cases  # noqa: E402
+import np_bnn as bn  # noqa: E402  (the reference)
+
+HEAD = 16
+
+
+def quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
+
+
+def make_act(fun, prm=None):
+    if prm is not None:
+        return bn.ActFun(fun=fun, prm=prm)
+    return bn.ActFun(fun=fun)
+
+
+def g1_grid():
+    out = {}
+    for case in cases.grid_cases():
+        inp = cases.grid_inputs(case)
+        act = make_act(case["fun"], inp["prm"])
+        x, w, lab = inp["x"], inp["weights"], inp["labels"]
+        sid = np.arange(x.shape[0])
+        z = bn.RunPredict(x, w, act, bn.RegressTransform)
+        y = bn.RunPredict(x, w, act, bn.SoftMax)
+        h0 = bn.RunHiddenLayer(x + 0, w[0], act, 0)
+        with np.errstate(divide="ignore"):
+            lik = [bn.calc_likelihood(y, lab, sid),
+                   bn.calc_likelihood(y, lab, sid, instance_weight=inp["inst_w"]),
+                   bn.calc_likelihood(y, lab, sid, class_weight=inp["class_w"]),
+                   bn.calc_likelihood(y, lab, sid, lik_temp=0.5)]
+        k = case["name"]
+        out[k + "/z_head"] = z[:HEAD]
+        out[k + "/y_head"] = y[:HEAD]
+        out[k + "/h0_head"] = h0[:HEAD]
+        out[k + "/z_colsum"] = z.sum(axis=0)
+        out[k + "/lik"] = np.array(lik, dtype=float)
+        out[k + "/pred"] = np.argmax(y, axis=1).astype(np.int16)
+        out[k + "/acc"] = np.array(bn.CalcAccuracy(y, lab))
+        out[k + "/label_acc"] = bn.CalcLabelAccuracy(y, lab)
+        out[k + "/label_freq"] = bn.CalcLabelFreq(y)
+    np.savez_compressed(os.path.join(HERE, "grid.npz"), **out)
+    print("grid.npz:", len(cases.grid_cases()), "cases")
+
+
+def g2_regression():
+    out = {}
+    act = bn.ActFun(fun="tanh")
+    inp = cases.regression_inputs()
+    x, w, t = inp["x"], inp["weights"], inp["targets"]
+    y = bn.RunPredict(x, w, act, bn.RegressTransform)
+    out["y"] = y
+    out["lik_sig1"] = np.array(bn.calc_likelihood_regression(y, t, None, sig2=1))
+    out["lik_sigvec"] = np.array(bn.calc_likelihood_regression(y, t, None, sig2=inp["sig_vec"]))
+    emp = np.std(y - t, axis=0)
+    out["emp_sigma"] = emp
+    out["lik_emp"] = np.array(bn.calc_likelihood_regression(y, t, None, sig2=emp))
+    out["lik_emp_temp"] = np.array(bn.calc_likelihood_regression(y, t, None, sig2=emp, lik_temp=0.7))
+    out["mse"] = np.array(bn.CalcAccuracyRegression(y, t))
+    out["mse_col"] = bn.CalcLabelAccuracyRegression(y, t)
+    inp2 = cases.regression_inputs(seed=12, double_out=True)
+    y2 = bn.RunPredict(inp2["x"], inp2["weights"], act, bn.RegressTransformError)
+    out["y_err"] = y2
+    out["lik_err"] = np.array(bn.calc_likelihood_regression_error(y2, inp2["targets"], None))
+    out["mse_err"] = np.array(bn.CalcAccuracyRegression(y2, inp2["targets"]))
+    np.savez_compressed(os.path.join(HERE, "regression.npz"), **out)
+    print("regression.npz")
+
+
+def g3_counts():
+    out = {}
+    act = bn.ActFun(fun="swish")
+    a = cases.count_inputs(seed=23, n_out=1, k=1)
+    z = bn.RunPredict(a["x"], a["weights"], act, bn.RegressTransform)
+    out["poi_z"] = z
+    out["poi"] = np.array(bn.poi_likelihood(z, a["counts"]))
+    out["poi_acc"] = np.array(bn.poi_acc(z, a["counts"]))
+    b = cases.count_inputs(seed=24, n_out=2, k=1)
+    z = bn.RunPredict(b["x"], b["weights"], act, bn.RegressTransform)
+    out["nb_z"] = z
+    out["nb"] = np.array(bn.negbin_likelihood(z, b["counts"]))
+    out["nb10"] = np.array(bn.negbin_likelihood_base10(z, b["counts"]))
+    out["nb_acc"] = np.array(bn.negbin_acc(z, b["counts"]))
+    out["nb10_acc"] = np.array(bn.negbin_acc_base10(z, b["counts"]))
+    out["gamma"] = np.array(bn.gamma_likelihood(z, b["counts"] + 0.5))
+    c = cases.count_inputs(seed=25, n_out=4, k=2)
+    z = bn.RunPredict(c["x"], c["weights"], act, bn.RegressTransform)
+    out["nb2d_z"] = z
+    out["nb2d"] = np.array(bn.negbin_likelihood2d(z, c["counts"]))
+    out["nb2d_acc"] = np.array(bn.negbin2d_acc(z, c["counts"]))
+    np.savez_compressed(os.path.join(HERE, "counts.npz"), **out)
+    print("counts.npz")
+
+
+class Recorder:
+    """Wraps a bound callable of a reference object and records calls."""
+
+    def __init__(self, fn, grab):
+        self.fn, self.grab, self.rows = fn, grab, []
+
+    def __call__(self, *a, **k):
+        r = self.fn(*a, **k)
+        self.rows.append(self.grab(r, a, k))
+        return r
+
+
+def build_reference_chain(cfg):
+    if cfg["kind"] == "classification":
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        extra = {}
+    else:
+        dat = cases.regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
+        extra = dict(estimation_mode="regression", empirical_error=cfg.get("empirical_error", False))
+    np.random.seed(1234)
+    bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]),
+                use_bias_node=cfg["bias"], prior_f=1, p_scale=1, seed=1234, init_std=0.1, **extra)
+    mcmc = bn.MCMC(bnn, **cfg["mcmc"])
+    return dat, bnn, mcmc
+
+
+def g4_traces():
+    for name, cfg in cases.TRACES.items():
+        dat, bnn, mcmc = build_reference_chain(cfg)
+        out = {}
+        for i, w in enumerate(bnn._w_layers):
+            out["w0_%d" % i] = w.copy()
+        out["init"] = np.array([mcmc._logLik, mcmc._logPrior, mcmc._accuracy, mcmc._test_accuracy], dtype=float)
+        out["init_label_acc"] = np.asarray(mcmc._label_acc, dtype=float)
+        out["update_n"] = np.asarray(mcmc._update_n)
+        lik_rec = Recorder(mcmc._likelihood_f, lambda r, a, k: float(r))
+        mcmc._likelihood_f = lik_rec
+        pri_rec = Recorder(bnn.calc_prior, lambda r, a, k: (float(r), [w.copy() for w in k["w"]]))
+        bnn.calc_prior = pri_rec
+        rows = []
+        for it in range(cfg["steps"]):
+            mcmc.mh_step(bnn)
+            rows.append([lik_rec.rows[-1], pri_rec.rows[-1][0], mcmc._last_accepted, mcmc._logLik,
+                         mcmc._logPost, mcmc._accuracy, mcmc._test_accuracy, mcmc._acceptance_rate])
+            if it < cfg["keep_w"]:
+                for li, w in enumerate(pri_rec.rows[-1][1]):
+                    out["wprime_%d_%d" % (it, li)] = w
+            pri_rec.rows[-1] = (pri_rec.rows[-1][0], None)
+        out["rows"] = np.array(rows, dtype=float)   # logLik', logPrior', accepted, logLik, logPost, acc, test_acc, acc_rate
+        for i, w in enumerate(bnn._w_layers):
+            out["wfinal_%d" % i] = w
+        out["final_update_n"] = np.asarray(mcmc._update_n)
+        out["final_update_ws0"] = np.array([u.flat[0] for u in mcmc._update_ws])
+        out["final_label_acc"] = np.asarray(mcmc._label_acc, dtype=float)
+        if cfg["kind"] == "regression":
+            out["final_error_prm"] = np.asarray(bnn._error_prm, dtype=float)
+        np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), **out)
+        print("trace_%s.npz: %d steps, acceptance %.3f" % (name, cfg["steps"], np.mean(out["rows"][:, 2])))
+
+
+def g5_mc3():
+    cfg = cases.MC3_TRACE
+    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+    np.random.seed(1234)
+    with tempfile.TemporaryDirectory() as tmp:
+        bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
+        logger = bn.postLogger(bnn, filename="MC3", wdir=tmp, log_all_weights=0)
+        mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"],
+                    n_iteration=cfg["n_iteration"], n_chains=cfg["n_chains"],
+                    swap_frequency=cfg["swap_frequency"], verbose=1)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            mc3.run_mcmc()
+        log_rows = np.loadtxt(logger._logfile, skiprows=1)
+    swapped = []
+    for line in buf.getvalue().splitlines():
+        m = re.match(r"^(\d+) SWAPPED (\S+) (\S+) (\S+) (\S+)", line)
+        if m:
+            swapped.append([float(m.group(i)) for i in range(1, 6)])
+    out = dict(rseeds=np.asarray(mc3.rseeds), temperatures0=np.asarray(mc3.temperatures, dtype=float),
+               swapped=np.array(swapped, dtype=float).reshape(-1, 5), log_rows=log_rows)
+    out["final_temperature"] = np.array([c[1]._temperature for c in mc3.singleChainArgs], dtype=float)
+    out["final_logPost"] = np.array([c[1]._logPost for c in mc3.singleChainArgs], dtype=float)
+    out["final_logLik"] = np.array([c[1]._logLik for c in mc3.singleChainArgs], dtype=float)
+    out["final_acc_rate"] = np.array([c[1]._acceptance_rate for c in mc3.singleChainArgs], dtype=float)
+    for ci, c in enumerate(mc3.singleChainArgs):
+        for li, w in enumerate(c[0]._w_layers):
+            out["w_c%d_l%d" % (ci, li)] = w
+    np.savez_compressed(os.path.join(HERE, "mc3.npz"), **out)
+    print("mc3.npz: %d swaps accepted of %d" % (len(swapped), mc3.n_mc3_iteration))
+
+
+def g6_masks():
+    out = {}
+    for bi, (nf, nodes, so, idx, npf) in enumerate(cases.BLOCK_LAYOUTS):
+        shapes = cases.layer_shapes(nf, nodes, so, -1)
+        w = [np.ones(s) for s in shapes]
+        m = bn.create_mask(w, indx_input_list=idx, nodes_per_feature_list=npf)
+        for li, mm in enumerate(m):
+            out["m%d_%d" % (bi, li)] = mm.astype(np.int8)
+    np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
+    print("masks.npz")
+
+
+if __name__ == "__main__":
+    print("reference np_bnn", bn.__version__, "numpy", np.__version__)
+    g1_grid()
+    g2_regression()
+    g3_counts()
+    g4_traces()
+    g5_mc3()
+    g6_masks()

@@ -1,0 +1,199 @@
+"""Pins the CPU oracle to the reference: every oracle function is checked
+against the golden vectors that tests/golden/make_golden.py produced by
+running the reference (np_bnn 0.1.23) on the same seeded inputs.
+
+float64 everywhere; forward/likelihood values must agree to ~1 ulp-level
+tolerances (same numpy/scipy build gives bit-equality, the small rtol only
+covers a different BLAS on the GPU box's host)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as orc
+
+RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def grid(golden_dir):
+    return np.load(os.path.join(golden_dir, "grid.npz"))
+
+
+def _act(case, inp):
+    return orc.Act(case["fun"], inp["prm"]) if inp["prm"] is not None else orc.Act(case["fun"])
+
+
+@pytest.mark.parametrize("case", cases.grid_cases(), ids=lambda c: c["name"])
+def test_g1_forward_and_categorical(case, grid):
+    inp = cases.grid_inputs(case)
+    act = _act(case, inp)
+    x, w, lab = inp["x"], inp["weights"], inp["labels"]
+    k = case["name"]
+    sid = np.arange(x.shape[0])
+    z = orc.forward_logits(x, w, act)
+    y = orc.forward(x, w, act, orc.out_softmax)
+    h0 = orc.hidden_layer(x + 0, w[0], act, 0)
+    np.testing.assert_allclose(z[:16], grid[k + "/z_head"], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(y[:16], grid[k + "/y_head"], rtol=RTOL, atol=1e-15)
+    np.testing.assert_allclose(h0[:16], grid[k + "/h0_head"], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(z.sum(axis=0), grid[k + "/z_colsum"], rtol=1e-10, atol=1e-10)
+    with np.errstate(divide="ignore"):
+        lik = [orc.lik_categorical(y, lab, sid),
+               orc.lik_categorical(y, lab, sid, instance_weight=inp["inst_w"]),
+               orc.lik_categorical(y, lab, sid, class_weight=inp["class_w"]),
+               orc.lik_categorical(y, lab, sid, lik_temp=0.5)]
+    np.testing.assert_allclose(lik, grid[k + "/lik"], rtol=RTOL)
+    assert np.array_equal(np.argmax(y, axis=1), grid[k + "/pred"])
+    assert orc.acc_classification(y, lab) == grid[k + "/acc"]
+    np.testing.assert_array_equal(orc.label_acc_classification(y, lab), grid[k + "/label_acc"])
+    np.testing.assert_array_equal(orc.label_freq(y), grid[k + "/label_freq"])
+    # the three statistics are functions of the confusion matrix (what the HIP epilogue emits)
+    cm = orc.confusion_counts(y, lab)
+    n = len(lab)
+    assert np.trace(cm) / n == grid[k + "/acc"]
+    np.testing.assert_allclose(cm.sum(axis=0) / n, grid[k + "/label_freq"], rtol=0, atol=0)
+    present = cm.sum(axis=1) > 0
+    np.testing.assert_allclose((np.diag(cm) / np.maximum(cm.sum(axis=1), 1))[present], grid[k + "/label_acc"])
+
+
+def test_class_and_instance_weights_branch_is_broken_like_upstream():
+    case = cases.grid_cases()[0]
+    inp = cases.grid_inputs(case)
+    y = orc.forward(inp["x"], inp["weights"], _act(case, inp), orc.out_softmax)
+    with pytest.raises(Exception):
+        orc.lik_categorical(y, inp["labels"], np.arange(len(y)), class_weight=inp["class_w"],
+                            instance_weight=inp["inst_w"])
+
+
+def test_g2_regression(golden_dir):
+    g = np.load(os.path.join(golden_dir, "regression.npz"))
+    act = orc.Act("tanh")
+    inp = cases.regression_inputs()
+    x, w, t = inp["x"], inp["weights"], inp["targets"]
+    y = orc.forward(x, w, act, orc.out_identity)
+    np.testing.assert_allclose(y, g["y"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(orc.lik_gaussian(y, t, None, sig2=1), g["lik_sig1"], rtol=RTOL)
+    np.testing.assert_allclose(orc.lik_gaussian(y, t, None, sig2=inp["sig_vec"]), g["lik_sigvec"], rtol=RTOL)
+    emp = np.std(y - t, axis=0)
+    np.testing.assert_allclose(emp, g["emp_sigma"], rtol=RTOL)
+    np.testing.assert_allclose(orc.lik_gaussian(y, t, None, sig2=emp), g["lik_emp"], rtol=RTOL)
+    # closed form used by the device epilogue == scipy form
+    ll, sig = orc.closed_gaussian_empirical(y, t)
+    np.testing.assert_allclose(ll, g["lik_emp"], rtol=1e-10)
+    np.testing.assert_allclose(sig, g["emp_sigma"], rtol=1e-10)
+    ll, _ = orc.closed_gaussian_empirical(y, t, lik_temp=0.7)
+    np.testing.assert_allclose(ll, g["lik_emp_temp"], rtol=1e-10)
+    np.testing.assert_allclose(orc.mse_all(y, t), g["mse"], rtol=RTOL)
+    np.testing.assert_allclose(orc.mse_per_column(y, t), g["mse_col"], rtol=RTOL)
+    inp2 = cases.regression_inputs(seed=12, double_out=True)
+    y2 = orc.forward(inp2["x"], inp2["weights"], act, orc.out_regress_error)
+    np.testing.assert_allclose(y2, g["y_err"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(orc.lik_gaussian_error(y2, inp2["targets"], None), g["lik_err"], rtol=RTOL)
+    np.testing.assert_allclose(orc.mse_all(y2, inp2["targets"]), g["mse_err"], rtol=RTOL)
+
+
+def test_g3_count_likelihoods(golden_dir):
+    g = np.load(os.path.join(golden_dir, "counts.npz"))
+    act = orc.Act("swish")
+    a = cases.count_inputs(seed=23, n_out=1, k=1)
+    z = orc.forward(a["x"], a["weights"], act, orc.out_identity)
+    np.testing.assert_allclose(z, g["poi_z"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(orc.lik_poisson(z, a["counts"]), g["poi"], rtol=RTOL)
+    np.testing.assert_allclose(orc.closed_poisson(z[:, 0], a["counts"][:, 0]), g["poi"], rtol=1e-10)
+    b = cases.count_inputs(seed=24, n_out=2, k=1)
+    z = orc.forward(b["x"], b["weights"], act, orc.out_identity)
+    np.testing.assert_allclose(orc.lik_negbin(z, b["counts"]), g["nb"], rtol=RTOL)
+    np.testing.assert_allclose(orc.lik_negbin_base10(z, b["counts"]), g["nb10"], rtol=RTOL)
+    np.testing.assert_allclose(orc.closed_negbin(z[:, 0], z[:, 1], b["counts"][:, 0]), g["nb"], rtol=1e-9)
+    np.testing.assert_allclose(orc.closed_negbin(z[:, 0], z[:, 1], b["counts"][:, 0], base10=True), g["nb10"], rtol=1e-9)
+    np.testing.assert_allclose(orc.lik_gamma(z, b["counts"] + 0.5), g["gamma"], rtol=RTOL)
+    c = cases.count_inputs(seed=25, n_out=4, k=2)
+    z = orc.forward(c["x"], c["weights"], act, orc.out_identity)
+    np.testing.assert_allclose(orc.lik_negbin2d(z, c["counts"]), g["nb2d"], rtol=RTOL)
+    np.testing.assert_allclose(orc.closed_negbin(z[:, :2], z[:, 2:], c["counts"]), g["nb2d"], rtol=1e-9)
+
+
+def _build_oracle_chain(cfg):
+    if cfg["kind"] == "classification":
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        extra = {}
+    else:
+        dat = cases.regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
+        extra = dict(mode="regression", empirical_error=cfg.get("empirical_error", False))
+    np.random.seed(1234)
+    st = orc.make_chain(dat["data"], dat["labels"], cfg["n_nodes"], act=orc.Act(cfg["fun"]),
+                        use_bias_node=cfg["bias"], prior_kind=1, p_scale=1,
+                        test_data=dat["test_data"], test_labels=dat["test_labels"],
+                        **extra, **cfg["mcmc"])
+    return st
+
+
+@pytest.mark.parametrize("name", list(cases.TRACES))
+def test_g4_mh_trace(name, golden_dir):
+    """Free-running chain: same seeds -> identical proposal, accept/reject and
+    state sequence as the reference, bit for bit in float64."""
+    cfg = cases.TRACES[name]
+    g = np.load(os.path.join(golden_dir, "trace_%s.npz" % name))
+    st = _build_oracle_chain(cfg)
+    for i, w in enumerate(st.w):
+        np.testing.assert_array_equal(w, g["w0_%d" % i])
+    np.testing.assert_allclose([st.logLik, st.logPrior, st.accuracy, st.test_accuracy], g["init"], rtol=RTOL)
+    np.testing.assert_array_equal(st.update_n, g["update_n"])
+    st.trace = []
+    rows = g["rows"]
+    for it in range(cfg["steps"]):
+        info = orc.mh_step(st)
+        np.testing.assert_allclose(info["logLik"], rows[it, 0], rtol=RTOL, err_msg="it %d" % it)
+        np.testing.assert_allclose(info["logPrior"], rows[it, 1], rtol=RTOL)
+        assert info["accepted"] == bool(rows[it, 2]), "accept/reject differs at it %d" % it
+        np.testing.assert_allclose([st.logLik, st.logPost, st.accuracy, st.test_accuracy, st.acceptance_rate],
+                                   rows[it, 3:8], rtol=RTOL)
+        if it < cfg["keep_w"]:
+            for li, w in enumerate(info["w_prime"]):
+                np.testing.assert_array_equal(w, g["wprime_%d_%d" % (it, li)])
+    for i, w in enumerate(st.w):
+        np.testing.assert_allclose(w, g["wfinal_%d" % i], rtol=0, atol=0)
+    np.testing.assert_array_equal(st.update_n, g["final_update_n"])
+    np.testing.assert_allclose([u.flat[0] for u in st.update_ws], g["final_update_ws0"], rtol=1e-15)
+    np.testing.assert_allclose(st.label_acc, g["final_label_acc"], rtol=RTOL)
+    if cfg["kind"] == "regression":
+        np.testing.assert_allclose(st.error_prm, g["final_error_prm"], rtol=RTOL)
+
+
+def test_g5_mc3_trace(golden_dir):
+    cfg = cases.MC3_TRACE
+    g = np.load(os.path.join(golden_dir, "mc3.npz"))
+    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+    np.random.seed(1234)
+    w0 = orc.init_weights(cfg["n_nodes"], cfg["n_features"], cfg["n_classes"], bias_node=cfg["bias"])
+
+    def factory(i, temp):
+        return orc.make_chain(dat["data"], dat["labels"], cfg["n_nodes"], act=orc.Act(), use_bias_node=cfg["bias"],
+                              init_w=[w + 0 for w in w0], test_data=dat["test_data"], test_labels=dat["test_labels"],
+                              temperature=temp, n_iteration=cfg["swap_frequency"], mcmc_id=i, randomize_seed=True,
+                              adapt_freq=50, adapt_f=0.1, adapt_fM=0.6, adapt_stop=1000)
+
+    mc = orc.mc3_make(factory, n_chains=cfg["n_chains"], swap_frequency=cfg["swap_frequency"],
+                      n_iteration=cfg["n_iteration"])
+    np.testing.assert_array_equal(mc.rseeds, g["rseeds"])
+    orc.mc3_run(mc)
+    accepted = [(i, s) for i, s in enumerate(mc.swaps) if s[4]]
+    assert [i for i, _ in accepted] == [int(r[0]) for r in g["swapped"]]
+    np.testing.assert_allclose([st.temperature for st in mc.chains], g["final_temperature"], rtol=0)
+    np.testing.assert_allclose([st.logPost for st in mc.chains], g["final_logPost"], rtol=RTOL)
+    np.testing.assert_allclose([st.logLik for st in mc.chains], g["final_logLik"], rtol=RTOL)
+    np.testing.assert_allclose([st.acceptance_rate for st in mc.chains], g["final_acc_rate"], rtol=RTOL)
+    for ci, st in enumerate(mc.chains):
+        for li, w in enumerate(st.w):
+            np.testing.assert_array_equal(w, g["w_c%d_l%d" % (ci, li)])
+
+
+def test_g6_block_masks(golden_dir):
+    g = np.load(os.path.join(golden_dir, "masks.npz"))
+    for bi, (nf, nodes, so, idx, npf) in enumerate(cases.BLOCK_LAYOUTS):
+        shapes = cases.layer_shapes(nf, nodes, so, -1)
+        m = orc.block_mask([np.ones(s) for s in shapes], idx, npf)
+        for li, mm in enumerate(m):
+            np.testing.assert_array_equal(mm.astype(np.int8), g["m%d_%d" % (bi, li)])

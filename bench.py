@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Benchmark of the npBNN MCMC hot path on MI355X.
+
+metric : MCMC iterations/sec, a full forward pass + likelihood per proposal
+         (BASELINE.json).  One "step" = one Metropolis-Hastings iteration of one chain
+         per GPU on BASELINE.json config 2: synthetic 100k x 256 features, 10 classes,
+         hidden [32, 8], tanh, bias nodes in input+hidden layers.
+N GPUs : one independent chain per GPU (MC3 layout, config 3), weak scaling; the only
+         exchange is the temperature-swap all-gather every `swap_frequency` iterations.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+       (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ROWS, N_FEATURES, N_CLASSES, HIDDEN = 100_000, 256, 10, [32, 8]
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def synthetic_config2():
+    rs = np.random.default_rng(0)
+    x = rs.standard_normal((N_ROWS, N_FEATURES))
+    y = rs.integers(0, N_CLASSES, N_ROWS)
+    return x, y
+
+
+def cpu_baseline(x, y, budget_s=15.0):
+    """The oracle's op-for-op numpy float64 restatement of MCMC.mh_step timed on the host
+    cores (reported baseline, not the target).  Bounded sample: as many iterations as fit
+    in ~budget_s seconds (at least 5)."""
+    import oracle as orc
+    np.random.seed(1234)
+    st = orc.make_chain(x, y, HIDDEN, act=orc.Act("tanh"), use_bias_node=2, prior_kind=1, p_scale=1)
+    orc.mh_step(st)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        orc.mh_step(st)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 5) or n >= 2000:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
+    return dict(value=n / el, unit="MCMC iterations/s", cores=int(blas_threads), kind="port",
+                sample="%d mh_step iterations of config 2 (100k x 256, [32,8]) with the numpy float64 oracle, "
+                       "%d BLAS threads of %d host CPUs" % (n, blas_threads, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from npbnn_amd import HipContext, _capi as capi
+    from bench_support import make_initial_weights
+
+    x, y = synthetic_config2()
+    w = make_initial_weights(HIDDEN, N_FEATURES, N_CLASSES, bias_node=2)
+    ctx = HipContext(local_rank)
+    ctx.set_data(x.astype(np.float32))
+    ctx.set_labels(y)
+    ctx.set_arch_from_weights(w, N_FEATURES, capi.ACT_TANH, capi.OUT_SOFTMAX, capi.LIK_CATEGORICAL)
+
+    from bench_support import StepRunner
+    runner = StepRunner(ctx, w, seed=1234 + rank)
+    runner.run(args.warmup)
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    runner.run(args.steps)
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        ms_kernel, ms_eval = ctx.time_eval(runner.weights, iters=50)
+        alg_bytes = 4.0 * N_ROWS * N_FEATURES + 4.0 * N_ROWS
+        achieved = alg_bytes / (ms_kernel * 1e-3)
+        line = {
+            "metric": "MCMC iterations/sec (full fwd+lik per proposal)",
+            "value": world * args.steps / el,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "config 2: 100k x 256 features, 10 classes, hidden [32,8], tanh, bias 2; "
+                                   "one chain per GPU", "chains": world, "mode": runner.mode},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "eval_kernel<2>",
+                         "kernel_ms": ms_kernel, "algorithmic_bytes": alg_bytes},
+            "accept_rate": runner.accept_rate(),
+            "loglik": runner.loglik,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(x, y)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

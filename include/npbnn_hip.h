@@ -1,0 +1,148 @@
+/*
+ * npbnn_hip.h — C ABI of the MI355X (gfx950) backend for npBNN's MCMC hot path.
+ *
+ * The reference (dsilvestro/npBNN, np_bnn 0.1.23) is pure Python and has no
+ * FFI of its own; its boundary for this path is the Python call surface.  Each
+ * entry point below names the reference function(s) it replaces (file:line
+ * relative to the upstream repository root).  INTEGRATION.md shows the ctypes
+ * stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative NPBNN_E_* code; the
+ *     message is available from npbnn_last_error(ctx) (ctx may be NULL for
+ *     errors raised before a context exists);
+ *   - the caller owns every host buffer and may free it as soon as the call
+ *     returns; the library owns all device memory for the lifetime of the ctx;
+ *   - one ctx = one chain = one HIP stream on one device; a ctx is not
+ *     thread-safe, distinct ctxs are independent;
+ *   - host matrices are dense row-major; weights are float64 as in the
+ *     reference and are converted to float32 on the device; the per-row
+ *     arithmetic is float32, every cross-row sum is float64 with a fixed
+ *     reduction order (results are run-to-run identical).
+ */
+#ifndef NPBNN_HIP_H
+#define NPBNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPBNN_ABI_VERSION 1
+#define NPBNN_MAX_LAYERS 8      /* weight matrices per network                    */
+#define NPBNN_MAX_WIDTH 128     /* max nodes of any hidden/output layer           */
+#define NPBNN_MAX_TARGETS 16    /* max target columns for the Gaussian/count liks */
+
+enum {
+    NPBNN_OK = 0,
+    NPBNN_E_ARG = -1,       /* bad argument / unsupported shape      */
+    NPBNN_E_STATE = -2,     /* call order (e.g. eval before set_arch) */
+    NPBNN_E_HIP = -3,       /* a HIP runtime call failed              */
+    NPBNN_E_NOMEM = -4,
+    NPBNN_E_COMM = -5       /* RCCL failure                           */
+};
+
+/* activation kinds — ActFun.activate selection, np_bnn/BNN_lib.py:50-87 */
+enum { NPBNN_ACT_RELU = 0, NPBNN_ACT_LEAKY = 1, NPBNN_ACT_SWISH = 2, NPBNN_ACT_TANH = 3 };
+
+/* output functions — np_bnn/BNN_lib.py:166-182 */
+enum {
+    NPBNN_OUT_SOFTMAX = 0,        /* SoftMax              :166-168 */
+    NPBNN_OUT_IDENTITY = 1,       /* RegressTransform     :174-175 */
+    NPBNN_OUT_SOFTPLUS_HALF = 2   /* RegressTransformError:177-182 */
+};
+
+/* likelihood kinds — np_bnn/BNN_lib.py:100-143 and np_bnn/BNN_lik.py:5-66 */
+enum {
+    NPBNN_LIK_CATEGORICAL = 0,     /* calc_likelihood                  BNN_lib.py:100-121 */
+    NPBNN_LIK_GAUSS = 1,           /* calc_likelihood_regression       BNN_lib.py:123-131, sigma given or
+                                      empirical (np.std of residuals, BNN_env.py:475-476) */
+    NPBNN_LIK_GAUSS_PRED_SIGMA = 2,/* calc_likelihood_regression_error BNN_lib.py:134-143 */
+    NPBNN_LIK_POISSON = 3,         /* poi_likelihood                   BNN_lik.py:5-14    */
+    NPBNN_LIK_NEGBIN = 4,          /* negbin_likelihood                BNN_lik.py:16-30   */
+    NPBNN_LIK_NEGBIN2D = 5,        /* negbin_likelihood2d              BNN_lik.py:33-49   */
+    NPBNN_LIK_NEGBIN_BASE10 = 6,   /* negbin_likelihood_base10         BNN_lik.py:55-66   */
+    NPBNN_LIK_NONE = 7             /* forward only                                         */
+};
+
+/* prior kinds — npBNN.__init__/calc_prior, np_bnn/BNN_env.py:135-150,180-194 */
+enum { NPBNN_PRIOR_UNIFORM = 0, NPBNN_PRIOR_NORMAL = 1, NPBNN_PRIOR_CAUCHY = 2, NPBNN_PRIOR_LAPLACE = 3 };
+
+enum { NPBNN_TRAIN = 0, NPBNN_TEST = 1 };
+
+typedef struct npbnn_ctx npbnn_ctx;
+
+/* Network description.  Layer l has a weight matrix out_dim[l] x (in_l + has_bias[l])
+ * with the bias in COLUMN 0 (init_weight_prm, np_bnn/BNN_mcmc.py:9-25;
+ * MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162); in_0 = in_dim, in_l = out_dim[l-1].
+ * Packed weights = the layer matrices concatenated, each row-major. */
+typedef struct {
+    int32_t n_layers;
+    int32_t in_dim;
+    int32_t out_dim[NPBNN_MAX_LAYERS];
+    int32_t has_bias[NPBNN_MAX_LAYERS];
+    int32_t act_kind;       /* hidden layers; the last layer has no activation (BNN_lib.py:253) */
+    int32_t out_kind;
+    int32_t lik_kind;
+    int32_t n_targets;      /* k target columns (Gaussian / count likelihoods), else 0 */
+} npbnn_arch;
+
+/* Result of one evaluation.  sum_r / sum_r2 are the per-column residual moments
+ * (targets - prediction) from which sigma, the Gaussian log-likelihood and the MSE
+ * statistics (CalcAccuracyRegression / CalcLabelAccuracyRegression, BNN_lib.py:195-201)
+ * all derive. */
+typedef struct {
+    double loglik;                       /* includes lik_temp */
+    double sigma[NPBNN_MAX_TARGETS];     /* sigma actually used (given or empirical) */
+    double sum_r[NPBNN_MAX_TARGETS];
+    double sum_r2[NPBNN_MAX_TARGETS];
+    int64_t n_rows;
+} npbnn_eval_out;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+int npbnn_abi_version(void);
+int npbnn_device_count(int* out);
+int npbnn_create(int device_id, npbnn_ctx** out);
+void npbnn_destroy(npbnn_ctx* ctx);
+const char* npbnn_last_error(const npbnn_ctx* ctx);
+
+/* ---- resident data: replaces npBNN._data/_labels/_test_data/_test_labels living in host
+ * numpy arrays and being copied every iteration (tmp = bnn_obj._data + 0, BNN_env.py:388) ---- */
+int npbnn_set_data_f64(npbnn_ctx* ctx, const double* X, int64_t n_rows, int32_t n_features, int which);
+int npbnn_set_data_f32(npbnn_ctx* ctx, const float* X, int64_t n_rows, int32_t n_features, int which);
+int npbnn_set_labels_i64(npbnn_ctx* ctx, const int64_t* y, int64_t n_rows, int which);
+int npbnn_set_targets_f64(npbnn_ctx* ctx, const double* Y, int64_t n_rows, int32_t k, int which);
+/* instance_weight / class_weight of calc_likelihood (BNN_lib.py:100-121); NULL clears. Train set only. */
+int npbnn_set_row_weights(npbnn_ctx* ctx, const double* instance_w, int64_t n_rows,
+                          const double* class_w, int32_t n_classes);
+int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch);
+
+/* ---- one proposal evaluation: replaces the per-layer RunHiddenLayer loop + output function +
+ * likelihood of MCMC.mh_step (BNN_env.py:449-473, 485-491) and of MCMC.__init__ (:299-319).
+ *   W_packed     float64 packed weights (mask / indicators already applied by the caller, :461-464)
+ *   act_prm      per-hidden-layer slope for NPBNN_ACT_LEAKY (ActFun._prm, BNN_lib.py:84-85) or NULL
+ *   col_override length in_dim or NULL: entries that are not NaN replace that feature column by the
+ *                given constant (data_transform_obj.transform, BNN_env.py:14-17)
+ *   sigma        k values, or NULL = empirical sigma (BNN_env.py:475-476); Gaussian likelihood only
+ *   confusion    n_classes x n_classes int64 [true label][argmax] or NULL; CalcAccuracy,
+ *                CalcLabelAccuracy and CalcLabelFreq (BNN_lib.py:203-233) are functions of it */
+int npbnn_eval(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
+               const double* col_override, double lik_temp, const double* sigma, int which,
+               npbnn_eval_out* out, int64_t* confusion);
+
+/* ---- predictions: replaces RunPredict / RunPredictInd (BNN_lib.py:245-272).
+ * out_y is n_rows x out_dim[last] float64; apply_out_fn=0 returns the last layer's pre-output values. */
+int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
+                  const double* col_override, int which, int apply_out_fn, double* out_y);
+
+/* ---- timing hook for bench.py: launches the evaluation kernels `iters` times on the ctx stream
+ * with weights already resident and returns the mean duration of the dominant kernel (HIP events
+ * around each launch) and of the whole evaluation, in milliseconds. */
+int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_main_kernel,
+                    double* ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPBNN_HIP_H */

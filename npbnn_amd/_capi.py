@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in ``include/npbnn_hip.h`` (libnpbnn_hip.so).
+
+There is no CPU fallback: if the shared library is missing or cannot be
+loaded the import of any device-backed functionality raises
+:class:`BackendUnavailable`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_LAYERS = 8
+MAX_WIDTH = 128
+MAX_TARGETS = 16
+
+ACT_RELU, ACT_LEAKY, ACT_SWISH, ACT_TANH = 0, 1, 2, 3
+OUT_SOFTMAX, OUT_IDENTITY, OUT_SOFTPLUS_HALF = 0, 1, 2
+(LIK_CATEGORICAL, LIK_GAUSS, LIK_GAUSS_PRED_SIGMA, LIK_POISSON, LIK_NEGBIN, LIK_NEGBIN2D,
+ LIK_NEGBIN_BASE10, LIK_NONE) = range(8)
+PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE = 0, 1, 2, 3
+TRAIN, TEST = 0, 1
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libnpbnn_hip.so")
+
+
+class BackendUnavailable(RuntimeError):
+    """The HIP shared library is missing or no MI355X is usable."""
+
+
+class NpbnnError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("npbnn_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class Arch(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("in_dim", C.c_int32),
+                ("out_dim", C.c_int32 * MAX_LAYERS), ("has_bias", C.c_int32 * MAX_LAYERS),
+                ("act_kind", C.c_int32), ("out_kind", C.c_int32), ("lik_kind", C.c_int32),
+                ("n_targets", C.c_int32)]
+
+
+class EvalOut(C.Structure):
+    _fields_ = [("loglik", C.c_double), ("sigma", C.c_double * MAX_TARGETS),
+                ("sum_r", C.c_double * MAX_TARGETS), ("sum_r2", C.c_double * MAX_TARGETS),
+                ("n_rows", C.c_int64)]
+
+
+_P = C.c_void_p
+_DP = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/npbnn_hip.h declares
+SIGNATURES = {
+    "npbnn_abi_version": (C.c_int, []),
+    "npbnn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "npbnn_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "npbnn_destroy": (None, [_P]),
+    "npbnn_last_error": (C.c_char_p, [_P]),
+    "npbnn_set_data_f64": (C.c_int, [_P, _DP, C.c_int64, C.c_int32, C.c_int]),
+    "npbnn_set_data_f32": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int]),
+    "npbnn_set_labels_i64": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int64, C.c_int]),
+    "npbnn_set_targets_f64": (C.c_int, [_P, _DP, C.c_int64, C.c_int32, C.c_int]),
+    "npbnn_set_row_weights": (C.c_int, [_P, _DP, C.c_int64, _DP, C.c_int32]),
+    "npbnn_set_arch": (C.c_int, [_P, C.POINTER(Arch)]),
+    "npbnn_eval": (C.c_int, [_P, _DP, _DP, _DP, C.c_double, _DP, C.c_int, C.POINTER(EvalOut),
+                             C.POINTER(C.c_int64)]),
+    "npbnn_predict": (C.c_int, [_P, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),
+    "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libnpbnn_hip.so and bind every declared symbol.  Raises
+    BackendUnavailable (never falls back) when that is impossible."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("NPBNN_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise BackendUnavailable(
+            "HIP backend library not found at %s; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C npbnn_amd/csrc` (there is no CPU fallback)" % p)
+    try:
+        lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise BackendUnavailable("cannot load %s: %s" % (p, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BackendUnavailable("%s does not export %s" % (p, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.npbnn_abi_version() != 1:
+        raise BackendUnavailable("ABI version mismatch in %s" % p)
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_DP)
+
+
+def check(lib, ctx, rc):
+    if rc != 0:
+        msg = lib.npbnn_last_error(ctx)
+        raise NpbnnError(rc, msg.decode() if msg else "?")

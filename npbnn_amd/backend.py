@@ -1,0 +1,154 @@
+"""Device context of one chain: thin object wrapper over the C ABI.
+
+``HipContext`` owns one ``npbnn_ctx`` (one HIP stream on one MI355X) holding
+the resident training / test matrices and the network description.  All
+numerics of the hot path run in the hand-written HIP kernels behind it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def pack_weights(weights):
+    """Concatenate the layer matrices (each row-major) into the packed float64
+    vector the C ABI takes."""
+    return np.concatenate([np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights])
+
+
+def default_device():
+    """Device of this process: NPBNN_DEVICE, else LOCAL_RANK (one process per
+    GPU under torch.distributed.run), else 0."""
+    for key in ("NPBNN_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None and v != "":
+            return int(v)
+    return 0
+
+
+class HipContext:
+    def __init__(self, device=None):
+        self._lib = capi.load_library()
+        self._ctx = capi._P()
+        dev = default_device() if device is None else int(device)
+        n = C.c_int(0)
+        rc = self._lib.npbnn_device_count(C.byref(n))
+        if rc != 0 or n.value < 1:
+            raise capi.BackendUnavailable("no HIP device visible: the npbnn_amd hot path needs an MI355X "
+                                          "(there is no CPU fallback)")
+        capi.check(self._lib, None, self._lib.npbnn_create(dev % n.value, C.byref(self._ctx)))
+        self.device = dev % n.value
+        self.arch = None
+        self.n_rows = {}
+        self.n_out = None
+
+    # -- lifecycle --------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.npbnn_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        capi.check(self._lib, self._ctx, rc)
+
+    # -- resident data ----------------------------------------------------------------
+    def set_data(self, X, which=capi.TRAIN):
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("data must be a 2-D matrix")
+        if X.dtype == np.float32:
+            Xc = np.ascontiguousarray(X)
+            self._chk(self._lib.npbnn_set_data_f32(self._ctx, Xc.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   X.shape[0], X.shape[1], which))
+        else:
+            Xc = capi.as_f64(X)
+            self._chk(self._lib.npbnn_set_data_f64(self._ctx, capi.dptr(Xc), X.shape[0], X.shape[1], which))
+        self.n_rows[which] = X.shape[0]
+
+    def set_labels(self, labels, which=capi.TRAIN):
+        lab = np.ascontiguousarray(labels, dtype=np.int64)
+        self._chk(self._lib.npbnn_set_labels_i64(self._ctx, lab.ctypes.data_as(C.POINTER(C.c_int64)), lab.shape[0], which))
+
+    def set_targets(self, targets, which=capi.TRAIN):
+        t = capi.as_f64(targets)
+        if t.ndim == 1:
+            t = t.reshape(-1, 1)
+        self._chk(self._lib.npbnn_set_targets_f64(self._ctx, capi.dptr(t), t.shape[0], t.shape[1], which))
+
+    def set_row_weights(self, instance_w=None, class_w=None):
+        iw = None if instance_w is None else capi.as_f64(instance_w)
+        cw = None if class_w is None or len(class_w) == 0 else capi.as_f64(class_w)
+        self._chk(self._lib.npbnn_set_row_weights(self._ctx, capi.dptr(iw), 0 if iw is None else iw.shape[0],
+                                                  capi.dptr(cw), 0 if cw is None else cw.shape[0]))
+
+    def set_arch(self, in_dim, out_dims, has_bias, act_kind, out_kind, lik_kind, n_targets=0):
+        if len(out_dims) > capi.MAX_LAYERS:
+            raise capi.NpbnnError(-1, "at most %d layers are supported" % capi.MAX_LAYERS)
+        a = capi.Arch()
+        a.n_layers = len(out_dims)
+        a.in_dim = int(in_dim)
+        for i, (o, b) in enumerate(zip(out_dims, has_bias)):
+            a.out_dim[i] = int(o)
+            a.has_bias[i] = int(bool(b))
+        a.act_kind, a.out_kind, a.lik_kind, a.n_targets = int(act_kind), int(out_kind), int(lik_kind), int(n_targets)
+        self._chk(self._lib.npbnn_set_arch(self._ctx, C.byref(a)))
+        self.arch = a
+        self.n_out = int(out_dims[-1])
+
+    def set_arch_from_weights(self, weights, in_dim, act_kind, out_kind, lik_kind, n_targets=0):
+        """Derive layer sizes and bias flags from the weight shapes: layer l has a
+        bias iff its matrix has in_l + 1 columns (reference: BNN_lib.py:157-161)."""
+        out_dims, has_bias = [], []
+        cur = in_dim
+        for w in weights:
+            out_dims.append(w.shape[0])
+            if w.shape[1] == cur:
+                has_bias.append(0)
+            elif w.shape[1] == cur + 1:
+                has_bias.append(1)
+            else:
+                raise ValueError("weight matrix with %d columns does not match %d inputs" % (w.shape[1], cur))
+            cur = w.shape[0]
+        self.set_arch(in_dim, out_dims, has_bias, act_kind, out_kind, lik_kind, n_targets)
+
+    # -- hot path ---------------------------------------------------------------------
+    def eval(self, weights, act_prm=None, col_override=None, lik_temp=1.0, sigma=None, which=capi.TRAIN,
+             want_confusion=False):
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights)
+        ap = None if act_prm is None else capi.as_f64(act_prm)
+        co = None if col_override is None else capi.as_f64(col_override)
+        sg = None if sigma is None else capi.as_f64(np.broadcast_to(sigma, (self.arch.n_targets,)))
+        out = capi.EvalOut()
+        conf = None
+        cptr = None
+        if want_confusion:
+            conf = np.zeros((self.n_out, self.n_out), dtype=np.int64)
+            cptr = conf.ctypes.data_as(C.POINTER(C.c_int64))
+        self._chk(self._lib.npbnn_eval(self._ctx, capi.dptr(w), capi.dptr(ap), capi.dptr(co), float(lik_temp),
+                                       capi.dptr(sg), which, C.byref(out), cptr))
+        k = self.arch.n_targets
+        return dict(loglik=out.loglik, sigma=np.array(out.sigma[:k]), sum_r=np.array(out.sum_r[:k]),
+                    sum_r2=np.array(out.sum_r2[:k]), n_rows=out.n_rows, confusion=conf)
+
+    def predict(self, weights, act_prm=None, col_override=None, which=capi.TRAIN, apply_out_fn=True):
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights)
+        ap = None if act_prm is None else capi.as_f64(act_prm)
+        co = None if col_override is None else capi.as_f64(col_override)
+        y = np.empty((self.n_rows[which], self.n_out), dtype=np.float64)
+        self._chk(self._lib.npbnn_predict(self._ctx, capi.dptr(w), capi.dptr(ap), capi.dptr(co), which,
+                                          1 if apply_out_fn else 0, capi.dptr(y)))
+        return y
+
+    def time_eval(self, weights, iters=20):
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights)
+        a, b = C.c_double(0), C.c_double(0)
+        self._chk(self._lib.npbnn_time_eval(self._ctx, capi.dptr(w), int(iters), C.byref(a), C.byref(b)))
+        return a.value, b.value

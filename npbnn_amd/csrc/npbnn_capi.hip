@@ -1,0 +1,622 @@
+// C ABI of the gfx950 backend (see include/npbnn_hip.h for the contract and the reference
+// functions each entry point replaces).  Host-side orchestration only: device buffers, launches,
+// the HIP stream of the chain.  No torch, no BLAS library, no CPU fallback for the numerics.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "npbnn_hip.h"
+#include "npbnn_kernels.hip.h"
+
+using namespace npbnn;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Dataset {
+    float* X = nullptr;
+    int* labels = nullptr;
+    float* targets = nullptr;
+    float* inst_w = nullptr;
+    int64_t n_rows = 0;
+    int n_tiles = 0;
+    int F = 0, Fp = 0, k = 0;
+};
+
+}  // namespace
+
+struct npbnn_ctx {
+    int device = 0;
+    int n_cu = 256;
+    size_t lds_limit = 160 * 1024;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Dataset ds[2];
+    double* d_classw = nullptr;
+    int n_classw = 0;
+    bool arch_set = false;
+    npbnn_arch arch{};
+    NetMeta net{};
+    int n_weights = 0;
+    int mt0_template = 1;
+    // device work buffers
+    double* d_wraw = nullptr;      // packed float64 weights
+    double* d_colov = nullptr;     // column override (in_dim doubles)
+    float* d_image = nullptr;
+    double* d_partials = nullptr;
+    int partial_waves = 0;
+    unsigned* d_conf = nullptr;    // NPBNN_MAX_WIDTH^2
+    npbnn_eval_out* d_out = nullptr;
+    float* d_y = nullptr;
+    size_t d_y_cap = 0;
+    // pinned host staging
+    double* h_w = nullptr;
+    size_t h_w_cap = 0;
+    npbnn_eval_out* h_out = nullptr;
+    unsigned* h_conf = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+int fail(npbnn_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, NPBNN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+void free_dataset(Dataset& d) {
+    if (d.X) (void)hipFree(d.X);
+    if (d.labels) (void)hipFree(d.labels);
+    if (d.targets) (void)hipFree(d.targets);
+    if (d.inst_w) (void)hipFree(d.inst_w);
+    d = Dataset();
+}
+
+template <typename T>
+int upload_matrix(npbnn_ctx* ctx, const T* X, int64_t n_rows, int32_t F, int which) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!X || n_rows <= 0 || F <= 0 || (which != 0 && which != 1))
+        return fail(ctx, NPBNN_E_ARG, "set_data: bad arguments (rows=%lld, features=%d, which=%d)",
+                    (long long)n_rows, F, which);
+    if (n_rows > (int64_t)1 << 30) return fail(ctx, NPBNN_E_ARG, "set_data: too many rows");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Dataset& d = ctx->ds[which];
+    free_dataset(d);
+    d.n_rows = n_rows;
+    d.F = F;
+    d.Fp = round_up(F, 16);
+    d.n_tiles = (int)((n_rows + 15) / 16);
+    const size_t n_pad = (size_t)d.n_tiles * 16;
+    const size_t bytes = n_pad * d.Fp * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&d.X, bytes));
+    // convert + pad on the host in slabs, so the staging buffer stays small
+    const size_t slab_rows = 16384;
+    std::vector<float> stage(slab_rows * d.Fp);
+    for (size_t r0 = 0; r0 < n_pad; r0 += slab_rows) {
+        const size_t nr = std::min(slab_rows, n_pad - r0);
+        std::fill(stage.begin(), stage.begin() + nr * d.Fp, 0.0f);
+        for (size_t r = 0; r < nr; ++r) {
+            const size_t gr = r0 + r;
+            if (gr >= (size_t)n_rows) break;
+            const T* src = X + gr * F;
+            float* dst = stage.data() + r * d.Fp;
+            for (int c = 0; c < F; ++c) dst[c] = (float)src[c];
+        }
+        HIP_TRY(ctx, hipMemcpy(d.X + r0 * d.Fp, stage.data(), nr * d.Fp * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return NPBNN_OK;
+}
+
+int check_rows(npbnn_ctx* ctx, int which, int64_t n_rows, const char* what) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (which != 0 && which != 1) return fail(ctx, NPBNN_E_ARG, "%s: which must be 0 or 1", what);
+    if (!ctx->ds[which].X) return fail(ctx, NPBNN_E_STATE, "%s: call npbnn_set_data first", what);
+    if (ctx->ds[which].n_rows != n_rows)
+        return fail(ctx, NPBNN_E_ARG, "%s: %lld rows but the data matrix has %lld", what, (long long)n_rows,
+                    (long long)ctx->ds[which].n_rows);
+    return NPBNN_OK;
+}
+
+int build_net(npbnn_ctx* ctx, const npbnn_arch* a) {
+    if (a->n_layers < 1 || a->n_layers > NPBNN_MAX_LAYERS)
+        return fail(ctx, NPBNN_E_ARG, "set_arch: n_layers=%d outside 1..%d", a->n_layers, NPBNN_MAX_LAYERS);
+    if (a->in_dim < 1) return fail(ctx, NPBNN_E_ARG, "set_arch: in_dim=%d", a->in_dim);
+    if (a->act_kind < 0 || a->act_kind > NPBNN_ACT_TANH) return fail(ctx, NPBNN_E_ARG, "set_arch: act_kind=%d", a->act_kind);
+    if (a->out_kind < 0 || a->out_kind > NPBNN_OUT_SOFTPLUS_HALF) return fail(ctx, NPBNN_E_ARG, "set_arch: out_kind=%d", a->out_kind);
+    if (a->lik_kind < 0 || a->lik_kind > NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_ARG, "set_arch: lik_kind=%d", a->lik_kind);
+    NetMeta net{};
+    net.n_layers = a->n_layers;
+    net.act_kind = a->act_kind;
+    net.out_kind = a->out_kind;
+    net.lik_kind = a->lik_kind;
+    net.k_targets = a->n_targets;
+    int in = a->in_dim, off = 0, woff = 0;
+    for (int l = 0; l < a->n_layers; ++l) {
+        const int out = a->out_dim[l];
+        if (out < 1 || out > NPBNN_MAX_WIDTH)
+            return fail(ctx, NPBNN_E_ARG, "set_arch: layer %d has %d nodes; this backend supports 1..%d per layer", l, out,
+                        NPBNN_MAX_WIDTH);
+        LayerMeta& L = net.L[l];
+        L.in_dim = in;
+        L.out_dim = out;
+        L.has_bias = a->has_bias[l] ? 1 : 0;
+        L.kt = (in + 15) / 16;
+        L.mt = (out + 15) / 16;
+        if (l == 0) {   // layer-0 tile count is a template parameter of the kernel: 1, 2, 4 or 8
+            int t = 1;
+            while (t < L.mt) t *= 2;
+            L.mt = t;
+        }
+        L.frag_off = off;
+        off += L.kt * L.mt * 256;
+        L.w_off = woff;
+        woff += out * (in + L.has_bias);
+        in = out;
+    }
+    for (int l = 0; l < a->n_layers; ++l) {
+        net.L[l].bias_off = off;
+        off += 16 * net.L[l].mt;
+    }
+    net.classw_off = off;
+    off += NPBNN_MAX_WIDTH;
+    net.image_floats = round_up(off, 256);
+    net.n_out = a->out_dim[a->n_layers - 1];
+    if (a->lik_kind == NPBNN_LIK_GAUSS) {
+        if (a->n_targets < 1 || a->n_targets > NPBNN_MAX_TARGETS || a->n_targets > net.n_out)
+            return fail(ctx, NPBNN_E_ARG, "set_arch: Gaussian likelihood needs 1..%d target columns (<= outputs), got %d",
+                        NPBNN_MAX_TARGETS, a->n_targets);
+    } else if (a->lik_kind != NPBNN_LIK_CATEGORICAL && a->lik_kind != NPBNN_LIK_NONE) {
+        return fail(ctx, NPBNN_E_ARG, "set_arch: likelihood kind %d is not implemented by this build", a->lik_kind);
+    }
+    ctx->net = net;
+    ctx->n_weights = woff;
+    ctx->mt0_template = net.L[0].mt;
+    return NPBNN_OK;
+}
+
+// waves per block such that the fragment image + per-wave rings fit the CU's LDS
+int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
+    for (int w = kMaxWavesPerBlock; w >= 1; w >>= 1) {
+        const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * kWaveLds;
+        if (need <= ctx->lds_limit) {
+            *lds_bytes = need;
+            return w;
+        }
+    }
+    return 0;
+}
+
+typedef void (*eval_fn_t)(EvalParams);
+
+eval_fn_t pick_kernel(int mt0) {
+    switch (mt0) {
+        case 1: return eval_kernel<1>;
+        case 2: return eval_kernel<2>;
+        case 4: return eval_kernel<4>;
+        default: return eval_kernel<8>;
+    }
+}
+
+struct LaunchPlan {
+    eval_fn_t fn;
+    int grid, wpb;
+    size_t lds;
+    int n_waves;
+};
+
+int plan_launch(npbnn_ctx* ctx, const Dataset& d, LaunchPlan* lp) {
+    size_t lds = 0;
+    const int wpb = pick_waves_per_block(ctx, &lds);
+    if (wpb == 0)
+        return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
+                    ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
+    lp->fn = pick_kernel(ctx->mt0_template);
+    lp->wpb = wpb;
+    lp->lds = lds;
+    int grid = (d.n_tiles + wpb - 1) / wpb;
+    if (grid > ctx->n_cu) grid = ctx->n_cu;     // persistent: one workgroup per CU
+    if (grid < 1) grid = 1;
+    lp->grid = grid;
+    lp->n_waves = grid * wpb;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return NPBNN_OK;
+}
+
+int ensure_work_buffers(npbnn_ctx* ctx, int n_waves) {
+    if (n_waves > ctx->partial_waves) {
+        if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+        ctx->d_partials = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_partials, (size_t)n_waves * kPartialStride * sizeof(double)));
+        ctx->partial_waves = n_waves;
+    }
+    return NPBNN_OK;
+}
+
+int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const double* col_override) {
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "call npbnn_set_arch first");
+    if (!W) return fail(ctx, NPBNN_E_ARG, "null weights");
+    memcpy(ctx->h_w, W, (size_t)ctx->n_weights * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wraw, ctx->h_w, (size_t)ctx->n_weights * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const double* d_co = nullptr;
+    if (col_override) {
+        double* h_co = ctx->h_w + ctx->n_weights;
+        memcpy(h_co, col_override, (size_t)ctx->arch.in_dim * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_colov, h_co, (size_t)ctx->arch.in_dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        d_co = ctx->d_colov;
+    }
+    for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
+    if (act_prm)
+        for (int l = 0; l + 1 < ctx->net.n_layers; ++l) ctx->net.act_prm[l] = (float)act_prm[l];
+    int total = NPBNN_MAX_WIDTH;
+    for (int l = 0; l < ctx->net.n_layers; ++l) total += ctx->net.L[l].kt * ctx->net.L[l].mt * 64 + 16 * ctx->net.L[l].mt;
+    const int blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_wraw, d_co,
+                       ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
+    HIP_TRY(ctx, hipGetLastError());
+    return NPBNN_OK;
+}
+
+EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
+    EvalParams p{};
+    p.X = d.X;
+    p.labels = d.labels;
+    p.targets = d.targets;
+    p.inst_w = nullptr;
+    p.image = ctx->d_image;
+    p.n_rows = d.n_rows;
+    p.n_tiles = d.n_tiles;
+    p.Fp = d.Fp;
+    p.net = ctx->net;
+    return p;
+}
+
+int check_dataset_for_lik(npbnn_ctx* ctx, const Dataset& d, int lik) {
+    if (!d.X) return fail(ctx, NPBNN_E_STATE, "no data matrix for this set");
+    if (d.F != ctx->arch.in_dim)
+        return fail(ctx, NPBNN_E_ARG, "data has %d features but the network expects %d", d.F, ctx->arch.in_dim);
+    if (lik == NPBNN_LIK_CATEGORICAL && !d.labels) return fail(ctx, NPBNN_E_STATE, "categorical likelihood needs labels (npbnn_set_labels_i64)");
+    if (lik == NPBNN_LIK_GAUSS) {
+        if (!d.targets) return fail(ctx, NPBNN_E_STATE, "Gaussian likelihood needs targets (npbnn_set_targets_f64)");
+        if (d.k != ctx->net.k_targets) return fail(ctx, NPBNN_E_ARG, "targets have %d columns, architecture says %d", d.k, ctx->net.k_targets);
+    }
+    return NPBNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int npbnn_abi_version(void) { return NPBNN_ABI_VERSION; }
+
+int npbnn_device_count(int* out) {
+    if (!out) return fail(nullptr, NPBNN_E_ARG, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        return fail(nullptr, NPBNN_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out = n;
+    return NPBNN_OK;
+}
+
+const char* npbnn_last_error(const npbnn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int npbnn_create(int device_id, npbnn_ctx** out) {
+    if (!out) return fail(nullptr, NPBNN_E_ARG, "null out");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, NPBNN_E_ARG, "device %d not present (%d devices)", device_id, n);
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, NPBNN_E_ARG, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    npbnn_ctx* c = new npbnn_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_limit = 160 * 1024;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&c->d_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&c->d_out, sizeof(npbnn_eval_out));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_out, sizeof(npbnn_eval_out));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev[0]);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev[1]);
+    if (e != hipSuccess) {
+        npbnn_destroy(c);
+        return fail(nullptr, NPBNN_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return NPBNN_OK;
+}
+
+void npbnn_destroy(npbnn_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_dataset(c->ds[0]);
+    free_dataset(c->ds[1]);
+    if (c->d_classw) (void)hipFree(c->d_classw);
+    if (c->d_wraw) (void)hipFree(c->d_wraw);
+    if (c->d_colov) (void)hipFree(c->d_colov);
+    if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_conf) (void)hipFree(c->d_conf);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_y) (void)hipFree(c->d_y);
+    if (c->h_w) (void)hipHostFree(c->h_w);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_conf) (void)hipHostFree(c->h_conf);
+    if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
+    if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int npbnn_set_data_f64(npbnn_ctx* ctx, const double* X, int64_t n_rows, int32_t F, int which) {
+    return upload_matrix<double>(ctx, X, n_rows, F, which);
+}
+
+int npbnn_set_data_f32(npbnn_ctx* ctx, const float* X, int64_t n_rows, int32_t F, int which) {
+    return upload_matrix<float>(ctx, X, n_rows, F, which);
+}
+
+int npbnn_set_labels_i64(npbnn_ctx* ctx, const int64_t* y, int64_t n_rows, int which) {
+    int rc = check_rows(ctx, which, n_rows, "set_labels");
+    if (rc) return rc;
+    if (!y) return fail(ctx, NPBNN_E_ARG, "set_labels: null labels");
+    Dataset& d = ctx->ds[which];
+    const size_t n_pad = (size_t)d.n_tiles * 16;
+    std::vector<int> tmp(n_pad, -1);
+    for (int64_t i = 0; i < n_rows; ++i) {
+        if (y[i] < 0 || y[i] >= NPBNN_MAX_WIDTH)
+            return fail(ctx, NPBNN_E_ARG, "set_labels: label %lld at row %lld outside 0..%d", (long long)y[i], (long long)i, NPBNN_MAX_WIDTH - 1);
+        tmp[i] = (int)y[i];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!d.labels) HIP_TRY(ctx, hipMalloc(&d.labels, n_pad * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(d.labels, tmp.data(), n_pad * sizeof(int), hipMemcpyHostToDevice));
+    return NPBNN_OK;
+}
+
+int npbnn_set_targets_f64(npbnn_ctx* ctx, const double* Y, int64_t n_rows, int32_t k, int which) {
+    int rc = check_rows(ctx, which, n_rows, "set_targets");
+    if (rc) return rc;
+    if (!Y || k < 1 || k > NPBNN_MAX_TARGETS) return fail(ctx, NPBNN_E_ARG, "set_targets: need 1..%d target columns, got %d", NPBNN_MAX_TARGETS, k);
+    Dataset& d = ctx->ds[which];
+    const size_t n_pad = (size_t)d.n_tiles * 16;
+    std::vector<float> tmp(n_pad * k, 0.0f);
+    for (size_t i = 0; i < (size_t)n_rows * k; ++i) tmp[i] = (float)Y[i];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (d.targets && d.k != k) { (void)hipFree(d.targets); d.targets = nullptr; }
+    if (!d.targets) HIP_TRY(ctx, hipMalloc(&d.targets, n_pad * k * sizeof(float)));
+    d.k = k;
+    HIP_TRY(ctx, hipMemcpy(d.targets, tmp.data(), n_pad * k * sizeof(float), hipMemcpyHostToDevice));
+    return NPBNN_OK;
+}
+
+int npbnn_set_row_weights(npbnn_ctx* ctx, const double* instance_w, int64_t n_rows, const double* class_w, int32_t n_classes) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    Dataset& d = ctx->ds[0];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (instance_w) {
+        int rc = check_rows(ctx, 0, n_rows, "set_row_weights");
+        if (rc) return rc;
+        const size_t n_pad = (size_t)d.n_tiles * 16;
+        std::vector<float> tmp(n_pad, 0.0f);
+        for (int64_t i = 0; i < n_rows; ++i) tmp[i] = (float)instance_w[i];
+        if (!d.inst_w) HIP_TRY(ctx, hipMalloc(&d.inst_w, n_pad * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(d.inst_w, tmp.data(), n_pad * sizeof(float), hipMemcpyHostToDevice));
+    } else if (d.inst_w) {
+        (void)hipFree(d.inst_w);
+        d.inst_w = nullptr;
+    }
+    if (class_w) {
+        if (n_classes < 1 || n_classes > NPBNN_MAX_WIDTH) return fail(ctx, NPBNN_E_ARG, "set_row_weights: n_classes=%d", n_classes);
+        if (!ctx->d_classw) HIP_TRY(ctx, hipMalloc(&ctx->d_classw, NPBNN_MAX_WIDTH * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_classw, class_w, (size_t)n_classes * sizeof(double), hipMemcpyHostToDevice));
+        ctx->n_classw = n_classes;
+    } else {
+        ctx->n_classw = 0;
+    }
+    return NPBNN_OK;
+}
+
+int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!arch) return fail(ctx, NPBNN_E_ARG, "null arch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = build_net(ctx, arch);
+    if (rc) return rc;
+    ctx->arch = *arch;
+    ctx->arch_set = false;
+    if (ctx->d_wraw) { (void)hipFree(ctx->d_wraw); ctx->d_wraw = nullptr; }
+    if (ctx->d_colov) { (void)hipFree(ctx->d_colov); ctx->d_colov = nullptr; }
+    if (ctx->d_image) { (void)hipFree(ctx->d_image); ctx->d_image = nullptr; }
+    if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)ctx->n_weights * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)ctx->net.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)ctx->net.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_w, ((size_t)ctx->n_weights + arch->in_dim) * sizeof(double)));
+    size_t lds = 0;
+    if (pick_waves_per_block(ctx, &lds) == 0)
+        return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
+                    ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
+    ctx->arch_set = true;
+    return NPBNN_OK;
+}
+
+int npbnn_eval(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, const double* col_override, double lik_temp,
+               const double* sigma, int which, npbnn_eval_out* out, int64_t* confusion) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!out) return fail(ctx, NPBNN_E_ARG, "eval: null out");
+    if (which != 0 && which != 1) return fail(ctx, NPBNN_E_ARG, "eval: which must be 0 or 1");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "eval: call npbnn_set_arch first");
+    const int lik = ctx->net.lik_kind;
+    if (lik == NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_STATE, "eval: architecture was set with NPBNN_LIK_NONE");
+    Dataset& d = ctx->ds[which];
+    int rc = check_dataset_for_lik(ctx, d, lik);
+    if (rc) return rc;
+    if (confusion && lik != NPBNN_LIK_CATEGORICAL) return fail(ctx, NPBNN_E_ARG, "eval: confusion counts need the categorical likelihood");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchPlan lp;
+    rc = plan_launch(ctx, d, &lp);
+    if (rc) return rc;
+    rc = ensure_work_buffers(ctx, lp.n_waves);
+    if (rc) return rc;
+    rc = stage_weights(ctx, W_packed, act_prm, col_override);
+    if (rc) return rc;
+    EvalParams p = make_params(ctx, d);
+    p.partials = ctx->d_partials;
+    p.inst_w = (which == 0) ? d.inst_w : nullptr;
+    p.use_classw = (which == 0 && ctx->n_classw > 0) ? 1 : 0;
+    const int C = ctx->net.n_out;
+    if (confusion) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_conf, 0, (size_t)C * C * sizeof(unsigned), ctx->stream));
+        p.confusion = ctx->d_conf;
+    }
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    FinalizeParams f{};
+    f.partials = ctx->d_partials;
+    f.n_waves = lp.n_waves;
+    f.lik_kind = lik;
+    f.k_targets = ctx->net.k_targets;
+    f.n_rows = d.n_rows;
+    f.lik_temp = lik_temp;
+    f.sigma_given = sigma ? 1 : 0;
+    if (sigma)
+        for (int j = 0; j < ctx->net.k_targets; ++j) f.sigma[j] = sigma[j];
+    f.out = ctx->d_out;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, f);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(npbnn_eval_out), hipMemcpyDeviceToHost, ctx->stream));
+    if (confusion)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_conf, ctx->d_conf, (size_t)C * C * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *ctx->h_out;
+    if (confusion)
+        for (int i = 0; i < C * C; ++i) confusion[i] = (int64_t)ctx->h_conf[i];
+    return NPBNN_OK;
+}
+
+int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, const double* col_override, int which,
+                  int apply_out_fn, double* out_y) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!out_y) return fail(ctx, NPBNN_E_ARG, "predict: null out_y");
+    if (which != 0 && which != 1) return fail(ctx, NPBNN_E_ARG, "predict: which must be 0 or 1");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "predict: call npbnn_set_arch first");
+    Dataset& d = ctx->ds[which];
+    int rc = check_dataset_for_lik(ctx, d, NPBNN_LIK_NONE);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchPlan lp;
+    rc = plan_launch(ctx, d, &lp);
+    if (rc) return rc;
+    rc = stage_weights(ctx, W_packed, act_prm, col_override);
+    if (rc) return rc;
+    const int C = ctx->net.n_out;
+    const size_t n_el = (size_t)d.n_rows * C;
+    if (n_el > ctx->d_y_cap) {
+        if (ctx->d_y) (void)hipFree(ctx->d_y);
+        ctx->d_y = nullptr;
+        ctx->d_y_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_y, n_el * sizeof(float)));
+        ctx->d_y_cap = n_el;
+    }
+    EvalParams p = make_params(ctx, d);
+    p.labels = nullptr;
+    p.targets = nullptr;
+    p.net.lik_kind = NPBNN_LIK_NONE;
+    p.y_out = ctx->d_y;
+    p.predict_mode = apply_out_fn ? 2 : 1;
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> tmp(n_el);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n_el; ++i) out_y[i] = (double)tmp[i];
+    return NPBNN_OK;
+}
+
+int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_main_kernel, double* ms_total) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (iters < 1 || !ms_main_kernel || !ms_total) return fail(ctx, NPBNN_E_ARG, "time_eval: bad arguments");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "time_eval: call npbnn_set_arch first");
+    const int lik = ctx->net.lik_kind;
+    Dataset& d = ctx->ds[0];
+    int rc = check_dataset_for_lik(ctx, d, lik);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchPlan lp;
+    rc = plan_launch(ctx, d, &lp);
+    if (rc) return rc;
+    rc = ensure_work_buffers(ctx, lp.n_waves);
+    if (rc) return rc;
+    rc = stage_weights(ctx, W_packed, nullptr, nullptr);
+    if (rc) return rc;
+    EvalParams p = make_params(ctx, d);
+    p.partials = ctx->d_partials;
+    p.inst_w = d.inst_w;
+    p.use_classw = ctx->n_classw > 0 ? 1 : 0;
+    FinalizeParams f{};
+    f.partials = ctx->d_partials;
+    f.n_waves = lp.n_waves;
+    f.lik_kind = lik;
+    f.k_targets = ctx->net.k_targets;
+    f.n_rows = d.n_rows;
+    f.lik_temp = 1.0;
+    f.out = ctx->d_out;
+    std::vector<hipEvent_t> evs(2 * (size_t)iters);
+    for (auto& e : evs) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int i = 0; i < iters; ++i) {
+        HIP_TRY(ctx, hipEventRecord(evs[2 * i], ctx->stream));
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
+        HIP_TRY(ctx, hipEventRecord(evs[2 * i + 1], ctx->stream));
+        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, f);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    double sum = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
+        sum += ms;
+    }
+    float tot = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[1]));
+    for (auto& e : evs) (void)hipEventDestroy(e);
+    *ms_main_kernel = sum / iters;
+    *ms_total = (double)tot / iters;
+    return NPBNN_OK;
+}
+
+}  // extern "C"

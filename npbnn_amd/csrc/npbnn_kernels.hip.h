@@ -1,0 +1,524 @@
+// Device code of the npBNN hot path for gfx950 (MI355X, CDNA4).
+//
+// One evaluation = one streaming pass over the resident feature matrix X:
+//   pack_weights_kernel : float64 packed weights -> float32 MFMA "fragment image" (+ padded biases)
+//   eval_kernel<MT0>    : fused forward pass of the whole MLP + likelihood terms (+ confusion counts,
+//                         + optional prediction output); per-wave float64 partial sums
+//   finalize_kernel     : fixed-order float64 reduction of the partials -> log-likelihood, sigma, moments
+//
+// Mapping to the reference (np_bnn 0.1.23): the layer loop of MCMC.mh_step (BNN_env.py:449-473) /
+// RunPredict (BNN_lib.py:245-256): RunHiddenLayer -> MatrixMultiplicationD (+ bias = column 0) -> ActFun.eval
+// (BNN_lib.py:184-193,154-162,83-87); output functions (BNN_lib.py:166-182); likelihoods
+// (BNN_lib.py:100-143, BNN_lik.py:5-66); accuracy reductions (BNN_lib.py:195-233).
+//
+// Design:
+//  * a wavefront owns a 16-row tile of X and computes the TRANSPOSED problem  H^T = W . X^T  with
+//    v_mfma_f32_16x16x4_f32: A = weight fragment (16 units x 4 k), B = X^T (4 k x 16 rows), so the
+//    accumulator of layer l (unit on the register/lane-group index, data row on lane&15) is directly the
+//    B operand of layer l+1 - the whole MLP chains through the matrix cores with no data movement
+//    between layers; bias is the initial accumulator; activations are elementwise on accumulators.
+//  * X tiles arrive by LDS-DMA (global_load_lds_dwordx4, one 1-KiB piece = 16 rows x 16 features per
+//    wave-instruction) into a private per-wave ring; the wave that issued a piece waits for it with a
+//    counted s_waitcnt vmcnt(N); no workgroup barrier in the main loop.
+//  * all weights live in LDS as a lane-linear fragment image (ds_read_b128, conflict free), staged once
+//    per persistent workgroup.
+//  * softmax / log-likelihood: 4-lane shuffle reductions (the 4 lane groups of a data row), per-row terms
+//    in float32, every cross-row sum in float64, one partial per wave, fixed order -> deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "npbnn_hip.h"
+
+namespace npbnn {
+
+constexpr int kMaxLayers = NPBNN_MAX_LAYERS;
+constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
+constexpr int kRing = 6;                       // X ring slots (1 KiB each) per wave
+constexpr int kMaxWavesPerBlock = 8;
+constexpr int kAuxSlots = 4;                   // per-wave row-aux buffers (labels / weights / targets)
+constexpr int kAuxBytes = 64 + 64 + 1024;      // labels, instance weights, 16x16 targets
+constexpr int kWaveLds = kRing * 1024 + kAuxSlots * kAuxBytes;
+constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LayerMeta {
+    int kt;        // 16-wide k tiles of the input dimension
+    int mt;        // 16-wide tiles of the output dimension
+    int frag_off;  // float offset of the fragment block in the image
+    int bias_off;  // float offset of the padded bias (16*mt floats)
+    int in_dim, out_dim, has_bias;
+    int w_off;     // double offset of the layer matrix in the packed weights
+};
+
+struct NetMeta {
+    int n_layers;
+    int image_floats;   // total floats of the image (multiple of 256)
+    int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats)
+    int act_kind, out_kind, lik_kind, n_out, k_targets;
+    LayerMeta L[kMaxLayers];
+    float act_prm[kMaxLayers];
+};
+
+struct EvalParams {
+    const float* X;           // [n_tiles*16][Fp] zero padded
+    const int* labels;        // [n_tiles*16], -1 on padding rows
+    const float* targets;     // [n_tiles*16][k] (k = k_targets), 0 on padding rows
+    const float* inst_w;      // [n_tiles*16] or nullptr
+    const float* image;       // fragment image in global memory
+    double* partials;         // [n_waves][kPartialStride]
+    unsigned* confusion;      // [n_out*n_out] or nullptr
+    float* y_out;             // [n_rows][n_out] or nullptr
+    long long n_rows;
+    int n_tiles;
+    int Fp;
+    int use_classw;
+    int predict_mode;         // 0 none, 1 raw last-layer values, 2 output function applied
+    NetMeta net;
+};
+
+// ------------------------------------------------------------------------------------------------
+// pack: float64 packed weights -> fragment image
+//   frag_l[((kt*MT + mt)*64 + lane)*4 + s] = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + s]
+//   (bias column excluded, zero outside the matrix); bias_l[o] = W_l[o][0] when the layer has a bias.
+//   Layer 0 with a column override (data_transform_obj, BNN_env.py:14-17): an overridden feature column
+//   is the constant v_c for every row, so its contribution v_c*W0[o][c] moves into the bias and the
+//   fragment entry becomes 0 - no extra pass over X.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
+                                                           const double* __restrict__ class_w, float* __restrict__ image,
+                                                           NetMeta net) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    int piece = gid;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerMeta& L = net.L[l];
+        const int n_pieces = L.kt * L.mt * 64;
+        if (piece < n_pieces) {
+            const int lane = piece & 63;
+            const int tile = piece >> 6;
+            const int mt = tile % L.mt, kt = tile / L.mt;
+            const int o = 16 * mt + (lane & 15);
+            const int c0 = 16 * kt + 4 * (lane >> 4);
+            const int ld = L.in_dim + L.has_bias;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (o < L.out_dim) {
+                const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
+                for (int s = 0; s < 4; ++s) {
+                    const int c = c0 + s;
+                    if (c < L.in_dim) {
+                        bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
+                        v[s] = overridden ? 0.f : (float)row[c];
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(image + L.frag_off + (long long)piece * 4) = v;
+            return;
+        }
+        piece -= n_pieces;
+    }
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerMeta& L = net.L[l];
+        const int nb = 16 * L.mt;
+        if (piece < nb) {
+            const int o = piece;
+            double b = 0.0;
+            if (o < L.out_dim) {
+                const int ld = L.in_dim + L.has_bias;
+                const double* row = w + L.w_off + (long long)o * ld;
+                if (L.has_bias) b = row[0];
+                if (l == 0 && col_override != nullptr) {
+                    for (int c = 0; c < L.in_dim; ++c) {
+                        const double ov = col_override[c];
+                        if (!isnan(ov)) b += ov * row[L.has_bias + c];
+                    }
+                }
+            }
+            image[L.bias_off + o] = (float)b;
+            return;
+        }
+        piece -= nb;
+    }
+    if (piece < NPBNN_MAX_WIDTH) {
+        image[net.classw_off + piece] = (class_w != nullptr && piece < net.n_out) ? (float)class_w[piece] : 1.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float z, int kind, float prm) {
+    switch (kind) {
+        case NPBNN_ACT_RELU: return z < 0.f ? 0.f : z;                              // BNN_lib.py:51
+        case NPBNN_ACT_LEAKY: return z < 0.f ? prm * z : z;                         // BNN_lib.py:55
+        case NPBNN_ACT_SWISH: return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));   // BNN_lib.py:60
+        default: return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f);   // BNN_lib.py:65 (exp-form tanh)
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ void act_tiles(f32x4 (&h)[kMaxMT], float prm) {
+#pragma unroll
+    for (int mt = 0; mt < kMaxMT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[mt][i] = act_apply(h[mt][i], KIND, prm);
+}
+
+__device__ __forceinline__ void act_all(f32x4 (&h)[kMaxMT], int kind, float prm) {   // wave-uniform kind
+    switch (kind) {
+        case NPBNN_ACT_RELU: act_tiles<NPBNN_ACT_RELU>(h, prm); break;
+        case NPBNN_ACT_LEAKY: act_tiles<NPBNN_ACT_LEAKY>(h, prm); break;
+        case NPBNN_ACT_SWISH: act_tiles<NPBNN_ACT_SWISH>(h, prm); break;
+        default: act_tiles<NPBNN_ACT_TANH>(h, prm); break;
+    }
+}
+
+__device__ __forceinline__ float softplus_f(float z) {   // np.logaddexp(0, z), BNN_lib.py:172
+    return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z)));
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+
+#define NPBNN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__device__ __forceinline__ void wait_younger(int younger) {   // wave-uniform argument
+    switch (younger) {
+        case 0: NPBNN_WAIT_VMCNT(0); break;
+        case 1: NPBNN_WAIT_VMCNT(1); break;
+        case 2: NPBNN_WAIT_VMCNT(2); break;
+        case 3: NPBNN_WAIT_VMCNT(3); break;
+        case 4: NPBNN_WAIT_VMCNT(4); break;
+        default: NPBNN_WAIT_VMCNT(5); break;
+    }
+}
+static_assert(kRing - 1 <= 5, "wait_younger covers at most 5 pieces in flight");
+
+typedef __attribute__((address_space(1))) const void gvoid;
+typedef __attribute__((address_space(3))) void lvoid;
+
+__device__ __forceinline__ void dma16(const float* g, char* l) {
+    __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* g, char* l) {
+    __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 4, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward + likelihood
+// ------------------------------------------------------------------------------------------------
+template <int MT0>
+__global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const img = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const NetMeta& net = p.net;
+    const int kWavesPerBlock = blockDim.x >> 6;
+    char* const ring = smem + (size_t)net.image_floats * 4 + (size_t)wave * kWaveLds;
+    char* const aux = ring + kRing * 1024;
+
+    // ---- stage the fragment image into LDS (lane-linear DMA copy), all waves share it ----
+    {
+        const int n_pieces = net.image_floats >> 8;   // 1-KiB pieces
+        for (int i = wave; i < n_pieces; i += kWavesPerBlock)
+            dma16(p.image + (size_t)i * 256 + lane * 4, smem + (size_t)i * 1024);
+    }
+
+    // ---- tile schedule: wave gw takes tiles gw, gw+stride, ... ----
+    const int KT0 = net.L[0].kt;
+    const int stride = gridDim.x * kWavesPerBlock;
+    const int gw = blockIdx.x * kWavesPerBlock + wave;
+    const int my_tiles = gw < p.n_tiles ? (p.n_tiles - gw + stride - 1) / stride : 0;
+    const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
+    int D = kRing - 1;                                  // prefetch distance in pieces
+    if (D > 2 * KT0) D = 2 * KT0;                       // at most 3 tiles in flight (aux slots)
+    const size_t row_bytes_f = (size_t)p.Fp;
+    const int kt_targets = net.k_targets;
+
+    // prefetch cursor
+    int pf_q = 0, pf_kt = 0, pf_tile = gw, pf_seq = 0;
+    auto issue_next = [&]() {
+        if (pf_kt == 0) {   // row-aux data of the tile travels ahead of its first X piece
+            char* a = aux + (pf_seq & (kAuxSlots - 1)) * kAuxBytes;
+            const size_t r0 = (size_t)pf_tile * 16;
+            if (lane < 16) {
+                if (p.labels) dma4(p.labels + r0 + lane, a);
+                if (p.inst_w) dma4(p.inst_w + r0 + lane, a + 64);
+            }
+            if (p.targets) {
+                const int total = 16 * kt_targets;       // contiguous floats of this tile's targets
+                for (int e = 0; e < total; e += 64) {
+                    int idx = e + lane;
+                    if (idx >= total) idx = total - 1;  // duplicate the last element, never read
+                    dma4(p.targets + r0 * kt_targets + idx, a + 128 + e * 4);
+                }
+            }
+        }
+        dma16(p.X + ((size_t)pf_tile * 16 + n) * row_bytes_f + 16 * pf_kt + 4 * kq, ring + (pf_q % kRing) * 1024);
+        ++pf_q;
+        if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; }
+    };
+    for (int i = 0; i < D && pf_q < Q; ++i) issue_next();
+
+    // fragment image must have landed for every wave before anyone reads it
+    if (Q > 0) {
+        // everything issued after the image copy may stay in flight only if counted; be simple here
+        NPBNN_WAIT_VMCNT(0);
+    } else {
+        NPBNN_WAIT_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+
+    double ll_acc = 0.0;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+
+    const float* frag0 = img + net.L[0].frag_off;
+    const float* bias0 = img + net.L[0].bias_off;
+    int q = 0;
+    int tile = gw;
+    for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
+        // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring ----------------
+        f32x4 acc0[MT0];
+#pragma unroll
+        for (int mt = 0; mt < MT0; ++mt)
+            acc0[mt] = *reinterpret_cast<const f32x4*>(bias0 + 16 * mt + 4 * kq);
+        for (int kt = 0; kt < KT0; ++kt, ++q) {
+            if (pf_q < Q) issue_next();                 // targets the slot consumed one piece ago
+            wait_younger(pf_q - q - 1);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(ring + (q % kRing) * 1024 + lane * 16);
+            f32x4 a[MT0];
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt)
+                a[mt] = *reinterpret_cast<const f32x4*>(frag0 + ((size_t)(kt * MT0 + mt) * 64 + lane) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT0; ++mt)
+                    acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[mt], 0, 0, 0);
+        }
+
+        // ---------------- layers 1..L-1 chained through the accumulators ----------------
+        f32x4 h[kMaxMT];
+#pragma unroll
+        for (int mt = 0; mt < kMaxMT; ++mt) h[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT0; ++mt) h[mt] = acc0[mt];
+        for (int l = 1; l < net.n_layers; ++l) {
+            const float prm = net.act_prm[l - 1];
+            act_all(h, net.act_kind, prm);
+            const LayerMeta& L = net.L[l];
+            const float* frag = img + L.frag_off;
+            const float* bias = img + L.bias_off;
+            f32x4 acc[kMaxMT];
+#pragma unroll
+            for (int mt = 0; mt < kMaxMT; ++mt) {
+                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (mt < L.mt) {
+                    acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
+#pragma unroll
+                    for (int ct = 0; ct < kMaxMT; ++ct) {
+                        if (ct < L.kt) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(frag + ((size_t)(ct * L.mt + mt) * 64 + lane) * 4);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], h[ct][s], acc[mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < kMaxMT; ++mt) h[mt] = acc[mt];
+        }
+        // h[mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n
+
+        // ---------------- epilogue ----------------
+        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * kAuxBytes;
+        const long long row = (long long)tile * 16 + n;
+        const bool row_ok = row < p.n_rows;
+        const int C = net.n_out;
+        const int MTL = net.L[net.n_layers - 1].mt;
+
+        float lse = 0.f;
+        const bool need_softmax = (net.lik_kind == NPBNN_LIK_CATEGORICAL) ||
+                                  (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
+        int best_i = 0;
+        if (need_softmax) {
+            float m = -INFINITY, bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int mt = 0; mt < kMaxMT; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 16 * mt + 4 * kq + i;
+                        if (o < C) {
+                            m = fmaxf(m, h[mt][i]);
+                            if (h[mt][i] > bv) { bv = h[mt][i]; bi = o; }
+                        }
+                    }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float se = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < kMaxMT; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (16 * mt + 4 * kq + i < C) se += __expf(h[mt][i] - m);
+            se += __shfl_xor(se, 16);
+            se += __shfl_xor(se, 32);
+            lse = m + __logf(se);
+            if (p.confusion) {   // np.argmax: first maximum wins (BNN_lib.py:207)
+#pragma unroll
+                for (int sh = 16; sh <= 32; sh <<= 1) {
+                    const float ov = __shfl_xor(bv, sh);
+                    const int oi = __shfl_xor(bi, sh);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                best_i = bi;
+            }
+        }
+
+        if (net.lik_kind == NPBNN_LIK_CATEGORICAL) {
+            const int lab = *reinterpret_cast<const int*>(a_slot + n * 4);
+            float zl = 0.f;
+            bool own = false;
+#pragma unroll
+            for (int mt = 0; mt < kMaxMT; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (16 * mt + 4 * kq + i == lab) { zl = h[mt][i]; own = true; }
+            float term = 0.f;
+            if (lab >= 0) {
+                if (own) term += zl;
+                if (kq == 0) term -= lse;
+                float wgt = 1.f;
+                if (p.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
+                if (p.use_classw) wgt *= img[net.classw_off + lab];
+                term *= wgt;
+                if (p.confusion && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
+            }
+            ll_acc += (double)term;
+        } else if (net.lik_kind == NPBNN_LIK_GAUSS) {
+            const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = 4 * kq + i;
+                if (o < kt_targets && row_ok) {
+                    const float r = tg[n * kt_targets + o] - h[0][i];
+                    s1[i] += (double)r;
+                    s2[i] += (double)r * (double)r;
+                }
+            }
+        }
+
+        if (p.predict_mode && row_ok) {
+#pragma unroll
+            for (int mt = 0; mt < kMaxMT; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 16 * mt + 4 * kq + i;
+                        if (o < C) {
+                            float v = h[mt][i];
+                            if (p.predict_mode == 2) {
+                                if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
+                                else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+                            }
+                            p.y_out[row * C + o] = v;
+                        }
+                    }
+        }
+    }
+
+    // ---------------- per-wave partials (float64, fixed order) ----------------
+    if (p.partials && gw < stride) {
+        double* out = p.partials + (size_t)gw * kPartialStride;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) ll_acc += shfl_xor_f64(ll_acc, sh);
+        if (lane == 0) out[0] = ll_acc;
+        if (net.lik_kind == NPBNN_LIK_GAUSS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    s1[i] += shfl_xor_f64(s1[i], sh);
+                    s2[i] += shfl_xor_f64(s2[i], sh);
+                }
+                if (n == 0) {
+                    out[1 + 4 * kq + i] = s1[i];
+                    out[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = s2[i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: reduce the per-wave partials in a fixed order and form the log-likelihood
+// ------------------------------------------------------------------------------------------------
+struct FinalizeParams {
+    const double* partials;
+    int n_waves;
+    int lik_kind;
+    int k_targets;
+    long long n_rows;
+    double lik_temp;
+    int sigma_given;
+    double sigma[NPBNN_MAX_TARGETS];
+    npbnn_eval_out* out;   // device
+};
+
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams f) {
+    __shared__ double red[256];
+    __shared__ double tot[kPartialStride];
+    const int tid = threadIdx.x;
+    const int nvals = (f.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+    for (int v = 0; v < nvals; ++v) {
+        double s = 0.0;
+        for (int w = tid; w < f.n_waves; w += 256) s += f.partials[(size_t)w * kPartialStride + v];
+        red[tid] = s;
+        __syncthreads();
+        for (int half = 128; half > 0; half >>= 1) {
+            if (tid < half) red[tid] += red[tid + half];
+            __syncthreads();
+        }
+        if (tid == 0) tot[v] = red[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        npbnn_eval_out o;
+        o.n_rows = f.n_rows;
+        for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { o.sigma[j] = 0; o.sum_r[j] = 0; o.sum_r2[j] = 0; }
+        if (f.lik_kind == NPBNN_LIK_GAUSS) {
+            // sum_j [ -N (0.5 log 2pi + log s_j) - S2_j / (2 s_j^2) ];  empirical s_j = population std of the residuals
+            // (np.std, BNN_env.py:475-476; scipy.stats.norm.logpdf, BNN_lib.py:131)
+            const double N = (double)f.n_rows;
+            double ll = 0.0;
+            for (int j = 0; j < f.k_targets; ++j) {
+                const double S1 = tot[1 + j], S2 = tot[1 + NPBNN_MAX_TARGETS + j];
+                double sg;
+                if (f.sigma_given) sg = f.sigma[j];
+                else {
+                    const double mean = S1 / N;
+                    sg = sqrt(S2 / N - mean * mean);
+                }
+                o.sigma[j] = sg; o.sum_r[j] = S1; o.sum_r2[j] = S2;
+                ll += -N * (0.9189385332046727418 + log(sg)) - S2 / (2.0 * sg * sg);
+            }
+            o.loglik = f.lik_temp * ll;
+        } else {
+            o.loglik = f.lik_temp * tot[0];
+        }
+        *f.out = o;
+    }
+}
+
+}  // namespace npbnn

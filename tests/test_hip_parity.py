@@ -1,0 +1,247 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle
+and against the committed golden vectors of the reference.
+
+Tolerances (float32 per-row arithmetic, float64 cross-row sums; BASELINE.json
+asks for log-likelihood within 1e-4 relative):
+  * last-layer values / predictions: |err| <= 2e-5 * max(1, |value|)
+  * log-likelihood: relative error <= 2e-6
+  * confusion counts: exact, except rows whose top-2 outputs are closer than
+    1e-5 (an fp32 tie the float64 reference resolves differently)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 2e-6
+Z_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import npbnn_amd
+    from npbnn_amd import _capi
+    _capi.load_library()
+    return npbnn_amd
+
+
+ACT_KIND = {"relu": 0, "leaky": 1, "swish": 2, "tanh": 3}
+
+
+def make_ctx(hip, x, weights, act, out_kind, lik_kind, labels=None, targets=None, n_targets=0):
+    ctx = hip.HipContext(0)
+    ctx.set_data(x)
+    if labels is not None:
+        ctx.set_labels(labels)
+    if targets is not None:
+        ctx.set_targets(targets)
+    ctx.set_arch_from_weights(weights, x.shape[1], ACT_KIND[act.kind], out_kind, lik_kind, n_targets)
+    return ctx
+
+
+def act_prm(act, n_hidden):
+    if act.kind != "leaky":
+        return None
+    return np.array([act.slope(i) for i in range(n_hidden)], dtype=float)
+
+
+def assert_close(got, want, tol=Z_TOL):
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= tol, "max scaled error %.3e" % err.max()
+
+
+def check_confusion(conf, y64, labels):
+    want = orc.confusion_counts(y64, labels)
+    if np.array_equal(conf, want):
+        return
+    top2 = np.sort(y64, axis=1)[:, -2:]
+    near_ties = int(np.sum(top2[:, 1] - top2[:, 0] < 1e-5))
+    assert np.abs(conf - want).sum() <= 2 * near_ties, "confusion counts differ beyond fp32 ties"
+    assert conf.sum() == want.sum()
+
+
+@pytest.fixture(scope="module")
+def grid(golden_dir):
+    return np.load(os.path.join(golden_dir, "grid.npz"))
+
+
+@pytest.mark.parametrize("case", cases.grid_cases(), ids=lambda c: c["name"])
+def test_g1_grid_against_reference_golden(case, grid, hip):
+    inp = cases.grid_inputs(case)
+    act = orc.Act(case["fun"], inp["prm"]) if inp["prm"] is not None else orc.Act(case["fun"])
+    x, w, lab = inp["x"], inp["weights"], inp["labels"]
+    k = case["name"]
+    ctx = make_ctx(hip, x, w, act, 0, 0, labels=lab)
+    ap = act_prm(act, len(w) - 1)
+    z = ctx.predict(w, act_prm=ap, apply_out_fn=False)
+    y = ctx.predict(w, act_prm=ap, apply_out_fn=True)
+    assert_close(z[:16], grid[k + "/z_head"])
+    assert_close(y[:16], grid[k + "/y_head"])
+    np.testing.assert_allclose(z.sum(axis=0), grid[k + "/z_colsum"], rtol=1e-4, atol=1e-3)
+    lik = grid[k + "/lik"]
+    finite = np.isfinite(lik[0])
+    r = ctx.eval(w, act_prm=ap, want_confusion=True)
+    if finite:   # log(softmax) underflows to -inf in the float64 reference for a few extreme cases
+        np.testing.assert_allclose(r["loglik"], lik[0], rtol=LL_RTOL)
+        np.testing.assert_allclose(ctx.eval(w, act_prm=ap, lik_temp=0.5)["loglik"], lik[3], rtol=LL_RTOL)
+        ctx.set_row_weights(instance_w=inp["inst_w"])
+        np.testing.assert_allclose(ctx.eval(w, act_prm=ap)["loglik"], lik[1], rtol=LL_RTOL)
+        ctx.set_row_weights(class_w=inp["class_w"])
+        np.testing.assert_allclose(ctx.eval(w, act_prm=ap)["loglik"], lik[2], rtol=LL_RTOL)
+    y64 = orc.forward(x, w, act, orc.out_softmax)
+    check_confusion(r["confusion"], y64, lab)
+    ctx.close()
+
+
+def test_g2_regression_against_reference_golden(golden_dir, hip):
+    g = np.load(os.path.join(golden_dir, "regression.npz"))
+    act = orc.Act("tanh")
+    inp = cases.regression_inputs()
+    x, w, t = inp["x"], inp["weights"], inp["targets"]
+    ctx = make_ctx(hip, x, w, act, 1, 1, targets=t, n_targets=t.shape[1])
+    assert_close(ctx.predict(w), g["y"])
+    np.testing.assert_allclose(ctx.eval(w, sigma=1.0)["loglik"], g["lik_sig1"], rtol=LL_RTOL)
+    np.testing.assert_allclose(ctx.eval(w, sigma=inp["sig_vec"])["loglik"], g["lik_sigvec"], rtol=LL_RTOL)
+    r = ctx.eval(w)                                   # empirical sigma
+    np.testing.assert_allclose(r["loglik"], g["lik_emp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sigma"], g["emp_sigma"], rtol=1e-5)
+    np.testing.assert_allclose(ctx.eval(w, lik_temp=0.7)["loglik"], g["lik_emp_temp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sum_r2"] / len(x), g["mse_col"], rtol=1e-5)
+    np.testing.assert_allclose(np.sum(r["sum_r2"]) / t.size, g["mse"], rtol=1e-5)
+    ctx.close()
+    # softplus-on-second-half output function
+    inp2 = cases.regression_inputs(seed=12, double_out=True)
+    ctx = make_ctx(hip, inp2["x"], inp2["weights"], act, 2, 7)
+    assert_close(ctx.predict(inp2["weights"]), g["y_err"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", list(cases.TRACES))
+def test_g4_teacher_forced_trace(name, golden_dir, hip):
+    """Replay the reference's recorded proposals: logLik' per proposal must match."""
+    cfg = cases.TRACES[name]
+    g = np.load(os.path.join(golden_dir, "trace_%s.npz" % name))
+    act = orc.Act(cfg["fun"])
+    if cfg["kind"] == "classification":
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        w0 = [g["w0_%d" % i] for i in range(len(cfg["n_nodes"]) + 1)]
+        ctx = make_ctx(hip, dat["data"], w0, act, 0, 0, labels=dat["labels"])
+    else:
+        dat = cases.regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
+        w0 = [g["w0_%d" % i] for i in range(len(cfg["n_nodes"]) + 1)]
+        ctx = make_ctx(hip, dat["data"], w0, act, 1, 1, targets=dat["labels"], n_targets=cfg["k"])
+    init_sigma = 1.0 if cfg["kind"] == "regression" else None
+    np.testing.assert_allclose(ctx.eval(w0, sigma=init_sigma)["loglik"], g["init"][0], rtol=LL_RTOL)
+    for it in range(cfg["keep_w"]):
+        wp = [g["wprime_%d_%d" % (it, li)] for li in range(len(w0))]
+        np.testing.assert_allclose(ctx.eval(wp)["loglik"], g["rows"][it, 0], rtol=LL_RTOL, err_msg="proposal %d" % it)
+    ctx.close()
+
+
+SHAPES = [
+    # n_rows, n_features, hidden, n_classes, bias
+    (1, 1, [1], 2, 0), (15, 3, [2], 2, 2), (16, 16, [16], 3, 3), (17, 17, [17, 3], 4, 2),
+    (33, 48, [50, 5], 5, 1), (1000, 130, [128, 64, 32, 16, 8, 4, 3], 9, 3), (257, 300, [65, 33], 128, 2),
+    (4099, 64, [16, 4], 2, -1),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "n%d_f%d_h%s_c%d_b%d" % (s[0], s[1], "x".join(map(str, s[2])), s[3], s[4]))
+@pytest.mark.parametrize("fun", ["ReLU", "tanh"])
+def test_ragged_and_extreme_shapes(shape, fun, hip):
+    n, f, hidden, c, bias = shape
+    rs = np.random.default_rng(n * 31 + f)
+    x = rs.standard_normal((n, f))
+    lab = rs.integers(0, c, n)
+    w = [rs.normal(0, 0.4 / np.sqrt(s[1] / 8 + 1), s) for s in cases.layer_shapes(f, hidden, c, bias)]
+    act = orc.Act(fun)
+    ctx = make_ctx(hip, x, w, act, 0, 0, labels=lab)
+    y64 = orc.forward(x, w, act, orc.out_softmax)
+    assert_close(ctx.predict(w), y64)
+    r = ctx.eval(w, want_confusion=True)
+    want = orc.lik_categorical(y64, lab, np.arange(n))
+    np.testing.assert_allclose(r["loglik"], want, rtol=5e-6)
+    check_confusion(r["confusion"], y64, lab)
+    ctx.close()
+
+
+def test_column_override_and_test_set(hip):
+    """data_transform (feature columns replaced by constants) folded into the layer-0 bias;
+    evaluation on the resident test set (RunPredictInd path)."""
+    rs = np.random.default_rng(5)
+    n, f, c = 500, 37, 4
+    x, xt = rs.standard_normal((n, f)), rs.standard_normal((123, f))
+    lab, labt = rs.integers(0, c, n), rs.integers(0, c, 123)
+    w = [rs.normal(0, 0.3, s) for s in cases.layer_shapes(f, [9, 6], c, 2)]
+    act = orc.Act("swish")
+    ctx = make_ctx(hip, x, w, act, 0, 0, labels=lab)
+    ctx.set_data(xt, which=1)
+    ctx.set_labels(labt, which=1)
+    ind = (rs.random(f) < 0.6).astype(int)
+    means = x.mean(axis=0)
+    ov = np.where(ind == 0, means, np.nan)
+    y64 = orc.forward(x, w, act, orc.out_softmax, col_override=(ind, means))
+    assert_close(ctx.predict(w, col_override=ov), y64)
+    np.testing.assert_allclose(ctx.eval(w, col_override=ov)["loglik"], orc.lik_categorical(y64, lab, np.arange(n)), rtol=5e-6)
+    yt = orc.forward(xt, w, act, orc.out_softmax)
+    assert_close(ctx.predict(w, which=1), yt)
+    rt = ctx.eval(w, which=1, want_confusion=True)
+    np.testing.assert_allclose(rt["loglik"], orc.lik_categorical(yt, labt, np.arange(123)), rtol=5e-6)
+    check_confusion(rt["confusion"], yt, labt)
+    ctx.close()
+
+
+def test_error_paths(hip):
+    from npbnn_amd import NpbnnError
+    ctx = hip.HipContext(0)
+    with pytest.raises(NpbnnError):
+        ctx.set_labels(np.zeros(3, dtype=int))              # labels before data
+    x = np.zeros((10, 4))
+    ctx.set_data(x)
+    with pytest.raises(NpbnnError):
+        ctx.set_labels(np.zeros(11, dtype=int))             # wrong length
+    with pytest.raises(NpbnnError):
+        ctx.set_arch(4, [200, 3], [1, 1], 0, 0, 0)           # layer wider than NPBNN_MAX_WIDTH
+    ctx.set_arch(4, [3, 2], [1, 0], 3, 0, 0)
+    with pytest.raises(NpbnnError):
+        ctx.eval([np.zeros((3, 5)), np.zeros((2, 3))])      # categorical likelihood without labels
+    ctx.close()
+
+
+def test_config2_full_size(hip):
+    """BASELINE.json config 2 (100k x 256, [32,8], 10 classes, tanh, bias 2): oracle comparison at
+    full size plus size-independent properties (determinism, additivity over row blocks)."""
+    rs = np.random.default_rng(0)
+    n, f, c = 100_000, 256, 10
+    x = rs.standard_normal((n, f))
+    lab = rs.integers(0, c, n)
+    np.random.seed(1234)
+    w = orc.init_weights([32, 8], f, c, bias_node=2)
+    act = orc.Act("tanh")
+    ctx = make_ctx(hip, x, w, act, 0, 0, labels=lab)
+    r1 = ctx.eval(w, want_confusion=True)
+    r2 = ctx.eval(w)
+    assert r1["loglik"] == r2["loglik"], "evaluation is not run-to-run deterministic"
+    y64 = orc.forward(x, w, act, orc.out_softmax)
+    want = orc.lik_categorical(y64, lab, np.arange(n))
+    assert abs(r1["loglik"] - want) / abs(want) < 1e-7
+    check_confusion(r1["confusion"], y64, lab)
+    # larger weights: saturated tanh, peaked softmax
+    w2 = [wi * 6 for wi in w]
+    y64 = orc.forward(x, w2, act, orc.out_softmax)
+    want = orc.lik_categorical(y64, lab, np.arange(n))
+    assert abs(ctx.eval(w2)["loglik"] - want) / abs(want) < 1e-6
+    ctx.close()
+    # additivity: loglik(all rows) == loglik(first 60%) + loglik(rest)
+    cut = 60_001
+    parts = 0.0
+    for sl in (slice(0, cut), slice(cut, n)):
+        c2 = make_ctx(hip, x[sl], w, act, 0, 0, labels=lab[sl])
+        parts += c2.eval(w)["loglik"]
+        c2.close()
+    assert abs(parts - r1["loglik"]) / abs(r1["loglik"]) < 1e-9

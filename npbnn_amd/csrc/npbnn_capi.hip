@@ -164,11 +164,6 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a) {
         L.has_bias = a->has_bias[l] ? 1 : 0;
         L.kt = (in + 15) / 16;
         L.mt = (out + 15) / 16;
-        if (l == 0) {   // layer-0 tile count is a template parameter of the kernel: 1, 2, 4 or 8
-            int t = 1;
-            while (t < L.mt) t *= 2;
-            L.mt = t;
-        }
         L.frag_off = off;
         off += L.kt * L.mt * 256;
         L.w_off = woff;
@@ -214,7 +209,11 @@ eval_fn_t pick_kernel(int mt0) {
     switch (mt0) {
         case 1: return eval_kernel<1>;
         case 2: return eval_kernel<2>;
+        case 3: return eval_kernel<3>;
         case 4: return eval_kernel<4>;
+        case 5: return eval_kernel<5>;
+        case 6: return eval_kernel<6>;
+        case 7: return eval_kernel<7>;
         default: return eval_kernel<8>;
     }
 }

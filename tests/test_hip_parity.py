@@ -146,7 +146,7 @@ def test_g4_teacher_forced_trace(name, golden_dir, hip):
 SHAPES = [
     # n_rows, n_features, hidden, n_classes, bias
     (1, 1, [1], 2, 0), (15, 3, [2], 2, 2), (16, 16, [16], 3, 3), (17, 17, [17, 3], 4, 2),
-    (33, 48, [50, 5], 5, 1), (1000, 130, [128, 64, 32, 16, 8, 4, 3], 9, 3), (257, 300, [65, 33], 128, 2),
+    (33, 48, [50, 5], 5, 1), (1000, 130, [128, 64, 32, 16, 8, 4, 3], 9, 3), (257, 300, [65, 33], 128, 2), (300, 700, [24, 40], 3, 2),
     (4099, 64, [16, 4], 2, -1),
 ]
 
@@ -207,6 +207,8 @@ def test_error_paths(hip):
         ctx.set_labels(np.zeros(11, dtype=int))             # wrong length
     with pytest.raises(NpbnnError):
         ctx.set_arch(4, [200, 3], [1, 1], 0, 0, 0)           # layer wider than NPBNN_MAX_WIDTH
+    with pytest.raises(NpbnnError, match="too large"):
+        ctx.set_arch(4000, [128, 3], [1, 1], 0, 0, 0)        # weight image cannot live in LDS
     ctx.set_arch(4, [3, 2], [1, 0], 3, 0, 0)
     with pytest.raises(NpbnnError):
         ctx.eval([np.zeros((3, 5)), np.zeros((2, 3))])      # categorical likelihood without labels

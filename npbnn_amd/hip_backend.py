@@ -1,0 +1,95 @@
+"""Binding between a model object (``npBNN``) and its resident device context.
+
+``HipBackend`` is the only evaluation backend the package ships.  It uploads the training / test
+matrices once, describes the network to the C ABI and then serves the sampler:
+
+    evaluate(weights, ...) -> log-likelihood (+ sigma, residual moments, confusion counts)
+    predict(weights, ...)  -> prediction matrix
+
+The sampler accepts any object with these two methods (the CPU test-suite injects an oracle-backed
+one); when none is given it builds a ``HipBackend`` and fails loudly if the HIP library or the GPU
+is missing.
+"""
+import numpy as np
+
+from . import _capi as capi
+from .backend import HipContext
+from .layers import output_kind
+from .likelihoods import likelihood_kind
+
+_FUSED = (capi.LIK_CATEGORICAL, capi.LIK_GAUSS)
+
+
+def bias_flags(weights, n_features):
+    """Layer l has a bias iff its matrix has in_l + 1 columns (bias = column 0;
+    reference: BNN_lib.py:157-161)."""
+    flags, cur = [], n_features
+    for w in weights:
+        if w.shape[1] == cur:
+            flags.append(0)
+        elif w.shape[1] == cur + 1:
+            flags.append(1)
+        else:
+            raise ValueError("weight matrix with %d columns does not match %d inputs" % (w.shape[1], cur))
+        cur = w.shape[0]
+    return flags
+
+
+class HipBackend:
+    def __init__(self, bnn, likelihood_f=None, device=None):
+        self.ctx = HipContext(device)
+        self.n_features = bnn._data.shape[1]
+        self.ctx.set_data(bnn._data, capi.TRAIN)
+        self.has_test = len(bnn._test_data) > 0
+        if self.has_test:
+            self.ctx.set_data(bnn._test_data, capi.TEST)
+        self.out_kind = output_kind(bnn._output_act_fun)          # None -> host callable
+        lik = likelihood_kind(likelihood_f) if likelihood_f is not None else None
+        self.lik_kind = lik if lik in _FUSED else capi.LIK_NONE
+        self.fused_likelihood = self.lik_kind != capi.LIK_NONE
+        self.n_targets = 0
+        classification = bnn._estimation_mode == "classification"
+        if classification:
+            self.ctx.set_labels(bnn._labels, capi.TRAIN)
+            if self.has_test and len(bnn._test_labels) > 0:
+                self.ctx.set_labels(bnn._test_labels, capi.TEST)
+        elif self.lik_kind == capi.LIK_GAUSS:
+            self.n_targets = bnn._labels.shape[1]
+            self.ctx.set_targets(bnn._labels, capi.TRAIN)
+            if self.has_test and len(bnn._test_labels) > 0:
+                self.ctx.set_targets(bnn._test_labels, capi.TEST)
+        if self.lik_kind == capi.LIK_CATEGORICAL:
+            iw = bnn._instance_weights
+            cw = bnn._class_w if len(bnn._class_w) else None
+            if iw is not None or cw is not None:
+                if iw is not None and cw is not None:
+                    # the reference's combined branch raises (np.sum(..., axis=1) on a vector, BNN_lib.py:105)
+                    raise np.exceptions.AxisError("axis 1 is out of bounds for array of dimension 1")
+                self.ctx.set_row_weights(instance_w=iw, class_w=cw)
+        self._shapes = None
+        self._act = bnn._act_fun
+        self._configure(bnn._w_layers)
+
+    def _configure(self, weights):
+        shapes = tuple(w.shape for w in weights)
+        if shapes == self._shapes:
+            return
+        flags = bias_flags(weights, self.n_features)
+        self.ctx.set_arch(self.n_features, [s[0] for s in shapes], flags, self._act.device_kind(),
+                          capi.OUT_IDENTITY if self.out_kind is None else self.out_kind, self.lik_kind,
+                          self.n_targets)
+        self._shapes = shapes
+
+    def evaluate(self, weights, slopes=None, col_override=None, lik_temp=1.0, sigma=None, which=capi.TRAIN,
+                 want_confusion=False):
+        self._configure(weights)
+        return self.ctx.eval(weights, act_prm=slopes, col_override=col_override, lik_temp=lik_temp, sigma=sigma,
+                             which=which, want_confusion=want_confusion)
+
+    def predict(self, weights, slopes=None, col_override=None, which=capi.TRAIN, apply_out_fn=True):
+        self._configure(weights)
+        return self.ctx.predict(weights, act_prm=slopes, col_override=col_override, which=which,
+                                apply_out_fn=apply_out_fn and self.out_kind is not None)
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,410 @@
+"""``MCMC`` — the Metropolis-Hastings state machine, with the forward pass + likelihood on the GPU.
+
+Host-side mirror of the reference sampler (np_bnn/BNN_env.py:273-550): same constructor, the same
+``mh_step(bnn_obj, additional_prob=0, return_bnn=False)`` contract, the same public attributes and
+the same consumption of the numpy ``Generator`` stream (so a chain draws the very proposals the
+reference draws for the same seed).  What changed is where the arithmetic happens:
+
+  * the per-layer forward loop, output function and likelihood of a proposal (BNN_env.py:449-491)
+    are ONE fused device evaluation (``backend.evaluate``);
+  * accuracy statistics and prediction matrices (``_accuracy``, ``_label_acc``, ``_label_freq``,
+    ``_test_accuracy``, ``_y``, ``_y_test``; BNN_env.py:507-518) are produced on demand from the
+    accepted weights instead of after every accepted step: they are functions of the accepted state
+    only, so the values are the same, and nothing is downloaded while nobody looks.
+"""
+import numpy as np
+
+from . import _capi as capi
+from .likelihoods import (CalcAccuracy, CalcAccuracyRegression, CalcLabelAccuracy,
+                          CalcLabelAccuracyRegression, SkipAccuracy, SkipAccuracyVec, calc_likelihood,
+                          calc_likelihood_regression, calc_likelihood_regression_error, likelihood_kind,
+                          stat_kind, stats_from_confusion)
+from .model import data_transform_obj, npBNN
+from .proposals import UpdateBinomial, UpdateNormal, UpdateNormal1D, multiplier_proposal_vector
+
+_LAZY = ("_y", "_y_test", "_accuracy", "_test_accuracy", "_label_acc", "_label_freq")
+
+
+def get_backend(bnn_obj, likelihood_f):
+    """The model's resident device context (created on first use, shared by every sampler built on
+    this model object)."""
+    be = bnn_obj.__dict__.get("_npbnn_backend")
+    if be is None or getattr(be, "_lik_f", None) is not likelihood_f:
+        from .hip_backend import HipBackend
+        be = HipBackend(bnn_obj, likelihood_f)
+        be._lik_f = likelihood_f
+        bnn_obj.__dict__["_npbnn_backend"] = be
+    return be
+
+
+class MCMC():
+    def __init__(self,
+                 bnn_obj: npBNN,
+                 update_f=None, update_ws=None,
+                 temperature=1, n_iteration=100000, sampling_f=100, print_f=1000, n_post_samples=1000,
+                 update_function=UpdateNormal, sample_from_prior=0, run_ID="", init_additional_prob=0,
+                 likelihood_tempering=1, mcmc_id=0, randomize_seed=False, adapt_f=0, estimate_error=True,
+                 adapt_fM=1, adapt_freq=1000, adapt_stop=None, likelihood_f=None, adapt_verbose=False,
+                 accuracy_f=None, accuracy_lab_f=None, backend=None):
+        n_layers = bnn_obj._n_layers
+        if update_ws is None:
+            update_ws = [0.075] * n_layers
+        if update_f is None:
+            update_f = [0.05] * n_layers
+        self._runID = bnn_obj._seed if run_ID == "" else run_ID
+        self._update_f = update_f[0:n_layers]
+        self._update_ws = [np.ones(bnn_obj._w_layers[i].shape) * update_ws[i] for i in range(n_layers)]
+        self._update_n = np.array([np.max([1, np.round(bnn_obj._w_layers[i].size * update_f[i]).astype(int)])
+                                   for i in range(n_layers)])
+        self._temperature = temperature
+        self._n_iterations = n_iteration
+        self._sampling_f = sampling_f
+        self._print_f = print_f
+        self._current_iteration = 0
+
+        mode = bnn_obj._estimation_mode
+        if likelihood_f is not None:
+            self._likelihood_f = likelihood_f
+        elif mode == "classification":
+            self._likelihood_f = calc_likelihood
+        elif mode == "regression":
+            self._likelihood_f = calc_likelihood_regression
+        elif mode == "regression-error":
+            self._likelihood_f = calc_likelihood_regression_error
+        regression_like = mode in ("regression", "regression-error")
+        if accuracy_f is None:
+            accuracy_f = CalcAccuracy if mode == "classification" else (
+                CalcAccuracyRegression if regression_like else SkipAccuracy)
+        if accuracy_lab_f is None:
+            accuracy_lab_f = CalcLabelAccuracy if mode == "classification" else (
+                CalcLabelAccuracyRegression if regression_like else SkipAccuracyVec)
+        self._accuracy_f = accuracy_f
+        self._accuracy_lab_f = accuracy_lab_f
+
+        self._bnn = bnn_obj
+        self._backend = backend if backend is not None else get_backend(bnn_obj, self._likelihood_f)
+        self._lazy = {}
+        self._accepted_override = None      # column override of the last accepted state (feature indicators)
+        self._lik_temp = likelihood_tempering
+        self._sample_from_prior = sample_from_prior
+        if sample_from_prior:
+            self._logLik = 0
+        else:
+            self._logLik, _ = self._log_likelihood(bnn_obj, bnn_obj._w_layers, bnn_obj._indicators, None,
+                                                   likelihood_tempering, bnn_obj._error_prm, init=True)
+        self._logPrior = bnn_obj.calc_prior() + init_additional_prob
+        self._logPost = self._logLik + self._logPrior
+        self.update_function = update_function
+        self._last_accepted = 1
+        self._last_accepted_mem = [self._last_accepted]
+        self._acceptance_rate = 0.
+        self._mcmc_id = mcmc_id
+        self._randomize_seed = randomize_seed
+        self._rs = np.random.default_rng(1234)
+        self._counter = 0
+        self._n_post_samples = n_post_samples
+        self._freq_layer_update = np.ones(n_layers)
+        self._adapt_f = adapt_f
+        self._adapt_fM = adapt_fM
+        self._adapt_verbose = adapt_verbose
+        self._adapt_stop = int(self._n_iterations * 0.05) if adapt_stop is None else adapt_stop
+        self._adapt_freq = adapt_freq
+        self._max_n = np.array([bnn_obj._w_layers[i].size for i in range(n_layers)]).astype(int)
+        # with estimate_error the regression sigma stays at 1 for the first iterations (BNN_env.py:375-379)
+        self._estimate_error = np.min([20000, 0.1 * self._n_iterations]) if estimate_error else self._n_iterations
+
+    # ------------------------------------------------------------------------------------------
+    # device evaluation
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _forward_weights(weights, indicators):
+        return [weights[0] * indicators] + list(weights[1:])
+
+    def _slopes(self, bnn_obj):
+        return bnn_obj._act_fun.device_slopes(bnn_obj._n_layers - 1)
+
+    def _host_predictions(self, bnn_obj, fw, override, which=capi.TRAIN):
+        y = self._backend.predict(fw, slopes=self._slopes(bnn_obj), col_override=override, which=which)
+        if getattr(self._backend, "out_kind", 0) is None:
+            y = bnn_obj._output_act_fun(y)      # user output function on the host
+        return y
+
+    def _log_likelihood(self, bnn_obj, weights, indicators, override, lik_temp, sigma, init=False):
+        """logLik of a weight set and the sigma it used.  Fused device path for the built-in
+        likelihoods; any other callable gets the prediction matrix (slow path)."""
+        fw = self._forward_weights(weights, indicators)
+        kind = likelihood_kind(self._likelihood_f)
+        if getattr(self._backend, "fused_likelihood", False) and kind in (capi.LIK_CATEGORICAL, capi.LIK_GAUSS):
+            sig = None
+            if kind == capi.LIK_GAUSS:
+                empirical = bnn_obj._empirical_error and not init
+                if not empirical:
+                    k = bnn_obj._labels.shape[1]
+                    sig = np.ones(k) * sigma if np.ndim(sigma) == 0 else np.asarray(sigma, dtype=float)
+            r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=override, lik_temp=lik_temp,
+                                       sigma=sig)
+            return r["loglik"], (r["sigma"] if kind == capi.LIK_GAUSS else sigma)
+        y = self._host_predictions(bnn_obj, fw, override)
+        if bnn_obj._estimation_mode == "regression" and bnn_obj._empirical_error and not init:
+            sigma = np.std(y - bnn_obj._labels, axis=0)
+        ll = self._likelihood_f(y, bnn_obj._labels, bnn_obj._sample_id, class_weight=bnn_obj._class_w,
+                                instance_weight=bnn_obj._instance_weights, lik_temp=lik_temp, sig2=sigma)
+        return ll, sigma
+
+    # ------------------------------------------------------------------------------------------
+    # statistics of the accepted state, produced on demand
+    # ------------------------------------------------------------------------------------------
+    def _invalidate(self):
+        self._lazy = {}
+
+    def _train_stats(self):
+        bnn_obj = self._bnn
+        fw = self._forward_weights(bnn_obj._w_layers, bnn_obj._indicators)
+        ka, kl = stat_kind(self._accuracy_f), stat_kind(self._accuracy_lab_f)
+        fused = getattr(self._backend, "fused_likelihood", False)
+        if fused and bnn_obj._estimation_mode == "classification" and ka == "acc" and kl == "label_acc":
+            r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+                                       want_confusion=True)
+            acc, lab_acc, freq = stats_from_confusion(r["confusion"])
+            self._lazy.update(_accuracy=acc, _label_acc=lab_acc, _label_freq=freq)
+            return
+        if fused and bnn_obj._estimation_mode == "regression" and ka == "mse" and kl == "label_mse":
+            r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+                                       sigma=np.ones(bnn_obj._labels.shape[1]))
+            mse_col = r["sum_r2"] / r["n_rows"]
+            self._lazy.update(_accuracy=float(np.mean(mse_col)), _label_acc=mse_col)
+            return
+        y = self._y
+        self._lazy.update(_accuracy=self._accuracy_f(y, bnn_obj._labels),
+                          _label_acc=self._accuracy_lab_f(y, bnn_obj._labels))
+
+    def _compute_lazy(self, name):
+        bnn_obj = self._bnn
+        fw = self._forward_weights(bnn_obj._w_layers, bnn_obj._indicators)
+        if name == "_y":
+            return self._host_predictions(bnn_obj, fw, self._accepted_override)
+        if name == "_y_test":
+            if len(bnn_obj._test_data) > 0:
+                return self._host_predictions(bnn_obj, fw, self._accepted_override, which=capi.TEST)
+            return []
+        if name == "_test_accuracy":
+            if len(bnn_obj._test_data) == 0:
+                return 0
+            fused = getattr(self._backend, "fused_likelihood", False)
+            if fused and bnn_obj._estimation_mode == "classification" and stat_kind(self._accuracy_f) == "acc":
+                r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+                                           which=capi.TEST, want_confusion=True)
+                return stats_from_confusion(r["confusion"])[0]
+            if fused and bnn_obj._estimation_mode == "regression" and stat_kind(self._accuracy_f) == "mse":
+                r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+                                           which=capi.TEST, sigma=np.ones(bnn_obj._labels.shape[1]))
+                return float(np.mean(r["sum_r2"] / r["n_rows"]))
+            return self._accuracy_f(self._y_test, bnn_obj._test_labels)
+        if name == "_label_freq":
+            if "_label_freq" not in self._lazy:
+                self._train_stats()
+            if "_label_freq" not in self._lazy:      # not classification: argmax over the output columns
+                y = self._y
+                pred = np.argmax(y, axis=1)
+                f = np.zeros(y.shape[1])
+                idx, cnt = np.unique(pred, return_counts=True)
+                f[idx] = cnt
+                self._lazy["_label_freq"] = f / len(pred)
+            return self._lazy["_label_freq"]
+        self._train_stats()
+        return self._lazy[name]
+
+    def _materialize(self):
+        for name in _LAZY:
+            getattr(self, name)
+
+    def __getstate__(self):
+        self._materialize()
+        state = dict(self.__dict__)
+        state.pop("_backend", None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_backend", None)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = v if k == "_backend" else copy.deepcopy(v, memo)
+        return new
+
+    # ------------------------------------------------------------------------------------------
+    # adaptation of the proposal sizes (reference: BNN_env.py:392-413)
+    # ------------------------------------------------------------------------------------------
+    def _adapt(self, bnn_obj):
+        if not (self._current_iteration % self._adapt_freq == 0 and self._current_iteration < self._adapt_stop):
+            return
+        for shrink in (True, False):
+            if shrink:
+                if not self._acceptance_rate < self._adapt_f:
+                    continue
+                self._freq_layer_update = self._freq_layer_update * 0.8
+                self.reset_update_f(np.array(self._update_f) * .85)
+                step_scale = 0.9
+            else:
+                if not (self._acceptance_rate > self._adapt_fM and np.sum(self._update_n) < bnn_obj._n_params):
+                    continue
+                self.reset_update_f(np.exp(np.log(np.array(self._update_f)) * .85))
+                step_scale = 1.2
+            n = (self._max_n * (self._update_f)).astype(int)
+            n[n < 1] = 1
+            self.reset_update_n(n)
+            self.reset_update_ws([i * step_scale for i in self._update_ws])
+            if self._adapt_verbose:
+                print(self._acceptance_rate, self._update_n, self._update_ws[0][0][0], self._freq_layer_update,
+                      self._update_f)
+
+    # ------------------------------------------------------------------------------------------
+    # one Metropolis-Hastings iteration (reference: BNN_env.py:381-532)
+    # ------------------------------------------------------------------------------------------
+    def mh_step(self, bnn_obj, additional_prob=0, return_bnn=False):
+        self._bnn = bnn_obj
+        if self._backend is None:
+            self._backend = get_backend(bnn_obj, self._likelihood_f)
+        if self._randomize_seed:
+            self._rs = np.random.default_rng(self._current_iteration + self._mcmc_id)
+        rs = self._rs
+        hastings = 0
+        indicators_prime = bnn_obj._indicators + 0
+        self._adapt(bnn_obj)
+
+        # trainable activation slopes: proposed from the accepted values, installed right away
+        if bnn_obj._act_fun._trainable:
+            prm_tmp, _, h = UpdateNormal1D(bnn_obj._act_fun._acc_prm, d=0.05, n=1, Mb=1, mb=0, rs=rs)
+            r = 10
+            additional_prob += np.log(r) * -np.sum(prm_tmp) * r      # exponential prior Exp(r)
+            hastings += h
+            bnn_obj._act_fun.reset_prm(prm_tmp)
+
+        # feature indicators -> constant-column override of the data matrix
+        override = None
+        if bnn_obj._feature_indicators is not None and self._current_iteration > self._adapt_stop:
+            if rs.random() < 0.2:
+                feature_indicators_prime = UpdateBinomial(bnn_obj._feature_indicators + 0, 0.5,
+                                                          bnn_obj._feature_indicators.shape)
+            else:
+                feature_indicators_prime = bnn_obj._feature_indicators + 0
+            override = data_transform_obj(feature_indicators_prime, bnn_obj._feature_means).column_override()
+        else:
+            feature_indicators_prime = bnn_obj._feature_indicators
+
+        # regression error parameter
+        error_prm_tmp = bnn_obj._error_prm
+        if bnn_obj._estimation_mode == "regression" and self._current_iteration > self._estimate_error:
+            if not bnn_obj._empirical_error:
+                error_prm_tmp, _, h = multiplier_proposal_vector(bnn_obj._error_prm, d=1.1, f=0.5, rs=rs)
+                r = 1
+                hastings += h
+                additional_prob += np.log(r) * -np.sum(error_prm_tmp) * r
+        else:
+            error_prm_tmp = 1
+
+        # weight proposals: at least one layer is always updated
+        rr = rs.random(bnn_obj._n_layers)
+        rr[np.argmin(rr)] = 0
+        w_layers_prime = []
+        for i in range(bnn_obj._n_layers):
+            if rr[i] >= bnn_obj._freq_indicator or i > 0:
+                if rr[i] < self._freq_layer_update[i]:
+                    update, _, h = self.update_function(bnn_obj._w_layers[i], d=self._update_ws[i],
+                                                        n=self._update_n[i], Mb=bnn_obj._w_bound,
+                                                        mb=-bnn_obj._w_bound, rs=rs)
+                    w_layers_prime.append(update)
+                    hastings += h
+                else:
+                    w_layers_prime.append(bnn_obj._w_layers[i] + 0)
+            else:
+                w_layers_prime.append(bnn_obj._w_layers[i] + 0)
+                indicators_prime = UpdateBinomial(bnn_obj._indicators, self._update_f[3], bnn_obj._indicators.shape)
+            if bnn_obj._mask is not None:
+                w_layers_prime[i] *= bnn_obj._mask[i]
+
+        logPrior_prime = bnn_obj.calc_prior(w=w_layers_prime, ind=indicators_prime) + additional_prob
+        if self._sample_from_prior:
+            logLik_prime = 0
+        else:
+            logLik_prime, error_prm_tmp = self._log_likelihood(bnn_obj, w_layers_prime, indicators_prime, override,
+                                                               self._lik_temp, error_prm_tmp)
+        logPost_prime = logLik_prime + logPrior_prime
+        rrr = np.log(rs.random())
+        if (logPost_prime - self._logPost) * self._temperature + hastings >= rrr:
+            bnn_obj.reset_weights(w_layers_prime)
+            bnn_obj.reset_indicators(indicators_prime)
+            if bnn_obj._feature_indicators is not None:
+                bnn_obj._feature_indicators = feature_indicators_prime + 0
+            if bnn_obj._estimation_mode == "regression":
+                # the reference stores the bare scalar 1 here while sigma is still fixed, which later breaks its own
+                # multiplier proposal (BNN_env.py:444,501 -> BNN_mcmc.py:105); keep a vector of ones instead
+                if np.ndim(error_prm_tmp) == 0:
+                    error_prm_tmp = np.ones(bnn_obj._size_output) * error_prm_tmp
+                bnn_obj.reset_error_prm(error_prm_tmp)
+            if bnn_obj._act_fun._trainable:
+                bnn_obj._act_fun.reset_accepted_prm()
+            self._logPost = logPost_prime
+            self._logLik = logLik_prime
+            self._logPrior = logPrior_prime
+            self._accepted_override = override
+            self._invalidate()
+            self._last_accepted = 1
+        else:
+            self._last_accepted = 0
+
+        self._last_accepted_mem.append(self._last_accepted)
+        self._acceptance_rate = np.mean(self._last_accepted_mem)
+        if len(self._last_accepted_mem) > 100:
+            self._last_accepted_mem = self._last_accepted_mem[-100:]
+        self._current_iteration += 1
+        if return_bnn:
+            return bnn_obj, self
+
+    def gibbs_step(self, bnn_obj):
+        bnn_obj.sample_prior_scale()
+        self._logPrior = bnn_obj.calc_prior()
+        self._logPost = self._logLik + self._logPrior
+        self._current_iteration += 1
+
+    def reset_update_n(self, n):
+        self._update_n = n
+
+    def reset_update_f(self, f):
+        self._update_f = f
+
+    def reset_update_ws(self, w):
+        self._update_ws = w
+
+    def reset_temperature(self, temp):
+        self._temperature = temp
+
+
+def _lazy_property(name):
+    def getter(self):
+        if name not in self._lazy:
+            self._lazy[name] = self._compute_lazy(name)
+        return self._lazy[name]
+
+    def setter(self, value):
+        self._lazy[name] = value
+
+    return property(getter, setter)
+
+
+for _name in _LAZY:
+    setattr(MCMC, _name, _lazy_property(_name))
+
+
+def predict(bnn_obj: npBNN, data: np.ndarray):
+    """Predictions of the current weights for a new data matrix (reference: BNN_env.py:662-670)."""
+    from .layers import RunPredict
+    transform = None
+    if bnn_obj._feature_indicators is not None:
+        transform = data_transform_obj(bnn_obj._feature_indicators, bnn_obj._feature_means)
+    return RunPredict(data, bnn_obj._w_layers, actFun=bnn_obj._act_fun, output_act_fun=bnn_obj._output_act_fun,
+                      data_transform=transform)

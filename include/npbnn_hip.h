@@ -142,6 +142,17 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
 int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_main_kernel,
                     double* ms_total);
 
+/* ---- MC3 temperature-swap exchange over RCCL (xGMI inside a node): replaces the multiprocessing pool
+ * round trip of whole pickled chains in MC3.run_mcmc (np_bnn/BNN_mc3.py:94-112), of which the swap
+ * decision only reads two scalars per chain.  One communicator per process / GPU; host buffers in and out.
+ * Errors are reported through npbnn_last_error(NULL). */
+typedef struct npbnn_comm npbnn_comm;
+int npbnn_comm_unique_id(char out[128]);                                  /* rank 0; ship the bytes to every rank */
+int npbnn_comm_init(int device_id, int rank, int nranks, const char id[128], npbnn_comm** out);
+int npbnn_comm_allgather_f64(npbnn_comm* comm, const double* send, int count, double* recv /* nranks*count */);
+int npbnn_comm_bcast_i64(npbnn_comm* comm, int64_t* buf, int count, int root);
+void npbnn_comm_destroy(npbnn_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

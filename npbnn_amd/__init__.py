@@ -24,5 +24,8 @@ from .model import data_transform_obj, npBNN  # noqa: F401
 from .sampler import MCMC, predict  # noqa: F401
 from .driver import run_mcmc  # noqa: F401
 from .files import SaveObject, load_obj  # noqa: F401
+from .logger import init_output_files, postLogger  # noqa: F401
+from .mc3 import MC3  # noqa: F401
+from . import comm  # noqa: F401
 
 BNN = npBNN                       # BASELINE.json's wording

@@ -67,6 +67,11 @@ SIGNATURES = {
                              C.POINTER(C.c_int64)]),
     "npbnn_predict": (C.c_int, [_P, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),
     "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
+    "npbnn_comm_unique_id": (C.c_int, [C.c_char * 128]),
+    "npbnn_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char * 128, C.POINTER(_P)]),
+    "npbnn_comm_allgather_f64": (C.c_int, [_P, _DP, C.c_int, _DP]),
+    "npbnn_comm_bcast_i64": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int, C.c_int]),
+    "npbnn_comm_destroy": (None, [_P]),
 }
 
 _lib = None

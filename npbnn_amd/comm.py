@@ -1,0 +1,173 @@
+"""Communicators for the MC3 temperature-swap exchange.
+
+The only data that ever crosses chains is, once per swap interval, two float64 per chain
+(log-posterior, temperature) and three integers back (j, k, accepted) — reference:
+np_bnn/BNN_mc3.py:98-112, where the same scalars are read out of whole pickled chain objects
+returned through a multiprocessing pool.
+
+    LocalComm      world of one process (all chains in this process)
+    RcclComm       one process per GPU, RCCL over xGMI through the C ABI (libnpbnn_hip.so)
+    TorchDistComm  torch.distributed process group (gloo on CPU for tests; "nccl" = RCCL on GPUs)
+"""
+import os
+import pickle
+import socket
+import struct
+import time
+
+import numpy as np
+
+
+class LocalComm:
+    rank, world_size = 0, 1
+
+    def allgather_f64(self, vec):
+        return np.asarray(vec, dtype=np.float64).reshape(1, -1)
+
+    def bcast_i64(self, vec, root=0):
+        return np.asarray(vec, dtype=np.int64)
+
+    def bcast_obj(self, obj, root=0):
+        return obj
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class TorchDistComm:
+    """Wraps an initialised torch.distributed default group (plumbing only)."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._torch, self._dist = torch, dist
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        self._device = device if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+
+    def allgather_f64(self, vec):
+        t = self._torch.tensor(np.asarray(vec, dtype=np.float64), device=self._device)
+        out = [self._torch.empty_like(t) for _ in range(self.world_size)]
+        self._dist.all_gather(out, t)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def bcast_i64(self, vec, root=0):
+        t = self._torch.tensor(np.asarray(vec, dtype=np.int64), device=self._device)
+        self._dist.broadcast(t, src=root)
+        return t.cpu().numpy()
+
+    def bcast_obj(self, obj, root=0):
+        box = [obj if self.rank == root else None]
+        self._dist.broadcast_object_list(box, src=root, device=self._device if self._device.type == "cuda" else None)
+        return box[0]
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def close(self):
+        pass
+
+
+def _exchange_unique_id(rank, world, uid, addr, port, timeout=120.0):
+    """Rank 0 hands the 128-byte RCCL unique id to every other rank over a TCP socket."""
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            conn, _ = srv.accept()
+            conn.sendall(uid)
+            conn.close()
+        srv.close()
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < 128:
+        chunk = s.recv(128 - len(buf))
+        if not chunk:
+            raise ConnectionError("unique id exchange interrupted")
+        buf += chunk
+    s.close()
+    return buf
+
+
+class RcclComm:
+    """RCCL communicator owned by the C library: ncclAllGather of the per-chain scalars and
+    ncclBroadcast of the decision, on this rank's GPU stream (over xGMI inside a node)."""
+
+    def __init__(self, rank=None, world_size=None, device=None, addr=None, port=None):
+        import ctypes as C
+        from . import _capi as capi
+        from .backend import default_device
+        self._C = C
+        self._lib = capi.load_library()
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+        dev = default_device() if device is None else device
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = port or (int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            capi.check(self._lib, None, self._lib.npbnn_comm_unique_id(uid))
+        raw = bytes(uid.raw) if self.rank == 0 else b""
+        raw = _exchange_unique_id(self.rank, self.world_size, raw, addr, port) if self.world_size > 1 else raw
+        C.memmove(uid, raw, 128)
+        self._comm = C.c_void_p()
+        capi.check(self._lib, None, self._lib.npbnn_comm_init(dev, self.rank, self.world_size, uid, C.byref(self._comm)))
+
+    def allgather_f64(self, vec):
+        from . import _capi as capi
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        out = np.empty((self.world_size, v.size), dtype=np.float64)
+        capi.check(self._lib, None, self._lib.npbnn_comm_allgather_f64(self._comm, capi.dptr(v), v.size, capi.dptr(out)))
+        return out
+
+    def bcast_i64(self, vec, root=0):
+        from . import _capi as capi
+        v = np.ascontiguousarray(vec, dtype=np.int64).copy()
+        capi.check(self._lib, None, self._lib.npbnn_comm_bcast_i64(
+            self._comm, v.ctypes.data_as(self._C.POINTER(self._C.c_int64)), v.size, root))
+        return v
+
+    def bcast_obj(self, obj, root=0):
+        """Small python objects (the cold chain's log row) as a length-prefixed byte broadcast."""
+        blob = pickle.dumps(obj) if self.rank == root else b""
+        n = int(self.bcast_i64(np.array([len(blob)]), root)[0])
+        words = np.zeros((n + 7) // 8, dtype=np.int64)
+        if self.rank == root:
+            words.view(np.uint8)[:n] = np.frombuffer(blob, dtype=np.uint8)
+        words = self.bcast_i64(words, root)
+        return pickle.loads(words.view(np.uint8)[:n].tobytes())
+
+    def barrier(self):
+        self.allgather_f64(np.zeros(1))
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.npbnn_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def struct_pack_check():   # keep struct imported for ABI size assertions in tests
+    return struct.calcsize("q")

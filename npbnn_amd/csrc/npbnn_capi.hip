@@ -305,6 +305,8 @@ int check_dataset_for_lik(npbnn_ctx* ctx, const Dataset& d, int lik) {
 
 }  // namespace
 
+extern "C" void npbnn_set_global_error_(const char* msg) { g_last_error = msg ? msg : ""; }
+
 extern "C" {
 
 int npbnn_abi_version(void) { return NPBNN_ABI_VERSION; }

@@ -1,0 +1,130 @@
+"""``postLogger`` — TSV log of the sampled states and the posterior weight samples.
+
+Same files and formats as the reference logger (np_bnn/BNN_env.py:553-658, header built in
+np_bnn/BNN_files.py:110-187) so that logs and pickles remain readable by upstream tooling:
+``<name>_l<nodes>.log`` (tab separated), optional ``..._W.log`` with every weight, and
+``<name>_l<nodes>.pkl`` holding ``[bnn_obj, mcmc_obj, logger]``.
+"""
+import csv
+import os
+
+import numpy as np
+
+from .files import SaveObject
+
+
+def init_output_files(bnn_obj, filename="bnn", sample_from_prior=0, outpath="", add_prms=None,
+                      continue_logfile=False, log_all_weights=0):
+    """Create the log file(s) with their header row; returns (logfile, weights file or None, pickle file)."""
+    outdir = os.path.dirname(filename)
+    if len(outdir) > 0 and not os.path.exists(outdir):
+        os.makedirs(outdir)
+    outname = "%s_l%s" % (filename, "_".join(map(str, bnn_obj._n_nodes)))
+    logfile_name = os.path.join(outpath, outname + ".log")
+    w_file_name = os.path.join(outpath, outname + "_W.log") if log_all_weights else None
+
+    head = ["it", "posterior", "likelihood", "prior"]
+    if bnn_obj._estimation_mode == "classification":
+        head += ["accuracy", "test_accuracy"] + ["acc_C%s" % i for i in range(bnn_obj._n_output_prm)]
+    elif bnn_obj._estimation_mode == "custom":
+        head += ["MSE", "test_MSE"]
+    else:
+        head += ["MSE", "test_MSE"] + ["MSE_prm%s" % i for i in range(bnn_obj._n_output_prm)]
+    head_w = ["it"]
+    for i in range(bnn_obj._n_layers):
+        head += ["mean_w%s" % i, "std_w%s" % i]
+        if bnn_obj._hyper_p:
+            head.append("prior_std_w%s" % i if bnn_obj._hyper_p == 1 else "mean_prior_std_w%s" % i)
+        if log_all_weights:
+            head_w += ["w_%s_%s" % (i, j) for j in range(bnn_obj._w_layers[i].size)]
+    if bnn_obj._freq_indicator:
+        head.append("mean_ind")
+    if add_prms:
+        head = head + add_prms
+    if bnn_obj._act_fun._trainable:
+        head += ["alpha_%s" % i for i in range(bnn_obj._n_layers - 1)]
+    if len(bnn_obj._error_prm):
+        head += ["sig_%s" % i for i in range(len(bnn_obj._error_prm))]
+    if bnn_obj._feature_indicators is not None:
+        head += ['feature_ind_%s' % i for i in range(bnn_obj._n_features)]
+    head += ["acc_prob", "mcmc_id"]
+
+    if not continue_logfile:
+        with open(logfile_name, "w", newline='') as f:
+            csv.writer(f, delimiter='\t').writerow(head)
+    if log_all_weights:
+        with open(w_file_name, "w", newline='') as f:
+            csv.writer(f, delimiter='\t').writerow(head_w)
+    return logfile_name, w_file_name, os.path.join(outpath, outname + ".pkl")
+
+
+class postLogger():
+    def __init__(self, bnn_obj, filename="BNN", wdir="", sample_from_prior=0, add_prms=None,
+                 continue_logfile=False, log_all_weights=0):
+        self._logfile, self._w_file, self._pklfile = init_output_files(
+            bnn_obj, filename, sample_from_prior, outpath=wdir, add_prms=add_prms,
+            continue_logfile=continue_logfile, log_all_weights=log_all_weights)
+        self._log_all_weights = log_all_weights
+        self._post_weight_samples = []
+        self._estimation_mode = bnn_obj._estimation_mode
+
+    def update_post_weight_samples(self, row):
+        self._post_weight_samples += [row]
+
+    def replace_post_weight_samples(self, post_weight_samples):
+        self._post_weight_samples = post_weight_samples
+
+    def control_weight_sample_length(self, maxlength):
+        if len(self._post_weight_samples) > maxlength:
+            self._post_weight_samples = self._post_weight_samples[-maxlength:]
+
+    def log_sample(self, bnn_obj, mcmc_obj, add_prms=None):
+        """Append one row to the TSV log (reference: BNN_env.py:585-620)."""
+        row = [mcmc_obj._current_iteration, mcmc_obj._logPost, mcmc_obj._logLik, mcmc_obj._logPrior,
+               mcmc_obj._accuracy, mcmc_obj._test_accuracy]
+        if self._estimation_mode != "custom":
+            row += list(mcmc_obj._label_acc)
+        for i in range(bnn_obj._n_layers):
+            row += [np.mean(bnn_obj._w_layers[i]), np.std(bnn_obj._w_layers[i])]
+            if bnn_obj._hyper_p:
+                row.append(bnn_obj._prior_scale[i] if bnn_obj._hyper_p == 1 else np.mean(bnn_obj._prior_scale[i]))
+        if bnn_obj._freq_indicator > 0:
+            row.append(np.mean(bnn_obj._indicators))
+        if add_prms:
+            row = row + add_prms
+        if bnn_obj._act_fun._trainable:
+            row += list(bnn_obj._act_fun._acc_prm)
+        if self._estimation_mode == "regression":
+            row += list(bnn_obj._error_prm)
+        if bnn_obj._feature_indicators is not None:
+            row += list(bnn_obj._feature_indicators)
+        row += [mcmc_obj._acceptance_rate, mcmc_obj._mcmc_id]
+        with open(self._logfile, "a", newline='') as f:
+            csv.writer(f, delimiter='\t').writerow(row)
+            f.flush()
+
+    def log_weights(self, bnn_obj, mcmc_obj, add_prms=None, add_obj=None):
+        """Keep the posterior weight sample (ring of n_post_samples) and rewrite the pickle, or append every
+        weight to the ``_W.log`` file (reference: BNN_env.py:622-658)."""
+        if self._log_all_weights:
+            row = [mcmc_obj._current_iteration] + list((bnn_obj._w_layers[0] * bnn_obj._indicators[0]).flatten())
+            for i in range(1, bnn_obj._n_layers):
+                row += list(bnn_obj._w_layers[i].flatten())
+            with open(self._w_file, "a", newline='') as f:
+                csv.writer(f, delimiter='\t').writerow(row)
+                f.flush()
+        else:
+            if bnn_obj._freq_indicator:
+                weights = [bnn_obj._w_layers[0] * bnn_obj._indicators] + list(bnn_obj._w_layers[1:])
+            else:
+                weights = bnn_obj._w_layers
+            sample = {'weights': weights, 'alphas': list(bnn_obj._act_fun._acc_prm),
+                      'mcmc_it': mcmc_obj._current_iteration}
+            if len(bnn_obj._error_prm):
+                sample['error_prm'] = list(bnn_obj._error_prm)
+            if add_prms:
+                sample['additional_prm'] = list(add_prms)
+            self.update_post_weight_samples(sample)
+            self.control_weight_sample_length(mcmc_obj._n_post_samples)
+        objs = [bnn_obj, mcmc_obj, self] + ([add_obj] if add_obj else [])
+        SaveObject(objs, self._pklfile)

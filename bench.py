@@ -77,19 +77,49 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from npbnn_amd import HipContext, _capi as capi
-    from bench_support import make_initial_weights
+    from bench_support import build_config2
 
     x, y = synthetic_config2()
-    w = make_initial_weights(HIDDEN, N_FEATURES, N_CLASSES, bias_node=2)
-    ctx = HipContext(local_rank)
-    ctx.set_data(x.astype(np.float32))
-    ctx.set_labels(y)
-    ctx.set_arch_from_weights(w, N_FEATURES, capi.ACT_TANH, capi.OUT_SOFTMAX, capi.LIK_CATEGORICAL)
+    # one chain per GPU, MC3 layout (config 3): chain r has mcmc_id r, temperature linspace(0.8, 1, world)[r]
+    temps = [1.0] if world == 1 else list(np.linspace(0.8, 1.0, world))
+    bnn, mcmc = build_config2(x.astype(np.float32), y, HIDDEN, mcmc_id=rank, temperature=temps[rank],
+                              randomize_seed=world > 1)
+    comm = None
+    swap_frequency = 100
+    if world > 1:
+        from npbnn_amd.comm import RcclComm, TorchDistComm
+        try:
+            comm = RcclComm(rank=rank, world_size=world, device=local_rank)
+            comm_kind = "rccl (C ABI)"
+        except Exception as e:                      # RCCL via torch.distributed is still RCCL over xGMI
+            print("[rank %d] native RCCL communicator unavailable (%s); using torch.distributed nccl" % (rank, e), flush=True)
+            comm = TorchDistComm()
+            comm_kind = "rccl (torch.distributed)"
+    else:
+        comm_kind = "none"
 
-    from bench_support import StepRunner
-    runner = StepRunner(ctx, w, seed=1234 + rank)
-    runner.run(args.warmup)
+    def advance(n):
+        """n iterations of every chain; with several chains, a temperature-swap exchange every swap_frequency."""
+        done = 0
+        while done < n:
+            k = min(swap_frequency, n - done) if world > 1 else n - done
+            mcmc.run_steps(bnn, k)
+            done += k
+            if world > 1 and done % swap_frequency == 0:
+                scal = comm.allgather_f64(np.array([mcmc._logPost, mcmc._temperature]))
+                dec = np.zeros(3, dtype=np.int64)
+                if rank == 0:
+                    j, k2 = np.random.choice(range(world), 2, replace=False)
+                    r = (scal[k2, 0] - scal[j, 0]) * scal[j, 1] + (scal[j, 0] - scal[k2, 0]) * scal[k2, 1]
+                    dec[:] = (j, k2, 1 if r >= np.log(np.random.random()) else 0)
+                j, k2, ok = (int(v) for v in comm.bcast_i64(dec, root=0))
+                if ok:
+                    if rank == j:
+                        mcmc.reset_temperature(scal[k2, 1])
+                    elif rank == k2:
+                        mcmc.reset_temperature(scal[j, 1])
+
+    advance(args.warmup)
 
     def sync():
         if dist is not None:
@@ -99,7 +129,7 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    runner.run(args.steps)
+    advance(args.steps)
     sync()
     el = time.perf_counter() - t0
     if dist is not None:
@@ -109,7 +139,8 @@ def main():
         el = float(t.item())
 
     if rank == 0:
-        ms_kernel, ms_eval = ctx.time_eval(runner.weights, iters=50)
+        ctx = mcmc._backend.ctx
+        ms_kernel, ms_eval = ctx.time_eval(bnn._w_layers, iters=50)
         alg_bytes = 4.0 * N_ROWS * N_FEATURES + 4.0 * N_ROWS
         achieved = alg_bytes / (ms_kernel * 1e-3)
         line = {
@@ -126,12 +157,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "config 2: 100k x 256 features, 10 classes, hidden [32,8], tanh, bias 2; "
-                                   "one chain per GPU", "chains": world, "mode": runner.mode},
+                                   "one chain per GPU", "chains": world, "swap_frequency": swap_frequency if world > 1 else None,
+                       "swap_exchange": comm_kind, "loop": "device-resident chain (npbnn_chain_run), proposals pre-drawn on the host"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "eval_kernel<2>",
                          "kernel_ms": ms_kernel, "algorithmic_bytes": alg_bytes},
-            "accept_rate": runner.accept_rate(),
-            "loglik": runner.loglik,
+            "accept_rate": float(mcmc._acceptance_rate),
+            "loglik": float(mcmc._logLik),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(x, y)
@@ -141,7 +173,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    mcmc._backend.close()
 
 
 if __name__ == "__main__":

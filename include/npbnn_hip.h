@@ -142,6 +142,38 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
 int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_main_kernel,
                     double* ms_total);
 
+/* ---- device-resident Metropolis-Hastings iterations: replaces K consecutive calls of MCMC.mh_step
+ * (np_bnn/BNN_env.py:381-532) on its default path - UpdateNormal proposals (np_bnn/BNN_mcmc.py:57-69), masks
+ * (BNN_env.py:461-462), prior (npBNN.calc_prior, BNN_env.py:180-194), accept test (BNN_env.py:493-494) - with the
+ * chain state resident on the GPU.  The host pre-draws the K iterations' random numbers from the very numpy Generator
+ * stream the reference consumes (npbnn_host_predraw in libnpbnn_host.so) and passes them here:
+ *   idx[t*M + j]   flat index into the packed weights of the j-th perturbed entry of iteration t, or -1 (skipped)
+ *   delta[t*M + j] the normal deviate added to that entry;  cnt[t] entries are used in row t
+ *   log_u[t]       log of the uniform draw of the accept test
+ * W_inout holds the current weights on entry and the chain's weights after K iterations on return. */
+typedef struct {
+    int32_t prior_kind;                        /* NPBNN_PRIOR_* */
+    double prior_scale[NPBNN_MAX_LAYERS];      /* npBNN._prior_scale, one per layer */
+    double w_bound;                            /* reflection bound, INFINITY for none */
+    double temperature;                        /* MCMC._temperature */
+    double lik_temp;                           /* MCMC._lik_temp */
+    int32_t sigma_given;                       /* Gaussian likelihood: 1 = use sigma[], 0 = empirical sigma */
+    double sigma[NPBNN_MAX_TARGETS];           /* on entry: sigma for proposals when sigma_given */
+    double cur_loglik, cur_logprior;           /* state of the chain on entry (MCMC._logLik / _logPrior) */
+    double cur_sigma[NPBNN_MAX_TARGETS];       /* npBNN._error_prm on entry */
+} npbnn_chain_cfg;
+
+typedef struct {
+    double loglik, logprior;                   /* state after the K iterations */
+    double sigma[NPBNN_MAX_TARGETS];
+    int64_t n_accepted;
+} npbnn_chain_result;
+
+int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed,
+                    int32_t K, int32_t M, const int32_t* idx, const double* delta, const int32_t* cnt,
+                    const double* log_u, uint8_t* out_accepted, double* out_loglik_prop, double* out_logprior_prop,
+                    npbnn_chain_result* result);
+
 /* ---- MC3 temperature-swap exchange over RCCL (xGMI inside a node): replaces the multiprocessing pool
  * round trip of whole pickled chains in MC3.run_mcmc (np_bnn/BNN_mc3.py:94-112), of which the swap
  * decision only reads two scalars per chain.  One communicator per process / GPU; host buffers in and out.

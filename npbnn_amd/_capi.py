@@ -47,6 +47,18 @@ class EvalOut(C.Structure):
                 ("n_rows", C.c_int64)]
 
 
+class ChainCfg(C.Structure):
+    _fields_ = [("prior_kind", C.c_int32), ("prior_scale", C.c_double * MAX_LAYERS), ("w_bound", C.c_double),
+                ("temperature", C.c_double), ("lik_temp", C.c_double), ("sigma_given", C.c_int32),
+                ("sigma", C.c_double * MAX_TARGETS), ("cur_loglik", C.c_double), ("cur_logprior", C.c_double),
+                ("cur_sigma", C.c_double * MAX_TARGETS)]
+
+
+class ChainResult(C.Structure):
+    _fields_ = [("loglik", C.c_double), ("logprior", C.c_double), ("sigma", C.c_double * MAX_TARGETS),
+                ("n_accepted", C.c_int64)]
+
+
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
 
@@ -67,6 +79,8 @@ SIGNATURES = {
                              C.POINTER(C.c_int64)]),
     "npbnn_predict": (C.c_int, [_P, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),
     "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
+    "npbnn_chain_run": (C.c_int, [_P, C.POINTER(ChainCfg), _DP, _DP, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _DP,
+                                  C.POINTER(C.c_int32), _DP, C.POINTER(C.c_uint8), _DP, _DP, C.POINTER(ChainResult)]),
     "npbnn_comm_unique_id": (C.c_int, [C.c_char * 128]),
     "npbnn_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char * 128, C.POINTER(_P)]),
     "npbnn_comm_allgather_f64": (C.c_int, [_P, _DP, C.c_int, _DP]),

@@ -152,3 +152,40 @@ class HipContext:
         a, b = C.c_double(0), C.c_double(0)
         self._chk(self._lib.npbnn_time_eval(self._ctx, capi.dptr(w), int(iters), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None):
+        """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
+        (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
+        K, M = idx.shape
+        cfg = capi.ChainCfg()
+        cfg.prior_kind = int(prior_kind)
+        for i, s in enumerate(prior_scale):
+            cfg.prior_scale[i] = float(s)
+        cfg.w_bound = float(w_bound)
+        cfg.temperature = float(temperature)
+        cfg.lik_temp = float(lik_temp)
+        cfg.sigma_given = 0 if sigma is None else 1
+        k = self.arch.n_targets
+        if sigma is not None:
+            for j, v in enumerate(np.broadcast_to(sigma, (k,))):
+                cfg.sigma[j] = float(v)
+        if cur_sigma is not None:
+            for j, v in enumerate(np.broadcast_to(cur_sigma, (k,))):
+                cfg.cur_sigma[j] = float(v)
+        cfg.cur_loglik, cfg.cur_logprior = float(cur_loglik), float(cur_logprior)
+        m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        delta = capi.as_f64(delta)
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+        log_u = capi.as_f64(log_u)
+        acc = np.empty(K, dtype=np.uint8)
+        llp, lpp = np.empty(K), np.empty(K)
+        res = capi.ChainResult()
+        self._chk(self._lib.npbnn_chain_run(
+            self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+            capi.dptr(delta), cnt.ctypes.data_as(C.POINTER(C.c_int32)), capi.dptr(log_u),
+            acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res)))
+        return w, acc, llp, lpp, dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]),
+                                      n_accepted=res.n_accepted)

@@ -61,6 +61,20 @@ struct npbnn_ctx {
     npbnn_eval_out* h_out = nullptr;
     unsigned* h_conf = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // device-resident chain
+    double* d_wcur = nullptr;
+    double* d_wprop = nullptr;
+    double* d_mask = nullptr;
+    ChainDev* d_chain = nullptr;
+    int* d_idx = nullptr;
+    double* d_delta = nullptr;
+    size_t draw_cap = 0;        // K*M capacity of d_idx / d_delta
+    int* d_cnt = nullptr;
+    double* d_logu = nullptr;
+    unsigned char* d_acc = nullptr;
+    double* d_llp = nullptr;
+    double* d_lpp = nullptr;
+    size_t iter_cap = 0;        // K capacity
 };
 
 namespace {
@@ -268,8 +282,7 @@ int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const 
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
     if (act_prm)
         for (int l = 0; l + 1 < ctx->net.n_layers; ++l) ctx->net.act_prm[l] = (float)act_prm[l];
-    int total = NPBNN_MAX_WIDTH;
-    for (int l = 0; l < ctx->net.n_layers; ++l) total += ctx->net.L[l].kt * ctx->net.L[l].mt * 64 + 16 * ctx->net.L[l].mt;
+    const int total = pack_item_count(ctx->net, true);
     const int blocks = (total + 255) / 256;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_wraw, d_co,
                        ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
@@ -372,6 +385,10 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
+    void* chain_bufs[] = {c->d_wcur, c->d_wprop, c->d_mask, c->d_chain, c->d_idx, c->d_delta, c->d_cnt, c->d_logu,
+                          c->d_acc, c->d_llp, c->d_lpp};
+    for (void* b : chain_bufs)
+        if (b) (void)hipFree(b);
     if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
     if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -459,6 +476,9 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     if (ctx->d_colov) { (void)hipFree(ctx->d_colov); ctx->d_colov = nullptr; }
     if (ctx->d_image) { (void)hipFree(ctx->d_image); ctx->d_image = nullptr; }
     if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
+    if (ctx->d_wcur) { (void)hipFree(ctx->d_wcur); ctx->d_wcur = nullptr; }
+    if (ctx->d_wprop) { (void)hipFree(ctx->d_wprop); ctx->d_wprop = nullptr; }
+    if (ctx->d_mask) { (void)hipFree(ctx->d_mask); ctx->d_mask = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)ctx->n_weights * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)ctx->net.image_floats * sizeof(float)));
@@ -562,6 +582,131 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n_el; ++i) out_y[i] = (double)tmp[i];
+    return NPBNN_OK;
+}
+
+int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed, int32_t K, int32_t M,
+                    const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, uint8_t* out_accepted,
+                    double* out_loglik_prop, double* out_logprior_prop, npbnn_chain_result* result) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!cfg || !W_inout || !result || K < 1 || M < 1 || !idx || !delta || !cnt || !log_u || !out_accepted)
+        return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run: call npbnn_set_arch first");
+    const int lik = ctx->net.lik_kind;
+    if (lik != NPBNN_LIK_CATEGORICAL && lik != NPBNN_LIK_GAUSS)
+        return fail(ctx, NPBNN_E_STATE, "chain_run: needs the categorical or Gaussian likelihood");
+    if (cfg->prior_kind < 0 || cfg->prior_kind > NPBNN_PRIOR_LAPLACE) return fail(ctx, NPBNN_E_ARG, "chain_run: prior_kind=%d", cfg->prior_kind);
+    for (int t = 0; t < K; ++t)
+        if (cnt[t] < 0 || cnt[t] > M) return fail(ctx, NPBNN_E_ARG, "chain_run: cnt[%d]=%d outside 0..%d", t, cnt[t], M);
+    for (size_t i = 0; i < (size_t)K * M; ++i)
+        if (idx[i] >= ctx->n_weights) return fail(ctx, NPBNN_E_ARG, "chain_run: weight index %d out of range", idx[i]);
+    Dataset& d = ctx->ds[0];
+    int rc = check_dataset_for_lik(ctx, d, lik);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchPlan lp;
+    rc = plan_launch(ctx, d, &lp);
+    if (rc) return rc;
+    rc = ensure_work_buffers(ctx, lp.n_waves);
+    if (rc) return rc;
+    const size_t wb = (size_t)ctx->n_weights * sizeof(double);
+    if (!ctx->d_wcur) HIP_TRY(ctx, hipMalloc(&ctx->d_wcur, wb));
+    if (!ctx->d_wprop) HIP_TRY(ctx, hipMalloc(&ctx->d_wprop, wb));
+    if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
+    if (!ctx->d_chain) HIP_TRY(ctx, hipMalloc(&ctx->d_chain, sizeof(ChainDev)));
+    const size_t need = (size_t)K * M;
+    if (need > ctx->draw_cap) {
+        if (ctx->d_idx) (void)hipFree(ctx->d_idx);
+        if (ctx->d_delta) (void)hipFree(ctx->d_delta);
+        ctx->d_idx = nullptr; ctx->d_delta = nullptr; ctx->draw_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_idx, need * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_delta, need * sizeof(double)));
+        ctx->draw_cap = need;
+    }
+    if ((size_t)K > ctx->iter_cap) {
+        void* olds[] = {ctx->d_cnt, ctx->d_logu, ctx->d_acc, ctx->d_llp, ctx->d_lpp};
+        for (void* b : olds)
+            if (b) (void)hipFree(b);
+        ctx->d_cnt = nullptr; ctx->d_logu = nullptr; ctx->d_acc = nullptr; ctx->d_llp = nullptr; ctx->d_lpp = nullptr;
+        ctx->iter_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_cnt, (size_t)K * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_logu, (size_t)K * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_acc, (size_t)K));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_llp, (size_t)K * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_lpp, (size_t)K * sizeof(double)));
+        ctx->iter_cap = (size_t)K;
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wcur, W_inout, wb, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wprop, ctx->d_wcur, wb, hipMemcpyDeviceToDevice, st));
+    if (mask_packed) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mask, mask_packed, wb, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_idx, idx, need * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_delta, delta, need * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cnt, cnt, (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_logu, log_u, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
+    ChainDev init{};
+    init.logLik = cfg->cur_loglik;
+    init.logPrior = cfg->cur_logprior;
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) init.sigma[j] = cfg->cur_sigma[j];
+    init.t = 0;
+    init.n_accepted = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chain, &init, sizeof(ChainDev), hipMemcpyHostToDevice, st));
+    // full image once (class weights, biases); the step kernel re-packs fragments + biases per proposal
+    for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
+    {
+        const int total = pack_item_count(ctx->net, true);
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ctx->d_wcur, (const double*)nullptr,
+                           ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
+    }
+    ChainParams c{};
+    c.st = ctx->d_chain;
+    c.w_cur = ctx->d_wcur;
+    c.w_prop = ctx->d_wprop;
+    c.mask = mask_packed ? ctx->d_mask : nullptr;
+    c.idx = ctx->d_idx;
+    c.delta = ctx->d_delta;
+    c.cnt = ctx->d_cnt;
+    c.log_u = ctx->d_logu;
+    c.hastings = nullptr;
+    c.out_acc = ctx->d_acc;
+    c.out_ll = ctx->d_llp;
+    c.out_lp = ctx->d_lpp;
+    c.partials = ctx->d_partials;
+    c.image = ctx->d_image;
+    c.K = K;
+    c.M = M;
+    c.n_weights = ctx->n_weights;
+    c.n_waves = lp.n_waves;
+    c.prior_kind = cfg->prior_kind;
+    for (int l = 0; l < kMaxLayers; ++l) c.prior_scale[l] = cfg->prior_scale[l];
+    c.w_bound = cfg->w_bound;
+    c.temperature = cfg->temperature;
+    c.lik_temp = cfg->lik_temp;
+    c.sigma_given = cfg->sigma_given;
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) c.sigma_fixed[j] = cfg->sigma[j];
+    c.n_rows = d.n_rows;
+    c.net = ctx->net;
+    EvalParams p = make_params(ctx, d);
+    p.partials = ctx->d_partials;
+    p.inst_w = d.inst_w;
+    p.use_classw = ctx->n_classw > 0 ? 1 : 0;
+    for (int t = 0; t < K; ++t) {
+        hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, c);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, p);
+    }
+    hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, c);
+    HIP_TRY(ctx, hipGetLastError());
+    ChainDev fin{};
+    HIP_TRY(ctx, hipMemcpyAsync(&fin, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(W_inout, ctx->d_wcur, wb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_accepted, ctx->d_acc, (size_t)K, hipMemcpyDeviceToHost, st));
+    if (out_loglik_prop) HIP_TRY(ctx, hipMemcpyAsync(out_loglik_prop, ctx->d_llp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (out_logprior_prop) HIP_TRY(ctx, hipMemcpyAsync(out_logprior_prop, ctx->d_lpp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    result->loglik = fin.logLik;
+    result->logprior = fin.logPrior;
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) result->sigma[j] = fin.sigma[j];
+    result->n_accepted = fin.n_accepted;
     return NPBNN_OK;
 }
 

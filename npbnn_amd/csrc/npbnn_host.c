@@ -1,0 +1,246 @@
+/*
+ * npbnn_host.c — host-side pre-draw of Metropolis-Hastings proposals with numpy-identical streams.
+ *
+ * The reference draws every proposal from a numpy Generator inside MCMC.mh_step
+ * (np_bnn/BNN_env.py:383-384, 446-447, 452-453, 493; UpdateNormal, np_bnn/BNN_mcmc.py:57-69).  With the
+ * default unbounded random-walk proposal the *draws* do not depend on the chain state, so K iterations
+ * can be drawn ahead of time and shipped to the GPU in one buffer while the chain itself runs on the
+ * device.  To keep seed parity the draws below come from numpy's own C distribution routines
+ * (libnpyrandom.a, shipped in the numpy wheel: random_standard_uniform_fill, random_bounded_uint64_fill,
+ * random_normal) driven either by the Generator's live bitgen_t (plain chains) or by a PCG64 seeded
+ * exactly like np.random.default_rng(seed) (MC3 chains re-seed every iteration with
+ * iteration + mcmc_id, BNN_env.py:384).
+ *
+ * Draw order of one iteration (must not change):
+ *   [reseed]  random(n_layers)  { integers(rows) integers(cols) normal(scale[ix,iy]) } per updated layer
+ *   random()  (accept test)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "numpy/random/bitgen.h"
+#include "numpy/random/distributions.h"
+
+#define NPBNN_HOST_MAX_LAYERS 8
+
+/* ---------------------------------------------------------------------------------------------
+ * SeedSequence(entropy).generate_state(4, uint64) for a non-negative integer seed
+ * (numpy/random/bit_generator.pyx; the algorithm of M.E. O'Neill's seed_seq_fe).
+ * ------------------------------------------------------------------------------------------- */
+#define SS_INIT_A 0x43b0d7e5u
+#define SS_MULT_A 0x931e8875u
+#define SS_INIT_B 0x8b51f9ddu
+#define SS_MULT_B 0x58f38dedu
+#define SS_MIX_L 0xca01f9ddu
+#define SS_MIX_R 0x4973f715u
+#define SS_XSHIFT 16
+#define SS_POOL 4
+
+static uint32_t ss_hashmix(uint32_t value, uint32_t* hash_const) {
+    value ^= *hash_const;
+    *hash_const *= SS_MULT_A;
+    value *= *hash_const;
+    value ^= value >> SS_XSHIFT;
+    return value;
+}
+
+static uint32_t ss_mix(uint32_t x, uint32_t y) {
+    uint32_t r = SS_MIX_L * x - SS_MIX_R * y;
+    r ^= r >> SS_XSHIFT;
+    return r;
+}
+
+static void seed_sequence_state(uint64_t seed, uint64_t out[4]) {
+    uint32_t entropy[2];
+    int n_ent = 1;
+    entropy[0] = (uint32_t)(seed & 0xffffffffu);
+    entropy[1] = (uint32_t)(seed >> 32);
+    if (entropy[1] != 0) n_ent = 2;
+    uint32_t pool[SS_POOL];
+    uint32_t hash_const = SS_INIT_A;
+    for (int i = 0; i < SS_POOL; ++i) pool[i] = ss_hashmix(i < n_ent ? entropy[i] : 0u, &hash_const);
+    for (int i_src = 0; i_src < SS_POOL; ++i_src)
+        for (int i_dst = 0; i_dst < SS_POOL; ++i_dst)
+            if (i_src != i_dst) pool[i_dst] = ss_mix(pool[i_dst], ss_hashmix(pool[i_src], &hash_const));
+    /* generate_state(8 x uint32) */
+    uint32_t words[8];
+    uint32_t hc = SS_INIT_B;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i % SS_POOL];
+        v ^= hc;
+        hc *= SS_MULT_B;
+        v *= hc;
+        v ^= v >> SS_XSHIFT;
+        words[i] = v;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = (uint64_t)words[2 * i] | ((uint64_t)words[2 * i + 1] << 32);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * PCG64 (XSL-RR 128/64), the default bit generator of np.random.default_rng
+ * ------------------------------------------------------------------------------------------- */
+typedef unsigned __int128 u128;
+
+typedef struct {
+    u128 state, inc;
+    int has_uint32;
+    uint32_t uinteger;
+} pcg64_t;
+
+#define PCG_MULT ((((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL)
+
+static inline void pcg_step(pcg64_t* r) { r->state = r->state * PCG_MULT + r->inc; }
+
+static void pcg64_seed(pcg64_t* r, uint64_t seed) {
+    uint64_t v[4];
+    seed_sequence_state(seed, v);
+    const u128 initstate = (((u128)v[0]) << 64) | v[1];
+    const u128 initseq = (((u128)v[2]) << 64) | v[3];
+    r->state = 0;
+    r->inc = (initseq << 1) | 1;
+    pcg_step(r);
+    r->state += initstate;
+    pcg_step(r);
+    r->has_uint32 = 0;
+    r->uinteger = 0;
+}
+
+static uint64_t pcg64_next64(void* st) {
+    pcg64_t* r = (pcg64_t*)st;
+    pcg_step(r);
+    const uint64_t hi = (uint64_t)(r->state >> 64), lo = (uint64_t)r->state;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(r->state >> 122);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+static uint32_t pcg64_next32(void* st) {
+    pcg64_t* r = (pcg64_t*)st;
+    if (r->has_uint32) {
+        r->has_uint32 = 0;
+        return r->uinteger;
+    }
+    const uint64_t next = pcg64_next64(st);
+    r->has_uint32 = 1;
+    r->uinteger = (uint32_t)(next >> 32);
+    return (uint32_t)(next & 0xffffffffu);
+}
+
+static double pcg64_next_double(void* st) { return (pcg64_next64(st) >> 11) * (1.0 / 9007199254740992.0); }
+
+static void pcg64_bitgen(pcg64_t* r, bitgen_t* bg) {
+    bg->state = r;
+    bg->next_uint64 = pcg64_next64;
+    bg->next_uint32 = pcg64_next32;
+    bg->next_double = pcg64_next_double;
+    bg->next_raw = pcg64_next64;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * pre-draw
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_layers;
+    int32_t rows[NPBNN_HOST_MAX_LAYERS];
+    int32_t cols[NPBNN_HOST_MAX_LAYERS];      /* including the bias column */
+    int32_t w_off[NPBNN_HOST_MAX_LAYERS];     /* offset of the layer in the packed weight vector */
+    int32_t update_n[NPBNN_HOST_MAX_LAYERS];  /* MCMC._update_n */
+    const double* update_ws[NPBNN_HOST_MAX_LAYERS]; /* MCMC._update_ws[i], rows*cols doubles */
+    double freq_layer_update[NPBNN_HOST_MAX_LAYERS];
+} npbnn_proposal_spec;
+
+int npbnn_host_abi_version(void) { return 1; }
+
+/* Seeds a PCG64 like np.random.default_rng(seed) and returns its first `n` doubles (self-test hook). */
+int npbnn_host_selftest_doubles(uint64_t seed, int n, double* out) {
+    pcg64_t r;
+    bitgen_t bg;
+    pcg64_seed(&r, seed);
+    pcg64_bitgen(&r, &bg);
+    random_standard_uniform_fill(&bg, n, out);
+    return 0;
+}
+
+/*
+ * Draw the proposals of K consecutive iterations.
+ *   bitgen            the Generator's bitgen_t* (Generator.bit_generator.ctypes.bit_generator); used when
+ *                     randomize_seed == 0 and advanced in place
+ *   randomize_seed    1: iteration t uses default_rng(first_iteration + t + mcmc_id)   (MC3 chains)
+ *   max_per_iter      M = capacity per iteration of idx/delta (>= sum of update_n)
+ * Outputs (row t = iteration t):
+ *   idx[t*M + j]      flat index into the packed weights, or -1 for an entry superseded by a later draw of
+ *                     the same position (numpy fancy-index assignment: the last write wins)
+ *   delta[t*M + j]    the normal deviate to add
+ *   cnt[t]            entries used in row t
+ *   log_u[t]          the uniform draw of the accept test (the caller takes np.log, as the reference does)
+ *   layer_mask[t]     bit i set when layer i was updated
+ * Returns 0, or -1 on bad arguments / capacity.
+ */
+int npbnn_host_predraw(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+                       const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
+                       int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights) {
+    if (!spec || K < 0 || spec->n_layers < 1 || spec->n_layers > NPBNN_HOST_MAX_LAYERS) return -1;
+    if (!randomize_seed && !bitgen) return -1;
+    int total = 0, max_n = 0;
+    for (int i = 0; i < spec->n_layers; ++i) {
+        total += spec->update_n[i];
+        if (spec->update_n[i] > max_n) max_n = spec->update_n[i];
+    }
+    if (total > max_per_iter) return -1;
+    int32_t* last = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_weights);
+    uint64_t* ix = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(max_n > 0 ? max_n : 1) * 2);
+    if (!last || !ix) {
+        free(last);
+        free(ix);
+        return -2;
+    }
+    uint64_t* iy = ix + (max_n > 0 ? max_n : 1);
+    for (int i = 0; i < n_weights; ++i) last[i] = -1;
+    pcg64_t local;
+    bitgen_t local_bg;
+    for (int t = 0; t < K; ++t) {
+        bitgen_t* bg = (bitgen_t*)bitgen;
+        if (randomize_seed) {
+            pcg64_seed(&local, (uint64_t)(first_iteration + t + mcmc_id));
+            pcg64_bitgen(&local, &local_bg);
+            bg = &local_bg;
+        }
+        double rr[NPBNN_HOST_MAX_LAYERS];
+        random_standard_uniform_fill(bg, spec->n_layers, rr);
+        int amin = 0;
+        for (int i = 1; i < spec->n_layers; ++i)
+            if (rr[i] < rr[amin]) amin = i;
+        rr[amin] = 0.0;
+        int32_t* row_idx = idx + (size_t)t * max_per_iter;
+        double* row_delta = delta + (size_t)t * max_per_iter;
+        int used = 0, mask = 0;
+        for (int i = 0; i < spec->n_layers; ++i) {
+            if (!(rr[i] < spec->freq_layer_update[i])) continue;
+            mask |= 1 << i;
+            const int n = spec->update_n[i];
+            random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->rows[i] - 1), n, 0, ix);
+            random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->cols[i] - 1), n, 0, iy);
+            const int base = used;
+            for (int j = 0; j < n; ++j) {
+                const int local_pos = (int)ix[j] * spec->cols[i] + (int)iy[j];
+                const double scale = spec->update_ws[i][local_pos];
+                const int flat = spec->w_off[i] + local_pos;
+                row_delta[base + j] = random_normal(bg, 0.0, scale);
+                if (last[flat] >= base) row_idx[last[flat]] = -1;   /* superseded within this layer */
+                row_idx[base + j] = flat;
+                last[flat] = base + j;
+            }
+            for (int j = 0; j < n; ++j)
+                if (row_idx[base + j] >= 0) last[row_idx[base + j]] = -1;
+            used += n;
+        }
+        cnt[t] = used;
+        layer_mask[t] = mask;
+        log_u[t] = random_standard_uniform(bg);
+    }
+    free(last);
+    free(ix);
+    return 0;
+}

@@ -85,11 +85,10 @@ struct EvalParams {
 //   is the constant v_c for every row, so its contribution v_c*W0[o][c] moves into the bias and the
 //   fragment entry becomes 0 - no extra pass over X.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
-                                                           const double* __restrict__ class_w, float* __restrict__ image,
-                                                           NetMeta net) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    int piece = gid;
+__device__ __forceinline__ void pack_item(int item, const double* __restrict__ w, const double* __restrict__ col_override,
+                                          const double* __restrict__ class_w, float* __restrict__ image, const NetMeta& net,
+                                          bool with_classw) {
+    int piece = item;
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerMeta& L = net.L[l];
         const int n_pieces = L.kt * L.mt * 64;
@@ -138,9 +137,21 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restr
         }
         piece -= nb;
     }
-    if (piece < NPBNN_MAX_WIDTH) {
+    if (with_classw && piece < NPBNN_MAX_WIDTH) {
         image[net.classw_off + piece] = (class_w != nullptr && piece < net.n_out) ? (float)class_w[piece] : 1.0f;
     }
+}
+
+__host__ __device__ inline int pack_item_count(const NetMeta& net, bool with_classw) {
+    int total = with_classw ? NPBNN_MAX_WIDTH : 0;
+    for (int l = 0; l < net.n_layers; ++l) total += net.L[l].kt * net.L[l].mt * 64 + 16 * net.L[l].mt;
+    return total;
+}
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
+                                                           const double* __restrict__ class_w, float* __restrict__ image,
+                                                           NetMeta net) {
+    pack_item(blockIdx.x * 256 + threadIdx.x, w, col_override, class_w, image, net, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,49 +487,188 @@ struct FinalizeParams {
     npbnn_eval_out* out;   // device
 };
 
-__global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams f) {
-    __shared__ double red[256];
-    __shared__ double tot[kPartialStride];
-    const int tid = threadIdx.x;
-    const int nvals = (f.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
-    for (int v = 0; v < nvals; ++v) {
+// Sum value v of every wave's partial record: wave (threadIdx>>6) of the block takes values v = wave, wave+nw, ...;
+// lane l adds records l, l+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_waves, int nvals, double* tot /*LDS*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int v = wave; v < nvals; v += nw) {
         double s = 0.0;
-        for (int w = tid; w < f.n_waves; w += 256) s += f.partials[(size_t)w * kPartialStride + v];
-        red[tid] = s;
-        __syncthreads();
-        for (int half = 128; half > 0; half >>= 1) {
-            if (tid < half) red[tid] += red[tid + half];
-            __syncthreads();
-        }
-        if (tid == 0) tot[v] = red[0];
-        __syncthreads();
+        for (int w = lane; w < n_waves; w += 64) s += partials[(size_t)w * kPartialStride + v];
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
+        if (lane == 0) tot[v] = s;
     }
-    if (tid == 0) {
-        npbnn_eval_out o;
-        o.n_rows = f.n_rows;
-        for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { o.sigma[j] = 0; o.sum_r[j] = 0; o.sum_r2[j] = 0; }
-        if (f.lik_kind == NPBNN_LIK_GAUSS) {
-            // sum_j [ -N (0.5 log 2pi + log s_j) - S2_j / (2 s_j^2) ];  empirical s_j = population std of the residuals
-            // (np.std, BNN_env.py:475-476; scipy.stats.norm.logpdf, BNN_lib.py:131)
-            const double N = (double)f.n_rows;
-            double ll = 0.0;
-            for (int j = 0; j < f.k_targets; ++j) {
-                const double S1 = tot[1 + j], S2 = tot[1 + NPBNN_MAX_TARGETS + j];
-                double sg;
-                if (f.sigma_given) sg = f.sigma[j];
-                else {
-                    const double mean = S1 / N;
-                    sg = sqrt(S2 / N - mean * mean);
-                }
-                o.sigma[j] = sg; o.sum_r[j] = S1; o.sum_r2[j] = S2;
-                ll += -N * (0.9189385332046727418 + log(sg)) - S2 / (2.0 * sg * sg);
+    __syncthreads();
+}
+
+// log-likelihood (and sigma / residual moments) from the reduced totals; one thread.
+__device__ __forceinline__ void loglik_from_totals(const double* tot, int lik_kind, int k_targets, long long n_rows, double lik_temp,
+                                                   int sigma_given, const double* sigma_in, npbnn_eval_out* o) {
+    o->n_rows = n_rows;
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { o->sigma[j] = 0; o->sum_r[j] = 0; o->sum_r2[j] = 0; }
+    if (lik_kind == NPBNN_LIK_GAUSS) {
+        // sum_j [ -N (0.5 log 2pi + log s_j) - S2_j / (2 s_j^2) ];  empirical s_j = population std of the residuals
+        // (np.std, BNN_env.py:475-476; scipy.stats.norm.logpdf, BNN_lib.py:131)
+        const double N = (double)n_rows;
+        double ll = 0.0;
+        for (int j = 0; j < k_targets; ++j) {
+            const double S1 = tot[1 + j], S2 = tot[1 + NPBNN_MAX_TARGETS + j];
+            double sg;
+            if (sigma_given) sg = sigma_in[j];
+            else {
+                const double mean = S1 / N;
+                sg = sqrt(S2 / N - mean * mean);
             }
-            o.loglik = f.lik_temp * ll;
-        } else {
-            o.loglik = f.lik_temp * tot[0];
+            o->sigma[j] = sg; o->sum_r[j] = S1; o->sum_r2[j] = S2;
+            ll += -N * (0.9189385332046727418 + log(sg)) - S2 / (2.0 * sg * sg);
         }
-        *f.out = o;
+        o->loglik = lik_temp * ll;
+    } else {
+        o->loglik = lik_temp * tot[0];
     }
+}
+
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams f) {
+    __shared__ double tot[kPartialStride];
+    const int nvals = (f.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+    reduce_partials(f.partials, f.n_waves, nvals, tot);
+    if (threadIdx.x == 0) loglik_from_totals(tot, f.lik_kind, f.k_targets, f.n_rows, f.lik_temp, f.sigma_given, f.sigma, f.out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident Metropolis-Hastings chain
+//
+// K iterations of MCMC.mh_step (BNN_env.py:381-532, default path: UpdateNormal proposals, BNN_mcmc.py:57-69)
+// run as an alternation  step_kernel(t) -> eval_kernel -> step_kernel(t+1) ...  on the chain's stream.  The host
+// pre-draws the random numbers of the K iterations (npbnn_host.c) so the proposals are the reference's.
+// step_kernel (one workgroup):
+//   1. finish iteration t-1: reduce the eval partials -> logLik', accept test
+//        (logPost' - logPost) * temperature + hastings >= log u          (BNN_env.py:493-494)
+//      on accept commit the changed weights into W_cur, else roll W_prop back;
+//   2. propose iteration t: W_prop[idx] = reflect(W_cur[idx] + delta) * mask   (BNN_mcmc.py:64-67, BNN_env.py:461-462);
+//   3. logPrior' = sum_l sum log p(W_prop_l; 0, scale_l)                       (npBNN.calc_prior, BNN_env.py:180-194);
+//   4. repack the float32 fragment image of W_prop for the eval kernel.
+// ------------------------------------------------------------------------------------------------
+struct ChainDev {          // device-resident chain state
+    double logLik, logPrior;
+    double sigma[NPBNN_MAX_TARGETS];
+    double cand_logPrior;
+    int t;
+    int n_accepted;
+};
+
+struct ChainParams {
+    ChainDev* st;
+    double* w_cur;
+    double* w_prop;
+    const double* mask;        // or nullptr
+    const int* idx;            // [K][M]
+    const double* delta;       // [K][M]
+    const int* cnt;            // [K]
+    const double* log_u;       // [K]
+    const double* hastings;    // [K] or nullptr
+    unsigned char* out_acc;    // [K]
+    double* out_ll;            // [K] proposed logLik
+    double* out_lp;            // [K] proposed logPrior
+    const double* partials;
+    float* image;
+    int K, M, n_weights, n_waves;
+    int prior_kind;
+    double prior_scale[kMaxLayers];
+    double w_bound;
+    double temperature, lik_temp;
+    int sigma_given;           // Gaussian: 1 = use sigma_fixed, 0 = empirical
+    double sigma_fixed[NPBNN_MAX_TARGETS];
+    long long n_rows;
+    NetMeta net;
+};
+
+__device__ __forceinline__ double log_prior_density(int kind, double w, double scale) {
+    if (kind == NPBNN_PRIOR_CAUCHY) return -log(3.14159265358979323846 * scale * (1.0 + (w / scale) * (w / scale)));
+    if (kind == NPBNN_PRIOR_LAPLACE) return -log(2.0 * scale) - fabs(w) / scale;
+    return -0.5 * (w / scale) * (w / scale) - log(scale) - 0.9189385332046727418;
+}
+
+__global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
+    __shared__ double tot[kPartialStride];
+    __shared__ double red[16];
+    __shared__ int s_accept;
+    const int tid = threadIdx.x;
+    ChainDev* st = c.st;
+    const int t = st->t;                       // iteration to propose now; t-1 is pending
+    __syncthreads();                           // everyone has read t before thread 0 bumps it
+
+    if (t > 0) {
+        const int nvals = (c.net.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+        reduce_partials(c.partials, c.n_waves, nvals, tot);
+        if (tid == 0) {
+            npbnn_eval_out o;
+            loglik_from_totals(tot, c.net.lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
+            const double lp = st->cand_logPrior;
+            const double h = c.hastings ? c.hastings[t - 1] : 0.0;
+            const double post_new = o.loglik + lp, post_old = st->logLik + st->logPrior;
+            const int acc = ((post_new - post_old) * c.temperature + h >= c.log_u[t - 1]) ? 1 : 0;
+            c.out_acc[t - 1] = (unsigned char)acc;
+            c.out_ll[t - 1] = o.loglik;
+            c.out_lp[t - 1] = lp;
+            if (acc) {
+                st->logLik = o.loglik;
+                st->logPrior = lp;
+                st->n_accepted += 1;
+                if (c.net.lik_kind == NPBNN_LIK_GAUSS)
+                    for (int j = 0; j < c.net.k_targets; ++j) st->sigma[j] = o.sigma[j];
+            }
+            s_accept = acc;
+        }
+        __syncthreads();
+        const int acc = s_accept;
+        const int n_prev = c.cnt[t - 1];
+        for (int j = tid; j < n_prev; j += blockDim.x) {
+            const int i = c.idx[(size_t)(t - 1) * c.M + j];
+            if (i >= 0) {
+                if (acc) c.w_cur[i] = c.w_prop[i];
+                else c.w_prop[i] = c.w_cur[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (t >= c.K) return;
+
+    const int n_new = c.cnt[t];
+    for (int j = tid; j < n_new; j += blockDim.x) {
+        const int i = c.idx[(size_t)t * c.M + j];
+        if (i >= 0) {
+            double v = c.w_cur[i] + c.delta[(size_t)t * c.M + j];
+            if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
+            if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
+            if (c.mask) v *= c.mask[i];
+            c.w_prop[i] = v;
+        }
+    }
+    __syncthreads();
+
+    // prior of the proposal, fixed summation order (thread-strided partial sums, then a tree)
+    double lp = 0.0;
+    if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+        for (int l = 0; l < c.net.n_layers; ++l) {
+            const LayerMeta& L = c.net.L[l];
+            const int n = L.out_dim * (L.in_dim + L.has_bias);
+            const double sc = c.prior_scale[l];
+            for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_prop[L.w_off + i], sc);
+        }
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) lp += shfl_xor_f64(lp, sh);
+    if ((tid & 63) == 0) red[tid >> 6] = lp;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        st->cand_logPrior = s;
+        st->t = t + 1;
+    }
+    const int items = pack_item_count(c.net, false);
+    for (int g = tid; g < items; g += blockDim.x) pack_item(g, c.w_prop, nullptr, nullptr, c.image, c.net, false);
 }
 
 }  // namespace npbnn

@@ -91,5 +91,10 @@ class HipBackend:
         return self.ctx.predict(weights, act_prm=slopes, col_override=col_override, which=which,
                                 apply_out_fn=apply_out_fn and self.out_kind is not None)
 
+    def run_chain(self, weights, **kw):
+        """Device-resident Metropolis-Hastings iterations; see HipContext.chain_run."""
+        self._configure(weights)
+        return self.ctx.chain_run(weights, **kw)
+
     def close(self):
         self.ctx.close()

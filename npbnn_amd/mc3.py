@@ -97,10 +97,8 @@ class MC3():
     def run_single_mcmc(self, arg_list):
         """Advance one chain by ``swap_frequency`` iterations (reference: BNN_mc3.py:80-85)."""
         [bnn_obj, mcmc_obj] = arg_list
-        for _ in range(self.swap_frequency - 1):
-            mcmc_obj.mh_step(bnn_obj)
-        bnn_obj_new, mcmc_obj_new = mcmc_obj.mh_step(bnn_obj, return_bnn=True)
-        return [bnn_obj_new, mcmc_obj_new]
+        mcmc_obj.run_steps(bnn_obj, self.swap_frequency)
+        return [bnn_obj, mcmc_obj]
 
     # -- the exchange step ---------------------------------------------------------------------
     def _gather_scalars(self):

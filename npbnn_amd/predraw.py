@@ -1,0 +1,72 @@
+"""Binding of libnpbnn_host.so: pre-draw of K Metropolis-Hastings iterations' random numbers with
+numpy-identical streams (see csrc/npbnn_host.c)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._capi import LIB_DIR, BackendUnavailable
+
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libnpbnn_host.so")
+MAX_LAYERS = 8
+
+
+class ProposalSpec(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("rows", C.c_int32 * MAX_LAYERS), ("cols", C.c_int32 * MAX_LAYERS),
+                ("w_off", C.c_int32 * MAX_LAYERS), ("update_n", C.c_int32 * MAX_LAYERS),
+                ("update_ws", C.POINTER(C.c_double) * MAX_LAYERS), ("freq_layer_update", C.c_double * MAX_LAYERS)]
+
+
+_lib = None
+
+
+def load_host_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise BackendUnavailable("host pre-draw library not found at %s; run `make -C npbnn_amd/csrc`" % HOST_LIB_PATH)
+        lib = C.CDLL(HOST_LIB_PATH)
+        lib.npbnn_host_predraw.restype = C.c_int
+        lib.npbnn_host_predraw.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.POINTER(ProposalSpec), C.c_int,
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]
+        lib.npbnn_host_selftest_doubles.restype = C.c_int
+        lib.npbnn_host_selftest_doubles.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+        _lib = lib
+    return _lib
+
+
+def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, update_ws, freq_layer_update):
+    """Draw K iterations' proposals.  ``rs`` is the chain's numpy Generator (advanced in place unless
+    ``randomize_seed``).  Returns (idx [K,M] int32, delta [K,M] float64, cnt [K], u [K], layer_mask [K])."""
+    lib = load_host_library()
+    spec = ProposalSpec()
+    n_layers = len(weights)
+    spec.n_layers = n_layers
+    keep = []
+    off = 0
+    for i, w in enumerate(weights):
+        spec.rows[i], spec.cols[i], spec.w_off[i] = w.shape[0], w.shape[1], off
+        off += w.size
+        spec.update_n[i] = int(update_n[i])
+        ws = np.ascontiguousarray(np.broadcast_to(update_ws[i], w.shape), dtype=np.float64)
+        keep.append(ws)
+        spec.update_ws[i] = ws.ctypes.data_as(C.POINTER(C.c_double))
+        spec.freq_layer_update[i] = float(freq_layer_update[i])
+    M = int(sum(int(n) for n in update_n))
+    idx = np.full((K, M), -1, dtype=np.int32)
+    delta = np.zeros((K, M), dtype=np.float64)
+    cnt = np.empty(K, dtype=np.int32)
+    u = np.empty(K, dtype=np.float64)
+    lmask = np.empty(K, dtype=np.int32)
+    bitgen = None
+    if not randomize_seed:
+        bitgen = rs.bit_generator.ctypes.bit_generator
+    with rs.bit_generator.lock:
+        rc = lib.npbnn_host_predraw(bitgen, 1 if randomize_seed else 0, int(first_iteration), int(mcmc_id), K, C.byref(spec), M,
+                                    idx.ctypes.data_as(C.POINTER(C.c_int32)), delta.ctypes.data_as(C.POINTER(C.c_double)),
+                                    cnt.ctypes.data_as(C.POINTER(C.c_int32)), u.ctypes.data_as(C.POINTER(C.c_double)),
+                                    lmask.ctypes.data_as(C.POINTER(C.c_int32)), off)
+    if rc != 0:
+        raise RuntimeError("npbnn_host_predraw failed with code %d" % rc)
+    return idx, delta, cnt, u, lmask

@@ -365,6 +365,90 @@ class MCMC():
         if return_bnn:
             return bnn_obj, self
 
+    # ------------------------------------------------------------------------------------------
+    # K iterations with the chain resident on the device
+    # ------------------------------------------------------------------------------------------
+    MAX_BATCH = 4096
+
+    def _device_loop_ok(self, bnn_obj, k):
+        """True when the next k iterations can run as a device-resident chain: the default proposal and no
+        feature of mh_step whose random draws depend on the chain state."""
+        be = self._backend
+        if be is None or not hasattr(be, "run_chain") or not getattr(be, "fused_likelihood", False):
+            return False
+        if self.update_function is not UpdateNormal or self._sample_from_prior:
+            return False
+        if bnn_obj._act_fun._trainable or bnn_obj._feature_indicators is not None or bnn_obj._freq_indicator:
+            return False
+        if likelihood_kind(self._likelihood_f) not in (capi.LIK_CATEGORICAL, capi.LIK_GAUSS):
+            return False
+        if any(np.ndim(s) != 0 for s in bnn_obj._prior_scale) or bnn_obj._hyper_p:
+            return False
+        if bnn_obj._estimation_mode == "regression" and not bnn_obj._empirical_error:
+            if self._current_iteration + k - 1 > self._estimate_error:
+                return False        # the sigma multiplier proposal of BNN_env.py:439 is state dependent
+        return True
+
+    def _next_adapt_boundary(self):
+        it = self._current_iteration
+        nxt = (it // self._adapt_freq + 1) * self._adapt_freq
+        return nxt if nxt < self._adapt_stop else None
+
+    def run_steps(self, bnn_obj, n_steps):
+        """Advance the chain by ``n_steps`` iterations: exactly ``n_steps`` calls of :meth:`mh_step` (same random
+        stream, same adaptation points, same bookkeeping), executed where possible as a device-resident chain
+        with the random numbers pre-drawn on the host."""
+        from . import predraw as pd
+        self._bnn = bnn_obj
+        if self._backend is None:
+            self._backend = get_backend(bnn_obj, self._likelihood_f)
+        remaining = int(n_steps)
+        while remaining > 0:
+            k = min(remaining, self.MAX_BATCH)
+            boundary = self._next_adapt_boundary()
+            if boundary is not None:
+                k = min(k, boundary - self._current_iteration)
+            if not self._device_loop_ok(bnn_obj, k):
+                self.mh_step(bnn_obj)
+                remaining -= 1
+                continue
+            self._adapt(bnn_obj)
+            it0 = self._current_iteration
+            idx, delta, cnt, u, _ = pd.predraw(self._rs, self._randomize_seed, it0, self._mcmc_id, k, bnn_obj._w_layers,
+                                               self._update_n, self._update_ws, self._freq_layer_update)
+            regression = bnn_obj._estimation_mode == "regression"
+            sigma = None
+            cur_sigma = None
+            if regression:
+                cur_sigma = np.ones(bnn_obj._size_output) * bnn_obj._error_prm
+                if not bnn_obj._empirical_error:
+                    sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
+            w_new, acc, _, _, res = self._backend.run_chain(
+                bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=np.log(u), prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0,
+                prior_scale=bnn_obj._prior_scale, w_bound=bnn_obj._w_bound, temperature=self._temperature,
+                lik_temp=self._lik_temp, cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma,
+                sigma=sigma, mask=bnn_obj._mask)
+            if res["n_accepted"] > 0:
+                layers, off = [], 0
+                for w in bnn_obj._w_layers:
+                    layers.append(w_new[off:off + w.size].reshape(w.shape))
+                    off += w.size
+                bnn_obj.reset_weights(layers)
+                self._logLik, self._logPrior = res["loglik"], res["logprior"]
+                self._logPost = self._logLik + self._logPrior
+                if regression:
+                    bnn_obj.reset_error_prm(res["sigma"])
+                self._accepted_override = None
+                self._invalidate()
+            history = self._last_accepted_mem + [int(a) for a in acc]
+            self._last_accepted = int(acc[-1])
+            self._acceptance_rate = np.mean(history[-101:]) if len(history) > 100 else np.mean(history)
+            self._last_accepted_mem = history[-100:] if len(history) > 100 else history
+            self._current_iteration += k
+            if self._randomize_seed:
+                self._rs = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
+            remaining -= k
+
     def gibbs_step(self, bnn_obj):
         bnn_obj.sample_prior_scale()
         self._logPrior = bnn_obj.calc_prior()

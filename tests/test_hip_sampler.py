@@ -1,0 +1,129 @@
+"""GPU tests of the sampler: MCMC.mh_step (one device evaluation per proposal) and MCMC.run_steps
+(device-resident chain with pre-drawn random numbers) against each other and against the reference's
+golden Metropolis-Hastings traces."""
+import contextlib
+import copy
+import io
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import npbnn_amd as bn
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
+
+
+def build(cfg, **mcmc_extra):
+    if cfg["kind"] == "classification":
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        extra = {}
+    else:
+        dat = cases.regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
+        extra = dict(estimation_mode="regression", empirical_error=cfg.get("empirical_error", False))
+    np.random.seed(1234)
+    bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
+                prior_f=1, p_scale=1, seed=1234, init_std=0.1, **extra)
+    kw = dict(cfg["mcmc"])
+    kw.update(mcmc_extra)
+    return bnn, bn.MCMC(bnn, **kw)
+
+
+@pytest.mark.parametrize("name", list(cases.TRACES))
+def test_free_running_chain_follows_reference_trace(name, golden_dir):
+    """Same seeds -> the float32 device chain follows the float64 reference accept/reject sequence.  A decision
+    may flip where |logPost' - logPost - log u| is below the float32 noise of the likelihood (~1e-3 here), after
+    which the chains legitimately diverge; require a long common prefix and a matching initial state."""
+    cfg = cases.TRACES[name]
+    g = np.load(os.path.join(golden_dir, "trace_%s.npz" % name))
+    bnn, mcmc = build(cfg)
+    np.testing.assert_allclose(mcmc._logLik, g["init"][0], rtol=2e-6)
+    np.testing.assert_allclose(mcmc._logPrior, g["init"][1], rtol=1e-12)
+    np.testing.assert_allclose([mcmc._accuracy, mcmc._test_accuracy], g["init"][2:4], rtol=1e-4)
+    rows = g["rows"]
+    n_match = 0
+    for it in range(cfg["steps"]):
+        mcmc.mh_step(bnn)
+        if mcmc._last_accepted != int(rows[it, 2]):
+            break
+        np.testing.assert_allclose(mcmc._logLik, rows[it, 3], rtol=2e-6)
+        n_match += 1
+    assert n_match >= min(150, cfg["steps"]), "chains diverged after %d iterations" % n_match
+    if n_match == cfg["steps"]:
+        for i, w in enumerate(bnn._w_layers):
+            np.testing.assert_array_equal(w, g["wfinal_%d" % i])     # weights are float64 on the host: bit-equal
+        np.testing.assert_allclose(mcmc._accuracy, rows[-1, 5], rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", list(cases.TRACES))
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_run_steps_equals_mh_step_loop(name, randomize_seed):
+    """The device-resident chain and the host loop run the same kernels on the same proposals."""
+    cfg = cases.TRACES[name]
+    bnn_a, mcmc_a = build(cfg, randomize_seed=randomize_seed, mcmc_id=2)
+    bnn_b, mcmc_b = build(cfg, randomize_seed=randomize_seed, mcmc_id=2)
+    n = 230                                   # crosses adaptation boundaries of the classification trace
+    for _ in range(n):
+        mcmc_a.mh_step(bnn_a)
+    mcmc_b.run_steps(bnn_b, 100)
+    mcmc_b.run_steps(bnn_b, n - 100)
+    assert mcmc_b._current_iteration == mcmc_a._current_iteration == n
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+    assert mcmc_a._acceptance_rate == mcmc_b._acceptance_rate
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(mcmc_a._update_n, mcmc_b._update_n)
+    np.testing.assert_allclose(mcmc_a._accuracy, mcmc_b._accuracy)
+    if cfg["kind"] == "regression":
+        np.testing.assert_allclose(bnn_a._error_prm, bnn_b._error_prm, rtol=1e-12)
+    if not randomize_seed:
+        assert mcmc_a._rs.random() == mcmc_b._rs.random()     # generator advanced identically
+
+
+def test_run_steps_with_block_mask_and_bounds():
+    """Masked (block-sparse) layers and a uniform prior with reflecting bounds, device loop vs host loop."""
+    dat = cases.regression_data(9, 1500, 24, 1)
+    res = []
+    for mode in ("host", "device"):
+        np.random.seed(3)
+        bnn = quiet(bn.npBNN, dat, n_nodes=[8, 4], estimation_mode="regression", actFun=bn.ActFun(fun="tanh"),
+                    use_bias_node=-1, prior_f=0, p_scale=0.6, empirical_error=True)
+        m = bn.create_mask(bnn._w_layers, indx_input_list=[list(np.repeat(np.arange(4), 6)), [], []],
+                           nodes_per_feature_list=[[2] * 4, [], []])
+        quiet(bnn.apply_mask, m)
+        mcmc = bn.MCMC(bnn, update_f=[0.2, 0.2, 0.5], update_ws=[0.3, 0.3, 0.3], n_iteration=1000, estimate_error=False)
+        if mode == "host":
+            for _ in range(120):
+                mcmc.mh_step(bnn)
+        else:
+            mcmc.run_steps(bnn, 120)
+        res.append((bnn, mcmc))
+    (ba, ma), (bb, mb) = res
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    for wa, wb, mk in zip(ba._w_layers, bb._w_layers, ba._mask):
+        np.testing.assert_array_equal(wa, wb)
+        assert np.all(wa[mk == 0] == 0) and np.all(np.abs(wa) <= 0.6)
+    np.testing.assert_allclose(ma._logLik, mb._logLik, rtol=1e-12)
+
+
+def test_driver_and_logger_end_to_end(tmp_path):
+    """bnn_classify.py call sequence (config 1 shape): run_mcmc + postLogger on the device backend."""
+    cfg = cases.TRACES["cfg1"]
+    bnn, mcmc = build(cfg, n_iteration=300, sampling_f=50, print_f=100)
+    logger = bn.postLogger(bnn, filename="BNN_cv0", wdir=str(tmp_path), log_all_weights=0)
+    quiet(bn.run_mcmc, bnn, mcmc, logger)
+    rows = np.loadtxt(logger._logfile, skiprows=1)
+    assert rows.shape[0] == 6 and rows[-1, 0] == 300
+    header = open(logger._logfile).readline().split()
+    assert header[:6] == ["it", "posterior", "likelihood", "prior", "accuracy", "test_accuracy"]
+    b2, m2, lg = bn.load_obj(logger._pklfile)
+    assert len(lg._post_weight_samples) == 6
+    assert m2._accuracy == mcmc._accuracy and mcmc._accuracy > 0.22

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,7 +49,8 @@ struct npbnn_ctx {
     // device work buffers
     double* d_wraw = nullptr;      // packed float64 weights
     double* d_colov = nullptr;     // column override (in_dim doubles)
-    float* d_image = nullptr;
+    float* d_image = nullptr;      // float32 fragment image
+    int* d_w2img = nullptr;        // packed-weight index -> image float index
     double* d_partials = nullptr;
     int partial_waves = 0;
     unsigned* d_conf = nullptr;    // NPBNN_MAX_WIDTH^2
@@ -206,9 +208,18 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a) {
 }
 
 // waves per block such that the fragment image + per-wave rings fit the CU's LDS
+int max_inner_tiles(const NetMeta& net) {
+    int mti = 1;
+    for (int l = 1; l < net.n_layers; ++l)
+        if (net.L[l].mt > mti) mti = net.L[l].mt;
+    if (net.n_layers == 1) mti = net.L[0].mt;        // the single layer's tiles are also the final tiles
+    return mti;
+}
+
 int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
-    for (int w = kMaxWavesPerBlock; w >= 1; w >>= 1) {
-        const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * kWaveLds;
+    const int top = max_inner_tiles(ctx->net) == 1 ? 16 : 8;     // launch bound of the kernel build in use
+    for (int w = top; w >= 1; w >>= 1) {
+        const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets);
         if (need <= ctx->lds_limit) {
             *lds_bytes = need;
             return w;
@@ -219,17 +230,23 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
 
 typedef void (*eval_fn_t)(EvalParams);
 
-eval_fn_t pick_kernel(int mt0) {
+template <int MTI>
+eval_fn_t pick_kernel_mt0(int mt0) {
     switch (mt0) {
-        case 1: return eval_kernel<1>;
-        case 2: return eval_kernel<2>;
-        case 3: return eval_kernel<3>;
-        case 4: return eval_kernel<4>;
-        case 5: return eval_kernel<5>;
-        case 6: return eval_kernel<6>;
-        case 7: return eval_kernel<7>;
-        default: return eval_kernel<8>;
+        case 1: return eval_kernel<1, MTI>;
+        case 2: return eval_kernel<2, MTI>;
+        case 3: return eval_kernel<3, MTI>;
+        case 4: return eval_kernel<4, MTI>;
+        case 5: return eval_kernel<5, MTI>;
+        case 6: return eval_kernel<6, MTI>;
+        case 7: return eval_kernel<7, MTI>;
+        default: return eval_kernel<8, MTI>;
     }
+}
+
+// MTI = 1 when every layer after the first (and the output) has <= 16 nodes, else the general MTI = 8 build
+eval_fn_t pick_kernel(const NetMeta& net) {
+    return max_inner_tiles(net) == 1 ? pick_kernel_mt0<1>(net.L[0].mt) : pick_kernel_mt0<8>(net.L[0].mt);
 }
 
 struct LaunchPlan {
@@ -245,7 +262,7 @@ int plan_launch(npbnn_ctx* ctx, const Dataset& d, LaunchPlan* lp) {
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
-    lp->fn = pick_kernel(ctx->mt0_template);
+    lp->fn = pick_kernel(ctx->net);
     lp->wpb = wpb;
     lp->lds = lds;
     int grid = (d.n_tiles + wpb - 1) / wpb;
@@ -283,8 +300,7 @@ int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const 
     if (act_prm)
         for (int l = 0; l + 1 < ctx->net.n_layers; ++l) ctx->net.act_prm[l] = (float)act_prm[l];
     const int total = pack_item_count(ctx->net, true);
-    const int blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_wraw, d_co,
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wraw, d_co,
                        ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
     HIP_TRY(ctx, hipGetLastError());
     return NPBNN_OK;
@@ -378,6 +394,7 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->d_wraw) (void)hipFree(c->d_wraw);
     if (c->d_colov) (void)hipFree(c->d_colov);
     if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_w2img) (void)hipFree(c->d_w2img);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_conf) (void)hipFree(c->d_conf);
     if (c->d_out) (void)hipFree(c->d_out);
@@ -475,6 +492,7 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     if (ctx->d_wraw) { (void)hipFree(ctx->d_wraw); ctx->d_wraw = nullptr; }
     if (ctx->d_colov) { (void)hipFree(ctx->d_colov); ctx->d_colov = nullptr; }
     if (ctx->d_image) { (void)hipFree(ctx->d_image); ctx->d_image = nullptr; }
+    if (ctx->d_w2img) { (void)hipFree(ctx->d_w2img); ctx->d_w2img = nullptr; }
     if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
     if (ctx->d_wcur) { (void)hipFree(ctx->d_wcur); ctx->d_wcur = nullptr; }
     if (ctx->d_wprop) { (void)hipFree(ctx->d_wprop); ctx->d_wprop = nullptr; }
@@ -483,6 +501,26 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)ctx->net.image_floats * sizeof(float)));
     HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)ctx->net.image_floats * sizeof(float)));
+    {   // where each packed weight lives in the image (bias column -> bias slot, else its MFMA fragment slot)
+        std::vector<int> map((size_t)ctx->n_weights);
+        for (int l = 0; l < ctx->net.n_layers; ++l) {
+            const LayerMeta& L = ctx->net.L[l];
+            const int ld = L.in_dim + L.has_bias;
+            for (int o = 0; o < L.out_dim; ++o)
+                for (int j = 0; j < ld; ++j) {
+                    int pos;
+                    if (L.has_bias && j == 0) pos = L.bias_off + o;
+                    else {
+                        const int c = j - L.has_bias;
+                        const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4, mt = o / 16, u = o % 16;
+                        pos = L.frag_off + ((kt * L.mt + mt) * 64 + kq * 16 + u) * 4 + sidx;
+                    }
+                    map[(size_t)L.w_off + (size_t)o * ld + j] = pos;
+                }
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_w2img, map.size() * sizeof(int)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_w2img, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_w, ((size_t)ctx->n_weights + arch->in_dim) * sizeof(double)));
     size_t lds = 0;
     if (pick_waves_per_block(ctx, &lds) == 0)
@@ -651,9 +689,8 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     init.t = 0;
     init.n_accepted = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chain, &init, sizeof(ChainDev), hipMemcpyHostToDevice, st));
-    // full image once (class weights, biases); the step kernel re-packs fragments + biases per proposal
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
-    {
+    {   // full image once (class weights, biases, fragments); the step kernel then patches single entries
         const int total = pack_item_count(ctx->net, true);
         hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ctx->d_wcur, (const double*)nullptr,
                            ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
@@ -673,6 +710,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.out_lp = ctx->d_lpp;
     c.partials = ctx->d_partials;
     c.image = ctx->d_image;
+    c.w2img = ctx->d_w2img;
     c.K = K;
     c.M = M;
     c.n_weights = ctx->n_weights;

@@ -1,7 +1,8 @@
 // Device code of the npBNN hot path for gfx950 (MI355X, CDNA4).
 //
 // One evaluation = one streaming pass over the resident feature matrix X:
-//   pack_weights_kernel : float64 packed weights -> float32 MFMA "fragment image" (+ padded biases)
+//   pack_weights_kernel : float64 packed weights -> float32 MFMA "fragment image" (+ padded biases); in the
+//                         device-resident chain the image is instead patched entry by entry (chain_step_kernel)
 //   eval_kernel<MT0>    : fused forward pass of the whole MLP + likelihood terms (+ confusion counts,
 //                         + optional prediction output); per-wave float64 partial sums
 //   finalize_kernel     : fixed-order float64 reduction of the partials -> log-likelihood, sigma, moments
@@ -33,11 +34,12 @@ namespace npbnn {
 
 constexpr int kMaxLayers = NPBNN_MAX_LAYERS;
 constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
-constexpr int kRing = 6;                       // X ring slots (1 KiB each) per wave
-constexpr int kMaxWavesPerBlock = 8;
+constexpr int kRing = 4;                       // X ring slots (1 KiB each) per wave (power of two)
+constexpr int kMaxWavesPerBlock = 16;
 constexpr int kAuxSlots = 4;                   // per-wave row-aux buffers (labels / weights / targets)
-constexpr int kAuxBytes = 64 + 64 + 1024;      // labels, instance weights, 16x16 targets
-constexpr int kWaveLds = kRing * 1024 + kAuxSlots * kAuxBytes;
+// per-wave aux slot: labels (64 B) + instance weights (64 B) + 16 x k targets; sized per network
+__host__ __device__ inline int aux_bytes(int k_targets) { return 128 + 64 * k_targets; }
+__host__ __device__ inline int wave_lds_bytes(int k_targets) { return kRing * 1024 + kAuxSlots * aux_bytes(k_targets); }
 constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,6 +58,7 @@ struct NetMeta {
     int image_floats;   // total floats of the image (multiple of 256)
     int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats)
     int act_kind, out_kind, lik_kind, n_out, k_targets;
+    int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
 };
@@ -65,7 +68,7 @@ struct EvalParams {
     const int* labels;        // [n_tiles*16], -1 on padding rows
     const float* targets;     // [n_tiles*16][k] (k = k_targets), 0 on padding rows
     const float* inst_w;      // [n_tiles*16] or nullptr
-    const float* image;       // fragment image in global memory
+    const float* image;       // float32 fragment image of the weights (global), DMA-copied into LDS
     double* partials;         // [n_waves][kPartialStride]
     unsigned* confusion;      // [n_out*n_out] or nullptr
     float* y_out;             // [n_rows][n_out] or nullptr
@@ -166,20 +169,23 @@ __device__ __forceinline__ float act_apply(float z, int kind, float prm) {
     }
 }
 
-template <int KIND>
-__device__ __forceinline__ void act_tiles(f32x4 (&h)[kMaxMT], float prm) {
+template <int KIND, int HT>
+__device__ __forceinline__ void act_tiles(f32x4 (&h)[HT], int live, float prm) {
 #pragma unroll
-    for (int mt = 0; mt < kMaxMT; ++mt)
+    for (int mt = 0; mt < HT; ++mt)
+        if (mt < live)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h[mt][i] = act_apply(h[mt][i], KIND, prm);
+            for (int i = 0; i < 4; ++i) h[mt][i] = act_apply(h[mt][i], KIND, prm);
 }
 
-__device__ __forceinline__ void act_all(f32x4 (&h)[kMaxMT], int kind, float prm) {   // wave-uniform kind
+// activation on the first `live` tiles only (wave-uniform kind and count)
+template <int HT>
+__device__ __forceinline__ void act_live(f32x4 (&h)[HT], int live, int kind, float prm) {
     switch (kind) {
-        case NPBNN_ACT_RELU: act_tiles<NPBNN_ACT_RELU>(h, prm); break;
-        case NPBNN_ACT_LEAKY: act_tiles<NPBNN_ACT_LEAKY>(h, prm); break;
-        case NPBNN_ACT_SWISH: act_tiles<NPBNN_ACT_SWISH>(h, prm); break;
-        default: act_tiles<NPBNN_ACT_TANH>(h, prm); break;
+        case NPBNN_ACT_RELU: act_tiles<NPBNN_ACT_RELU>(h, live, prm); break;
+        case NPBNN_ACT_LEAKY: act_tiles<NPBNN_ACT_LEAKY>(h, live, prm); break;
+        case NPBNN_ACT_SWISH: act_tiles<NPBNN_ACT_SWISH>(h, live, prm); break;
+        default: act_tiles<NPBNN_ACT_TANH>(h, live, prm); break;
     }
 }
 
@@ -196,17 +202,13 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 
 #define NPBNN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-__device__ __forceinline__ void wait_younger(int younger) {   // wave-uniform argument
-    switch (younger) {
-        case 0: NPBNN_WAIT_VMCNT(0); break;
-        case 1: NPBNN_WAIT_VMCNT(1); break;
-        case 2: NPBNN_WAIT_VMCNT(2); break;
-        case 3: NPBNN_WAIT_VMCNT(3); break;
-        case 4: NPBNN_WAIT_VMCNT(4); break;
-        default: NPBNN_WAIT_VMCNT(5); break;
-    }
+__device__ __forceinline__ void wait_younger(int younger) {   // wave-uniform argument; tail / shallow-ring path only
+    if (younger >= 3) NPBNN_WAIT_VMCNT(3);
+    else if (younger == 2) NPBNN_WAIT_VMCNT(2);
+    else if (younger == 1) NPBNN_WAIT_VMCNT(1);
+    else NPBNN_WAIT_VMCNT(0);
 }
-static_assert(kRing - 1 <= 5, "wait_younger covers at most 5 pieces in flight");
+static_assert(kRing == 4, "the steady-state wait assumes 3 pieces in flight");
 
 typedef __attribute__((address_space(1))) const void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
@@ -220,9 +222,13 @@ __device__ __forceinline__ void dma4(const void* g, char* l) {
 
 // ------------------------------------------------------------------------------------------------
 // fused forward + likelihood
+//   MT0 : 16-unit tiles of layer 0's output (accumulators of the streamed GEMM)
+//   MTI : max 16-unit tiles of any later layer's output (1 covers every net whose hidden layers after the first
+//         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
 // ------------------------------------------------------------------------------------------------
-template <int MT0>
-__global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams p) {
+template <int MT0, int MTI>
+__global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalParams p) {
+    constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const img = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x;
@@ -230,112 +236,133 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const NetMeta& net = p.net;
-    const int kWavesPerBlock = blockDim.x >> 6;
-    char* const ring = smem + (size_t)net.image_floats * 4 + (size_t)wave * kWaveLds;
+    const int wpb = blockDim.x >> 6;
+    const int k_targets = net.k_targets;
+    const int aux_sz = aux_bytes(k_targets);
+    char* const ring = smem + (size_t)net.image_floats * 4 + (size_t)wave * wave_lds_bytes(k_targets);
     char* const aux = ring + kRing * 1024;
 
-    // ---- stage the fragment image into LDS (lane-linear DMA copy), all waves share it ----
+    // ---- stage the fragment image into LDS: lane-linear DMA copy shared by the workgroup ----
     {
         const int n_pieces = net.image_floats >> 8;   // 1-KiB pieces
-        for (int i = wave; i < n_pieces; i += kWavesPerBlock)
-            dma16(p.image + (size_t)i * 256 + lane * 4, smem + (size_t)i * 1024);
+        for (int i = wave; i < n_pieces; i += wpb) dma16(p.image + (size_t)i * 256 + lane * 4, smem + (size_t)i * 1024);
     }
 
-    // ---- tile schedule: wave gw takes tiles gw, gw+stride, ... ----
+    // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
+    //      tile counts of the waves (and SIMDs) of one CU differ by at most one ----
     const int KT0 = net.L[0].kt;
-    const int stride = gridDim.x * kWavesPerBlock;
-    const int gw = blockIdx.x * kWavesPerBlock + wave;
-    const int my_tiles = gw < p.n_tiles ? (p.n_tiles - gw + stride - 1) / stride : 0;
+    const int G = gridDim.x;
+    const int first_tile = blockIdx.x + G * wave;
+    const int stride = G * wpb;
+    const int my_tiles = first_tile < p.n_tiles ? (p.n_tiles - first_tile + stride - 1) / stride : 0;
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
     int D = kRing - 1;                                  // prefetch distance in pieces
     if (D > 2 * KT0) D = 2 * KT0;                       // at most 3 tiles in flight (aux slots)
-    const size_t row_bytes_f = (size_t)p.Fp;
-    const int kt_targets = net.k_targets;
+    const bool full_depth = (D == kRing - 1);
 
-    // prefetch cursor
-    int pf_q = 0, pf_kt = 0, pf_tile = gw, pf_seq = 0;
-    auto issue_next = [&]() {
-        if (pf_kt == 0) {   // row-aux data of the tile travels ahead of its first X piece
-            char* a = aux + (pf_seq & (kAuxSlots - 1)) * kAuxBytes;
-            const size_t r0 = (size_t)pf_tile * 16;
-            if (lane < 16) {
-                if (p.labels) dma4(p.labels + r0 + lane, a);
-                if (p.inst_w) dma4(p.inst_w + r0 + lane, a + 64);
-            }
-            if (p.targets) {
-                const int total = 16 * kt_targets;       // contiguous floats of this tile's targets
-                for (int e = 0; e < total; e += 64) {
-                    int idx = e + lane;
-                    if (idx >= total) idx = total - 1;  // duplicate the last element, never read
-                    dma4(p.targets + r0 * kt_targets + idx, a + 128 + e * 4);
-                }
+    // prefetch cursor: a per-lane running source pointer and a scalar ring offset
+    const float* pf_ptr = p.X + ((size_t)first_tile * 16 + n) * (size_t)p.Fp + 4 * kq;
+    const size_t tile_jump = (size_t)stride * 16 * (size_t)p.Fp - (size_t)KT0 * 16;
+    int pf_q = 0, pf_kt = 0, pf_tile = first_tile, pf_seq = 0, pf_slot = 0;
+    auto issue_aux = [&]() {   // row-aux data of a tile travels ahead of its first X piece
+        char* a = aux + (pf_seq & (kAuxSlots - 1)) * aux_sz;
+        const size_t r0 = (size_t)pf_tile * 16;
+        if (lane < 16) {
+            if (p.labels) dma4(p.labels + r0 + lane, a);
+            if (p.inst_w) dma4(p.inst_w + r0 + lane, a + 64);
+        }
+        if (p.targets) {
+            const int total = 16 * k_targets;           // contiguous floats of this tile's targets
+            for (int e = 0; e < total; e += 64) {
+                int idx = e + lane;
+                if (idx >= total) idx = total - 1;      // duplicate the last element, never read
+                dma4(p.targets + r0 * k_targets + idx, a + 128 + e * 4);
             }
         }
-        dma16(p.X + ((size_t)pf_tile * 16 + n) * row_bytes_f + 16 * pf_kt + 4 * kq, ring + (pf_q % kRing) * 1024);
+    };
+    auto issue_next = [&]() {
+        if (pf_kt == 0) issue_aux();
+        dma16(pf_ptr, ring + pf_slot);
+        pf_ptr += 16;
+        pf_slot = (pf_slot + 1024) & (kRing * 1024 - 1);
         ++pf_q;
-        if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; }
+        if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
     for (int i = 0; i < D && pf_q < Q; ++i) issue_next();
 
-    // fragment image must have landed for every wave before anyone reads it
-    if (Q > 0) {
-        // everything issued after the image copy may stay in flight only if counted; be simple here
-        NPBNN_WAIT_VMCNT(0);
-    } else {
-        NPBNN_WAIT_VMCNT(0);
-    }
+    // the image (issued first) has landed once at most 3 of the >= 3 operations issued after it are still in
+    // flight; a wave with fewer pieces simply drains.  Every wave then meets at the barrier before anyone reads the image.
+    if (pf_q >= 3) NPBNN_WAIT_VMCNT(3);
+    else NPBNN_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
 
     double ll_acc = 0.0;
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
 
-    const float* frag0 = img + net.L[0].frag_off;
-    const float* bias0 = img + net.L[0].bias_off;
-    int q = 0;
-    int tile = gw;
+    const float* const frag0 = img + net.L[0].frag_off + lane * 4;
+    const float* const bias0 = img + net.L[0].bias_off + 4 * kq;
+    const int n_layers = net.n_layers;
+    const int C = net.n_out;
+    const int MTL = net.L[n_layers - 1].mt;
+    const int lik_kind = net.lik_kind;
+    const bool need_softmax = (lik_kind == NPBNN_LIK_CATEGORICAL) || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
+    int q = 0, cs_slot = 0;
+    int tile = first_tile;
     for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
         // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring ----------------
         f32x4 acc0[MT0];
 #pragma unroll
-        for (int mt = 0; mt < MT0; ++mt)
-            acc0[mt] = *reinterpret_cast<const f32x4*>(bias0 + 16 * mt + 4 * kq);
-        for (int kt = 0; kt < KT0; ++kt, ++q) {
-            if (pf_q < Q) issue_next();                 // targets the slot consumed one piece ago
-            wait_younger(pf_q - q - 1);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(ring + (q % kRing) * 1024 + lane * 16);
+        for (int mt = 0; mt < MT0; ++mt) acc0[mt] = *reinterpret_cast<const f32x4*>(bias0 + 16 * mt);
+        const float* fr = frag0;
+        auto consume = [&]() {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);
+            cs_slot = (cs_slot + 1024) & (kRing * 1024 - 1);
             f32x4 a[MT0];
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt)
-                a[mt] = *reinterpret_cast<const f32x4*>(frag0 + ((size_t)(kt * MT0 + mt) * 64 + lane) * 4);
+            for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
+            fr += MT0 * 256;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int mt = 0; mt < MT0; ++mt)
                     acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[mt], 0, 0, 0);
+        };
+        if (full_depth && pf_q + KT0 <= Q) {
+            // steady state: every piece consumed is replaced by one issued, exactly 3 younger pieces in flight
+            for (int kt = 0; kt < KT0; ++kt) {
+                issue_next();                           // targets the slot consumed one piece ago
+                NPBNN_WAIT_VMCNT(3);
+                consume();
+            }
+            q += KT0;
+        } else {
+            for (int kt = 0; kt < KT0; ++kt, ++q) {
+                if (pf_q < Q) issue_next();
+                wait_younger(pf_q - q - 1);
+                consume();
+            }
         }
 
         // ---------------- layers 1..L-1 chained through the accumulators ----------------
-        f32x4 h[kMaxMT];
+        f32x4 h[HT];
 #pragma unroll
-        for (int mt = 0; mt < kMaxMT; ++mt) h[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mt = 0; mt < MT0; ++mt) h[mt] = acc0[mt];
-        for (int l = 1; l < net.n_layers; ++l) {
-            const float prm = net.act_prm[l - 1];
-            act_all(h, net.act_kind, prm);
+        for (int mt = 0; mt < HT; ++mt) h[mt] = mt < MT0 ? acc0[mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int l = 1; l < n_layers; ++l) {
             const LayerMeta& L = net.L[l];
-            const float* frag = img + L.frag_off;
-            const float* bias = img + L.bias_off;
-            f32x4 acc[kMaxMT];
+            const int lkt = L.kt, lmt = L.mt;
+            act_live(h, lkt, net.act_kind, net.act_prm[l - 1]);
+            const float* frag = img + L.frag_off + lane * 4;
+            const float* bias = img + L.bias_off + 4 * kq;
+            f32x4 acc[MTI];
 #pragma unroll
-            for (int mt = 0; mt < kMaxMT; ++mt) {
+            for (int mt = 0; mt < MTI; ++mt) {
                 acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (mt < L.mt) {
-                    acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
+                if (mt < lmt) {
+                    acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
 #pragma unroll
-                    for (int ct = 0; ct < kMaxMT; ++ct) {
-                        if (ct < L.kt) {
-                            const f32x4 a = *reinterpret_cast<const f32x4*>(frag + ((size_t)(ct * L.mt + mt) * 64 + lane) * 4);
+                    for (int ct = 0; ct < HT; ++ct) {
+                        if (ct < lkt) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * lmt + mt) * 256);
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
                                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], h[ct][s], acc[mt], 0, 0, 0);
@@ -344,26 +371,23 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
                 }
             }
 #pragma unroll
-            for (int mt = 0; mt < kMaxMT; ++mt) h[mt] = acc[mt];
+            for (int mt = 0; mt < MTI; ++mt) h[mt] = acc[mt];
         }
-        // h[mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n
+        if (net.final_act) act_live(h, MTL, net.act_kind, net.act_prm[n_layers - 1]);
+        // h[mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
 
         // ---------------- epilogue ----------------
-        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * kAuxBytes;
+        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
         const long long row = (long long)tile * 16 + n;
         const bool row_ok = row < p.n_rows;
-        const int C = net.n_out;
-        const int MTL = net.L[net.n_layers - 1].mt;
 
         float lse = 0.f;
-        const bool need_softmax = (net.lik_kind == NPBNN_LIK_CATEGORICAL) ||
-                                  (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
         int best_i = 0;
         if (need_softmax) {
             float m = -INFINITY, bv = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
-            for (int mt = 0; mt < kMaxMT; ++mt)
+            for (int mt = 0; mt < MTI; ++mt)
                 if (mt < MTL)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -377,7 +401,7 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
             m = fmaxf(m, __shfl_xor(m, 32));
             float se = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < kMaxMT; ++mt)
+            for (int mt = 0; mt < MTI; ++mt)
                 if (mt < MTL)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -396,12 +420,12 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
             }
         }
 
-        if (net.lik_kind == NPBNN_LIK_CATEGORICAL) {
+        if (lik_kind == NPBNN_LIK_CATEGORICAL) {
             const int lab = *reinterpret_cast<const int*>(a_slot + n * 4);
             float zl = 0.f;
             bool own = false;
 #pragma unroll
-            for (int mt = 0; mt < kMaxMT; ++mt)
+            for (int mt = 0; mt < MTI; ++mt)
                 if (mt < MTL)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -417,13 +441,13 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
                 if (p.confusion && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
             }
             ll_acc += (double)term;
-        } else if (net.lik_kind == NPBNN_LIK_GAUSS) {
+        } else if (lik_kind == NPBNN_LIK_GAUSS) {
             const float* tg = reinterpret_cast<const float*>(a_slot + 128);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int o = 4 * kq + i;
-                if (o < kt_targets && row_ok) {
-                    const float r = tg[n * kt_targets + o] - h[0][i];
+                if (o < k_targets && row_ok) {
+                    const float r = tg[n * k_targets + o] - h[0][i];
                     s1[i] += (double)r;
                     s2[i] += (double)r * (double)r;
                 }
@@ -432,7 +456,7 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
 
         if (p.predict_mode && row_ok) {
 #pragma unroll
-            for (int mt = 0; mt < kMaxMT; ++mt)
+            for (int mt = 0; mt < MTI; ++mt)
                 if (mt < MTL)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -450,12 +474,12 @@ __global__ void __launch_bounds__(kMaxWavesPerBlock * 64) eval_kernel(EvalParams
     }
 
     // ---------------- per-wave partials (float64, fixed order) ----------------
-    if (p.partials && gw < stride) {
-        double* out = p.partials + (size_t)gw * kPartialStride;
+    if (p.partials) {
+        double* out = p.partials + (size_t)(blockIdx.x * wpb + wave) * kPartialStride;
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) ll_acc += shfl_xor_f64(ll_acc, sh);
         if (lane == 0) out[0] = ll_acc;
-        if (net.lik_kind == NPBNN_LIK_GAUSS) {
+        if (lik_kind == NPBNN_LIK_GAUSS) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -490,13 +514,20 @@ struct FinalizeParams {
 // Sum value v of every wave's partial record: wave (threadIdx>>6) of the block takes values v = wave, wave+nw, ...;
 // lane l adds records l, l+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_waves, int nvals, double* tot /*LDS*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int v = wave; v < nvals; v += nw) {
+    __shared__ double part[kPartialStride][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;   // nw <= 16
+    for (int v = 0; v < nvals; ++v) {
         double s = 0.0;
-        for (int w = lane; w < n_waves; w += 64) s += partials[(size_t)w * kPartialStride + v];
+        for (int w = threadIdx.x; w < n_waves; w += blockDim.x) s += partials[(size_t)w * kPartialStride + v];
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
-        if (lane == 0) tot[v] = s;
+        if (lane == 0) part[v][wave] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nvals) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += part[threadIdx.x][w];
+        tot[threadIdx.x] = s;
     }
     __syncthreads();
 }
@@ -547,7 +578,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams f) {
 //      on accept commit the changed weights into W_cur, else roll W_prop back;
 //   2. propose iteration t: W_prop[idx] = reflect(W_cur[idx] + delta) * mask   (BNN_mcmc.py:64-67, BNN_env.py:461-462);
 //   3. logPrior' = sum_l sum log p(W_prop_l; 0, scale_l)                       (npBNN.calc_prior, BNN_env.py:180-194);
-//   4. repack the float32 fragment image of W_prop for the eval kernel.
+//   4. patch the float32 fragment image at the touched entries (w2img map) for the eval kernel.
 // ------------------------------------------------------------------------------------------------
 struct ChainDev {          // device-resident chain state
     double logLik, logPrior;
@@ -571,7 +602,8 @@ struct ChainParams {
     double* out_ll;            // [K] proposed logLik
     double* out_lp;            // [K] proposed logPrior
     const double* partials;
-    float* image;
+    float* image;              // fragment image read by the eval kernel
+    const int* w2img;          // packed-weight index -> float index in the image
     int K, M, n_weights, n_waves;
     int prior_kind;
     double prior_scale[kMaxLayers];
@@ -601,8 +633,8 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
     if (t > 0) {
         const int nvals = (c.net.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
         reduce_partials(c.partials, c.n_waves, nvals, tot);
+        __shared__ npbnn_eval_out o;
         if (tid == 0) {
-            npbnn_eval_out o;
             loglik_from_totals(tot, c.net.lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
             const double lp = st->cand_logPrior;
             const double h = c.hastings ? c.hastings[t - 1] : 0.0;
@@ -627,7 +659,11 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
             const int i = c.idx[(size_t)(t - 1) * c.M + j];
             if (i >= 0) {
                 if (acc) c.w_cur[i] = c.w_prop[i];
-                else c.w_prop[i] = c.w_cur[i];
+                else {
+                    const double v = c.w_cur[i];
+                    c.w_prop[i] = v;
+                    c.image[c.w2img[i]] = (float)v;      // roll the rejected entry back in the image too
+                }
             }
         }
         __syncthreads();
@@ -643,6 +679,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
             if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
             if (c.mask) v *= c.mask[i];
             c.w_prop[i] = v;
+            c.image[c.w2img[i]] = (float)v;
         }
     }
     __syncthreads();
@@ -654,7 +691,15 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
             const LayerMeta& L = c.net.L[l];
             const int n = L.out_dim * (L.in_dim + L.has_bias);
             const double sc = c.prior_scale[l];
-            for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_prop[L.w_off + i], sc);
+            if (c.prior_kind == NPBNN_PRIOR_NORMAL) {
+                const double inv = 1.0 / sc;
+                double q = 0.0;
+                for (int i = tid; i < n; i += blockDim.x) { const double z = c.w_prop[L.w_off + i] * inv; q += z * z; }
+                lp += -0.5 * q;
+                if (tid == 0) lp -= (double)n * (log(sc) + 0.9189385332046727418);
+            } else {
+                for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_prop[L.w_off + i], sc);
+            }
         }
     }
 #pragma unroll
@@ -667,8 +712,6 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
         st->cand_logPrior = s;
         st->t = t + 1;
     }
-    const int items = pack_item_count(c.net, false);
-    for (int g = tid; g < items; g += blockDim.x) pack_item(g, c.w_prop, nullptr, nullptr, c.image, c.net, false);
 }
 
 }  // namespace npbnn

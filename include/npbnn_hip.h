@@ -40,7 +40,8 @@ enum {
     NPBNN_E_STATE = -2,     /* call order (e.g. eval before set_arch) */
     NPBNN_E_HIP = -3,       /* a HIP runtime call failed              */
     NPBNN_E_NOMEM = -4,
-    NPBNN_E_COMM = -5       /* RCCL failure                           */
+    NPBNN_E_COMM = -5,      /* RCCL failure                           */
+    NPBNN_E_RANGE = -6      /* value outside the fp16-split range      */
 };
 
 /* activation kinds — ActFun.activate selection, np_bnn/BNN_lib.py:50-87 */
@@ -86,6 +87,7 @@ typedef struct {
     int32_t out_kind;
     int32_t lik_kind;
     int32_t n_targets;      /* k target columns (Gaussian / count likelihoods), else 0 */
+    int32_t final_act;      /* 1: the activation also follows the last layer (RunHiddenLayer on its own, BNN_lib.py:190-191) */
 } npbnn_arch;
 
 /* Result of one evaluation.  sum_r / sum_r2 are the per-column residual moments
@@ -117,6 +119,21 @@ int npbnn_set_targets_f64(npbnn_ctx* ctx, const double* Y, int64_t n_rows, int32
 int npbnn_set_row_weights(npbnn_ctx* ctx, const double* instance_w, int64_t n_rows,
                           const double* class_w, int32_t n_classes);
 int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch);
+
+/* ---- options / introspection.
+ * NPBNN_OPT_L0_PRECISION selects how the first layer's product X.W0^T (MatrixMultiplicationD, BNN_lib.py:154-162; float64
+ * np.dot in the reference) is computed:
+ *   NPBNN_L0_F32   float32 matrix cores (v_mfma_f32_16x16x4_f32), bit-exact float32 fused-multiply-add chain;
+ *   NPBNN_L0_F16   "fp16-split": every x and w is held as a pair of fp16 numbers (high + low part, ~22 significant bits,
+ *                  features scaled per column by a power of two), three fp16 matrix-core products accumulated in float32;
+ *                  same HBM bytes as float32, 5x less matrix-core time;
+ *   NPBNN_L0_AUTO  fp16-split whenever the data and weights are representable (finite, in range), else float32; an
+ *                  evaluation whose weights leave the fp16 range is transparently repeated in float32 (default). */
+enum { NPBNN_OPT_L0_PRECISION = 1 };
+enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
+enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3 };
+int npbnn_set_option(npbnn_ctx* ctx, int option, int value);
+int npbnn_get_info(npbnn_ctx* ctx, int what, int* out);
 
 /* ---- one proposal evaluation: replaces the per-layer RunHiddenLayer loop + output function +
  * likelihood of MCMC.mh_step (BNN_env.py:449-473, 485-491) and of MCMC.__init__ (:299-319).
@@ -161,6 +178,7 @@ typedef struct {
     double sigma[NPBNN_MAX_TARGETS];           /* on entry: sigma for proposals when sigma_given */
     double cur_loglik, cur_logprior;           /* state of the chain on entry (MCMC._logLik / _logPrior) */
     double cur_sigma[NPBNN_MAX_TARGETS];       /* npBNN._error_prm on entry */
+    int32_t force_f32;                         /* 1: run this batch on the float32 layer-0 path (after NPBNN_E_RANGE) */
 } npbnn_chain_cfg;
 
 typedef struct {

@@ -19,6 +19,10 @@ OUT_SOFTMAX, OUT_IDENTITY, OUT_SOFTPLUS_HALF = 0, 1, 2
  LIK_NEGBIN_BASE10, LIK_NONE) = range(8)
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE = 0, 1, 2, 3
 TRAIN, TEST = 0, 1
+OPT_L0_PRECISION = 1
+L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
+INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU = 1, 2, 3
+E_RANGE = -6
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnpbnn_hip.so")
@@ -38,7 +42,7 @@ class Arch(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("in_dim", C.c_int32),
                 ("out_dim", C.c_int32 * MAX_LAYERS), ("has_bias", C.c_int32 * MAX_LAYERS),
                 ("act_kind", C.c_int32), ("out_kind", C.c_int32), ("lik_kind", C.c_int32),
-                ("n_targets", C.c_int32)]
+                ("n_targets", C.c_int32), ("final_act", C.c_int32)]
 
 
 class EvalOut(C.Structure):
@@ -51,7 +55,7 @@ class ChainCfg(C.Structure):
     _fields_ = [("prior_kind", C.c_int32), ("prior_scale", C.c_double * MAX_LAYERS), ("w_bound", C.c_double),
                 ("temperature", C.c_double), ("lik_temp", C.c_double), ("sigma_given", C.c_int32),
                 ("sigma", C.c_double * MAX_TARGETS), ("cur_loglik", C.c_double), ("cur_logprior", C.c_double),
-                ("cur_sigma", C.c_double * MAX_TARGETS)]
+                ("cur_sigma", C.c_double * MAX_TARGETS), ("force_f32", C.c_int32)]
 
 
 class ChainResult(C.Structure):
@@ -75,6 +79,8 @@ SIGNATURES = {
     "npbnn_set_targets_f64": (C.c_int, [_P, _DP, C.c_int64, C.c_int32, C.c_int]),
     "npbnn_set_row_weights": (C.c_int, [_P, _DP, C.c_int64, _DP, C.c_int32]),
     "npbnn_set_arch": (C.c_int, [_P, C.POINTER(Arch)]),
+    "npbnn_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "npbnn_get_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "npbnn_eval": (C.c_int, [_P, _DP, _DP, _DP, C.c_double, _DP, C.c_int, C.POINTER(EvalOut),
                              C.POINTER(C.c_int64)]),
     "npbnn_predict": (C.c_int, [_P, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),

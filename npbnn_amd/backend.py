@@ -40,6 +40,9 @@ class HipContext:
                                           "(there is no CPU fallback)")
         capi.check(self._lib, None, self._lib.npbnn_create(dev % n.value, C.byref(self._ctx)))
         self.device = dev % n.value
+        opt = os.environ.get("NPBNN_L0", "").lower()
+        if opt in ("f32", "f16", "auto"):
+            self.set_l0_precision(opt)
         self.arch = None
         self.n_rows = {}
         self.n_out = None
@@ -58,6 +61,21 @@ class HipContext:
 
     def _chk(self, rc):
         capi.check(self._lib, self._ctx, rc)
+
+    # -- options ----------------------------------------------------------------------
+    def set_l0_precision(self, mode):
+        """'auto' (default): fp16-split first layer when the data allows, else float32; 'f32'; 'f16'."""
+        value = {"auto": capi.L0_AUTO, "f32": capi.L0_F32, "f16": capi.L0_F16}[mode]
+        self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_L0_PRECISION, value))
+
+    def info(self, what):
+        out = C.c_int(0)
+        self._chk(self._lib.npbnn_get_info(self._ctx, what, C.byref(out)))
+        return out.value
+
+    def l0_mode(self):
+        """Layer-0 path of the most recent launch: 'f16-split' or 'f32'."""
+        return "f16-split" if self.info(capi.INFO_L0_F16) else "f32"
 
     # -- resident data ----------------------------------------------------------------
     def set_data(self, X, which=capi.TRAIN):
@@ -89,7 +107,7 @@ class HipContext:
         self._chk(self._lib.npbnn_set_row_weights(self._ctx, capi.dptr(iw), 0 if iw is None else iw.shape[0],
                                                   capi.dptr(cw), 0 if cw is None else cw.shape[0]))
 
-    def set_arch(self, in_dim, out_dims, has_bias, act_kind, out_kind, lik_kind, n_targets=0):
+    def set_arch(self, in_dim, out_dims, has_bias, act_kind, out_kind, lik_kind, n_targets=0, final_activation=False):
         if len(out_dims) > capi.MAX_LAYERS:
             raise capi.NpbnnError(-1, "at most %d layers are supported" % capi.MAX_LAYERS)
         a = capi.Arch()
@@ -99,11 +117,12 @@ class HipContext:
             a.out_dim[i] = int(o)
             a.has_bias[i] = int(bool(b))
         a.act_kind, a.out_kind, a.lik_kind, a.n_targets = int(act_kind), int(out_kind), int(lik_kind), int(n_targets)
+        a.final_act = 1 if final_activation else 0
         self._chk(self._lib.npbnn_set_arch(self._ctx, C.byref(a)))
         self.arch = a
         self.n_out = int(out_dims[-1])
 
-    def set_arch_from_weights(self, weights, in_dim, act_kind, out_kind, lik_kind, n_targets=0):
+    def set_arch_from_weights(self, weights, in_dim, act_kind, out_kind, lik_kind, n_targets=0, final_activation=False):
         """Derive layer sizes and bias flags from the weight shapes: layer l has a
         bias iff its matrix has in_l + 1 columns (reference: BNN_lib.py:157-161)."""
         out_dims, has_bias = [], []
@@ -117,7 +136,7 @@ class HipContext:
             else:
                 raise ValueError("weight matrix with %d columns does not match %d inputs" % (w.shape[1], cur))
             cur = w.shape[0]
-        self.set_arch(in_dim, out_dims, has_bias, act_kind, out_kind, lik_kind, n_targets)
+        self.set_arch(in_dim, out_dims, has_bias, act_kind, out_kind, lik_kind, n_targets, final_activation)
 
     # -- hot path ---------------------------------------------------------------------
     def eval(self, weights, act_prm=None, col_override=None, lik_temp=1.0, sigma=None, which=capi.TRAIN,
@@ -183,9 +202,15 @@ class HipContext:
         acc = np.empty(K, dtype=np.uint8)
         llp, lpp = np.empty(K), np.empty(K)
         res = capi.ChainResult()
-        self._chk(self._lib.npbnn_chain_run(
-            self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(C.POINTER(C.c_int32)),
-            capi.dptr(delta), cnt.ctypes.data_as(C.POINTER(C.c_int32)), capi.dptr(log_u),
-            acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res)))
+        for attempt in (0, 1):
+            cfg.force_f32 = attempt
+            rc = self._lib.npbnn_chain_run(
+                self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                capi.dptr(delta), cnt.ctypes.data_as(C.POINTER(C.c_int32)), capi.dptr(log_u),
+                acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res))
+            if rc == capi.E_RANGE and attempt == 0:
+                continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)
+            self._chk(rc)
+            break
         return w, acc, llp, lpp, dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]),
                                       n_accepted=res.n_accepted)

@@ -28,6 +28,9 @@ struct Dataset {
     int64_t n_rows = 0;
     int n_tiles = 0;
     int F = 0, Fp = 0, k = 0;
+    float* X16 = nullptr;      // fp16-split copy (built lazily on the device), row stride Fp16 floats
+    int Fp16 = 0;
+    int f16_state = 0;         // 0 not built, 1 usable, -1 not representable (inf/NaN or outside the fp16 range)
 };
 
 }  // namespace
@@ -46,6 +49,12 @@ struct npbnn_ctx {
     NetMeta net{};
     int n_weights = 0;
     int mt0_template = 1;
+    int l0_option = 0;             // NPBNN_L0_AUTO / _F32 / _F16
+    float* d_xscale = nullptr;     // per-feature power-of-two scales of the fp16-split path (from the training matrix)
+    float* d_wscale = nullptr;
+    int scale_F = 0;
+    int* d_overflow = nullptr;
+    float* d_w2scale = nullptr;
     // device work buffers
     double* d_wraw = nullptr;      // packed float64 weights
     double* d_colov = nullptr;     // column override (in_dim doubles)
@@ -107,6 +116,7 @@ void free_dataset(Dataset& d) {
     if (d.labels) (void)hipFree(d.labels);
     if (d.targets) (void)hipFree(d.targets);
     if (d.inst_w) (void)hipFree(d.inst_w);
+    if (d.X16) (void)hipFree(d.X16);
     d = Dataset();
 }
 
@@ -120,6 +130,13 @@ int upload_matrix(npbnn_ctx* ctx, const T* X, int64_t n_rows, int32_t F, int whi
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Dataset& d = ctx->ds[which];
     free_dataset(d);
+    if (which == 0) {            // the fp16-split scales come from the training matrix
+        if (ctx->d_xscale) { (void)hipFree(ctx->d_xscale); ctx->d_xscale = nullptr; }
+        if (ctx->d_wscale) { (void)hipFree(ctx->d_wscale); ctx->d_wscale = nullptr; }
+        ctx->scale_F = 0;
+        if (ctx->ds[1].X16) { (void)hipFree(ctx->ds[1].X16); ctx->ds[1].X16 = nullptr; }
+        ctx->ds[1].f16_state = 0;
+    }
     d.n_rows = n_rows;
     d.F = F;
     d.Fp = round_up(F, 16);
@@ -155,7 +172,7 @@ int check_rows(npbnn_ctx* ctx, int which, int64_t n_rows, const char* what) {
     return NPBNN_OK;
 }
 
-int build_net(npbnn_ctx* ctx, const npbnn_arch* a) {
+int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     if (a->n_layers < 1 || a->n_layers > NPBNN_MAX_LAYERS)
         return fail(ctx, NPBNN_E_ARG, "set_arch: n_layers=%d outside 1..%d", a->n_layers, NPBNN_MAX_LAYERS);
     if (a->in_dim < 1) return fail(ctx, NPBNN_E_ARG, "set_arch: in_dim=%d", a->in_dim);
@@ -168,6 +185,8 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a) {
     net.out_kind = a->out_kind;
     net.lik_kind = a->lik_kind;
     net.k_targets = a->n_targets;
+    net.final_act = a->final_act ? 1 : 0;
+    net.l0_f16 = f16 ? 1 : 0;
     int in = a->in_dim, off = 0, woff = 0;
     for (int l = 0; l < a->n_layers; ++l) {
         const int out = a->out_dim[l];
@@ -178,7 +197,7 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a) {
         L.in_dim = in;
         L.out_dim = out;
         L.has_bias = a->has_bias[l] ? 1 : 0;
-        L.kt = (in + 15) / 16;
+        L.kt = (l == 0 && f16) ? 2 * ((in + 31) / 32) : (in + 15) / 16;   // 1-KiB pieces (16 rows x 64 B) per tile
         L.mt = (out + 15) / 16;
         L.frag_off = off;
         off += L.kt * L.mt * 256;
@@ -218,7 +237,7 @@ int max_inner_tiles(const NetMeta& net) {
 
 int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
     const int top = max_inner_tiles(ctx->net) == 1 ? 16 : 8;     // launch bound of the kernel build in use
-    for (int w = top; w >= 1; w >>= 1) {
+    for (int w = top; w >= 1; w -= (w > 8 ? 2 : (w > 1 ? w / 2 : 1))) {
         const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets);
         if (need <= ctx->lds_limit) {
             *lds_bytes = need;
@@ -230,24 +249,84 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
 
 typedef void (*eval_fn_t)(EvalParams);
 
-template <int MTI>
+template <int MTI, bool F16>
 eval_fn_t pick_kernel_mt0(int mt0) {
     switch (mt0) {
-        case 1: return eval_kernel<1, MTI>;
-        case 2: return eval_kernel<2, MTI>;
-        case 3: return eval_kernel<3, MTI>;
-        case 4: return eval_kernel<4, MTI>;
-        case 5: return eval_kernel<5, MTI>;
-        case 6: return eval_kernel<6, MTI>;
-        case 7: return eval_kernel<7, MTI>;
-        default: return eval_kernel<8, MTI>;
+        case 1: return eval_kernel<1, MTI, F16>;
+        case 2: return eval_kernel<2, MTI, F16>;
+        case 3: return eval_kernel<3, MTI, F16>;
+        case 4: return eval_kernel<4, MTI, F16>;
+        case 5: return eval_kernel<5, MTI, F16>;
+        case 6: return eval_kernel<6, MTI, F16>;
+        case 7: return eval_kernel<7, MTI, F16>;
+        default: return eval_kernel<8, MTI, F16>;
     }
 }
 
 // MTI = 1 when every layer after the first (and the output) has <= 16 nodes, else the general MTI = 8 build
 eval_fn_t pick_kernel(const NetMeta& net) {
-    return max_inner_tiles(net) == 1 ? pick_kernel_mt0<1>(net.L[0].mt) : pick_kernel_mt0<8>(net.L[0].mt);
+    const int mt0 = net.L[0].mt;
+    if (max_inner_tiles(net) == 1) return net.l0_f16 ? pick_kernel_mt0<1, true>(mt0) : pick_kernel_mt0<1, false>(mt0);
+    return net.l0_f16 ? pick_kernel_mt0<8, true>(mt0) : pick_kernel_mt0<8, false>(mt0);
 }
+
+// ---- fp16-split data: scales from the training matrix, split copies built on the device ----
+int ensure_scales(npbnn_ctx* ctx) {
+    Dataset& tr = ctx->ds[0];
+    if (!tr.X) return fail(ctx, NPBNN_E_STATE, "the fp16-split path needs the training matrix first");
+    if (ctx->d_xscale && ctx->scale_F == tr.F) return NPBNN_OK;
+    const int Fp16 = round_up(tr.F, 32);
+    unsigned* d_max = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_max, (size_t)Fp16 * sizeof(unsigned)));
+    HIP_TRY(ctx, hipMemsetAsync(d_max, 0, (size_t)Fp16 * sizeof(unsigned), ctx->stream));
+    const int row_blocks = (int)((tr.n_rows + 1023) / 1024);
+    hipLaunchKernelGGL(col_absmax_kernel, dim3((tr.Fp + 255) / 256, row_blocks), dim3(256), 0, ctx->stream, tr.X,
+                       (long long)tr.n_rows, tr.Fp, d_max);
+    if (!ctx->d_xscale) HIP_TRY(ctx, hipMalloc(&ctx->d_xscale, (size_t)Fp16 * sizeof(float)));
+    if (!ctx->d_wscale) HIP_TRY(ctx, hipMalloc(&ctx->d_wscale, (size_t)Fp16 * sizeof(float)));
+    hipLaunchKernelGGL(col_scale_kernel, dim3((Fp16 + 255) / 256), dim3(256), 0, ctx->stream, d_max, Fp16, ctx->d_xscale,
+                       ctx->d_wscale);
+    std::vector<unsigned> h((size_t)Fp16);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_max, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_max);
+    ctx->scale_F = tr.F;
+    tr.f16_state = 0;
+    for (unsigned bits : h) {
+        float m;
+        memcpy(&m, &bits, 4);
+        if (!std::isfinite(m)) tr.f16_state = -1;     // inf / NaN in the data: stay on the exact float32 path
+    }
+    return NPBNN_OK;
+}
+
+// 1 = the set has a usable fp16-split copy, 0 = it cannot be represented (the caller stays on float32)
+int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
+    *usable = 0;
+    int rc = ensure_scales(ctx);
+    if (rc) return rc;
+    if (ctx->ds[0].f16_state < 0) return NPBNN_OK;
+    Dataset& d = ctx->ds[which];
+    if (d.f16_state == 0) {
+        d.Fp16 = round_up(d.F, 32);
+        const size_t n_pad = (size_t)d.n_tiles * 16;
+        if (!d.X16) HIP_TRY(ctx, hipMalloc(&d.X16, n_pad * d.Fp16 * sizeof(float)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), ctx->stream));
+        const long long items = (long long)n_pad * (d.Fp16 / 8);
+        hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, d.X, (long long)n_pad, d.Fp,
+                           d.Fp16, ctx->d_xscale, d.X16, reinterpret_cast<unsigned*>(ctx->d_overflow));
+        unsigned bits = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&bits, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float m;
+        memcpy(&m, &bits, 4);
+        d.f16_state = (std::isfinite(m) && m <= kF16Safe) ? 1 : -1;    // a test set far outside the training range
+    }
+    *usable = d.f16_state > 0 ? 1 : 0;
+    return NPBNN_OK;
+}
+
+int rebuild_net(npbnn_ctx* ctx, bool f16);
 
 struct LaunchPlan {
     eval_fn_t fn;
@@ -256,7 +335,21 @@ struct LaunchPlan {
     int n_waves;
 };
 
-int plan_launch(npbnn_ctx* ctx, const Dataset& d, LaunchPlan* lp) {
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0) {
+    Dataset& d = ctx->ds[which];
+    bool want_f16 = false;
+    if (!force_f32 && ctx->l0_option != NPBNN_L0_F32) {
+        int usable = 0;
+        int rc0 = ensure_x16(ctx, which, &usable);
+        if (rc0) return rc0;
+        if (!usable && ctx->l0_option == NPBNN_L0_F16)
+            return fail(ctx, NPBNN_E_RANGE, "fp16-split layer 0 was requested but the data cannot be represented in it");
+        want_f16 = usable != 0;
+    }
+    if ((ctx->net.l0_f16 != 0) != want_f16) {
+        int rc0 = rebuild_net(ctx, want_f16);
+        if (rc0) return rc0;
+    }
     size_t lds = 0;
     const int wpb = pick_waves_per_block(ctx, &lds);
     if (wpb == 0)
@@ -300,22 +393,24 @@ int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const 
     if (act_prm)
         for (int l = 0; l + 1 < ctx->net.n_layers; ++l) ctx->net.act_prm[l] = (float)act_prm[l];
     const int total = pack_item_count(ctx->net, true);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wraw, d_co,
-                       ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
+                       ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net,
+                       ctx->net.l0_f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
     HIP_TRY(ctx, hipGetLastError());
     return NPBNN_OK;
 }
 
 EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
     EvalParams p{};
-    p.X = d.X;
+    p.X = ctx->net.l0_f16 ? d.X16 : d.X;
     p.labels = d.labels;
     p.targets = d.targets;
     p.inst_w = nullptr;
     p.image = ctx->d_image;
     p.n_rows = d.n_rows;
     p.n_tiles = d.n_tiles;
-    p.Fp = d.Fp;
+    p.Fp = ctx->net.l0_f16 ? d.Fp16 : d.Fp;
     p.net = ctx->net;
     return p;
 }
@@ -328,6 +423,63 @@ int check_dataset_for_lik(npbnn_ctx* ctx, const Dataset& d, int lik) {
     if (lik == NPBNN_LIK_GAUSS) {
         if (!d.targets) return fail(ctx, NPBNN_E_STATE, "Gaussian likelihood needs targets (npbnn_set_targets_f64)");
         if (d.k != ctx->net.k_targets) return fail(ctx, NPBNN_E_ARG, "targets have %d columns, architecture says %d", d.k, ctx->net.k_targets);
+    }
+    return NPBNN_OK;
+}
+
+}  // namespace
+
+namespace {
+int rebuild_net(npbnn_ctx* ctx, bool f16) {
+    int rc = build_net(ctx, &ctx->arch, f16);
+    if (rc) return rc;
+    if (ctx->d_image) { (void)hipFree(ctx->d_image); ctx->d_image = nullptr; }
+    if (ctx->d_w2img) { (void)hipFree(ctx->d_w2img); ctx->d_w2img = nullptr; }
+    if (ctx->d_w2scale) { (void)hipFree(ctx->d_w2scale); ctx->d_w2scale = nullptr; }
+    size_t lds = 0;
+    if (pick_waves_per_block(ctx, &lds) == 0)
+        return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
+                    ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
+    HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)ctx->net.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)ctx->net.image_floats * sizeof(float)));
+    // where each packed weight lives in the image (bias column -> bias slot, else its MFMA fragment slot)
+    std::vector<int> map((size_t)ctx->n_weights);
+    std::vector<float> scale;
+    std::vector<float> wscale;
+    if (f16) {
+        scale.assign((size_t)ctx->n_weights, 1.0f);
+        wscale.resize((size_t)round_up(ctx->arch.in_dim, 32));
+        HIP_TRY(ctx, hipMemcpy(wscale.data(), ctx->d_wscale, wscale.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    for (int l = 0; l < ctx->net.n_layers; ++l) {
+        const LayerMeta& L = ctx->net.L[l];
+        const int ld = L.in_dim + L.has_bias;
+        for (int o = 0; o < L.out_dim; ++o)
+            for (int j = 0; j < ld; ++j) {
+                const size_t wi = (size_t)L.w_off + (size_t)o * ld + j;
+                int pos;
+                if (L.has_bias && j == 0) pos = L.bias_off + o;
+                else {
+                    const int c = j - L.has_bias;
+                    const int mt = o / 16, u = o % 16;
+                    if (l == 0 && f16) {
+                        const int ks = c / 32, kg = (c % 32) / 8, jj = c % 8;
+                        const int half_index = 2 * L.frag_off + ((((ks * L.mt + mt) * 2) * 64) + kg * 16 + u) * 8 + jj;
+                        pos = (int)(0x80000000u | (unsigned)half_index);
+                        scale[wi] = wscale[(size_t)c];
+                    } else {
+                        const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4;
+                        pos = L.frag_off + ((kt * L.mt + mt) * 64 + kq * 16 + u) * 4 + sidx;
+                    }
+                }
+                map[wi] = pos;
+            }
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_w2img, map.size() * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_w2img, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (f16) {
+        HIP_TRY(ctx, hipMalloc(&ctx->d_w2scale, scale.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_w2scale, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     return NPBNN_OK;
 }
@@ -372,6 +524,7 @@ int npbnn_create(int device_id, npbnn_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&c->d_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&c->d_out, sizeof(npbnn_eval_out));
+    if (e == hipSuccess) e = hipMalloc(&c->d_overflow, sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_out, sizeof(npbnn_eval_out));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
     if (e == hipSuccess) e = hipEventCreate(&c->ev[0]);
@@ -393,6 +546,10 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->d_classw) (void)hipFree(c->d_classw);
     if (c->d_wraw) (void)hipFree(c->d_wraw);
     if (c->d_colov) (void)hipFree(c->d_colov);
+    if (c->d_xscale) (void)hipFree(c->d_xscale);
+    if (c->d_wscale) (void)hipFree(c->d_wscale);
+    if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_w2scale) (void)hipFree(c->d_w2scale);
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_w2img) (void)hipFree(c->d_w2img);
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -485,66 +642,51 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
     if (!arch) return fail(ctx, NPBNN_E_ARG, "null arch");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = build_net(ctx, arch);
-    if (rc) return rc;
-    ctx->arch = *arch;
     ctx->arch_set = false;
+    const npbnn_arch previous = ctx->arch;
+    ctx->arch = *arch;
+    int rc = rebuild_net(ctx, false);            // float32 layout first; plan_launch switches to fp16-split when it applies
+    if (rc) {
+        ctx->arch = previous;
+        return rc;
+    }
     if (ctx->d_wraw) { (void)hipFree(ctx->d_wraw); ctx->d_wraw = nullptr; }
     if (ctx->d_colov) { (void)hipFree(ctx->d_colov); ctx->d_colov = nullptr; }
-    if (ctx->d_image) { (void)hipFree(ctx->d_image); ctx->d_image = nullptr; }
-    if (ctx->d_w2img) { (void)hipFree(ctx->d_w2img); ctx->d_w2img = nullptr; }
     if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
     if (ctx->d_wcur) { (void)hipFree(ctx->d_wcur); ctx->d_wcur = nullptr; }
     if (ctx->d_wprop) { (void)hipFree(ctx->d_wprop); ctx->d_wprop = nullptr; }
     if (ctx->d_mask) { (void)hipFree(ctx->d_mask); ctx->d_mask = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)ctx->n_weights * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)ctx->net.image_floats * sizeof(float)));
-    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)ctx->net.image_floats * sizeof(float)));
-    {   // where each packed weight lives in the image (bias column -> bias slot, else its MFMA fragment slot)
-        std::vector<int> map((size_t)ctx->n_weights);
-        for (int l = 0; l < ctx->net.n_layers; ++l) {
-            const LayerMeta& L = ctx->net.L[l];
-            const int ld = L.in_dim + L.has_bias;
-            for (int o = 0; o < L.out_dim; ++o)
-                for (int j = 0; j < ld; ++j) {
-                    int pos;
-                    if (L.has_bias && j == 0) pos = L.bias_off + o;
-                    else {
-                        const int c = j - L.has_bias;
-                        const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4, mt = o / 16, u = o % 16;
-                        pos = L.frag_off + ((kt * L.mt + mt) * 64 + kq * 16 + u) * 4 + sidx;
-                    }
-                    map[(size_t)L.w_off + (size_t)o * ld + j] = pos;
-                }
-        }
-        HIP_TRY(ctx, hipMalloc(&ctx->d_w2img, map.size() * sizeof(int)));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_w2img, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-    }
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_w, ((size_t)ctx->n_weights + arch->in_dim) * sizeof(double)));
-    size_t lds = 0;
-    if (pick_waves_per_block(ctx, &lds) == 0)
-        return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
-                    ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
     ctx->arch_set = true;
     return NPBNN_OK;
 }
 
-int npbnn_eval(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, const double* col_override, double lik_temp,
-               const double* sigma, int which, npbnn_eval_out* out, int64_t* confusion) {
+int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
-    if (!out) return fail(ctx, NPBNN_E_ARG, "eval: null out");
-    if (which != 0 && which != 1) return fail(ctx, NPBNN_E_ARG, "eval: which must be 0 or 1");
-    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "eval: call npbnn_set_arch first");
+    if (option == NPBNN_OPT_L0_PRECISION) {
+        if (value < NPBNN_L0_AUTO || value > NPBNN_L0_F16) return fail(ctx, NPBNN_E_ARG, "set_option: layer-0 precision %d", value);
+        ctx->l0_option = value;
+        return NPBNN_OK;
+    }
+    return fail(ctx, NPBNN_E_ARG, "set_option: unknown option %d", option);
+}
+
+int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
+    if (!ctx || !out) return fail(ctx, NPBNN_E_ARG, "get_info: bad arguments");
+    if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
+    if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds); return NPBNN_OK; }
+    if (what == NPBNN_INFO_N_CU) { *out = ctx->n_cu; return NPBNN_OK; }
+    return fail(ctx, NPBNN_E_ARG, "get_info: unknown item %d", what);
+}
+
+static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, const double* col_override, double lik_temp,
+                     const double* sigma, int which, npbnn_eval_out* out, int64_t* confusion, int force_f32, int* overflowed) {
     const int lik = ctx->net.lik_kind;
-    if (lik == NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_STATE, "eval: architecture was set with NPBNN_LIK_NONE");
     Dataset& d = ctx->ds[which];
-    int rc = check_dataset_for_lik(ctx, d, lik);
-    if (rc) return rc;
-    if (confusion && lik != NPBNN_LIK_CATEGORICAL) return fail(ctx, NPBNN_E_ARG, "eval: confusion counts need the categorical likelihood");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, d, &lp);
+    int rc = plan_launch(ctx, which, &lp, force_f32);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
@@ -577,11 +719,37 @@ int npbnn_eval(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, co
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(npbnn_eval_out), hipMemcpyDeviceToHost, ctx->stream));
     if (confusion)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_conf, ctx->d_conf, (size_t)C * C * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *overflowed = ctx->net.l0_f16 && ovf;
+    if (*overflowed) return NPBNN_OK;
     *out = *ctx->h_out;
     if (confusion)
         for (int i = 0; i < C * C; ++i) confusion[i] = (int64_t)ctx->h_conf[i];
     return NPBNN_OK;
+}
+
+int npbnn_eval(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, const double* col_override, double lik_temp,
+               const double* sigma, int which, npbnn_eval_out* out, int64_t* confusion) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!out) return fail(ctx, NPBNN_E_ARG, "eval: null out");
+    if (which != 0 && which != 1) return fail(ctx, NPBNN_E_ARG, "eval: which must be 0 or 1");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "eval: call npbnn_set_arch first");
+    const int lik = ctx->net.lik_kind;
+    if (lik == NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_STATE, "eval: architecture was set with NPBNN_LIK_NONE");
+    int rc = check_dataset_for_lik(ctx, ctx->ds[which], lik);
+    if (rc) return rc;
+    if (confusion && lik != NPBNN_LIK_CATEGORICAL) return fail(ctx, NPBNN_E_ARG, "eval: confusion counts need the categorical likelihood");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int overflowed = 0;
+    rc = eval_once(ctx, W_packed, act_prm, col_override, lik_temp, sigma, which, out, confusion, 0, &overflowed);
+    if (rc) return rc;
+    if (overflowed) {   // a scaled layer-0 weight left the fp16 range: this evaluation runs on the exact float32 path
+        if (ctx->l0_option == NPBNN_L0_F16) return fail(ctx, NPBNN_E_RANGE, "eval: a layer-0 weight left the fp16 range");
+        rc = eval_once(ctx, W_packed, act_prm, col_override, lik_temp, sigma, which, out, confusion, 1, &overflowed);
+    }
+    return rc;
 }
 
 int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm, const double* col_override, int which,
@@ -594,13 +762,15 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     int rc = check_dataset_for_lik(ctx, d, NPBNN_LIK_NONE);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int C = ctx->net.n_out;
+    const size_t n_el = (size_t)d.n_rows * C;
+    std::vector<float> tmp(n_el);
+    for (int attempt = 0; attempt < 2; ++attempt) {
     LaunchPlan lp;
-    rc = plan_launch(ctx, d, &lp);
+    rc = plan_launch(ctx, which, &lp, attempt);
     if (rc) return rc;
     rc = stage_weights(ctx, W_packed, act_prm, col_override);
     if (rc) return rc;
-    const int C = ctx->net.n_out;
-    const size_t n_el = (size_t)d.n_rows * C;
     if (n_el > ctx->d_y_cap) {
         if (ctx->d_y) (void)hipFree(ctx->d_y);
         ctx->d_y = nullptr;
@@ -616,9 +786,13 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     p.predict_mode = apply_out_fn ? 2 : 1;
     hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
-    std::vector<float> tmp(n_el);
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!(ctx->net.l0_f16 && ovf)) break;
+    if (ctx->l0_option == NPBNN_L0_F16) return fail(ctx, NPBNN_E_RANGE, "predict: a layer-0 weight left the fp16 range");
+    }
     for (size_t i = 0; i < n_el; ++i) out_y[i] = (double)tmp[i];
     return NPBNN_OK;
 }
@@ -643,7 +817,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, d, &lp);
+    rc = plan_launch(ctx, 0, &lp, cfg->force_f32);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
@@ -692,8 +866,10 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
     {   // full image once (class weights, biases, fragments); the step kernel then patches single entries
         const int total = pack_item_count(ctx->net, true);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), st));
         hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ctx->d_wcur, (const double*)nullptr,
-                           ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net);
+                           ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net,
+                           ctx->net.l0_f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
     }
     ChainParams c{};
     c.st = ctx->d_chain;
@@ -711,6 +887,8 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.partials = ctx->d_partials;
     c.image = ctx->d_image;
     c.w2img = ctx->d_w2img;
+    c.w2scale = ctx->d_w2scale;
+    c.overflow = ctx->d_overflow;
     c.K = K;
     c.M = M;
     c.n_weights = ctx->n_weights;
@@ -736,6 +914,11 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     HIP_TRY(ctx, hipGetLastError());
     ChainDev fin{};
     HIP_TRY(ctx, hipMemcpyAsync(&fin, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->net.l0_f16 && ovf)     // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
+        return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
     HIP_TRY(ctx, hipMemcpyAsync(W_inout, ctx->d_wcur, wb, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(out_accepted, ctx->d_acc, (size_t)K, hipMemcpyDeviceToHost, st));
     if (out_loglik_prop) HIP_TRY(ctx, hipMemcpyAsync(out_loglik_prop, ctx->d_llp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -758,7 +941,7 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, d, &lp);
+    rc = plan_launch(ctx, 0, &lp);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;

@@ -34,7 +34,10 @@ namespace npbnn {
 
 constexpr int kMaxLayers = NPBNN_MAX_LAYERS;
 constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
-constexpr int kRing = 4;                       // X ring slots (1 KiB each) per wave (power of two)
+#ifndef NPBNN_RING
+#define NPBNN_RING 6
+#endif
+constexpr int kRing = NPBNN_RING;              // X ring slots (1 KiB each) per wave; kRing-1 pieces stay in flight
 constexpr int kMaxWavesPerBlock = 16;
 constexpr int kAuxSlots = 4;                   // per-wave row-aux buffers (labels / weights / targets)
 // per-wave aux slot: labels (64 B) + instance weights (64 B) + 16 x k targets; sized per network
@@ -43,6 +46,7 @@ __host__ __device__ inline int wave_lds_bytes(int k_targets) { return kRing * 10
 constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct LayerMeta {
     int kt;        // 16-wide k tiles of the input dimension
@@ -59,12 +63,14 @@ struct NetMeta {
     int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats)
     int act_kind, out_kind, lik_kind, n_out, k_targets;
     int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
+    int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
 };
 
 struct EvalParams {
-    const float* X;           // [n_tiles*16][Fp] zero padded
+    const float* X;           // [n_tiles*16][Fp] zero padded; in fp16-split mode the same bytes hold, per 8 features,
+                              // 8 x fp16 high parts then 8 x fp16 low parts of the column-scaled values
     const int* labels;        // [n_tiles*16], -1 on padding rows
     const float* targets;     // [n_tiles*16][k] (k = k_targets), 0 on padding rows
     const float* inst_w;      // [n_tiles*16] or nullptr
@@ -88,9 +94,25 @@ struct EvalParams {
 //   is the constant v_c for every row, so its contribution v_c*W0[o][c] moves into the bias and the
 //   fragment entry becomes 0 - no extra pass over X.
 // ------------------------------------------------------------------------------------------------
+// fp16 split of a float: hi = fp16(v), lo = fp16(v - hi); hi + lo carries ~22 significant bits of v
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+constexpr float kF16Safe = 60000.0f;   // |value| above this does not survive fp16 (max 65504)
+
+// One item of the weight image.  Layer-l fragment layouts (16-byte entries, one per lane):
+//   float32 : entry ((kt*MT + mt)*64 + lane) = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + 0..3]
+//   fp16-split layer 0 : entry (((ks*MT + mt)*2 + part)*64 + lane) = part (0 high, 1 low) of
+//                        W_0[o][c = 32ks + 8(lane>>4) + 0..7] * w_scale[c]
+//   (bias column excluded, zero outside the matrix); bias_l[o] = W_l[o][0] when the layer has a bias.
+// Layer 0 with a column override (data_transform_obj, BNN_env.py:14-17): an overridden feature column is the
+// constant v_c for every row, so its contribution v_c*W0[o][c] moves into the bias and the fragment entry
+// becomes 0 - no extra pass over X.
 __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w, const double* __restrict__ col_override,
                                           const double* __restrict__ class_w, float* __restrict__ image, const NetMeta& net,
-                                          bool with_classw) {
+                                          bool with_classw, const float* __restrict__ w_scale = nullptr, int* overflow = nullptr) {
     int piece = item;
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerMeta& L = net.L[l];
@@ -98,10 +120,34 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
         if (piece < n_pieces) {
             const int lane = piece & 63;
             const int tile = piece >> 6;
+            const int ld = L.in_dim + L.has_bias;
+            if (l == 0 && net.l0_f16) {
+                const int part = tile & 1, rest = tile >> 1;
+                const int mt = rest % L.mt, ks = rest / L.mt;
+                const int o = 16 * mt + (lane & 15);
+                const int c0 = 32 * ks + 8 * (lane >> 4);
+                f16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+                if (o < L.out_dim) {
+                    const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = c0 + j;
+                        if (c < L.in_dim) {
+                            const bool overridden = (col_override != nullptr && !isnan(col_override[c]));
+                            const float wv = overridden ? 0.f : (float)(row[c] * (double)w_scale[c]);
+                            if (overflow && !(fabsf(wv) <= kF16Safe)) *overflow = 1;
+                            _Float16 hi, lo;
+                            split_f16(wv, hi, lo);
+                            v[j] = part ? lo : hi;
+                        }
+                    }
+                }
+                *reinterpret_cast<f16x8*>(image + L.frag_off + (long long)piece * 4) = v;
+                return;
+            }
             const int mt = tile % L.mt, kt = tile / L.mt;
             const int o = 16 * mt + (lane & 15);
             const int c0 = 16 * kt + 4 * (lane >> 4);
-            const int ld = L.in_dim + L.has_bias;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (o < L.out_dim) {
                 const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
@@ -153,8 +199,65 @@ __host__ __device__ inline int pack_item_count(const NetMeta& net, bool with_cla
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
                                                            const double* __restrict__ class_w, float* __restrict__ image,
-                                                           NetMeta net) {
-    pack_item(blockIdx.x * 256 + threadIdx.x, w, col_override, class_w, image, net, true);
+                                                           NetMeta net, const float* __restrict__ w_scale, int* overflow) {
+    pack_item(blockIdx.x * 256 + threadIdx.x, w, col_override, class_w, image, net, true, w_scale, overflow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16-split copy of the feature matrix (built once per data set, on the device)
+//   col_absmax_kernel : per-column max |x| (atomic max on the bit pattern of the non-negative floats)
+//   col_scale_kernel  : x_scale[c] = 2^-e, w_scale[c] = 2^e with 2^(e-1) <= max|x_c| < 2^e  (exact powers of two)
+//   split_x_kernel    : per row and per 8 features: 8 x fp16 high parts, then 8 x fp16 low parts of x * x_scale
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) col_absmax_kernel(const float* __restrict__ X, long long n_rows, int Fp, unsigned* __restrict__ absmax) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Fp) return;
+    const long long r0 = (long long)blockIdx.y * 1024;
+    long long r1 = r0 + 1024;
+    if (r1 > n_rows) r1 = n_rows;
+    float m = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        const float a = fabsf(X[r * Fp + c]);
+        m = (a > m || isnan(a)) ? a : m;
+    }
+    atomicMax(absmax + c, __float_as_uint(m));     // NaN / inf bit patterns compare above every finite value
+}
+
+__global__ void __launch_bounds__(256) col_scale_kernel(const unsigned* __restrict__ absmax, int Fp, float* __restrict__ x_scale,
+                                                        float* __restrict__ w_scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Fp) return;
+    const float m = __uint_as_float(absmax[c]);
+    int e = 0;
+    if (m > 0.f && isfinite(m)) (void)frexpf(m, &e);
+    x_scale[c] = ldexpf(1.f, -e);
+    w_scale[c] = ldexpf(1.f, e);
+}
+
+__global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ X, long long n_rows_pad, int Fp, int Fp16,
+                                                      const float* __restrict__ x_scale, float* __restrict__ X16,
+                                                      unsigned* __restrict__ absmax_scaled) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per (row, group of 8 features)
+    const int groups = Fp16 >> 3;
+    if (g >= n_rows_pad * groups) return;
+    const long long r = g / groups;
+    const int c0 = (int)(g % groups) * 8;
+    f16x8 hi, lo;
+    float m = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const float v = c < Fp ? X[r * Fp + c] * x_scale[c] : 0.f;
+        _Float16 h, l;
+        split_f16(v, h, l);
+        hi[j] = h;
+        lo[j] = l;
+        const float a = fabsf(v);
+        m = (a > m || isnan(a)) ? a : m;
+    }
+    f16x8* dst = reinterpret_cast<f16x8*>(X16 + r * Fp16 + c0);
+    dst[0] = hi;
+    dst[1] = lo;
+    if (m > 1.0f || isnan(m)) atomicMax(absmax_scaled, __float_as_uint(m));   // only a test set scaled by the training scales
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,7 +265,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float z, int kind, float prm) {
     switch (kind) {
-        case NPBNN_ACT_RELU: return z < 0.f ? 0.f : z;                              // BNN_lib.py:51
+        case NPBNN_ACT_RELU: return fmaxf(z, 0.f);                                  // BNN_lib.py:51
         case NPBNN_ACT_LEAKY: return z < 0.f ? prm * z : z;                         // BNN_lib.py:55
         case NPBNN_ACT_SWISH: return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));   // BNN_lib.py:60
         default: return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f);   // BNN_lib.py:65 (exp-form tanh)
@@ -200,15 +303,45 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     return __hiloint2double(hi, lo);
 }
 
-#define NPBNN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define NPBNN_WAIT_VMCNT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define NPBNN_WAIT_VMCNT(n) NPBNN_WAIT_VMCNT_(n)
+#define NPBNN_DEPTH (NPBNN_RING - 1)
+#if NPBNN_RING == 4
+#define NPBNN_DEPTH_LIT 3
+#elif NPBNN_RING == 6
+#define NPBNN_DEPTH_LIT 5
+#elif NPBNN_RING == 8
+#define NPBNN_DEPTH_LIT 7
+#else
+#error "NPBNN_RING must be 4, 6 or 8"
+#endif
 
 __device__ __forceinline__ void wait_younger(int younger) {   // wave-uniform argument; tail / shallow-ring path only
-    if (younger >= 3) NPBNN_WAIT_VMCNT(3);
+    if (younger >= 7) NPBNN_WAIT_VMCNT(7);
+    else if (younger == 6) NPBNN_WAIT_VMCNT(6);
+    else if (younger == 5) NPBNN_WAIT_VMCNT(5);
+    else if (younger == 4) NPBNN_WAIT_VMCNT(4);
+    else if (younger == 3) NPBNN_WAIT_VMCNT(3);
     else if (younger == 2) NPBNN_WAIT_VMCNT(2);
     else if (younger == 1) NPBNN_WAIT_VMCNT(1);
     else NPBNN_WAIT_VMCNT(0);
 }
-static_assert(kRing == 4, "the steady-state wait assumes 3 pieces in flight");
+template <int N>
+__device__ __forceinline__ void wait_depth() {
+    static_assert(N >= 0 && N <= 7, "ring depth");
+    if constexpr (N == 7) NPBNN_WAIT_VMCNT(7);
+    else if constexpr (N == 6) NPBNN_WAIT_VMCNT(6);
+    else if constexpr (N == 5) NPBNN_WAIT_VMCNT(5);
+    else if constexpr (N == 4) NPBNN_WAIT_VMCNT(4);
+    else if constexpr (N == 3) NPBNN_WAIT_VMCNT(3);
+    else if constexpr (N == 2) NPBNN_WAIT_VMCNT(2);
+    else if constexpr (N == 1) NPBNN_WAIT_VMCNT(1);
+    else NPBNN_WAIT_VMCNT(0);
+}
+__device__ __forceinline__ int ring_next(int slot) {            // byte offset of the next 1-KiB ring slot
+    slot += 1024;
+    return slot == kRing * 1024 ? 0 : slot;
+}
 
 typedef __attribute__((address_space(1))) const void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
@@ -226,8 +359,9 @@ __device__ __forceinline__ void dma4(const void* g, char* l) {
 //   MTI : max 16-unit tiles of any later layer's output (1 covers every net whose hidden layers after the first
 //         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
 // ------------------------------------------------------------------------------------------------
-template <int MT0, int MTI>
+template <int MT0, int MTI, bool F16>
 __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalParams p) {
+    constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
     constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const img = reinterpret_cast<float*>(smem);
@@ -256,9 +390,9 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalPara
     const int stride = G * wpb;
     const int my_tiles = first_tile < p.n_tiles ? (p.n_tiles - first_tile + stride - 1) / stride : 0;
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
-    int D = kRing - 1;                                  // prefetch distance in pieces
+    int D = DEPTH;                                      // prefetch distance in pieces
     if (D > 2 * KT0) D = 2 * KT0;                       // at most 3 tiles in flight (aux slots)
-    const bool full_depth = (D == kRing - 1);
+    const bool full_depth = (D == DEPTH);
 
     // prefetch cursor: a per-lane running source pointer and a scalar ring offset
     const float* pf_ptr = p.X + ((size_t)first_tile * 16 + n) * (size_t)p.Fp + 4 * kq;
@@ -284,15 +418,15 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalPara
         if (pf_kt == 0) issue_aux();
         dma16(pf_ptr, ring + pf_slot);
         pf_ptr += 16;
-        pf_slot = (pf_slot + 1024) & (kRing * 1024 - 1);
+        pf_slot = ring_next(pf_slot);
         ++pf_q;
         if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
     for (int i = 0; i < D && pf_q < Q; ++i) issue_next();
 
-    // the image (issued first) has landed once at most 3 of the >= 3 operations issued after it are still in
-    // flight; a wave with fewer pieces simply drains.  Every wave then meets at the barrier before anyone reads the image.
-    if (pf_q >= 3) NPBNN_WAIT_VMCNT(3);
+    // the image (issued first) has landed once at most kRing-1 of the >= kRing-1 operations issued after it are
+    // still in flight; a wave with fewer pieces simply drains.  Every wave then meets at the barrier before anyone reads the image.
+    if (pf_q >= DEPTH) wait_depth<DEPTH>();
     else NPBNN_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
 
@@ -315,30 +449,63 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalPara
         for (int mt = 0; mt < MT0; ++mt) acc0[mt] = *reinterpret_cast<const f32x4*>(bias0 + 16 * mt);
         const float* fr = frag0;
         auto consume = [&]() {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);
-            cs_slot = (cs_slot + 1024) & (kRing * 1024 - 1);
-            f32x4 a[MT0];
+            if constexpr (F16) {
+                // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high
+                // parts) and 2(kg&1)+1 (low parts); three MFMAs per tile: wh.xh + wl.xh + wh.xl
+                const int slot_b = ring_next(cs_slot);
+                const char* px = ring + ((kq >> 1) ? slot_b : cs_slot) + ((2 * (kq & 1)) * 16 + n) * 16;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(px);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(px + 256);
+                cs_slot = ring_next(slot_b);
+                f16x8 wh[MT0], wl[MT0];
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
-            fr += MT0 * 256;
+                for (int mt = 0; mt < MT0; ++mt) {
+                    wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
+                    wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
+                }
+                fr += MT0 * 512;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int mt = 0; mt < MT0; ++mt) acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT0; ++mt)
-                    acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT0; ++mt) acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT0; ++mt) acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[mt], 0, 0, 0);
+            } else {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);
+                cs_slot = ring_next(cs_slot);
+                f32x4 a[MT0];
+#pragma unroll
+                for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
+                fr += MT0 * 256;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt)
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[mt], 0, 0, 0);
+            }
         };
-        if (full_depth && pf_q + KT0 <= Q) {
-            // steady state: every piece consumed is replaced by one issued, exactly 3 younger pieces in flight
-            for (int kt = 0; kt < KT0; ++kt) {
-                issue_next();                           // targets the slot consumed one piece ago
-                NPBNN_WAIT_VMCNT(3);
+        constexpr int STEP = F16 ? 2 : 1;               // pieces per consume()
+        if (full_depth) {
+            // steady part: every step consumed is replaced by one issued -> exactly DEPTH younger pieces in flight;
+            // once the wave's last piece has been issued, drain once and consume what is left without waiting
+            int n_issue = Q - pf_q;
+            if (n_issue > KT0) n_issue = KT0;
+            for (int kt = 0; kt < n_issue; kt += STEP) {
+                issue_next();                           // targets the slot(s) consumed one step ago
+                if constexpr (F16) issue_next();
+                wait_depth<DEPTH>();
                 consume();
+            }
+            if (n_issue < KT0) {
+                NPBNN_WAIT_VMCNT(0);
+                for (int kt = n_issue; kt < KT0; kt += STEP) consume();
             }
             q += KT0;
         } else {
-            for (int kt = 0; kt < KT0; ++kt, ++q) {
-                if (pf_q < Q) issue_next();
-                wait_younger(pf_q - q - 1);
+            for (int kt = 0; kt < KT0; kt += STEP, q += STEP) {
+                for (int i = 0; i < STEP; ++i)
+                    if (pf_q < Q) issue_next();
+                wait_younger(pf_q - q - STEP);
                 consume();
             }
         }
@@ -603,7 +770,10 @@ struct ChainParams {
     double* out_lp;            // [K] proposed logPrior
     const double* partials;
     float* image;              // fragment image read by the eval kernel
-    const int* w2img;          // packed-weight index -> float index in the image
+    const int* w2img;          // packed-weight index -> float index in the image; bit 31 set: fp16-split layer-0 entry,
+                               // the low bits are then the half index of the high part (low part 512 halfs later)
+    const float* w2scale;      // per-weight column scale of the fp16-split layer 0 (1 elsewhere) or nullptr
+    int* overflow;             // set when a scaled weight leaves the fp16 range
     int K, M, n_weights, n_waves;
     int prior_kind;
     double prior_scale[kMaxLayers];
@@ -619,6 +789,22 @@ __device__ __forceinline__ double log_prior_density(int kind, double w, double s
     if (kind == NPBNN_PRIOR_CAUCHY) return -log(3.14159265358979323846 * scale * (1.0 + (w / scale) * (w / scale)));
     if (kind == NPBNN_PRIOR_LAPLACE) return -log(2.0 * scale) - fabs(w) / scale;
     return -0.5 * (w / scale) * (w / scale) - log(scale) - 0.9189385332046727418;
+}
+
+__device__ __forceinline__ void patch_image(const ChainParams& c, int i, double v) {
+    const int pos = c.w2img[i];
+    if (pos < 0) {                                   // fp16-split layer-0 entry
+        const float wv = (float)(v * (double)c.w2scale[i]);
+        if (!(fabsf(wv) <= kF16Safe)) *c.overflow = 1;
+        _Float16 hi, lo;
+        split_f16(wv, hi, lo);
+        _Float16* img16 = reinterpret_cast<_Float16*>(c.image);
+        const int h = pos & 0x7fffffff;
+        img16[h] = hi;
+        img16[h + 512] = lo;
+    } else {
+        c.image[pos] = (float)v;
+    }
 }
 
 __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
@@ -662,7 +848,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
                 else {
                     const double v = c.w_cur[i];
                     c.w_prop[i] = v;
-                    c.image[c.w2img[i]] = (float)v;      // roll the rejected entry back in the image too
+                    patch_image(c, i, v);                // roll the rejected entry back in the image too
                 }
             }
         }
@@ -679,7 +865,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
             if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
             if (c.mask) v *= c.mask[i];
             c.w_prop[i] = v;
-            c.image[c.w2img[i]] = (float)v;
+            patch_image(c, i, v);
         }
     }
     __syncthreads();

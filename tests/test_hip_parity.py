@@ -247,3 +247,62 @@ def test_config2_full_size(hip):
         parts += c2.eval(w)["loglik"]
         c2.close()
     assert abs(parts - r1["loglik"]) / abs(r1["loglik"]) < 1e-9
+
+
+# ---- layer-0 precision modes -------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_l0_modes_against_oracle(mode, hip):
+    """Both layer-0 paths (exact float32 MFMA and fp16-split) meet the same tolerances; badly scaled feature
+    columns (1e-3 ... 1e4) exercise the per-column power-of-two scaling of the fp16-split path."""
+    rs = np.random.default_rng(11)
+    n, f, c = 3001, 70, 6
+    x = rs.standard_normal((n, f)) * (10.0 ** rs.uniform(-3, 4, f))
+    x[:, 5] = 0.0                                           # an all-zero column
+    lab = rs.integers(0, c, n)
+    w = [rs.normal(0, 0.3, s) for s in cases.layer_shapes(f, [24, 9], c, 2)]
+    w[0][:, 1:] /= np.maximum(np.abs(x).max(axis=0), 1e-3)  # keep the pre-activations O(1)
+    act = orc.Act("tanh")
+    ctx = make_ctx(hip, x, w, act, 0, 0, labels=lab)
+    ctx.set_l0_precision(mode)
+    y64 = orc.forward(x, w, act, orc.out_softmax)
+    assert_close(ctx.predict(w), y64)
+    r = ctx.eval(w, want_confusion=True)
+    assert ctx.l0_mode() == ("f16-split" if mode == "f16" else "f32")
+    np.testing.assert_allclose(r["loglik"], orc.lik_categorical(y64, lab, np.arange(n)), rtol=LL_RTOL)
+    check_confusion(r["confusion"], y64, lab)
+    ctx.close()
+
+
+def test_auto_mode_falls_back_to_f32(hip):
+    """auto: data with inf, or weights beyond the fp16 range after column scaling, run on the float32 path."""
+    from npbnn_amd import NpbnnError
+    rs = np.random.default_rng(12)
+    n, f, c = 500, 40, 3
+    x = rs.standard_normal((n, f))
+    lab = rs.integers(0, c, n)
+    w = [rs.normal(0, 0.3, s) for s in cases.layer_shapes(f, [8], c, 2)]
+    act = orc.Act("ReLU")
+    ctx = make_ctx(hip, x, w, act, 0, 0, labels=lab)
+    r = ctx.eval(w)
+    assert ctx.l0_mode() == "f16-split"
+    big = [wi.copy() for wi in w]
+    big[0][0, 3] = 3e5                                      # leaves the fp16 range -> this evaluation repeats in float32
+    y64 = orc.forward(x, big, act, orc.out_softmax)
+    with np.errstate(divide="ignore"):
+        want = orc.lik_categorical(y64, lab, np.arange(n))
+    got = ctx.eval(big)["loglik"]
+    assert ctx.l0_mode() == "f32"
+    if np.isfinite(want):
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+    np.testing.assert_allclose(ctx.eval(w)["loglik"], r["loglik"], rtol=0)      # back on the fp16-split path, same bits
+    assert ctx.l0_mode() == "f16-split"
+    ctx.set_l0_precision("f16")
+    with pytest.raises(NpbnnError):
+        ctx.eval(big)
+    ctx.close()
+    x2 = x.copy()
+    x2[7, 3] = np.inf
+    ctx = make_ctx(hip, x2, w, act, 0, 0, labels=lab)
+    ctx.eval(w)
+    assert ctx.l0_mode() == "f32"
+    ctx.close()

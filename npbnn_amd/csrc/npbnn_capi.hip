@@ -54,12 +54,19 @@ struct npbnn_ctx {
     float* d_wscale = nullptr;
     int scale_F = 0;
     int* d_overflow = nullptr;
+    // parameter blocks of the kernels: device copies (kernels take a pointer) + pinned host staging
+    EvalParams* d_eparams = nullptr;
+    FinalizeParams* d_fparams = nullptr;
+    ChainParams* d_cparams = nullptr;
+    char* h_params = nullptr;      // pinned: EvalParams | FinalizeParams | ChainParams
     float* d_w2scale = nullptr;
     // device work buffers
     double* d_wraw = nullptr;      // packed float64 weights
     double* d_colov = nullptr;     // column override (in_dim doubles)
     float* d_image = nullptr;      // float32 fragment image
     int* d_w2img = nullptr;        // packed-weight index -> image float index
+    std::vector<int> h_w2img;      // host copies, to gather per-draw image positions for the chain
+    std::vector<float> h_w2scale;
     double* d_partials = nullptr;
     int partial_waves = 0;
     unsigned* d_conf = nullptr;    // NPBNN_MAX_WIDTH^2
@@ -79,6 +86,8 @@ struct npbnn_ctx {
     ChainDev* d_chain = nullptr;
     int* d_idx = nullptr;
     double* d_delta = nullptr;
+    int* d_pos = nullptr;
+    float* d_pscale = nullptr;
     size_t draw_cap = 0;        // K*M capacity of d_idx / d_delta
     int* d_cnt = nullptr;
     double* d_logu = nullptr;
@@ -247,7 +256,7 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
     return 0;
 }
 
-typedef void (*eval_fn_t)(EvalParams);
+typedef void (*eval_fn_t)(const EvalParams*);
 
 template <int MTI, bool F16>
 eval_fn_t pick_kernel_mt0(int mt0) {
@@ -362,7 +371,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0) {
     if (grid > ctx->n_cu) grid = ctx->n_cu;     // persistent: one workgroup per CU
     if (grid < 1) grid = 1;
     lp->grid = grid;
-    lp->n_waves = grid * wpb;
+    lp->n_waves = grid;            // one partial record per workgroup
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NPBNN_OK;
 }
@@ -398,6 +407,26 @@ int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const 
                        ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net,
                        ctx->net.l0_f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
     HIP_TRY(ctx, hipGetLastError());
+    return NPBNN_OK;
+}
+
+// copy a parameter block to its device slot through the pinned staging area (stream ordered; the staging slot is
+// reused only after the stream has been synchronised by the caller's epilogue)
+int push_eval_params(npbnn_ctx* ctx, const EvalParams& p) {
+    memcpy(ctx->h_params, &p, sizeof(EvalParams));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eparams, ctx->h_params, sizeof(EvalParams), hipMemcpyHostToDevice, ctx->stream));
+    return NPBNN_OK;
+}
+int push_finalize_params(npbnn_ctx* ctx, const FinalizeParams& f) {
+    char* slot = ctx->h_params + sizeof(EvalParams);
+    memcpy(slot, &f, sizeof(FinalizeParams));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_fparams, slot, sizeof(FinalizeParams), hipMemcpyHostToDevice, ctx->stream));
+    return NPBNN_OK;
+}
+int push_chain_params(npbnn_ctx* ctx, const ChainParams& c) {
+    char* slot = ctx->h_params + sizeof(EvalParams) + sizeof(FinalizeParams);
+    memcpy(slot, &c, sizeof(ChainParams));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cparams, slot, sizeof(ChainParams), hipMemcpyHostToDevice, ctx->stream));
     return NPBNN_OK;
 }
 
@@ -477,6 +506,8 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
     }
     HIP_TRY(ctx, hipMalloc(&ctx->d_w2img, map.size() * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_w2img, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctx->h_w2img = map;
+    ctx->h_w2scale = scale;
     if (f16) {
         HIP_TRY(ctx, hipMalloc(&ctx->d_w2scale, scale.size() * sizeof(float)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_w2scale, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -525,6 +556,10 @@ int npbnn_create(int device_id, npbnn_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&c->d_out, sizeof(npbnn_eval_out));
     if (e == hipSuccess) e = hipMalloc(&c->d_overflow, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_eparams, sizeof(EvalParams));
+    if (e == hipSuccess) e = hipMalloc(&c->d_fparams, sizeof(FinalizeParams));
+    if (e == hipSuccess) e = hipMalloc(&c->d_cparams, sizeof(ChainParams));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_params, sizeof(EvalParams) + sizeof(FinalizeParams) + sizeof(ChainParams));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_out, sizeof(npbnn_eval_out));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
     if (e == hipSuccess) e = hipEventCreate(&c->ev[0]);
@@ -549,6 +584,10 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->d_xscale) (void)hipFree(c->d_xscale);
     if (c->d_wscale) (void)hipFree(c->d_wscale);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_eparams) (void)hipFree(c->d_eparams);
+    if (c->d_fparams) (void)hipFree(c->d_fparams);
+    if (c->d_cparams) (void)hipFree(c->d_cparams);
+    if (c->h_params) (void)hipHostFree(c->h_params);
     if (c->d_w2scale) (void)hipFree(c->d_w2scale);
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_w2img) (void)hipFree(c->d_w2img);
@@ -559,7 +598,7 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_wcur, c->d_wprop, c->d_mask, c->d_chain, c->d_idx, c->d_delta, c->d_cnt, c->d_logu,
+    void* chain_bufs[] = {c->d_wcur, c->d_wprop, c->d_mask, c->d_chain, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu,
                           c->d_acc, c->d_llp, c->d_lpp};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
@@ -701,7 +740,9 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_conf, 0, (size_t)C * C * sizeof(unsigned), ctx->stream));
         p.confusion = ctx->d_conf;
     }
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
+    rc = push_eval_params(ctx, p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
     HIP_TRY(ctx, hipGetLastError());
     FinalizeParams f{};
     f.partials = ctx->d_partials;
@@ -714,7 +755,9 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     if (sigma)
         for (int j = 0; j < ctx->net.k_targets; ++j) f.sigma[j] = sigma[j];
     f.out = ctx->d_out;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, f);
+    rc = push_finalize_params(ctx, f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, (const FinalizeParams*)ctx->d_fparams);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(npbnn_eval_out), hipMemcpyDeviceToHost, ctx->stream));
     if (confusion)
@@ -784,7 +827,9 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     p.net.lik_kind = NPBNN_LIK_NONE;
     p.y_out = ctx->d_y;
     p.predict_mode = apply_out_fn ? 2 : 1;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
+    rc = push_eval_params(ctx, p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     int ovf = 0;
@@ -830,9 +875,13 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (need > ctx->draw_cap) {
         if (ctx->d_idx) (void)hipFree(ctx->d_idx);
         if (ctx->d_delta) (void)hipFree(ctx->d_delta);
-        ctx->d_idx = nullptr; ctx->d_delta = nullptr; ctx->draw_cap = 0;
+        if (ctx->d_pos) (void)hipFree(ctx->d_pos);
+        if (ctx->d_pscale) (void)hipFree(ctx->d_pscale);
+        ctx->d_idx = nullptr; ctx->d_delta = nullptr; ctx->d_pos = nullptr; ctx->d_pscale = nullptr; ctx->draw_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_idx, need * sizeof(int)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_delta, need * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pos, need * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pscale, need * sizeof(float)));
         ctx->draw_cap = need;
     }
     if ((size_t)K > ctx->iter_cap) {
@@ -854,6 +903,19 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (mask_packed) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mask, mask_packed, wb, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_idx, idx, need * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_delta, delta, need * sizeof(double), hipMemcpyHostToDevice, st));
+    {   // image position (and fp16-split scale) of every drawn entry, so the step kernel needs no dependent lookup
+        std::vector<int> hpos(need, 0);
+        std::vector<float> hsc;
+        const bool f16 = ctx->net.l0_f16 != 0;
+        if (f16) hsc.assign(need, 1.0f);
+        for (size_t i = 0; i < need; ++i)
+            if (idx[i] >= 0) {
+                hpos[i] = ctx->h_w2img[(size_t)idx[i]];
+                if (f16) hsc[i] = ctx->h_w2scale[(size_t)idx[i]];
+            }
+        HIP_TRY(ctx, hipMemcpy(ctx->d_pos, hpos.data(), need * sizeof(int), hipMemcpyHostToDevice));
+        if (f16) HIP_TRY(ctx, hipMemcpy(ctx->d_pscale, hsc.data(), need * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cnt, cnt, (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_logu, log_u, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
     ChainDev init{};
@@ -888,7 +950,15 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.image = ctx->d_image;
     c.w2img = ctx->d_w2img;
     c.w2scale = ctx->d_w2scale;
+    c.pos = ctx->d_pos;
+    c.pscale = ctx->net.l0_f16 ? ctx->d_pscale : nullptr;
     c.overflow = ctx->d_overflow;
+    unsigned long long* d_stamps = nullptr;
+    if (getenv("NPBNN_STEP_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the step kernel
+        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)(K + 1) * 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)(K + 1) * 8 * sizeof(unsigned long long)));
+    }
+    c.stamps = d_stamps;
     c.K = K;
     c.M = M;
     c.n_weights = ctx->n_weights;
@@ -906,11 +976,15 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
-    for (int t = 0; t < K; ++t) {
-        hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, c);
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, p);
+    rc = push_eval_params(ctx, p);
+    if (rc) return rc;
+    rc = push_chain_params(ctx, c);
+    if (rc) return rc;
+    for (int t = 0; t <= K; ++t) {
+        hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, t,
+                           t > 0 ? cnt[t - 1] : 0, t < K ? cnt[t] : 0);
+        if (t < K) hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams);
     }
-    hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, c);
     HIP_TRY(ctx, hipGetLastError());
     ChainDev fin{};
     HIP_TRY(ctx, hipMemcpyAsync(&fin, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
@@ -924,6 +998,20 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (out_loglik_prop) HIP_TRY(ctx, hipMemcpyAsync(out_loglik_prop, ctx->d_llp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
     if (out_logprior_prop) HIP_TRY(ctx, hipMemcpyAsync(out_logprior_prop, ctx->d_lpp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (d_stamps) {
+        std::vector<unsigned long long> hs((size_t)(K + 1) * 8);
+        (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_stamps);
+        double acc[8] = {0};
+        int n = 0;
+        for (int t = 1; t < K; ++t) {
+            const unsigned long long* r = &hs[(size_t)t * 8];
+            for (int k = 1; k <= 6; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 0.01;   // 100 MHz wall clock -> us
+            ++n;
+        }
+        fprintf(stderr, "[npbnn step stamps] prefetch %.2f  t0-prior %.2f  reduce+decide %.2f  commit/rollback %.2f  propose %.2f  prior-sum %.2f us (mean of %d)\n",
+                acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
+    }
     result->loglik = fin.logLik;
     result->logprior = fin.logPrior;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) result->sigma[j] = fin.sigma[j];
@@ -959,15 +1047,19 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     f.n_rows = d.n_rows;
     f.lik_temp = 1.0;
     f.out = ctx->d_out;
+    rc = push_eval_params(ctx, p);
+    if (rc) return rc;
+    rc = push_finalize_params(ctx, f);
+    if (rc) return rc;
     std::vector<hipEvent_t> evs(2 * (size_t)iters);
     for (auto& e : evs) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i) {
         HIP_TRY(ctx, hipEventRecord(evs[2 * i], ctx->stream));
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, p);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
         HIP_TRY(ctx, hipEventRecord(evs[2 * i + 1], ctx->stream));
-        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, f);
+        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, (const FinalizeParams*)ctx->d_fparams);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -75,7 +75,7 @@ struct EvalParams {
     const float* targets;     // [n_tiles*16][k] (k = k_targets), 0 on padding rows
     const float* inst_w;      // [n_tiles*16] or nullptr
     const float* image;       // float32 fragment image of the weights (global), DMA-copied into LDS
-    double* partials;         // [n_waves][kPartialStride]
+    double* partials;         // [kPartialStride][n_workgroups]
     unsigned* confusion;      // [n_out*n_out] or nullptr
     float* y_out;             // [n_rows][n_out] or nullptr
     long long n_rows;
@@ -360,7 +360,10 @@ __device__ __forceinline__ void dma4(const void* g, char* l) {
 //         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
 // ------------------------------------------------------------------------------------------------
 template <int MT0, int MTI, bool F16>
-__global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalParams p) {
+__global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const EvalParams* __restrict__ pp) {
+    // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
+    // kernel argument of this size costs several microseconds of cold scalar loads per launch
+    const EvalParams& p = *pp;
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
     constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -640,25 +643,35 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(EvalPara
         }
     }
 
-    // ---------------- per-wave partials (float64, fixed order) ----------------
+    // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> wave 0 -> global [value][workgroup] ----
     if (p.partials) {
-        double* out = p.partials + (size_t)(blockIdx.x * wpb + wave) * kPartialStride;
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) ll_acc += shfl_xor_f64(ll_acc, sh);
-        if (lane == 0) out[0] = ll_acc;
         if (lik_kind == NPBNN_LIK_GAUSS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int sh = 1; sh < 16; sh <<= 1) {
                     s1[i] += shfl_xor_f64(s1[i], sh);
                     s2[i] += shfl_xor_f64(s2[i], sh);
                 }
-                if (n == 0) {
-                    out[1 + 4 * kq + i] = s1[i];
-                    out[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = s2[i];
-                }
+        }
+        __syncthreads();                                   // every wave is done with its ring: reuse it as scratch
+        double* wsum = reinterpret_cast<double*>(smem + (size_t)net.image_floats * 4);    // [wave][kPartialStride]
+        if (lane == 0) wsum[wave * kPartialStride] = ll_acc;
+        if (lik_kind == NPBNN_LIK_GAUSS && n == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wsum[wave * kPartialStride + 1 + 4 * kq + i] = s1[i];
+                wsum[wave * kPartialStride + 1 + NPBNN_MAX_TARGETS + 4 * kq + i] = s2[i];
             }
+        }
+        __syncthreads();
+        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+        if (tid < nvals) {
+            double s = 0.0;
+            for (int w = 0; w < wpb; ++w) s += wsum[w * kPartialStride + tid];
+            p.partials[(size_t)tid * gridDim.x + blockIdx.x] = s;
         }
     }
 }
@@ -680,21 +693,17 @@ struct FinalizeParams {
 
 // Sum value v of every wave's partial record: wave (threadIdx>>6) of the block takes values v = wave, wave+nw, ...;
 // lane l adds records l, l+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_waves, int nvals, double* tot /*LDS*/) {
-    __shared__ double part[kPartialStride][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;   // nw <= 16
-    for (int v = 0; v < nvals; ++v) {
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int nvals, double* tot /*LDS*/) {
+    // partials are laid out [value][workgroup]; wave w of this block sums values w, w+nw, ...: each lane adds workgroups
+    // lane, lane+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int v = wave; v < nvals; v += nw) {
         double s = 0.0;
-        for (int w = threadIdx.x; w < n_waves; w += blockDim.x) s += partials[(size_t)w * kPartialStride + v];
+#pragma unroll 4
+        for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)v * n_blocks + b];
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
-        if (lane == 0) part[v][wave] = s;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nvals) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += part[threadIdx.x][w];
-        tot[threadIdx.x] = s;
+        if (lane == 0) tot[v] = s;
     }
     __syncthreads();
 }
@@ -726,7 +735,8 @@ __device__ __forceinline__ void loglik_from_totals(const double* tot, int lik_ki
     }
 }
 
-__global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams f) {
+__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams* __restrict__ fp) {
+    const FinalizeParams& f = *fp;
     __shared__ double tot[kPartialStride];
     const int nvals = (f.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
     reduce_partials(f.partials, f.n_waves, nvals, tot);
@@ -773,7 +783,10 @@ struct ChainParams {
     const int* w2img;          // packed-weight index -> float index in the image; bit 31 set: fp16-split layer-0 entry,
                                // the low bits are then the half index of the high part (low part 512 halfs later)
     const float* w2scale;      // per-weight column scale of the fp16-split layer 0 (1 elsewhere) or nullptr
+    const int* pos;            // [K][M] w2img[idx] gathered on the host, so the kernel has no dependent lookup
+    const float* pscale;       // [K][M] w2scale[idx] (fp16-split) or nullptr
     int* overflow;             // set when a scaled weight leaves the fp16 range
+    unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1): 8 wall-clock stamps per launch, else nullptr
     int K, M, n_weights, n_waves;
     int prior_kind;
     double prior_scale[kMaxLayers];
@@ -791,10 +804,9 @@ __device__ __forceinline__ double log_prior_density(int kind, double w, double s
     return -0.5 * (w / scale) * (w / scale) - log(scale) - 0.9189385332046727418;
 }
 
-__device__ __forceinline__ void patch_image(const ChainParams& c, int i, double v) {
-    const int pos = c.w2img[i];
+__device__ __forceinline__ void patch_image_at(const ChainParams& c, int pos, float scale, double v) {
     if (pos < 0) {                                   // fp16-split layer-0 entry
-        const float wv = (float)(v * (double)c.w2scale[i]);
+        const float wv = (float)(v * (double)scale);
         if (!(fabsf(wv) <= kF16Safe)) *c.overflow = 1;
         _Float16 hi, lo;
         split_f16(wv, hi, lo);
@@ -807,96 +819,157 @@ __device__ __forceinline__ void patch_image(const ChainParams& c, int i, double 
     }
 }
 
-__global__ void __launch_bounds__(1024) chain_step_kernel(ChainParams c) {
+__device__ __forceinline__ void patch_image(const ChainParams& c, int i, double v) {
+    const int pos = c.w2img[i];
+    patch_image_at(c, pos, pos < 0 ? c.w2scale[i] : 1.0f, v);
+}
+
+// block-wide sum of one double per thread, fixed order; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 doubles*/) {
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) v += shfl_xor_f64(v, sh);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+// change of the log prior density when an entry moves from `b` to `v` (scale sc); the normal prior needs no
+// transcendental: -(v^2 - b^2) / (2 sc^2)
+__device__ __forceinline__ double prior_delta(int kind, double v, double b, double sc) {
+    if (kind == NPBNN_PRIOR_NORMAL) return -0.5 * (v * v - b * b) / (sc * sc);
+    if (kind == NPBNN_PRIOR_LAPLACE) return -(fabs(v) - fabs(b)) / sc;
+    return log((sc * sc + b * b) / (sc * sc + v * v));                  // Cauchy
+}
+
+__global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int t_arg, int n_prev_arg, int n_new_arg) {
+    const ChainParams& c = *cp;           // device-resident parameter block; only the per-launch scalars travel as arguments
     __shared__ double tot[kPartialStride];
     __shared__ double red[16];
+    __shared__ npbnn_eval_out o;
     __shared__ int s_accept;
     const int tid = threadIdx.x;
     ChainDev* st = c.st;
-    const int t = st->t;                       // iteration to propose now; t-1 is pending
-    __syncthreads();                           // everyone has read t before thread 0 bumps it
+    const int t = t_arg;                       // iteration to propose now; t-1 is pending
+#define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)t * 8 + (k)] = wall_clock64(); } while (0)
+    NPBNN_STAMP(0);
+    const bool have_prev = t > 0, have_new = t < c.K;
+    const int n_prev = n_prev_arg, n_new = n_new_arg;
+    const size_t row_prev = (size_t)(have_prev ? t - 1 : 0) * c.M, row_new = (size_t)(have_new ? t : 0) * c.M;
+    const int* idx_prev = c.idx + row_prev;
+    const int* idx_new = c.idx + row_new;
+    const double* delta_new = c.delta + row_new;
 
-    if (t > 0) {
+    // ---- everything that does not depend on the accept decision is fetched first (first 1024 entries; wider
+    //      proposals take the plain loops below), so the decision only waits for the partial sums ----
+    const int ip = tid < n_prev ? idx_prev[tid] : -1;
+    const int in_ = tid < n_new ? idx_new[tid] : -1;
+    const double dl = tid < n_new ? delta_new[tid] : 0.0;
+    const int pos_p = tid < n_prev ? c.pos[row_prev + tid] : 0;
+    const int pos_n = tid < n_new ? c.pos[row_new + tid] : 0;
+    const float sc_p = (c.pscale && tid < n_prev) ? c.pscale[row_prev + tid] : 1.0f;
+    const float sc_n = (c.pscale && tid < n_new) ? c.pscale[row_new + tid] : 1.0f;
+    const double wc_p = ip >= 0 ? c.w_cur[ip] : 0.0;
+    const double wp_p = ip >= 0 ? c.w_prop[ip] : 0.0;
+    const double wc_n = in_ >= 0 ? c.w_cur[in_] : 0.0;
+    const double wp_n = in_ >= 0 ? c.w_prop[in_] : 0.0;
+    const double mk = (in_ >= 0 && c.mask) ? c.mask[in_] : 1.0;
+
+    NPBNN_STAMP(1);
+    // at the start of a batch the prior of the current state is summed in full (later proposals update it
+    // incrementally from the touched entries, so rounding drift cannot accumulate across batches)
+    if (t == 0 && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+        double lp = 0.0;
+        for (int l = 0; l < c.net.n_layers; ++l) {
+            const LayerMeta& L = c.net.L[l];
+            const int n = L.out_dim * (L.in_dim + L.has_bias);
+            const double sc = c.prior_scale[l];
+            if (c.prior_kind == NPBNN_PRIOR_NORMAL) {
+                double q = 0.0;
+                for (int i = tid; i < n; i += blockDim.x) { const double w = c.w_cur[L.w_off + i]; q += w * w; }
+                lp += -0.5 * q / (sc * sc);
+                if (tid == 0) lp -= (double)n * (log(sc) + 0.9189385332046727418);
+            } else {
+                for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_cur[L.w_off + i], sc);
+            }
+        }
+        const double s = block_sum(lp, red);
+        if (tid == 0) st->logPrior = s;
+        __syncthreads();
+    }
+
+    int acc = 0;
+    if (have_prev) {
         const int nvals = (c.net.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
         reduce_partials(c.partials, c.n_waves, nvals, tot);
-        __shared__ npbnn_eval_out o;
+        NPBNN_STAMP(2);
         if (tid == 0) {
             loglik_from_totals(tot, c.net.lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
             const double lp = st->cand_logPrior;
             const double h = c.hastings ? c.hastings[t - 1] : 0.0;
             const double post_new = o.loglik + lp, post_old = st->logLik + st->logPrior;
-            const int acc = ((post_new - post_old) * c.temperature + h >= c.log_u[t - 1]) ? 1 : 0;
-            c.out_acc[t - 1] = (unsigned char)acc;
+            const int a = ((post_new - post_old) * c.temperature + h >= c.log_u[t - 1]) ? 1 : 0;
+            c.out_acc[t - 1] = (unsigned char)a;
             c.out_ll[t - 1] = o.loglik;
             c.out_lp[t - 1] = lp;
-            if (acc) {
+            if (a) {
                 st->logLik = o.loglik;
                 st->logPrior = lp;
                 st->n_accepted += 1;
                 if (c.net.lik_kind == NPBNN_LIK_GAUSS)
                     for (int j = 0; j < c.net.k_targets; ++j) st->sigma[j] = o.sigma[j];
             }
-            s_accept = acc;
+            s_accept = a;
         }
         __syncthreads();
-        const int acc = s_accept;
-        const int n_prev = c.cnt[t - 1];
-        for (int j = tid; j < n_prev; j += blockDim.x) {
-            const int i = c.idx[(size_t)(t - 1) * c.M + j];
+        NPBNN_STAMP(3);
+        acc = s_accept;
+        // commit (accepted) or roll back (rejected) the entries the pending proposal touched
+        if (ip >= 0) {
+            if (acc) c.w_cur[ip] = wp_p;
+            else { c.w_prop[ip] = wc_p; patch_image_at(c, pos_p, sc_p, wc_p); }
+        }
+        for (int j = tid + 1024; j < n_prev; j += 1024) {
+            const int i = idx_prev[j];
             if (i >= 0) {
                 if (acc) c.w_cur[i] = c.w_prop[i];
-                else {
-                    const double v = c.w_cur[i];
-                    c.w_prop[i] = v;
-                    patch_image(c, i, v);                // roll the rejected entry back in the image too
-                }
+                else { const double v = c.w_cur[i]; c.w_prop[i] = v; patch_image(c, i, v); }
             }
         }
-        __syncthreads();
+        __syncthreads();        // roll-backs land before the new proposal may touch the same entries
+        NPBNN_STAMP(4);
     }
-    if (t >= c.K) return;
+    if (!have_new) return;
 
-    const int n_new = c.cnt[t];
-    for (int j = tid; j < n_new; j += blockDim.x) {
-        const int i = c.idx[(size_t)t * c.M + j];
-        if (i >= 0) {
-            double v = c.w_cur[i] + c.delta[(size_t)t * c.M + j];
-            if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
-            if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
-            if (c.mask) v *= c.mask[i];
-            c.w_prop[i] = v;
-            patch_image(c, i, v);
+    // ---- propose iteration t.  W_prop differs from W_cur only at the pending entries, so the value an entry has
+    //      after the decision is (accepted ? W_prop : W_cur) at that index - both were fetched above ----
+    double dlp = 0.0;
+    for (int j = tid; j < n_new; j += 1024) {
+        const bool first = j < 1024;
+        const int i = first ? in_ : idx_new[j];
+        if (i < 0) continue;
+        const double base = first ? (acc ? wp_n : wc_n) : c.w_cur[i];      // w_cur is final after the barrier
+        const double m = first ? mk : (c.mask ? c.mask[i] : 1.0);
+        double v = base + (first ? dl : delta_new[j]);
+        if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
+        if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
+        v *= m;
+        c.w_prop[i] = v;
+        if (first) patch_image_at(c, pos_n, sc_n, v);
+        else patch_image(c, i, v);
+        if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+            int l = 0;
+            while (l + 1 < c.net.n_layers && i >= c.net.L[l + 1].w_off) ++l;
+            dlp += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
         }
     }
-    __syncthreads();
-
-    // prior of the proposal, fixed summation order (thread-strided partial sums, then a tree)
-    double lp = 0.0;
-    if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
-        for (int l = 0; l < c.net.n_layers; ++l) {
-            const LayerMeta& L = c.net.L[l];
-            const int n = L.out_dim * (L.in_dim + L.has_bias);
-            const double sc = c.prior_scale[l];
-            if (c.prior_kind == NPBNN_PRIOR_NORMAL) {
-                const double inv = 1.0 / sc;
-                double q = 0.0;
-                for (int i = tid; i < n; i += blockDim.x) { const double z = c.w_prop[L.w_off + i] * inv; q += z * z; }
-                lp += -0.5 * q;
-                if (tid == 0) lp -= (double)n * (log(sc) + 0.9189385332046727418);
-            } else {
-                for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_prop[L.w_off + i], sc);
-            }
-        }
-    }
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) lp += shfl_xor_f64(lp, sh);
-    if ((tid & 63) == 0) red[tid >> 6] = lp;
-    __syncthreads();
+    NPBNN_STAMP(5);
+    const double s = block_sum(dlp, red);
+    NPBNN_STAMP(6);
     if (tid == 0) {
-        double s = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-        st->cand_logPrior = s;
-        st->t = t + 1;
+        st->cand_logPrior = st->logPrior + s;
     }
 }
 

@@ -65,8 +65,6 @@ struct npbnn_ctx {
     double* d_colov = nullptr;     // column override (in_dim doubles)
     float* d_image = nullptr;      // float32 fragment image
     int* d_w2img = nullptr;        // packed-weight index -> image float index
-    std::vector<int> h_w2img;      // host copies, to gather per-draw image positions for the chain
-    std::vector<float> h_w2scale;
     double* d_partials = nullptr;
     int partial_waves = 0;
     unsigned* d_conf = nullptr;    // NPBNN_MAX_WIDTH^2
@@ -506,8 +504,6 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
     }
     HIP_TRY(ctx, hipMalloc(&ctx->d_w2img, map.size() * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_w2img, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-    ctx->h_w2img = map;
-    ctx->h_w2scale = scale;
     if (f16) {
         HIP_TRY(ctx, hipMalloc(&ctx->d_w2scale, scale.size() * sizeof(float)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_w2scale, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -904,17 +900,10 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_idx, idx, need * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_delta, delta, need * sizeof(double), hipMemcpyHostToDevice, st));
     {   // image position (and fp16-split scale) of every drawn entry, so the step kernel needs no dependent lookup
-        std::vector<int> hpos(need, 0);
-        std::vector<float> hsc;
         const bool f16 = ctx->net.l0_f16 != 0;
-        if (f16) hsc.assign(need, 1.0f);
-        for (size_t i = 0; i < need; ++i)
-            if (idx[i] >= 0) {
-                hpos[i] = ctx->h_w2img[(size_t)idx[i]];
-                if (f16) hsc[i] = ctx->h_w2scale[(size_t)idx[i]];
-            }
-        HIP_TRY(ctx, hipMemcpy(ctx->d_pos, hpos.data(), need * sizeof(int), hipMemcpyHostToDevice));
-        if (f16) HIP_TRY(ctx, hipMemcpy(ctx->d_pscale, hsc.data(), need * sizeof(float), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(gather_pos_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, (const int*)ctx->d_idx, (long long)need,
+                           (const int*)ctx->d_w2img, (const float*)(f16 ? ctx->d_w2scale : nullptr), ctx->d_pos,
+                           f16 ? ctx->d_pscale : (float*)nullptr);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cnt, cnt, (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_logu, log_u, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1051,28 +1040,30 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     if (rc) return rc;
     rc = push_finalize_params(ctx, f);
     if (rc) return rc;
-    std::vector<hipEvent_t> evs(2 * (size_t)iters);
-    for (auto& e : evs) HIP_TRY(ctx, hipEventCreate(&e));
+    // (1) the dominant kernel alone: `iters` back-to-back launches between one pair of events (per-launch event pairs
+    //     would add ~4 us of command-processor overhead to each 20 us kernel); includes the ~1.5 us launch boundary
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float burst = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&burst, ctx->ev[0], ctx->ev[1]));
+    const double sum = (double)burst;
+    // (2) evaluation = eval kernel + finalize
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i) {
-        HIP_TRY(ctx, hipEventRecord(evs[2 * i], ctx->stream));
         hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
-        HIP_TRY(ctx, hipEventRecord(evs[2 * i + 1], ctx->stream));
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, (const FinalizeParams*)ctx->d_fparams);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
-    double sum = 0.0;
-    for (int i = 0; i < iters; ++i) {
-        float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
-        sum += ms;
-    }
     float tot = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[1]));
-    for (auto& e : evs) (void)hipEventDestroy(e);
     *ms_main_kernel = sum / iters;
     *ms_total = (double)tot / iters;
     return NPBNN_OK;

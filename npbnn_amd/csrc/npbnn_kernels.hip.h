@@ -699,7 +699,6 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int v = wave; v < nvals; v += nw) {
         double s = 0.0;
-#pragma unroll 4
         for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)v * n_blocks + b];
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
@@ -834,6 +833,16 @@ __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 d
     if (threadIdx.x == 0)
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
     return s;
+}
+
+// image position / fp16-split scale of every pre-drawn entry, gathered once per batch
+__global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__ idx, long long n, const int* __restrict__ w2img,
+                                                         const float* __restrict__ w2scale, int* __restrict__ pos, float* __restrict__ pscale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int w = idx[i];
+    pos[i] = w >= 0 ? w2img[w] : 0;
+    if (pscale) pscale[i] = (w >= 0 && w2scale) ? w2scale[w] : 1.0f;
 }
 
 // change of the log prior density when an entry moves from `b` to `v` (scale sc); the normal prior needs no

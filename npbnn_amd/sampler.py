@@ -24,6 +24,18 @@ from .proposals import UpdateBinomial, UpdateNormal, UpdateNormal1D, multiplier_
 
 _LAZY = ("_y", "_y_test", "_accuracy", "_test_accuracy", "_label_acc", "_label_freq")
 
+_POOL = None
+
+
+def _draw_pool():
+    """One helper thread that pre-draws the next sub-batch of random numbers while the GPU runs the current one
+    (both the pre-draw and the device call release the GIL)."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="npbnn-predraw")
+    return _POOL
+
 
 def get_backend(bnn_obj, likelihood_f):
     """The model's resident device context (created on first use, shared by every sampler built on
@@ -368,8 +380,6 @@ class MCMC():
     # ------------------------------------------------------------------------------------------
     # K iterations with the chain resident on the device
     # ------------------------------------------------------------------------------------------
-    MAX_BATCH = 4096
-
     def _device_loop_ok(self, bnn_obj, k):
         """True when the next k iterations can run as a device-resident chain: the default proposal and no
         feature of mh_step whose random draws depend on the chain state."""
@@ -397,57 +407,76 @@ class MCMC():
     def run_steps(self, bnn_obj, n_steps):
         """Advance the chain by ``n_steps`` iterations: exactly ``n_steps`` calls of :meth:`mh_step` (same random
         stream, same adaptation points, same bookkeeping), executed where possible as a device-resident chain
-        with the random numbers pre-drawn on the host."""
+        with the random numbers pre-drawn on the host (the draws of the next sub-batch are produced by a helper
+        thread while the GPU runs the current one)."""
         from . import predraw as pd
         self._bnn = bnn_obj
         if self._backend is None:
             self._backend = get_backend(bnn_obj, self._likelihood_f)
         remaining = int(n_steps)
         while remaining > 0:
-            k = min(remaining, self.MAX_BATCH)
+            seg = remaining                       # iterations over which the proposal settings stay constant
             boundary = self._next_adapt_boundary()
             if boundary is not None:
-                k = min(k, boundary - self._current_iteration)
-            if not self._device_loop_ok(bnn_obj, k):
+                seg = min(seg, boundary - self._current_iteration)
+            if not self._device_loop_ok(bnn_obj, seg):
                 self.mh_step(bnn_obj)
                 remaining -= 1
                 continue
             self._adapt(bnn_obj)
-            it0 = self._current_iteration
-            idx, delta, cnt, u, _ = pd.predraw(self._rs, self._randomize_seed, it0, self._mcmc_id, k, bnn_obj._w_layers,
-                                               self._update_n, self._update_ws, self._freq_layer_update)
-            regression = bnn_obj._estimation_mode == "regression"
-            sigma = None
-            cur_sigma = None
+            shapes = [np.empty(w.shape) for w in bnn_obj._w_layers]      # predraw only needs the shapes
+
+            def draw(first_it, k):
+                return pd.predraw(self._rs, self._randomize_seed, first_it, self._mcmc_id, k, shapes, self._update_n,
+                                  self._update_ws, self._freq_layer_update)
+
+            sizes = [min(self.SUB_BATCH, seg - o) for o in range(0, seg, self.SUB_BATCH)]
+            pool = _draw_pool()
+            it = self._current_iteration
+            pending = pool.submit(draw, it, sizes[0])
+            for n, k in enumerate(sizes):
+                idx, delta, cnt, u, _ = pending.result()
+                it += k
+                if n + 1 < len(sizes):
+                    pending = pool.submit(draw, it, sizes[n + 1])
+                self._run_device_batch(bnn_obj, idx, delta, cnt, u)
+            remaining -= seg
+
+    SUB_BATCH = 256
+
+    def _run_device_batch(self, bnn_obj, idx, delta, cnt, u):
+        k = len(cnt)
+        regression = bnn_obj._estimation_mode == "regression"
+        sigma = None
+        cur_sigma = None
+        if regression:
+            cur_sigma = np.ones(bnn_obj._size_output) * bnn_obj._error_prm
+            if not bnn_obj._empirical_error:
+                sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
+        w_new, acc, _, _, res = self._backend.run_chain(
+            bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=np.log(u),
+            prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
+            w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
+            cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma, mask=bnn_obj._mask)
+        if res["n_accepted"] > 0:
+            layers, off = [], 0
+            for w in bnn_obj._w_layers:
+                layers.append(w_new[off:off + w.size].reshape(w.shape))
+                off += w.size
+            bnn_obj.reset_weights(layers)
+            self._logLik, self._logPrior = res["loglik"], res["logprior"]
+            self._logPost = self._logLik + self._logPrior
             if regression:
-                cur_sigma = np.ones(bnn_obj._size_output) * bnn_obj._error_prm
-                if not bnn_obj._empirical_error:
-                    sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
-            w_new, acc, _, _, res = self._backend.run_chain(
-                bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=np.log(u), prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0,
-                prior_scale=bnn_obj._prior_scale, w_bound=bnn_obj._w_bound, temperature=self._temperature,
-                lik_temp=self._lik_temp, cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma,
-                sigma=sigma, mask=bnn_obj._mask)
-            if res["n_accepted"] > 0:
-                layers, off = [], 0
-                for w in bnn_obj._w_layers:
-                    layers.append(w_new[off:off + w.size].reshape(w.shape))
-                    off += w.size
-                bnn_obj.reset_weights(layers)
-                self._logLik, self._logPrior = res["loglik"], res["logprior"]
-                self._logPost = self._logLik + self._logPrior
-                if regression:
-                    bnn_obj.reset_error_prm(res["sigma"])
-                self._accepted_override = None
-                self._invalidate()
-            history = self._last_accepted_mem + [int(a) for a in acc]
-            self._last_accepted = int(acc[-1])
-            self._acceptance_rate = np.mean(history[-101:]) if len(history) > 100 else np.mean(history)
-            self._last_accepted_mem = history[-100:] if len(history) > 100 else history
-            self._current_iteration += k
-            if self._randomize_seed:
-                self._rs = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
-            remaining -= k
+                bnn_obj.reset_error_prm(res["sigma"])
+            self._accepted_override = None
+            self._invalidate()
+        history = self._last_accepted_mem + [int(a) for a in acc]
+        self._last_accepted = int(acc[-1])
+        self._acceptance_rate = np.mean(history[-101:]) if len(history) > 100 else np.mean(history)
+        self._last_accepted_mem = history[-100:] if len(history) > 100 else history
+        self._current_iteration += k
+        if self._randomize_seed:
+            self._rs = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
 
     def gibbs_step(self, bnn_obj):
         bnn_obj.sample_prior_scale()

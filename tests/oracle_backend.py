@@ -54,3 +54,49 @@ class OracleBackend:
             out["sum_r"] = r.sum(axis=0)
             out["sum_r2"] = (r * r).sum(axis=0)
         return out
+
+
+class OracleChainBackend(OracleBackend):
+    """Adds a float64 numpy stand-in for npbnn_chain_run so that MCMC.run_steps (batching, pre-draw pipeline,
+    bookkeeping) can be tested on CPU against the plain mh_step loop."""
+
+    def run_chain(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None):
+        shapes = [w.shape for w in weights]
+        cur = np.concatenate([np.asarray(w, dtype=float).ravel() for w in weights])
+        m = None if mask is None else np.concatenate([np.asarray(x, dtype=float).ravel() for x in mask])
+
+        def unpack(v):
+            out, off = [], 0
+            for s in shapes:
+                n = int(np.prod(s))
+                out.append(v[off:off + n].reshape(s))
+                off += n
+            return out
+
+        ll, lp = cur_loglik, cur_logprior
+        sig = cur_sigma
+        K = len(cnt)
+        acc = np.zeros(K, dtype=np.uint8)
+        llp, lpp = np.zeros(K), np.zeros(K)
+        n_acc = 0
+        for t in range(K):
+            prop = cur.copy()
+            sel = idx[t, :cnt[t]]
+            ok = sel >= 0
+            v = cur[sel[ok]] + delta[t, :cnt[t]][ok]
+            v = np.where(v > w_bound, w_bound - (v - w_bound), v)
+            v = np.where(v < -w_bound, -w_bound + (-w_bound - v), v)
+            prop[sel[ok]] = v
+            if m is not None:
+                prop = prop * m
+            wl = unpack(prop)
+            r = self.evaluate(wl, lik_temp=lik_temp, sigma=sigma)
+            p = orc.log_prior(wl, prior_kind, prior_scale)
+            llp[t], lpp[t] = r["loglik"], p
+            if ((r["loglik"] + p) - (ll + lp)) * temperature >= log_u[t]:
+                cur, ll, lp, acc[t] = prop, r["loglik"], p, 1
+                n_acc += 1
+                if r["sigma"] is not None:
+                    sig = r["sigma"]
+        return cur, acc, llp, lpp, dict(loglik=ll, logprior=lp, sigma=sig, n_accepted=n_acc)

@@ -127,3 +127,32 @@ def test_pickle_and_deepcopy_drop_device_handles():
     c = copy.deepcopy(bnn)
     assert c._w_layers[0] is not bnn._w_layers[0]
     np.testing.assert_array_equal(c._w_layers[0], bnn._w_layers[0])
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg4s"])
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_run_steps_batching_equals_mh_step_loop_on_cpu(name, randomize_seed):
+    """run_steps (segments cut at adaptation boundaries, sub-batches, pre-draw helper thread) drives a numpy
+    stand-in of the device chain and must reproduce the plain mh_step loop."""
+    from oracle_backend import OracleChainBackend
+    cfg = dict(cases.TRACES[name])
+    cfg["mcmc"] = dict(cfg["mcmc"], randomize_seed=randomize_seed, mcmc_id=3)
+    bnn_a, mcmc_a, _ = build(cfg)
+    bnn_b, mcmc_b, _ = build(cfg)
+    out_kind = 0 if cfg["kind"] == "classification" else 1
+    mcmc_b._backend = OracleChainBackend(bnn_b, out_kind)
+    mcmc_b.SUB_BATCH = 37                         # several sub-batches per segment
+    n = 260
+    for _ in range(n):
+        mcmc_a.mh_step(bnn_a)
+    mcmc_b.run_steps(bnn_b, 111)
+    mcmc_b.run_steps(bnn_b, n - 111)
+    assert mcmc_a._current_iteration == mcmc_b._current_iteration == n
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+    assert sum(mcmc_a._last_accepted_mem) > 10
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-12)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(mcmc_a._update_n, mcmc_b._update_n)
+    assert mcmc_a._acceptance_rate == mcmc_b._acceptance_rate

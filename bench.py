@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 
 N_ROWS, N_FEATURES, N_CLASSES, HIDDEN = 100_000, 256, 10, [32, 8]
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+# HBM bytes per evaluation measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this workload
+# (profiles/r01_eval_pmc_*.csv): (2 x 50619.6 KiB [gfx950 reports half of a wide streaming read] + 8 KiB)
+MEASURED_TRAFFIC_BYTES = (2 * 50619.625 + 8.0) * 1024
 
 
 def synthetic_config2():
@@ -158,9 +161,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "config 2: 100k x 256 features, 10 classes, hidden [32,8], tanh, bias 2; "
                                    "one chain per GPU", "chains": world, "swap_frequency": swap_frequency if world > 1 else None,
-                       "swap_exchange": comm_kind, "loop": "device-resident chain (npbnn_chain_run), proposals pre-drawn on the host"},
+                       "swap_exchange": comm_kind, "layer0": mcmc._backend.ctx.l0_mode(), "loop": "device-resident chain (npbnn_chain_run), proposals pre-drawn on the host"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "eval_kernel<2>",
+                         "frac": achieved / HBM_PEAK, "traffic": MEASURED_TRAFFIC_BYTES,
+                         "traffic_source": "profiles/r01_eval_pmc_FETCH_SIZE.csv + r01_eval_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, separate passes)",
+                         "kernel": "eval_kernel<MT0=2,MTI=1,%s>" % ("fp16-split" if ctx.l0_mode() == "f16-split" else "f32"),
                          "kernel_ms": ms_kernel, "algorithmic_bytes": alg_bytes},
             "accept_rate": float(mcmc._acceptance_rate),
             "loglik": float(mcmc._logLik),

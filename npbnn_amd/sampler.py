@@ -430,7 +430,7 @@ class MCMC():
                 return pd.predraw(self._rs, self._randomize_seed, first_it, self._mcmc_id, k, shapes, self._update_n,
                                   self._update_ws, self._freq_layer_update)
 
-            sizes = [min(self.SUB_BATCH, seg - o) for o in range(0, seg, self.SUB_BATCH)]
+            sizes = self._sub_batches(seg)
             pool = _draw_pool()
             it = self._current_iteration
             pending = pool.submit(draw, it, sizes[0])
@@ -442,7 +442,17 @@ class MCMC():
                 self._run_device_batch(bnn_obj, idx, delta, cnt, u)
             remaining -= seg
 
-    SUB_BATCH = 256
+    SUB_BATCH = 128          # first sub-batch of a segment (its pre-draw is not overlapped); later ones double
+    SUB_BATCH_MAX = 2048
+
+    def _sub_batches(self, seg):
+        sizes, k = [], self.SUB_BATCH
+        while seg > 0:
+            n = min(k, seg)
+            sizes.append(n)
+            seg -= n
+            k = min(2 * k, self.SUB_BATCH_MAX)
+        return sizes
 
     def _run_device_batch(self, bnn_obj, idx, delta, cnt, u):
         k = len(cnt)

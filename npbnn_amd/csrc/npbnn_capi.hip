@@ -224,8 +224,14 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         if (a->n_targets < 1 || a->n_targets > NPBNN_MAX_TARGETS || a->n_targets > net.n_out)
             return fail(ctx, NPBNN_E_ARG, "set_arch: Gaussian likelihood needs 1..%d target columns (<= outputs), got %d",
                         NPBNN_MAX_TARGETS, a->n_targets);
-    } else if (a->lik_kind != NPBNN_LIK_CATEGORICAL && a->lik_kind != NPBNN_LIK_NONE) {
-        return fail(ctx, NPBNN_E_ARG, "set_arch: likelihood kind %d is not implemented by this build", a->lik_kind);
+    } else if (lik_needs_row_scratch(a->lik_kind)) {
+        const int k = a->n_targets;
+        int need_out = 1;
+        if (a->lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA || a->lik_kind == NPBNN_LIK_NEGBIN2D) need_out = 2 * k;
+        else if (a->lik_kind != NPBNN_LIK_POISSON) need_out = 2;
+        if (k < 1 || k > 8 || net.n_out > 16 || net.n_out < need_out)
+            return fail(ctx, NPBNN_E_ARG, "set_arch: likelihood kind %d needs 1..8 target columns and %d..16 outputs (got %d targets, %d outputs)",
+                        a->lik_kind, need_out, k, net.n_out);
     }
     ctx->net = net;
     ctx->n_weights = woff;
@@ -245,7 +251,7 @@ int max_inner_tiles(const NetMeta& net) {
 int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
     const int top = max_inner_tiles(ctx->net) == 1 ? 16 : 8;     // launch bound of the kernel build in use
     for (int w = top; w >= 1; w -= (w > 8 ? 2 : (w > 1 ? w / 2 : 1))) {
-        const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets);
+        const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets, ctx->net.lik_kind);
         if (need <= ctx->lds_limit) {
             *lds_bytes = need;
             return w;
@@ -447,8 +453,8 @@ int check_dataset_for_lik(npbnn_ctx* ctx, const Dataset& d, int lik) {
     if (d.F != ctx->arch.in_dim)
         return fail(ctx, NPBNN_E_ARG, "data has %d features but the network expects %d", d.F, ctx->arch.in_dim);
     if (lik == NPBNN_LIK_CATEGORICAL && !d.labels) return fail(ctx, NPBNN_E_STATE, "categorical likelihood needs labels (npbnn_set_labels_i64)");
-    if (lik == NPBNN_LIK_GAUSS) {
-        if (!d.targets) return fail(ctx, NPBNN_E_STATE, "Gaussian likelihood needs targets (npbnn_set_targets_f64)");
+    if (lik == NPBNN_LIK_GAUSS || lik_needs_row_scratch(lik)) {
+        if (!d.targets) return fail(ctx, NPBNN_E_STATE, "this likelihood needs targets (npbnn_set_targets_f64)");
         if (d.k != ctx->net.k_targets) return fail(ctx, NPBNN_E_ARG, "targets have %d columns, architecture says %d", d.k, ctx->net.k_targets);
     }
     return NPBNN_OK;
@@ -846,8 +852,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
     if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run: call npbnn_set_arch first");
     const int lik = ctx->net.lik_kind;
-    if (lik != NPBNN_LIK_CATEGORICAL && lik != NPBNN_LIK_GAUSS)
-        return fail(ctx, NPBNN_E_STATE, "chain_run: needs the categorical or Gaussian likelihood");
+    if (lik == NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_STATE, "chain_run: the architecture has no likelihood");
     if (cfg->prior_kind < 0 || cfg->prior_kind > NPBNN_PRIOR_LAPLACE) return fail(ctx, NPBNN_E_ARG, "chain_run: prior_kind=%d", cfg->prior_kind);
     for (int t = 0; t < K; ++t)
         if (cnt[t] < 0 || cnt[t] > M) return fail(ctx, NPBNN_E_ARG, "chain_run: cnt[%d]=%d outside 0..%d", t, cnt[t], M);

@@ -42,7 +42,13 @@ constexpr int kMaxWavesPerBlock = 16;
 constexpr int kAuxSlots = 4;                   // per-wave row-aux buffers (labels / weights / targets)
 // per-wave aux slot: labels (64 B) + instance weights (64 B) + 16 x k targets; sized per network
 __host__ __device__ inline int aux_bytes(int k_targets) { return 128 + 64 * k_targets; }
-__host__ __device__ inline int wave_lds_bytes(int k_targets) { return kRing * 1024 + kAuxSlots * aux_bytes(k_targets); }
+// likelihoods that combine several outputs of one row (predicted sigma, count data) exchange them through 1 KiB of LDS
+__host__ __device__ inline bool lik_needs_row_scratch(int lik_kind) {
+    return lik_kind >= NPBNN_LIK_GAUSS_PRED_SIGMA && lik_kind <= NPBNN_LIK_NEGBIN_BASE10;
+}
+__host__ __device__ inline int wave_lds_bytes(int k_targets, int lik_kind) {
+    return kRing * 1024 + kAuxSlots * aux_bytes(k_targets) + (lik_needs_row_scratch(lik_kind) ? 1024 : 0);
+}
 constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -376,8 +382,9 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
     const int wpb = blockDim.x >> 6;
     const int k_targets = net.k_targets;
     const int aux_sz = aux_bytes(k_targets);
-    char* const ring = smem + (size_t)net.image_floats * 4 + (size_t)wave * wave_lds_bytes(k_targets);
+    char* const ring = smem + (size_t)net.image_floats * 4 + (size_t)wave * wave_lds_bytes(k_targets, net.lik_kind);
     char* const aux = ring + kRing * 1024;
+    float* const row_scratch = reinterpret_cast<float*>(aux + kAuxSlots * aux_sz);   // [16 rows][16 outputs], generic likelihoods
 
     // ---- stage the fragment image into LDS: lane-linear DMA copy shared by the workgroup ----
     {
@@ -611,6 +618,46 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
                 if (p.confusion && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
             }
             ll_acc += (double)term;
+        } else if (lik_needs_row_scratch(lik_kind)) {
+            // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
+            // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
+            *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[0];
+            const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+            double term = 0.0;
+            if (row_ok) {
+                for (int j = kq; j < k_targets; j += 4) {
+                    const double y = (double)tg[n * k_targets + j];
+                    if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
+                        const double mu = (double)row_scratch[n * 16 + j];
+                        const double zs = (double)row_scratch[n * 16 + k_targets + j];
+                        const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));      // softplus, BNN_lib.py:172,181
+                        const double r = (y - mu) / sg;
+                        term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
+                    } else if (lik_kind == NPBNN_LIK_POISSON) {
+                        if (j == 0) {
+                            const double eta = (double)row_scratch[n * 16];
+                            term += y * eta - exp(eta) - lgamma(y + 1.0);             // poisson.logpmf(k, exp(eta))
+                        }
+                    } else {
+                        const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
+                        if (one_col && j > 0) continue;
+                        const int jp = one_col ? 1 : k_targets + j;
+                        const double e0 = (double)row_scratch[n * 16 + j], e1 = (double)row_scratch[n * 16 + jp];
+                        double mean, pr;
+                        if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
+                            mean = exp(2.302585092994046 * e0);
+                            pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+                        } else {
+                            mean = exp(e0);
+                            pr = 1.0 / (1.0 + exp(-e1));
+                        }
+                        const double nn = pr * mean / (1.0 - pr);
+                        // nbinom.logpmf(k; n, p) = lgamma(k+n) - lgamma(k+1) - lgamma(n) + n log p + k log(1-p)
+                        term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
+                    }
+                }
+            }
+            ll_acc += term;
         } else if (lik_kind == NPBNN_LIK_GAUSS) {
             const float* tg = reinterpret_cast<const float*>(a_slot + 128);
 #pragma unroll
@@ -657,7 +704,7 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
                 }
         }
         __syncthreads();                                   // every wave is done with its ring: reuse it as scratch
-        double* wsum = reinterpret_cast<double*>(smem + (size_t)net.image_floats * 4);    // [wave][kPartialStride]
+        double* wsum = reinterpret_cast<double*>(smem + (size_t)net.image_floats * 4);    // [wave][kPartialStride] (<= 4.2 KB, inside the rings)
         if (lane == 0) wsum[wave * kPartialStride] = ll_acc;
         if (lik_kind == NPBNN_LIK_GAUSS && n == 0) {
 #pragma unroll
@@ -730,7 +777,8 @@ __device__ __forceinline__ void loglik_from_totals(const double* tot, int lik_ki
         }
         o->loglik = lik_temp * ll;
     } else {
-        o->loglik = lik_temp * tot[0];
+        // the plug-in count likelihoods ignore lik_temp (BNN_lik.py:5-66)
+        o->loglik = (lik_kind >= NPBNN_LIK_POISSON && lik_kind <= NPBNN_LIK_NEGBIN_BASE10 ? 1.0 : lik_temp) * tot[0];
     }
 }
 

@@ -17,7 +17,9 @@ from .backend import HipContext
 from .layers import output_kind
 from .likelihoods import likelihood_kind
 
-_FUSED = (capi.LIK_CATEGORICAL, capi.LIK_GAUSS)
+_FUSED = (capi.LIK_CATEGORICAL, capi.LIK_GAUSS, capi.LIK_GAUSS_PRED_SIGMA, capi.LIK_POISSON, capi.LIK_NEGBIN,
+          capi.LIK_NEGBIN2D, capi.LIK_NEGBIN_BASE10)
+_TARGET_KINDS = _FUSED[1:]
 
 
 def bias_flags(weights, n_features):
@@ -53,7 +55,7 @@ class HipBackend:
             self.ctx.set_labels(bnn._labels, capi.TRAIN)
             if self.has_test and len(bnn._test_labels) > 0:
                 self.ctx.set_labels(bnn._test_labels, capi.TEST)
-        elif self.lik_kind == capi.LIK_GAUSS:
+        elif self.lik_kind in _TARGET_KINDS:
             self.n_targets = bnn._labels.shape[1]
             self.ctx.set_targets(bnn._labels, capi.TRAIN)
             if self.has_test and len(bnn._test_labels) > 0:

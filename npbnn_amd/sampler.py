@@ -146,7 +146,7 @@ class MCMC():
         likelihoods; any other callable gets the prediction matrix (slow path)."""
         fw = self._forward_weights(weights, indicators)
         kind = likelihood_kind(self._likelihood_f)
-        if getattr(self._backend, "fused_likelihood", False) and kind in (capi.LIK_CATEGORICAL, capi.LIK_GAUSS):
+        if getattr(self._backend, "fused_likelihood", False) and kind is not None and kind != capi.LIK_NONE:
             sig = None
             if kind == capi.LIK_GAUSS:
                 empirical = bnn_obj._empirical_error and not init
@@ -390,7 +390,7 @@ class MCMC():
             return False
         if bnn_obj._act_fun._trainable or bnn_obj._feature_indicators is not None or bnn_obj._freq_indicator:
             return False
-        if likelihood_kind(self._likelihood_f) not in (capi.LIK_CATEGORICAL, capi.LIK_GAUSS):
+        if likelihood_kind(self._likelihood_f) in (None, capi.LIK_NONE):
             return False
         if any(np.ndim(s) != 0 for s in bnn_obj._prior_scale) or bnn_obj._hyper_p:
             return False

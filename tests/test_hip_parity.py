@@ -306,3 +306,35 @@ def test_auto_mode_falls_back_to_f32(hip):
     ctx.eval(w)
     assert ctx.l0_mode() == "f32"
     ctx.close()
+
+
+# ---- plug-in likelihoods (BNN_lik.py) and the predicted-sigma Gaussian ----------------------------
+def test_g3_count_likelihoods_against_reference_golden(golden_dir, hip):
+    g = np.load(os.path.join(golden_dir, "counts.npz"))
+    act = orc.Act("swish")
+    a = cases.count_inputs(seed=23, n_out=1, k=1)
+    ctx = make_ctx(hip, a["x"], a["weights"], act, 1, 3, targets=a["counts"], n_targets=1)
+    np.testing.assert_allclose(ctx.eval(a["weights"])["loglik"], g["poi"], rtol=LL_RTOL)
+    np.testing.assert_allclose(ctx.eval(a["weights"], lik_temp=0.3)["loglik"], g["poi"], rtol=LL_RTOL)   # lik_temp is ignored upstream
+    ctx.close()
+    b = cases.count_inputs(seed=24, n_out=2, k=1)
+    ctx = make_ctx(hip, b["x"], b["weights"], act, 1, 4, targets=b["counts"], n_targets=1)
+    np.testing.assert_allclose(ctx.eval(b["weights"])["loglik"], g["nb"], rtol=5e-6)
+    ctx.close()
+    ctx = make_ctx(hip, b["x"], b["weights"], act, 1, 6, targets=b["counts"], n_targets=1)
+    np.testing.assert_allclose(ctx.eval(b["weights"])["loglik"], g["nb10"], rtol=5e-6)
+    ctx.close()
+    c = cases.count_inputs(seed=25, n_out=4, k=2)
+    ctx = make_ctx(hip, c["x"], c["weights"], act, 1, 5, targets=c["counts"], n_targets=2)
+    np.testing.assert_allclose(ctx.eval(c["weights"])["loglik"], g["nb2d"], rtol=5e-6)
+    ctx.close()
+
+
+def test_g2_predicted_sigma_likelihood(golden_dir, hip):
+    g = np.load(os.path.join(golden_dir, "regression.npz"))
+    inp2 = cases.regression_inputs(seed=12, double_out=True)
+    ctx = make_ctx(hip, inp2["x"], inp2["weights"], orc.Act("tanh"), 2, 2, targets=inp2["targets"], n_targets=2)
+    np.testing.assert_allclose(ctx.eval(inp2["weights"])["loglik"], g["lik_err"], rtol=LL_RTOL)
+    np.testing.assert_allclose(ctx.eval(inp2["weights"], lik_temp=0.5)["loglik"], 0.5 * g["lik_err"], rtol=LL_RTOL)
+    assert_close(ctx.predict(inp2["weights"]), g["y_err"])
+    ctx.close()

@@ -192,6 +192,25 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
                     const double* log_u, uint8_t* out_accepted, double* out_loglik_prop, double* out_logprior_prop,
                     npbnn_chain_result* result);
 
+/* ---- stand-alone operators on host arrays (float64): the reference's call-surface helpers when user code calls them on an
+ * explicit matrix instead of through the sampler.  Each call uploads, runs one device kernel and downloads.
+ *   npbnn_op_activation  relu_f / leaky_relu_f / swish_f / tanh_f (BNN_lib.py:50-66); kind 4 = SoftPlus (:170-172); in place
+ *   npbnn_op_output      SoftMax / RegressTransformError on the rows of a matrix (BNN_lib.py:166-182); in place; ind < 0: cols/2
+ *   npbnn_op_likelihood  calc_likelihood* (BNN_lib.py:100-143) and the BNN_lik.py plug-ins on a prediction matrix
+ *   npbnn_op_confusion   argmax predictions -> [true][predicted] counts and predicted-class counts
+ *                        (CalcAccuracy / CalcLabelAccuracy / CalcLabelFreq, BNN_lib.py:203-233)
+ *   npbnn_op_sse         per-column sum of squared errors, link 0 identity / 1 exp / 2 10^x
+ *                        (CalcAccuracyRegression, CalcLabelAccuracyRegression BNN_lib.py:195-201; *_acc BNN_lik.py:81-99) */
+int npbnn_op_activation(int device, int kind, double prm, double* inout, int64_t n);
+int npbnn_op_output(int device, int out_kind, double* inout, int64_t rows, int32_t cols, int32_t ind);
+int npbnn_op_likelihood(int device, int lik_kind, const double* pred, int64_t rows, int32_t cols, const int64_t* labels,
+                        const double* targets, int32_t k, const double* inst_w, const double* class_w, int32_t n_class_w,
+                        double lik_temp, const double* sigma, double* out);
+int npbnn_op_confusion(int device, const double* pred, int64_t rows, int32_t cols, const int64_t* labels, int64_t* conf,
+                       int64_t* pred_counts);
+int npbnn_op_sse(int device, const double* pred, const double* targets, int64_t rows, int32_t cols_pred, int32_t k, int link,
+                 double* out_per_col);
+
 /* ---- MC3 temperature-swap exchange over RCCL (xGMI inside a node): replaces the multiprocessing pool
  * round trip of whole pickled chains in MC3.run_mcmc (np_bnn/BNN_mc3.py:94-112), of which the swap
  * decision only reads two scalars per chain.  One communicator per process / GPU; host buffers in and out.

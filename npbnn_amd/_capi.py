@@ -87,6 +87,13 @@ SIGNATURES = {
     "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
     "npbnn_chain_run": (C.c_int, [_P, C.POINTER(ChainCfg), _DP, _DP, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _DP,
                                   C.POINTER(C.c_int32), _DP, C.POINTER(C.c_uint8), _DP, _DP, C.POINTER(ChainResult)]),
+    "npbnn_op_activation": (C.c_int, [C.c_int, C.c_int, C.c_double, _DP, C.c_int64]),
+    "npbnn_op_output": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.c_int32]),
+    "npbnn_op_likelihood": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.POINTER(C.c_int64), _DP, C.c_int32, _DP, _DP,
+                                      C.c_int32, C.c_double, _DP, _DP]),
+    "npbnn_op_confusion": (C.c_int, [C.c_int, _DP, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64)]),
+    "npbnn_op_sse": (C.c_int, [C.c_int, _DP, _DP, C.c_int64, C.c_int32, C.c_int32, C.c_int, _DP]),
     "npbnn_comm_unique_id": (C.c_int, [C.c_char * 128]),
     "npbnn_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char * 128, C.POINTER(_P)]),
     "npbnn_comm_allgather_f64": (C.c_int, [_P, _DP, C.c_int, _DP]),

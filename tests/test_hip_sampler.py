@@ -127,3 +127,44 @@ def test_driver_and_logger_end_to_end(tmp_path):
     b2, m2, lg = bn.load_obj(logger._pklfile)
     assert len(lg._post_weight_samples) == 6
     assert m2._accuracy == mcmc._accuracy and mcmc._accuracy > 0.22
+
+
+def test_mc3_four_chains_on_one_gpu_follow_reference(golden_dir, tmp_path):
+    """bnn_runner_MC3.py call sequence: 4 chains in this process (each with its own resident context), device-resident
+    chains between swaps.  The float32 chains follow the float64 reference swap sequence for the first swaps."""
+    cfg = cases.MC3_TRACE
+    g = np.load(os.path.join(golden_dir, "mc3.npz"))
+    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+    np.random.seed(1234)
+    bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
+    logger = bn.postLogger(bnn, filename="MC3", wdir=str(tmp_path), log_all_weights=0)
+    mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"], n_iteration=cfg["n_iteration"],
+                n_chains=cfg["n_chains"], swap_frequency=cfg["swap_frequency"], verbose=0)
+    np.testing.assert_array_equal(mc3.rseeds, g["rseeds"])
+    quiet(mc3.run_mcmc)
+    assert len(mc3.swap_log) == 30
+    accepted = [i for i, s in enumerate(mc3.swap_log) if s[4]]
+    want = [int(r[0]) for r in g["swapped"]]
+    n_common = 0
+    for a, b in zip(accepted, want):
+        if a != b:
+            break
+        n_common += 1
+    assert n_common >= 5, "swap sequences diverged immediately: %s vs %s" % (accepted, want)
+    rows = np.loadtxt(logger._logfile, skiprows=1)
+    assert rows.shape[0] >= 25                      # the cold chain is logged after every swap interval
+    np.testing.assert_allclose(rows[:3, 2], g["log_rows"][:3, 2], rtol=2e-6)     # likelihood column of the first samples
+    temps = sorted(c[1]._temperature for c in mc3.singleChainArgs)
+    np.testing.assert_allclose(temps, sorted(g["temperatures0"]))
+
+
+def test_rccl_communicator_single_rank():
+    """The native RCCL communicator of the C ABI (one rank: all-gather and broadcast are identities)."""
+    from npbnn_amd.comm import RcclComm
+    comm = RcclComm(rank=0, world_size=1, device=0)
+    out = comm.allgather_f64(np.array([1.5, -2.25]))
+    np.testing.assert_array_equal(out, [[1.5, -2.25]])
+    np.testing.assert_array_equal(comm.bcast_i64(np.array([3, 1, 1])), [3, 1, 1])
+    assert comm.bcast_obj({"a": [1, 2, 3]}) == {"a": [1, 2, 3]}
+    comm.barrier()
+    comm.close()

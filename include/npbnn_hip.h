@@ -179,12 +179,17 @@ typedef struct {
     double cur_loglik, cur_logprior;           /* state of the chain on entry (MCMC._logLik / _logPrior) */
     double cur_sigma[NPBNN_MAX_TARGETS];       /* npBNN._error_prm on entry */
     int32_t force_f32;                         /* 1: run this batch on the float32 layer-0 path (after NPBNN_E_RANGE) */
+    int32_t n_candidates;                      /* proposals evaluated per pass over X (speculative Metropolis-Hastings: iteration t and
+                                                  t+1.. assuming the earlier ones are rejected; the chain is unchanged); 0 = as many
+                                                  as fit (<= 3), 1 = strictly one evaluation per iteration */
 } npbnn_chain_cfg;
 
 typedef struct {
     double loglik, logprior;                   /* state after the K iterations */
     double sigma[NPBNN_MAX_TARGETS];
     int64_t n_accepted;
+    int32_t n_passes;                          /* passes over X used for the K iterations */
+    int32_t n_candidates;                      /* candidates per pass actually used */
 } npbnn_chain_result;
 
 int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed,

@@ -12,9 +12,24 @@
 #include <vector>
 
 #include "npbnn_hip.h"
+#define NPBNN_KERNELS_MAIN
 #include "npbnn_kernels.hip.h"
 
 using namespace npbnn;
+
+// the evaluation-kernel instantiations live in npbnn_eval_inst_*.hip (compiled in parallel)
+namespace npbnn {
+eval_fn_t pick_eval_mti8(int mt0, int f16);
+eval_fn_t pick_eval_d1(int mt0, int f16);
+eval_fn_t pick_eval_d2(int mt0, int f16);
+eval_fn_t pick_eval_d3(int mt0, int f16);
+}
+
+static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand) {
+    if (mti != 1) return pick_eval_mti8(mt0, f16);
+    if (n_cand <= 1) return pick_eval_d1(mt0, f16);
+    return n_cand == 2 ? pick_eval_d2(mt0, f16) : pick_eval_d3(mt0, f16);
+}
 
 namespace {
 
@@ -79,7 +94,9 @@ struct npbnn_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     // device-resident chain
     double* d_wcur = nullptr;
-    double* d_wprop = nullptr;
+    double* d_pv = nullptr;        // [kMaxCand][M] proposed values of the candidates in flight
+    size_t pv_cap = 0;
+    PassDesc* d_pass = nullptr;
     double* d_mask = nullptr;
     ChainDev* d_chain = nullptr;
     int* d_idx = nullptr;
@@ -248,10 +265,10 @@ int max_inner_tiles(const NetMeta& net) {
     return mti;
 }
 
-int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
+int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand = 1) {
     const int top = max_inner_tiles(ctx->net) == 1 ? 16 : 8;     // launch bound of the kernel build in use
-    for (int w = top; w >= 1; w -= (w > 8 ? 2 : (w > 1 ? w / 2 : 1))) {
-        const size_t need = (size_t)ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets, ctx->net.lik_kind);
+    for (int w = top; w >= 1; --w) {
+        const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets, ctx->net.lik_kind);
         if (need <= ctx->lds_limit) {
             *lds_bytes = need;
             return w;
@@ -260,27 +277,9 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes) {
     return 0;
 }
 
-typedef void (*eval_fn_t)(const EvalParams*);
 
-template <int MTI, bool F16>
-eval_fn_t pick_kernel_mt0(int mt0) {
-    switch (mt0) {
-        case 1: return eval_kernel<1, MTI, F16>;
-        case 2: return eval_kernel<2, MTI, F16>;
-        case 3: return eval_kernel<3, MTI, F16>;
-        case 4: return eval_kernel<4, MTI, F16>;
-        case 5: return eval_kernel<5, MTI, F16>;
-        case 6: return eval_kernel<6, MTI, F16>;
-        case 7: return eval_kernel<7, MTI, F16>;
-        default: return eval_kernel<8, MTI, F16>;
-    }
-}
-
-// MTI = 1 when every layer after the first (and the output) has <= 16 nodes, else the general MTI = 8 build
-eval_fn_t pick_kernel(const NetMeta& net) {
-    const int mt0 = net.L[0].mt;
-    if (max_inner_tiles(net) == 1) return net.l0_f16 ? pick_kernel_mt0<1, true>(mt0) : pick_kernel_mt0<1, false>(mt0);
-    return net.l0_f16 ? pick_kernel_mt0<8, true>(mt0) : pick_kernel_mt0<8, false>(mt0);
+eval_fn_t pick_kernel(const NetMeta& net, int n_cand) {
+    return npbnn_pick_eval_kernel(net.L[0].mt, max_inner_tiles(net) == 1 ? 1 : 8, net.l0_f16, n_cand);
 }
 
 // ---- fp16-split data: scales from the training matrix, split copies built on the device ----
@@ -343,12 +342,13 @@ int rebuild_net(npbnn_ctx* ctx, bool f16);
 
 struct LaunchPlan {
     eval_fn_t fn;
+    int n_cand;
     int grid, wpb;
     size_t lds;
     int n_waves;
 };
 
-int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0) {
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1) {
     Dataset& d = ctx->ds[which];
     bool want_f16 = false;
     if (!force_f32 && ctx->l0_option != NPBNN_L0_F32) {
@@ -364,11 +364,16 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0) {
         if (rc0) return rc0;
     }
     size_t lds = 0;
-    const int wpb = pick_waves_per_block(ctx, &lds);
+    // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
+    int n_cand = max_inner_tiles(ctx->net) == 1 ? want_cand : 1;
+    if (n_cand > kMaxCand) n_cand = kMaxCand;
+    while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand) < 8) --n_cand;
+    lp->n_cand = n_cand;
+    const int wpb = pick_waves_per_block(ctx, &lds, n_cand);
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
-    lp->fn = pick_kernel(ctx->net);
+    lp->fn = pick_kernel(ctx->net, n_cand);
     lp->wpb = wpb;
     lp->lds = lds;
     int grid = (d.n_tiles + wpb - 1) / wpb;
@@ -384,7 +389,7 @@ int ensure_work_buffers(npbnn_ctx* ctx, int n_waves) {
     if (n_waves > ctx->partial_waves) {
         if (ctx->d_partials) (void)hipFree(ctx->d_partials);
         ctx->d_partials = nullptr;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_partials, (size_t)n_waves * kPartialStride * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_partials, (size_t)kMaxCand * n_waves * kPartialStride * sizeof(double)));
         ctx->partial_waves = n_waves;
     }
     return NPBNN_OK;
@@ -443,6 +448,7 @@ EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
     p.image = ctx->d_image;
     p.n_rows = d.n_rows;
     p.n_tiles = d.n_tiles;
+    p.pass = nullptr;
     p.Fp = ctx->net.l0_f16 ? d.Fp16 : d.Fp;
     p.net = ctx->net;
     return p;
@@ -600,7 +606,7 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_wcur, c->d_wprop, c->d_mask, c->d_chain, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu,
+    void* chain_bufs[] = {c->d_wcur, c->d_pv, c->d_pass, c->d_mask, c->d_chain, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu,
                           c->d_acc, c->d_llp, c->d_lpp};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
@@ -695,7 +701,6 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     if (ctx->d_colov) { (void)hipFree(ctx->d_colov); ctx->d_colov = nullptr; }
     if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
     if (ctx->d_wcur) { (void)hipFree(ctx->d_wcur); ctx->d_wcur = nullptr; }
-    if (ctx->d_wprop) { (void)hipFree(ctx->d_wprop); ctx->d_wprop = nullptr; }
     if (ctx->d_mask) { (void)hipFree(ctx->d_mask); ctx->d_mask = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)ctx->n_weights * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
@@ -863,15 +868,24 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, 0, &lp, cfg->force_f32);
+    int want_cand = cfg->n_candidates;
+    if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
+    rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
+    const int D = lp.n_cand;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
     if (!ctx->d_wcur) HIP_TRY(ctx, hipMalloc(&ctx->d_wcur, wb));
-    if (!ctx->d_wprop) HIP_TRY(ctx, hipMalloc(&ctx->d_wprop, wb));
     if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
     if (!ctx->d_chain) HIP_TRY(ctx, hipMalloc(&ctx->d_chain, sizeof(ChainDev)));
+    if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, sizeof(PassDesc)));
+    if ((size_t)M > ctx->pv_cap) {
+        if (ctx->d_pv) (void)hipFree(ctx->d_pv);
+        ctx->d_pv = nullptr; ctx->pv_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pv, (size_t)kMaxCand * M * sizeof(double)));
+        ctx->pv_cap = (size_t)M;
+    }
     const size_t need = (size_t)K * M;
     if (need > ctx->draw_cap) {
         if (ctx->d_idx) (void)hipFree(ctx->d_idx);
@@ -900,16 +914,14 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     }
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wcur, W_inout, wb, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wprop, ctx->d_wcur, wb, hipMemcpyDeviceToDevice, st));
     if (mask_packed) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mask, mask_packed, wb, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_idx, idx, need * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_delta, delta, need * sizeof(double), hipMemcpyHostToDevice, st));
-    {   // image position (and fp16-split scale) of every drawn entry, so the step kernel needs no dependent lookup
-        const bool f16 = ctx->net.l0_f16 != 0;
-        hipLaunchKernelGGL(gather_pos_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, (const int*)ctx->d_idx, (long long)need,
-                           (const int*)ctx->d_w2img, (const float*)(f16 ? ctx->d_w2scale : nullptr), ctx->d_pos,
-                           f16 ? ctx->d_pscale : (float*)nullptr);
-    }
+    const bool f16 = ctx->net.l0_f16 != 0;
+    // image position (and fp16-split scale) of every drawn entry, so no kernel needs a dependent lookup
+    hipLaunchKernelGGL(gather_pos_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, (const int*)ctx->d_idx, (long long)need,
+                       (const int*)ctx->d_w2img, (const float*)(f16 ? ctx->d_w2scale : nullptr), ctx->d_pos,
+                       f16 ? ctx->d_pscale : (float*)nullptr);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cnt, cnt, (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_logu, log_u, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
     ChainDev init{};
@@ -920,17 +932,17 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     init.n_accepted = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chain, &init, sizeof(ChainDev), hipMemcpyHostToDevice, st));
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
-    {   // full image once (class weights, biases, fragments); the step kernel then patches single entries
+    {   // weight image of the current state; accepted candidates are committed to it entry by entry
         const int total = pack_item_count(ctx->net, true);
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), st));
         hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ctx->d_wcur, (const double*)nullptr,
                            ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net,
-                           ctx->net.l0_f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
+                           f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
     }
     ChainParams c{};
     c.st = ctx->d_chain;
+    c.pass = ctx->d_pass;
     c.w_cur = ctx->d_wcur;
-    c.w_prop = ctx->d_wprop;
     c.mask = mask_packed ? ctx->d_mask : nullptr;
     c.idx = ctx->d_idx;
     c.delta = ctx->d_delta;
@@ -942,21 +954,15 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.out_lp = ctx->d_lpp;
     c.partials = ctx->d_partials;
     c.image = ctx->d_image;
-    c.w2img = ctx->d_w2img;
-    c.w2scale = ctx->d_w2scale;
     c.pos = ctx->d_pos;
-    c.pscale = ctx->net.l0_f16 ? ctx->d_pscale : nullptr;
+    c.pscale = f16 ? ctx->d_pscale : nullptr;
+    c.pv = ctx->d_pv;
     c.overflow = ctx->d_overflow;
-    unsigned long long* d_stamps = nullptr;
-    if (getenv("NPBNN_STEP_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the step kernel
-        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)(K + 1) * 8 * sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)(K + 1) * 8 * sizeof(unsigned long long)));
-    }
-    c.stamps = d_stamps;
+    c.stamps = nullptr;
     c.K = K;
     c.M = M;
-    c.n_weights = ctx->n_weights;
-    c.n_waves = lp.n_waves;
+    c.D = D;
+    c.n_blocks = lp.n_waves;
     c.prior_kind = cfg->prior_kind;
     for (int l = 0; l < kMaxLayers; ++l) c.prior_scale[l] = cfg->prior_scale[l];
     c.w_bound = cfg->w_bound;
@@ -970,16 +976,33 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
+    p.pass = ctx->d_pass;
+    p.pv = ctx->d_pv;
+    p.pos = ctx->d_pos;
+    p.pscale = f16 ? ctx->d_pscale : nullptr;
+    p.M = M;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     rc = push_chain_params(ctx, c);
     if (rc) return rc;
-    for (int t = 0; t <= K; ++t) {
-        hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, t,
-                           t > 0 ? cnt[t - 1] : 0, t < K ? cnt[t] : 0);
-        if (t < K) hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams);
+    // step (prepare candidates) -> [eval -> step (decide + prepare)]* ; a pass consumes 1..D iterations, so the number of
+    // passes is only known on the device: launch the least number that can finish, look at the counter, repeat
+    hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
+    int t_done = 0, n_passes = 0;
+    while (t_done < K) {
+        const int n = (K - t_done + D - 1) / D;
+        for (int i = 0; i < n; ++i) {
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams);
+            hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
+        }
+        n_passes += n;
+        HIP_TRY(ctx, hipGetLastError());
+        ChainDev now{};
+        HIP_TRY(ctx, hipMemcpyAsync(&now, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (now.t <= t_done) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now.t);
+        t_done = now.t;
     }
-    HIP_TRY(ctx, hipGetLastError());
     ChainDev fin{};
     HIP_TRY(ctx, hipMemcpyAsync(&fin, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
     int ovf = 0;
@@ -992,24 +1015,12 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (out_loglik_prop) HIP_TRY(ctx, hipMemcpyAsync(out_loglik_prop, ctx->d_llp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
     if (out_logprior_prop) HIP_TRY(ctx, hipMemcpyAsync(out_logprior_prop, ctx->d_lpp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (d_stamps) {
-        std::vector<unsigned long long> hs((size_t)(K + 1) * 8);
-        (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(d_stamps);
-        double acc[8] = {0};
-        int n = 0;
-        for (int t = 1; t < K; ++t) {
-            const unsigned long long* r = &hs[(size_t)t * 8];
-            for (int k = 1; k <= 6; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 0.01;   // 100 MHz wall clock -> us
-            ++n;
-        }
-        fprintf(stderr, "[npbnn step stamps] prefetch %.2f  t0-prior %.2f  reduce+decide %.2f  commit/rollback %.2f  propose %.2f  prior-sum %.2f us (mean of %d)\n",
-                acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
-    }
     result->loglik = fin.logLik;
     result->logprior = fin.logPrior;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) result->sigma[j] = fin.sigma[j];
     result->n_accepted = fin.n_accepted;
+    result->n_passes = n_passes;
+    result->n_candidates = D;
     return NPBNN_OK;
 }
 

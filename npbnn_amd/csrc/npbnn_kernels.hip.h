@@ -74,6 +74,19 @@ struct NetMeta {
     float act_prm[kMaxLayers];
 };
 
+constexpr int kMaxCand = 3;    // candidates evaluated per pass over X by a speculative chain
+
+// One pass of a device-resident chain evaluates, against a single streaming read of X, the proposal of iteration t0 and
+// the proposals of iterations t0+1 .. t0+n_cand-1 *under the assumption that the earlier ones are rejected* (each is the
+// current state plus its own pre-drawn perturbation).  The step kernel then decides them in order and stops at the first
+// accepted one: the chain is exactly the sequential Metropolis-Hastings chain ("prefetching" / speculative MH).
+struct PassDesc {
+    int t0;                   // first iteration evaluated by the pass
+    int n_cand;               // candidates in the pass (0: the batch is finished, the evaluation kernel exits at once)
+    int cnt[kMaxCand];        // touched entries per candidate
+    int pad[3];
+};
+
 struct EvalParams {
     const float* X;           // [n_tiles*16][Fp] zero padded; in fp16-split mode the same bytes hold, per 8 features,
                               // 8 x fp16 high parts then 8 x fp16 low parts of the column-scaled values
@@ -81,7 +94,7 @@ struct EvalParams {
     const float* targets;     // [n_tiles*16][k] (k = k_targets), 0 on padding rows
     const float* inst_w;      // [n_tiles*16] or nullptr
     const float* image;       // float32 fragment image of the weights (global), DMA-copied into LDS
-    double* partials;         // [kPartialStride][n_workgroups]
+    double* partials;         // [candidate][kPartialStride][n_workgroups]
     unsigned* confusion;      // [n_out*n_out] or nullptr
     float* y_out;             // [n_rows][n_out] or nullptr
     long long n_rows;
@@ -89,6 +102,12 @@ struct EvalParams {
     int Fp;
     int use_classw;
     int predict_mode;         // 0 none, 1 raw last-layer values, 2 output function applied
+    // speculative multi-candidate pass of a device-resident chain (nullptr / unused for a plain evaluation):
+    const PassDesc* pass;     // which candidates this pass evaluates
+    const double* pv;         // [kMaxCand][M] proposed values of the touched entries of each candidate
+    const int* pos;           // [K][M] image position of every pre-drawn entry (w2img gather)
+    const float* pscale;      // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
+    int M;
     NetMeta net;
 };
 
@@ -203,11 +222,13 @@ __host__ __device__ inline int pack_item_count(const NetMeta& net, bool with_cla
     return total;
 }
 
+#ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
                                                            const double* __restrict__ class_w, float* __restrict__ image,
                                                            NetMeta net, const float* __restrict__ w_scale, int* overflow) {
     pack_item(blockIdx.x * 256 + threadIdx.x, w, col_override, class_w, image, net, true, w_scale, overflow);
 }
+#endif  // NPBNN_KERNELS_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // fp16-split copy of the feature matrix (built once per data set, on the device)
@@ -215,6 +236,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restr
 //   col_scale_kernel  : x_scale[c] = 2^-e, w_scale[c] = 2^e with 2^(e-1) <= max|x_c| < 2^e  (exact powers of two)
 //   split_x_kernel    : per row and per 8 features: 8 x fp16 high parts, then 8 x fp16 low parts of x * x_scale
 // ------------------------------------------------------------------------------------------------
+#ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) col_absmax_kernel(const float* __restrict__ X, long long n_rows, int Fp, unsigned* __restrict__ absmax) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Fp) return;
@@ -228,7 +250,9 @@ __global__ void __launch_bounds__(256) col_absmax_kernel(const float* __restrict
     }
     atomicMax(absmax + c, __float_as_uint(m));     // NaN / inf bit patterns compare above every finite value
 }
+#endif  // NPBNN_KERNELS_MAIN
 
+#ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) col_scale_kernel(const unsigned* __restrict__ absmax, int Fp, float* __restrict__ x_scale,
                                                         float* __restrict__ w_scale) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -239,7 +263,9 @@ __global__ void __launch_bounds__(256) col_scale_kernel(const unsigned* __restri
     x_scale[c] = ldexpf(1.f, -e);
     w_scale[c] = ldexpf(1.f, e);
 }
+#endif  // NPBNN_KERNELS_MAIN
 
+#ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ X, long long n_rows_pad, int Fp, int Fp16,
                                                       const float* __restrict__ x_scale, float* __restrict__ X16,
                                                       unsigned* __restrict__ absmax_scaled) {
@@ -265,6 +291,7 @@ __global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ 
     dst[1] = lo;
     if (m > 1.0f || isnan(m)) atomicMax(absmax_scaled, __float_as_uint(m));   // only a test set scaled by the training scales
 }
+#endif  // NPBNN_KERNELS_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // helpers
@@ -364,16 +391,203 @@ __device__ __forceinline__ void dma4(const void* g, char* l) {
 //   MT0 : 16-unit tiles of layer 0's output (accumulators of the streamed GEMM)
 //   MTI : max 16-unit tiles of any later layer's output (1 covers every net whose hidden layers after the first
 //         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
+//   F16 : fp16-split layer 0
+//   D   : weight sets ("candidates") evaluated against one streaming read of X (speculative chain passes; 1 otherwise)
 // ------------------------------------------------------------------------------------------------
-template <int MT0, int MTI, bool F16>
+typedef void (*eval_fn_t)(const EvalParams*);
+
+struct TileAcc {            // per-candidate float64 accumulators of one wave
+    double ll;
+    double s1[4], s2[4];
+};
+
+// layers 1..L-1 and the likelihood epilogue of one 16-row tile for one candidate (weight image `img` in LDS)
+template <int MT0, int MTI>
+__device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img, const f32x4 (&acc0)[MT0], int lane, int n, int kq,
+                                          const char* a_slot, float* row_scratch, long long row, bool row_ok, bool primary,
+                                          TileAcc& A) {
+    constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
+    const NetMeta& net = p.net;
+    const int n_layers = net.n_layers;
+    const int C = net.n_out;
+    const int MTL = net.L[n_layers - 1].mt;
+    const int lik_kind = net.lik_kind;
+    const int k_targets = net.k_targets;
+    const bool need_softmax = (lik_kind == NPBNN_LIK_CATEGORICAL) || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
+    // ---------------- layers 1..L-1 chained through the accumulators ----------------
+    f32x4 h[HT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) h[mt] = mt < MT0 ? acc0[mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 1; l < n_layers; ++l) {
+        const LayerMeta& L = net.L[l];
+        const int lkt = L.kt, lmt = L.mt;
+        act_live(h, lkt, net.act_kind, net.act_prm[l - 1]);
+        const float* frag = img + L.frag_off + lane * 4;
+        const float* bias = img + L.bias_off + 4 * kq;
+        f32x4 acc[MTI];
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt) {
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mt < lmt) {
+                acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
+#pragma unroll
+                for (int ct = 0; ct < HT; ++ct) {
+                    if (ct < lkt) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * lmt + mt) * 256);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], h[ct][s], acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt) h[mt] = acc[mt];
+    }
+    if (net.final_act) act_live(h, MTL, net.act_kind, net.act_prm[n_layers - 1]);
+    // h[mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
+
+    // ---------------- epilogue ----------------
+
+    float lse = 0.f;
+    int best_i = 0;
+    if (need_softmax) {
+        float m = -INFINITY, bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 16 * mt + 4 * kq + i;
+                    if (o < C) {
+                        m = fmaxf(m, h[mt][i]);
+                        if (h[mt][i] > bv) { bv = h[mt][i]; bi = o; }
+                    }
+                }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float se = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * mt + 4 * kq + i < C) se += __expf(h[mt][i] - m);
+        se += __shfl_xor(se, 16);
+        se += __shfl_xor(se, 32);
+        lse = m + __logf(se);
+        if (p.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207)
+#pragma unroll
+            for (int sh = 16; sh <= 32; sh <<= 1) {
+                const float ov = __shfl_xor(bv, sh);
+                const int oi = __shfl_xor(bi, sh);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            best_i = bi;
+        }
+    }
+
+    if (lik_kind == NPBNN_LIK_CATEGORICAL) {
+        const int lab = *reinterpret_cast<const int*>(a_slot + n * 4);
+        float zl = 0.f;
+        bool own = false;
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * mt + 4 * kq + i == lab) { zl = h[mt][i]; own = true; }
+        float term = 0.f;
+        if (lab >= 0) {
+            if (own) term += zl;
+            if (kq == 0) term -= lse;
+            float wgt = 1.f;
+            if (p.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
+            if (p.use_classw) wgt *= img[net.classw_off + lab];
+            term *= wgt;
+            if (p.confusion && primary && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
+        }
+        A.ll += (double)term;
+    } else if (lik_needs_row_scratch(lik_kind)) {
+        // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
+        // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
+        *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[0];
+        const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+        double term = 0.0;
+        if (row_ok) {
+            for (int j = kq; j < k_targets; j += 4) {
+                const double y = (double)tg[n * k_targets + j];
+                if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
+                    const double mu = (double)row_scratch[n * 16 + j];
+                    const double zs = (double)row_scratch[n * 16 + k_targets + j];
+                    const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));      // softplus, BNN_lib.py:172,181
+                    const double r = (y - mu) / sg;
+                    term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
+                } else if (lik_kind == NPBNN_LIK_POISSON) {
+                    if (j == 0) {
+                        const double eta = (double)row_scratch[n * 16];
+                        term += y * eta - exp(eta) - lgamma(y + 1.0);             // poisson.logpmf(k, exp(eta))
+                    }
+                } else {
+                    const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
+                    if (one_col && j > 0) continue;
+                    const int jp = one_col ? 1 : k_targets + j;
+                    const double e0 = (double)row_scratch[n * 16 + j], e1 = (double)row_scratch[n * 16 + jp];
+                    double mean, pr;
+                    if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
+                        mean = exp(2.302585092994046 * e0);
+                        pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+                    } else {
+                        mean = exp(e0);
+                        pr = 1.0 / (1.0 + exp(-e1));
+                    }
+                    const double nn = pr * mean / (1.0 - pr);
+                    // nbinom.logpmf(k; n, p) = lgamma(k+n) - lgamma(k+1) - lgamma(n) + n log p + k log(1-p)
+                    term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
+                }
+            }
+        }
+        A.ll += term;
+    } else if (lik_kind == NPBNN_LIK_GAUSS) {
+        const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 4 * kq + i;
+            if (o < k_targets && row_ok) {
+                const float r = tg[n * k_targets + o] - h[0][i];
+                A.s1[i] += (double)r;
+                A.s2[i] += (double)r * (double)r;
+            }
+        }
+    }
+
+    if (p.predict_mode && primary && row_ok) {
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 16 * mt + 4 * kq + i;
+                    if (o < C) {
+                        float v = h[mt][i];
+                        if (p.predict_mode == 2) {
+                            if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
+                            else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+                        }
+                        p.y_out[row * C + o] = v;
+                    }
+                }
+    }
+}
+
+template <int MT0, int MTI, bool F16, int D>
 __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const EvalParams* __restrict__ pp) {
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
-    constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const img = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -382,14 +596,33 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
     const int wpb = blockDim.x >> 6;
     const int k_targets = net.k_targets;
     const int aux_sz = aux_bytes(k_targets);
-    char* const ring = smem + (size_t)net.image_floats * 4 + (size_t)wave * wave_lds_bytes(k_targets, net.lik_kind);
+    const size_t IB = (size_t)net.image_floats * 4;                 // bytes of one weight image
+
+    // ---- which candidates does this pass evaluate? ----
+    int n_cand = 1, t0 = 0;
+    int cnt[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) cnt[j] = 0;
+    if (p.pass) {
+        n_cand = p.pass->n_cand;
+        if (n_cand == 0) return;                                    // the chain batch is finished
+        if (n_cand > D) n_cand = D;
+        t0 = p.pass->t0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cnt[j] = p.pass->cnt[j];
+    }
+
+    char* const ring = smem + D * IB + (size_t)wave * wave_lds_bytes(k_targets, net.lik_kind);
     char* const aux = ring + kRing * 1024;
     float* const row_scratch = reinterpret_cast<float*>(aux + kAuxSlots * aux_sz);   // [16 rows][16 outputs], generic likelihoods
 
-    // ---- stage the fragment image into LDS: lane-linear DMA copy shared by the workgroup ----
+    // ---- stage the weight image of the current state into LDS, once per candidate: lane-linear DMA copies ----
     {
         const int n_pieces = net.image_floats >> 8;   // 1-KiB pieces
-        for (int i = wave; i < n_pieces; i += wpb) dma16(p.image + (size_t)i * 256 + lane * 4, smem + (size_t)i * 1024);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < n_cand)
+                for (int i = wave; i < n_pieces; i += wpb) dma16(p.image + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
     }
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
@@ -400,9 +633,9 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
     const int stride = G * wpb;
     const int my_tiles = first_tile < p.n_tiles ? (p.n_tiles - first_tile + stride - 1) / stride : 0;
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
-    int D = DEPTH;                                      // prefetch distance in pieces
-    if (D > 2 * KT0) D = 2 * KT0;                       // at most 3 tiles in flight (aux slots)
-    const bool full_depth = (D == DEPTH);
+    int Dp = DEPTH;                                     // prefetch distance in pieces
+    if (Dp > 2 * KT0) Dp = 2 * KT0;                     // at most 3 tiles in flight (aux slots)
+    const bool full_depth = (Dp == DEPTH);
 
     // prefetch cursor: a per-lane running source pointer and a scalar ring offset
     const float* pf_ptr = p.X + ((size_t)first_tile * 16 + n) * (size_t)p.Fp + 4 * kq;
@@ -432,32 +665,74 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
         ++pf_q;
         if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
-    for (int i = 0; i < D && pf_q < Q; ++i) issue_next();
+    for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
 
-    // the image (issued first) has landed once at most kRing-1 of the >= kRing-1 operations issued after it are
-    // still in flight; a wave with fewer pieces simply drains.  Every wave then meets at the barrier before anyone reads the image.
-    if (pf_q >= DEPTH) wait_depth<DEPTH>();
-    else NPBNN_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
+    // ---- candidates = current state + their own touched entries: fetch the first entry per thread now (its latency
+    //      hides under the image copy), meet, patch the LDS images, meet again.  The first barrier also waits for this
+    //      wave's image pieces and first X pieces (needed next anyway). ----
+    int ppos[D];
+    double pval[D];
+    float psc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
+        if (p.pass && j < n_cand && tid < cnt[j]) {
+            const size_t k = (size_t)(t0 + j) * p.M + tid;
+            ppos[j] = p.pos[k];
+            pval[j] = p.pv[(size_t)j * p.M + tid];
+            if (p.pscale) psc[j] = p.pscale[k];
+        }
+    }
+    __syncthreads();
+    if (p.pass) {
+        auto patch = [&](int j, int pos, double v, float sc) {
+            if (pos == 0x7fffffff) return;                  // superseded entry (a later draw of the same position wins)
+            float* imgj = reinterpret_cast<float*>(smem + j * IB);
+            if (pos < 0) {                               // fp16-split layer-0 entry
+                _Float16 hi, lo;
+                split_f16((float)(v * (double)sc), hi, lo);
+                _Float16* i16 = reinterpret_cast<_Float16*>(imgj);
+                const int hpos = pos & 0x7fffffff;
+                i16[hpos] = hi;
+                i16[hpos + 512] = lo;
+            } else {
+                imgj[pos] = (float)v;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < n_cand) {
+                if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
+                for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
+                    const size_t k = (size_t)(t0 + j) * p.M + e;
+                    patch(j, p.pos[k], p.pv[(size_t)j * p.M + e], p.pscale ? p.pscale[k] : 1.0f);
+                }
+            }
+        __syncthreads();
+    }
 
-    double ll_acc = 0.0;
-    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    TileAcc A[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        A[j].ll = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { A[j].s1[i] = 0.0; A[j].s2[i] = 0.0; }
+    }
 
-    const float* const frag0 = img + net.L[0].frag_off + lane * 4;
-    const float* const bias0 = img + net.L[0].bias_off + 4 * kq;
-    const int n_layers = net.n_layers;
-    const int C = net.n_out;
-    const int MTL = net.L[n_layers - 1].mt;
+    const int frag0_off = net.L[0].frag_off + lane * 4;            // float offsets inside an image
+    const int bias0_off = net.L[0].bias_off + 4 * kq;
     const int lik_kind = net.lik_kind;
-    const bool need_softmax = (lik_kind == NPBNN_LIK_CATEGORICAL) || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
     int q = 0, cs_slot = 0;
     int tile = first_tile;
     for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
-        // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring ----------------
-        f32x4 acc0[MT0];
+        // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring, every candidate on the same X piece ----------------
+        f32x4 acc0[D][MT0];
 #pragma unroll
-        for (int mt = 0; mt < MT0; ++mt) acc0[mt] = *reinterpret_cast<const f32x4*>(bias0 + 16 * mt);
-        const float* fr = frag0;
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt)
+                acc0[j][mt] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + j * IB) + bias0_off + 16 * mt);
+        int fr_off = frag0_off;
         auto consume = [&]() {
             if constexpr (F16) {
                 // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high
@@ -467,31 +742,43 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(px);
                 const f16x8 xl = *reinterpret_cast<const f16x8*>(px + 256);
                 cs_slot = ring_next(slot_b);
-                f16x8 wh[MT0], wl[MT0];
 #pragma unroll
-                for (int mt = 0; mt < MT0; ++mt) {
-                    wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
-                    wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
+                for (int j = 0; j < D; ++j) {
+                    if (j < n_cand) {
+                        const float* fr = reinterpret_cast<const float*>(smem + j * IB) + fr_off;
+                        f16x8 wh[MT0], wl[MT0];
+#pragma unroll
+                        for (int mt = 0; mt < MT0; ++mt) {
+                            wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
+                            wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
+                    }
                 }
-                fr += MT0 * 512;
-#pragma unroll
-                for (int mt = 0; mt < MT0; ++mt) acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT0; ++mt) acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT0; ++mt) acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[mt], 0, 0, 0);
+                fr_off += MT0 * 512;
             } else {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);
                 cs_slot = ring_next(cs_slot);
-                f32x4 a[MT0];
 #pragma unroll
-                for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
-                fr += MT0 * 256;
+                for (int j = 0; j < D; ++j) {
+                    if (j < n_cand) {
+                        const float* fr = reinterpret_cast<const float*>(smem + j * IB) + fr_off;
+                        f32x4 a[MT0];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                        for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt)
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[mt], 0, 0, 0);
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int mt = 0; mt < MT0; ++mt)
+                                acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[j][mt], 0, 0, 0);
+                    }
+                }
+                fr_off += MT0 * 256;
             }
         };
         constexpr int STEP = F16 ? 2 : 1;               // pieces per consume()
@@ -520,205 +807,54 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
             }
         }
 
-        // ---------------- layers 1..L-1 chained through the accumulators ----------------
-        f32x4 h[HT];
-#pragma unroll
-        for (int mt = 0; mt < HT; ++mt) h[mt] = mt < MT0 ? acc0[mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int l = 1; l < n_layers; ++l) {
-            const LayerMeta& L = net.L[l];
-            const int lkt = L.kt, lmt = L.mt;
-            act_live(h, lkt, net.act_kind, net.act_prm[l - 1]);
-            const float* frag = img + L.frag_off + lane * 4;
-            const float* bias = img + L.bias_off + 4 * kq;
-            f32x4 acc[MTI];
-#pragma unroll
-            for (int mt = 0; mt < MTI; ++mt) {
-                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (mt < lmt) {
-                    acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
-#pragma unroll
-                    for (int ct = 0; ct < HT; ++ct) {
-                        if (ct < lkt) {
-                            const f32x4 a = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * lmt + mt) * 256);
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], h[ct][s], acc[mt], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTI; ++mt) h[mt] = acc[mt];
-        }
-        if (net.final_act) act_live(h, MTL, net.act_kind, net.act_prm[n_layers - 1]);
-        // h[mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
-
-        // ---------------- epilogue ----------------
+        // ---------------- layers 1..L-1 + likelihood terms, candidate by candidate ----------------
         const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
         const long long row = (long long)tile * 16 + n;
         const bool row_ok = row < p.n_rows;
-
-        float lse = 0.f;
-        int best_i = 0;
-        if (need_softmax) {
-            float m = -INFINITY, bv = -INFINITY;
-            int bi = 0x7fffffff;
 #pragma unroll
-            for (int mt = 0; mt < MTI; ++mt)
-                if (mt < MTL)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int o = 16 * mt + 4 * kq + i;
-                        if (o < C) {
-                            m = fmaxf(m, h[mt][i]);
-                            if (h[mt][i] > bv) { bv = h[mt][i]; bi = o; }
-                        }
-                    }
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float se = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MTI; ++mt)
-                if (mt < MTL)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (16 * mt + 4 * kq + i < C) se += __expf(h[mt][i] - m);
-            se += __shfl_xor(se, 16);
-            se += __shfl_xor(se, 32);
-            lse = m + __logf(se);
-            if (p.confusion) {   // np.argmax: first maximum wins (BNN_lib.py:207)
-#pragma unroll
-                for (int sh = 16; sh <= 32; sh <<= 1) {
-                    const float ov = __shfl_xor(bv, sh);
-                    const int oi = __shfl_xor(bi, sh);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                best_i = bi;
-            }
-        }
-
-        if (lik_kind == NPBNN_LIK_CATEGORICAL) {
-            const int lab = *reinterpret_cast<const int*>(a_slot + n * 4);
-            float zl = 0.f;
-            bool own = false;
-#pragma unroll
-            for (int mt = 0; mt < MTI; ++mt)
-                if (mt < MTL)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (16 * mt + 4 * kq + i == lab) { zl = h[mt][i]; own = true; }
-            float term = 0.f;
-            if (lab >= 0) {
-                if (own) term += zl;
-                if (kq == 0) term -= lse;
-                float wgt = 1.f;
-                if (p.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
-                if (p.use_classw) wgt *= img[net.classw_off + lab];
-                term *= wgt;
-                if (p.confusion && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
-            }
-            ll_acc += (double)term;
-        } else if (lik_needs_row_scratch(lik_kind)) {
-            // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
-            // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
-            *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[0];
-            const float* tg = reinterpret_cast<const float*>(a_slot + 128);
-            double term = 0.0;
-            if (row_ok) {
-                for (int j = kq; j < k_targets; j += 4) {
-                    const double y = (double)tg[n * k_targets + j];
-                    if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
-                        const double mu = (double)row_scratch[n * 16 + j];
-                        const double zs = (double)row_scratch[n * 16 + k_targets + j];
-                        const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));      // softplus, BNN_lib.py:172,181
-                        const double r = (y - mu) / sg;
-                        term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
-                    } else if (lik_kind == NPBNN_LIK_POISSON) {
-                        if (j == 0) {
-                            const double eta = (double)row_scratch[n * 16];
-                            term += y * eta - exp(eta) - lgamma(y + 1.0);             // poisson.logpmf(k, exp(eta))
-                        }
-                    } else {
-                        const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
-                        if (one_col && j > 0) continue;
-                        const int jp = one_col ? 1 : k_targets + j;
-                        const double e0 = (double)row_scratch[n * 16 + j], e1 = (double)row_scratch[n * 16 + jp];
-                        double mean, pr;
-                        if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
-                            mean = exp(2.302585092994046 * e0);
-                            pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
-                        } else {
-                            mean = exp(e0);
-                            pr = 1.0 / (1.0 + exp(-e1));
-                        }
-                        const double nn = pr * mean / (1.0 - pr);
-                        // nbinom.logpmf(k; n, p) = lgamma(k+n) - lgamma(k+1) - lgamma(n) + n log p + k log(1-p)
-                        term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
-                    }
-                }
-            }
-            ll_acc += term;
-        } else if (lik_kind == NPBNN_LIK_GAUSS) {
-            const float* tg = reinterpret_cast<const float*>(a_slot + 128);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int o = 4 * kq + i;
-                if (o < k_targets && row_ok) {
-                    const float r = tg[n * k_targets + o] - h[0][i];
-                    s1[i] += (double)r;
-                    s2[i] += (double)r * (double)r;
-                }
-            }
-        }
-
-        if (p.predict_mode && row_ok) {
-#pragma unroll
-            for (int mt = 0; mt < MTI; ++mt)
-                if (mt < MTL)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int o = 16 * mt + 4 * kq + i;
-                        if (o < C) {
-                            float v = h[mt][i];
-                            if (p.predict_mode == 2) {
-                                if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
-                                else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
-                            }
-                            p.y_out[row * C + o] = v;
-                        }
-                    }
-        }
+        for (int j = 0; j < D; ++j)
+            if (j < n_cand)
+                tile_tail<MT0, MTI>(p, reinterpret_cast<const float*>(smem + j * IB), acc0[j], lane, n, kq, a_slot, row_scratch, row,
+                                    row_ok, j == 0, A[j]);
     }
 
-    // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> wave 0 -> global [value][workgroup] ----
+    // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
     if (p.partials) {
+        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
 #pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) ll_acc += shfl_xor_f64(ll_acc, sh);
-        if (lik_kind == NPBNN_LIK_GAUSS) {
+        for (int j = 0; j < D; ++j) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int sh = 1; sh < 64; sh <<= 1) A[j].ll += shfl_xor_f64(A[j].ll, sh);
+            if (lik_kind == NPBNN_LIK_GAUSS) {
 #pragma unroll
-                for (int sh = 1; sh < 16; sh <<= 1) {
-                    s1[i] += shfl_xor_f64(s1[i], sh);
-                    s2[i] += shfl_xor_f64(s2[i], sh);
-                }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int sh = 1; sh < 16; sh <<= 1) {
+                        A[j].s1[i] += shfl_xor_f64(A[j].s1[i], sh);
+                        A[j].s2[i] += shfl_xor_f64(A[j].s2[i], sh);
+                    }
+            }
         }
-        __syncthreads();                                   // every wave is done with its ring: reuse it as scratch
-        double* wsum = reinterpret_cast<double*>(smem + (size_t)net.image_floats * 4);    // [wave][kPartialStride] (<= 4.2 KB, inside the rings)
-        if (lane == 0) wsum[wave * kPartialStride] = ll_acc;
-        if (lik_kind == NPBNN_LIK_GAUSS && n == 0) {
+        __syncthreads();                                   // every wave is done with its ring: reuse the rings as scratch
+        double* wsum = reinterpret_cast<double*>(smem + D * IB);    // [candidate][wave][kPartialStride]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wsum[wave * kPartialStride + 1 + 4 * kq + i] = s1[i];
-                wsum[wave * kPartialStride + 1 + NPBNN_MAX_TARGETS + 4 * kq + i] = s2[i];
+        for (int j = 0; j < D; ++j) {
+            double* ws = wsum + ((size_t)j * wpb + wave) * kPartialStride;
+            if (lane == 0) ws[0] = A[j].ll;
+            if (lik_kind == NPBNN_LIK_GAUSS && n == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ws[1 + 4 * kq + i] = A[j].s1[i];
+                    ws[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = A[j].s2[i];
+                }
             }
         }
         __syncthreads();
-        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
-        if (tid < nvals) {
+        for (int item = tid; item < n_cand * nvals; item += blockDim.x) {
+            const int j = item / nvals, v = item % nvals;
             double s = 0.0;
-            for (int w = 0; w < wpb; ++w) s += wsum[w * kPartialStride + tid];
-            p.partials[(size_t)tid * gridDim.x + blockIdx.x] = s;
+            for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
+            p.partials[((size_t)j * kPartialStride + v) * gridDim.x + blockIdx.x] = s;
         }
     }
 }
@@ -782,6 +918,7 @@ __device__ __forceinline__ void loglik_from_totals(const double* tot, int lik_ki
     }
 }
 
+#ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams* __restrict__ fp) {
     const FinalizeParams& f = *fp;
     __shared__ double tot[kPartialStride];
@@ -789,6 +926,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams* __r
     reduce_partials(f.partials, f.n_waves, nvals, tot);
     if (threadIdx.x == 0) loglik_from_totals(tot, f.lik_kind, f.k_targets, f.n_rows, f.lik_temp, f.sigma_given, f.sigma, f.out);
 }
+#endif  // NPBNN_KERNELS_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // device-resident Metropolis-Hastings chain
@@ -807,17 +945,17 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams* __r
 struct ChainDev {          // device-resident chain state
     double logLik, logPrior;
     double sigma[NPBNN_MAX_TARGETS];
-    double cand_logPrior;
-    int t;
+    double cand_logPrior[kMaxCand];
+    int t;                  // iterations decided so far in this batch
     int n_accepted;
 };
 
 struct ChainParams {
     ChainDev* st;
-    double* w_cur;
-    double* w_prop;
+    PassDesc* pass;            // candidates of the pass in flight (read by the evaluation kernel)
+    double* w_cur;             // float64 master copy of the current weights
     const double* mask;        // or nullptr
-    const int* idx;            // [K][M]
+    const int* idx;            // [K][M] pre-drawn packed-weight indices (-1: superseded entry)
     const double* delta;       // [K][M]
     const int* cnt;            // [K]
     const double* log_u;       // [K]
@@ -825,16 +963,15 @@ struct ChainParams {
     unsigned char* out_acc;    // [K]
     double* out_ll;            // [K] proposed logLik
     double* out_lp;            // [K] proposed logPrior
-    const double* partials;
-    float* image;              // fragment image read by the eval kernel
-    const int* w2img;          // packed-weight index -> float index in the image; bit 31 set: fp16-split layer-0 entry,
-                               // the low bits are then the half index of the high part (low part 512 halfs later)
-    const float* w2scale;      // per-weight column scale of the fp16-split layer 0 (1 elsewhere) or nullptr
-    const int* pos;            // [K][M] w2img[idx] gathered on the host, so the kernel has no dependent lookup
-    const float* pscale;       // [K][M] w2scale[idx] (fp16-split) or nullptr
+    const double* partials;    // [candidate][kPartialStride][n_blocks]
+    float* image;              // fragment image of the current weights, read by the evaluation kernel
+    const int* pos;            // [K][M] image position of every pre-drawn entry; bit 31 set: fp16-split layer-0 entry (the
+                               // low bits are the half index of the high part, low part 512 halfs later); kSkipPos: none
+    const float* pscale;       // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
+    double* pv;                // [kMaxCand][M] proposed values of the candidates in flight
     int* overflow;             // set when a scaled weight leaves the fp16 range
-    unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1): 8 wall-clock stamps per launch, else nullptr
-    int K, M, n_weights, n_waves;
+    unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1), else nullptr
+    int K, M, D, n_blocks;
     int prior_kind;
     double prior_scale[kMaxLayers];
     double w_bound;
@@ -845,16 +982,37 @@ struct ChainParams {
     NetMeta net;
 };
 
+constexpr int kSkipPos = 0x7fffffff;
+
 __device__ __forceinline__ double log_prior_density(int kind, double w, double scale) {
     if (kind == NPBNN_PRIOR_CAUCHY) return -log(3.14159265358979323846 * scale * (1.0 + (w / scale) * (w / scale)));
     if (kind == NPBNN_PRIOR_LAPLACE) return -log(2.0 * scale) - fabs(w) / scale;
     return -0.5 * (w / scale) * (w / scale) - log(scale) - 0.9189385332046727418;
 }
 
-__device__ __forceinline__ void patch_image_at(const ChainParams& c, int pos, float scale, double v) {
+// change of the log prior density when an entry moves from `b` to `v` (scale sc); the normal prior needs no
+// transcendental: -(v^2 - b^2) / (2 sc^2)
+__device__ __forceinline__ double prior_delta(int kind, double v, double b, double sc) {
+    if (kind == NPBNN_PRIOR_NORMAL) return -0.5 * (v * v - b * b) / (sc * sc);
+    if (kind == NPBNN_PRIOR_LAPLACE) return -(fabs(v) - fabs(b)) / sc;
+    return log((sc * sc + b * b) / (sc * sc + v * v));                  // Cauchy
+}
+
+// image position / fp16-split scale of every pre-drawn entry, gathered once per batch
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__ idx, long long n, const int* __restrict__ w2img,
+                                                         const float* __restrict__ w2scale, int* __restrict__ pos, float* __restrict__ pscale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int w = idx[i];
+    pos[i] = w >= 0 ? w2img[w] : kSkipPos;
+    if (pscale) pscale[i] = (w >= 0 && w2scale) ? w2scale[w] : 1.0f;
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+__device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) {
     if (pos < 0) {                                   // fp16-split layer-0 entry
         const float wv = (float)(v * (double)scale);
-        if (!(fabsf(wv) <= kF16Safe)) *c.overflow = 1;
         _Float16 hi, lo;
         split_f16(wv, hi, lo);
         _Float16* img16 = reinterpret_cast<_Float16*>(c.image);
@@ -866,15 +1024,11 @@ __device__ __forceinline__ void patch_image_at(const ChainParams& c, int pos, fl
     }
 }
 
-__device__ __forceinline__ void patch_image(const ChainParams& c, int i, double v) {
-    const int pos = c.w2img[i];
-    patch_image_at(c, pos, pos < 0 ? c.w2scale[i] : 1.0f, v);
-}
-
 // block-wide sum of one double per thread, fixed order; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 doubles*/) {
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) v += shfl_xor_f64(v, sh);
+    __syncthreads();                                  // `red` may still be read from a previous call
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
@@ -883,61 +1037,35 @@ __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 d
     return s;
 }
 
-// image position / fp16-split scale of every pre-drawn entry, gathered once per batch
-__global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__ idx, long long n, const int* __restrict__ w2img,
-                                                         const float* __restrict__ w2scale, int* __restrict__ pos, float* __restrict__ pscale) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int w = idx[i];
-    pos[i] = w >= 0 ? w2img[w] : 0;
-    if (pscale) pscale[i] = (w >= 0 && w2scale) ? w2scale[w] : 1.0f;
-}
-
-// change of the log prior density when an entry moves from `b` to `v` (scale sc); the normal prior needs no
-// transcendental: -(v^2 - b^2) / (2 sc^2)
-__device__ __forceinline__ double prior_delta(int kind, double v, double b, double sc) {
-    if (kind == NPBNN_PRIOR_NORMAL) return -0.5 * (v * v - b * b) / (sc * sc);
-    if (kind == NPBNN_PRIOR_LAPLACE) return -(fabs(v) - fabs(b)) / sc;
-    return log((sc * sc + b * b) / (sc * sc + v * v));                  // Cauchy
-}
-
-__global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int t_arg, int n_prev_arg, int n_new_arg) {
-    const ChainParams& c = *cp;           // device-resident parameter block; only the per-launch scalars travel as arguments
-    __shared__ double tot[kPartialStride];
+// ------------------------------------------------------------------------------------------------
+// device-resident Metropolis-Hastings chain, speculative over D candidates per pass
+//
+// K iterations of MCMC.mh_step (BNN_env.py:381-532, default path: UpdateNormal proposals, BNN_mcmc.py:57-69) run as an
+// alternation  step -> eval -> step -> eval ...  on the chain's stream; the host pre-draws the random numbers of the K
+// iterations (npbnn_host.c), so the proposals are the reference's.  chain_step_kernel (one workgroup):
+//   1. decide the candidates of the pass just evaluated, in iteration order (fixed-order reduction of the per-workgroup
+//      partials -> logLik', accept test (logPost' - logPost) * temperature + hastings >= log u, BNN_env.py:493-494) and stop
+//      at the first accepted one: it is committed to W_cur and to the weight image; later candidates of the pass were
+//      computed from a state that no longer exists and are simply dropped (their iterations are evaluated again);
+//   2. prepare the next candidates: for j < D, W_cur[idx] + delta of iteration t+j, reflected at +-bound and masked
+//      (BNN_mcmc.py:64-67, BNN_env.py:461-462), stored as a patch list (the evaluation kernel applies it to its LDS image);
+//      logPrior' = logPrior + sum of per-entry prior changes (npBNN.calc_prior, BNN_env.py:180-194; full sum at batch start).
+// ------------------------------------------------------------------------------------------------
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int first_launch) {
+    const ChainParams& c = *cp;           // device-resident parameter block; only the per-launch scalar travels as an argument
+    __shared__ double tot[kMaxCand][kPartialStride];
     __shared__ double red[16];
     __shared__ npbnn_eval_out o;
-    __shared__ int s_accept;
+    __shared__ int s_accepted, s_t;
     const int tid = threadIdx.x;
     ChainDev* st = c.st;
-    const int t = t_arg;                       // iteration to propose now; t-1 is pending
-#define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)t * 8 + (k)] = wall_clock64(); } while (0)
-    NPBNN_STAMP(0);
-    const bool have_prev = t > 0, have_new = t < c.K;
-    const int n_prev = n_prev_arg, n_new = n_new_arg;
-    const size_t row_prev = (size_t)(have_prev ? t - 1 : 0) * c.M, row_new = (size_t)(have_new ? t : 0) * c.M;
-    const int* idx_prev = c.idx + row_prev;
-    const int* idx_new = c.idx + row_new;
-    const double* delta_new = c.delta + row_new;
+    const int lik_kind = c.net.lik_kind;
+#define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)(c.pass->t0 & 1023) * 8 + (k)] = wall_clock64(); } while (0)
 
-    // ---- everything that does not depend on the accept decision is fetched first (first 1024 entries; wider
-    //      proposals take the plain loops below), so the decision only waits for the partial sums ----
-    const int ip = tid < n_prev ? idx_prev[tid] : -1;
-    const int in_ = tid < n_new ? idx_new[tid] : -1;
-    const double dl = tid < n_new ? delta_new[tid] : 0.0;
-    const int pos_p = tid < n_prev ? c.pos[row_prev + tid] : 0;
-    const int pos_n = tid < n_new ? c.pos[row_new + tid] : 0;
-    const float sc_p = (c.pscale && tid < n_prev) ? c.pscale[row_prev + tid] : 1.0f;
-    const float sc_n = (c.pscale && tid < n_new) ? c.pscale[row_new + tid] : 1.0f;
-    const double wc_p = ip >= 0 ? c.w_cur[ip] : 0.0;
-    const double wp_p = ip >= 0 ? c.w_prop[ip] : 0.0;
-    const double wc_n = in_ >= 0 ? c.w_cur[in_] : 0.0;
-    const double wp_n = in_ >= 0 ? c.w_prop[in_] : 0.0;
-    const double mk = (in_ >= 0 && c.mask) ? c.mask[in_] : 1.0;
-
-    NPBNN_STAMP(1);
-    // at the start of a batch the prior of the current state is summed in full (later proposals update it
+    // at the start of a batch the prior of the current state is summed in full (proposals then update it
     // incrementally from the touched entries, so rounding drift cannot accumulate across batches)
-    if (t == 0 && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+    if (first_launch && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
         double lp = 0.0;
         for (int l = 0; l < c.net.n_layers; ++l) {
             const LayerMeta& L = c.net.L[l];
@@ -954,80 +1082,117 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
         }
         const double s = block_sum(lp, red);
         if (tid == 0) st->logPrior = s;
-        __syncthreads();
     }
 
-    int acc = 0;
-    if (have_prev) {
-        const int nvals = (c.net.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
-        reduce_partials(c.partials, c.n_waves, nvals, tot);
-        NPBNN_STAMP(2);
+    // ---- 1. decide the pending candidates ----
+    const int t0 = first_launch ? 0 : c.pass->t0;
+    const int n_pend = first_launch ? 0 : c.pass->n_cand;
+    if (n_pend > 0) {
+        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+        {   // wave w sums items w, w+nw, ... (item = candidate * nvals + value): lanes add workgroups lane, lane+64, ... in order
+            const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+            for (int item = wave; item < n_pend * nvals; item += nw) {
+                const int j = item / nvals, v = item % nvals;
+                const double* src = c.partials + ((size_t)j * kPartialStride + v) * c.n_blocks;
+                double s = 0.0;
+                for (int b = lane; b < c.n_blocks; b += 64) s += src[b];
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
+                if (lane == 0) tot[j][v] = s;
+            }
+        }
+        __syncthreads();
         if (tid == 0) {
-            loglik_from_totals(tot, c.net.lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
-            const double lp = st->cand_logPrior;
-            const double h = c.hastings ? c.hastings[t - 1] : 0.0;
-            const double post_new = o.loglik + lp, post_old = st->logLik + st->logPrior;
-            const int a = ((post_new - post_old) * c.temperature + h >= c.log_u[t - 1]) ? 1 : 0;
-            c.out_acc[t - 1] = (unsigned char)a;
-            c.out_ll[t - 1] = o.loglik;
-            c.out_lp[t - 1] = lp;
-            if (a) {
-                st->logLik = o.loglik;
-                st->logPrior = lp;
-                st->n_accepted += 1;
-                if (c.net.lik_kind == NPBNN_LIK_GAUSS)
-                    for (int j = 0; j < c.net.k_targets; ++j) st->sigma[j] = o.sigma[j];
+            int accepted = -1, n_done = n_pend;
+            for (int j = 0; j < n_pend; ++j) {
+                const int t = t0 + j;
+                loglik_from_totals(tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
+                const double lp = st->cand_logPrior[j];
+                const double h = c.hastings ? c.hastings[t] : 0.0;
+                const double post_new = o.loglik + lp, post_old = st->logLik + st->logPrior;
+                const int a = ((post_new - post_old) * c.temperature + h >= c.log_u[t]) ? 1 : 0;
+                c.out_acc[t] = (unsigned char)a;
+                c.out_ll[t] = o.loglik;
+                c.out_lp[t] = lp;
+                if (a) {
+                    st->logLik = o.loglik;
+                    st->logPrior = lp;
+                    st->n_accepted += 1;
+                    if (lik_kind == NPBNN_LIK_GAUSS)
+                        for (int q = 0; q < c.net.k_targets; ++q) st->sigma[q] = o.sigma[q];
+                    accepted = j;
+                    n_done = j + 1;
+                    break;
+                }
             }
-            s_accept = a;
+            st->t = t0 + n_done;
+            s_accepted = accepted;
+            s_t = t0 + n_done;
         }
         __syncthreads();
-        NPBNN_STAMP(3);
-        acc = s_accept;
-        // commit (accepted) or roll back (rejected) the entries the pending proposal touched
-        if (ip >= 0) {
-            if (acc) c.w_cur[ip] = wp_p;
-            else { c.w_prop[ip] = wc_p; patch_image_at(c, pos_p, sc_p, wc_p); }
-        }
-        for (int j = tid + 1024; j < n_prev; j += 1024) {
-            const int i = idx_prev[j];
-            if (i >= 0) {
-                if (acc) c.w_cur[i] = c.w_prop[i];
-                else { const double v = c.w_cur[i]; c.w_prop[i] = v; patch_image(c, i, v); }
+        const int a = s_accepted;
+        if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
+            const size_t row = (size_t)(t0 + a) * c.M;
+            const int n = c.cnt[t0 + a];
+            for (int e = tid; e < n; e += blockDim.x) {
+                const int i = c.idx[row + e];
+                if (i >= 0) {
+                    const double v = c.pv[(size_t)a * c.M + e];
+                    c.w_cur[i] = v;
+                    patch_global_image(c, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, v);
+                }
             }
         }
-        __syncthreads();        // roll-backs land before the new proposal may touch the same entries
-        NPBNN_STAMP(4);
+        __syncthreads();
+    } else if (tid == 0) {
+        s_t = first_launch ? 0 : st->t;
+        if (first_launch) st->t = 0;
     }
-    if (!have_new) return;
+    __syncthreads();
 
-    // ---- propose iteration t.  W_prop differs from W_cur only at the pending entries, so the value an entry has
-    //      after the decision is (accepted ? W_prop : W_cur) at that index - both were fetched above ----
-    double dlp = 0.0;
-    for (int j = tid; j < n_new; j += 1024) {
-        const bool first = j < 1024;
-        const int i = first ? in_ : idx_new[j];
-        if (i < 0) continue;
-        const double base = first ? (acc ? wp_n : wc_n) : c.w_cur[i];      // w_cur is final after the barrier
-        const double m = first ? mk : (c.mask ? c.mask[i] : 1.0);
-        double v = base + (first ? dl : delta_new[j]);
-        if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
-        if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
-        v *= m;
-        c.w_prop[i] = v;
-        if (first) patch_image_at(c, pos_n, sc_n, v);
-        else patch_image(c, i, v);
-        if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
-            int l = 0;
-            while (l + 1 < c.net.n_layers && i >= c.net.L[l + 1].w_off) ++l;
-            dlp += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
+    // ---- 2. prepare the next candidates: each is the current state plus its own iteration's perturbation ----
+    const int t_new = s_t;
+    int n_new = c.K - t_new;
+    if (n_new > c.D) n_new = c.D;
+    if (n_new < 0) n_new = 0;
+    double cand_lp[kMaxCand];
+#pragma unroll
+    for (int j = 0; j < kMaxCand; ++j) {
+        cand_lp[j] = 0.0;
+        if (j < n_new) {
+            const size_t row = (size_t)(t_new + j) * c.M;
+            const int n = c.cnt[t_new + j];
+            double dlp = 0.0;
+            for (int e = tid; e < n; e += blockDim.x) {
+                const int i = c.idx[row + e];
+                if (i < 0) continue;
+                const double base = c.w_cur[i];
+                double v = base + c.delta[row + e];
+                if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
+                if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
+                if (c.mask) v *= c.mask[i];
+                c.pv[(size_t)j * c.M + e] = v;
+                if (c.pscale && c.pos[row + e] < 0 && !(fabs(v * (double)c.pscale[row + e]) <= (double)kF16Safe)) *c.overflow = 1;
+                if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+                    int l = 0;
+                    while (l + 1 < c.net.n_layers && i >= c.net.L[l + 1].w_off) ++l;
+                    dlp += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
+                }
+            }
+            cand_lp[j] = block_sum(dlp, red);
         }
     }
-    NPBNN_STAMP(5);
-    const double s = block_sum(dlp, red);
-    NPBNN_STAMP(6);
     if (tid == 0) {
-        st->cand_logPrior = st->logPrior + s;
+        const double base_lp = st->logPrior;
+        for (int j = 0; j < n_new; ++j) st->cand_logPrior[j] = base_lp + cand_lp[j];
+        PassDesc d;
+        d.t0 = t_new;
+        d.n_cand = n_new;
+        for (int j = 0; j < kMaxCand; ++j) d.cnt[j] = j < n_new ? c.cnt[t_new + j] : 0;
+        d.pad[0] = d.pad[1] = d.pad[2] = 0;
+        *c.pass = d;
     }
 }
+#endif  // NPBNN_KERNELS_MAIN
 
 }  // namespace npbnn

@@ -442,6 +442,9 @@ class MCMC():
                 self._run_device_batch(bnn_obj, idx, delta, cnt, u)
             remaining -= seg
 
+    n_candidates = 0         # proposals evaluated per pass over the data by the device chain: 0 = as many as fit (<= 3)
+    _device_passes = 0
+    _device_iterations = 0
     SUB_BATCH = 128          # first sub-batch of a segment (its pre-draw is not overlapped); later ones double
     SUB_BATCH_MAX = 2048
 
@@ -467,7 +470,10 @@ class MCMC():
             bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=np.log(u),
             prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
             w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
-            cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma, mask=bnn_obj._mask)
+            cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma, mask=bnn_obj._mask,
+            n_candidates=self.n_candidates)
+        self._device_passes += res.get("n_passes", k)
+        self._device_iterations += k
         if res["n_accepted"] > 0:
             layers, off = [], 0
             for w in bnn_obj._w_layers:

@@ -61,7 +61,7 @@ class OracleChainBackend(OracleBackend):
     bookkeeping) can be tested on CPU against the plain mh_step loop."""
 
     def run_chain(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
-                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None):
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0):
         shapes = [w.shape for w in weights]
         cur = np.concatenate([np.asarray(w, dtype=float).ravel() for w in weights])
         m = None if mask is None else np.concatenate([np.asarray(x, dtype=float).ravel() for x in mask])
@@ -99,4 +99,4 @@ class OracleChainBackend(OracleBackend):
                 n_acc += 1
                 if r["sigma"] is not None:
                     sig = r["sigma"]
-        return cur, acc, llp, lpp, dict(loglik=ll, logprior=lp, sigma=sig, n_accepted=n_acc)
+        return cur, acc, llp, lpp, dict(loglik=ll, logprior=lp, sigma=sig, n_accepted=n_acc, n_passes=K, n_candidates=1)

@@ -227,6 +227,10 @@ int npbnn_comm_allgather_f64(npbnn_comm* comm, const double* send, int count, do
 int npbnn_comm_bcast_i64(npbnn_comm* comm, int64_t* buf, int count, int root);
 void npbnn_comm_destroy(npbnn_comm* comm);
 
+/* timing hook for a speculative chain pass: the evaluation kernel with n_candidates weight sets (0 = as many as fit),
+ * `iters` back-to-back launches between one pair of HIP events on the ctx stream; mean milliseconds per launch */
+int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, int iters, double* ms_kernel, int* used_candidates);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,13 @@ class HipContext:
         self._chk(self._lib.npbnn_time_eval(self._ctx, capi.dptr(w), int(iters), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def time_pass(self, weights, n_candidates=0, iters=20):
+        """Mean duration (ms) of the evaluation kernel of a speculative chain pass and the candidates it evaluates."""
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights)
+        ms, used = C.c_double(0), C.c_int(0)
+        self._chk(self._lib.npbnn_time_pass(self._ctx, capi.dptr(w), int(n_candidates), int(iters), C.byref(ms), C.byref(used)))
+        return ms.value, used.value
+
     def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
                   cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0):
         """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns

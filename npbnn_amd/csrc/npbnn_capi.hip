@@ -20,13 +20,16 @@ using namespace npbnn;
 // the evaluation-kernel instantiations live in npbnn_eval_inst_*.hip (compiled in parallel)
 namespace npbnn {
 eval_fn_t pick_eval_mti8(int mt0, int f16);
+eval_fn_t pick_eval_mti8gen(int mt0, int f16);
 eval_fn_t pick_eval_d1(int mt0, int f16);
+eval_fn_t pick_eval_d1gen(int mt0, int f16);
 eval_fn_t pick_eval_d2(int mt0, int f16);
 eval_fn_t pick_eval_d3(int mt0, int f16);
 }
 
-static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand) {
-    if (mti != 1) return pick_eval_mti8(mt0, f16);
+static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int gen) {
+    if (mti != 1) return gen ? pick_eval_mti8gen(mt0, f16) : pick_eval_mti8(mt0, f16);
+    if (gen) return pick_eval_d1gen(mt0, f16);
     if (n_cand <= 1) return pick_eval_d1(mt0, f16);
     return n_cand == 2 ? pick_eval_d2(mt0, f16) : pick_eval_d3(mt0, f16);
 }
@@ -266,7 +269,7 @@ int max_inner_tiles(const NetMeta& net) {
 }
 
 int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand = 1) {
-    const int top = max_inner_tiles(ctx->net) == 1 ? 16 : 8;     // launch bound of the kernel build in use
+    const int top = max_waves_for(max_inner_tiles(ctx->net) == 1 ? 1 : 8, n_cand);     // launch bound of the kernel build in use
     for (int w = top; w >= 1; --w) {
         const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets, ctx->net.lik_kind);
         if (need <= ctx->lds_limit) {
@@ -279,7 +282,8 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand = 1
 
 
 eval_fn_t pick_kernel(const NetMeta& net, int n_cand) {
-    return npbnn_pick_eval_kernel(net.L[0].mt, max_inner_tiles(net) == 1 ? 1 : 8, net.l0_f16, n_cand);
+    return npbnn_pick_eval_kernel(net.L[0].mt, max_inner_tiles(net) == 1 ? 1 : 8, net.l0_f16, n_cand,
+                                  lik_needs_row_scratch(net.lik_kind) ? 1 : 0);
 }
 
 // ---- fp16-split data: scales from the training matrix, split copies built on the device ----
@@ -365,7 +369,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     }
     size_t lds = 0;
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
-    int n_cand = max_inner_tiles(ctx->net) == 1 ? want_cand : 1;
+    int n_cand = (max_inner_tiles(ctx->net) == 1 && !lik_needs_row_scratch(ctx->net.lik_kind)) ? want_cand : 1;
     if (n_cand > kMaxCand) n_cand = kMaxCand;
     while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand) < 8) --n_cand;
     lp->n_cand = n_cand;
@@ -958,13 +962,21 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.pscale = f16 ? ctx->d_pscale : nullptr;
     c.pv = ctx->d_pv;
     c.overflow = ctx->d_overflow;
-    c.stamps = nullptr;
+    unsigned long long* d_stamps = nullptr;
+    if (getenv("NPBNN_STEP_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the step kernel
+        HIP_TRY(ctx, hipMalloc(&d_stamps, 1024 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(d_stamps, 0, 1024 * 8 * sizeof(unsigned long long)));
+    }
+    c.stamps = d_stamps;
     c.K = K;
     c.M = M;
     c.D = D;
     c.n_blocks = lp.n_waves;
     c.prior_kind = cfg->prior_kind;
-    for (int l = 0; l < kMaxLayers; ++l) c.prior_scale[l] = cfg->prior_scale[l];
+    for (int l = 0; l < kMaxLayers; ++l) {
+        c.prior_scale[l] = cfg->prior_scale[l];
+        c.half_inv_s2[l] = cfg->prior_scale[l] > 0 ? 0.5 / (cfg->prior_scale[l] * cfg->prior_scale[l]) : 0.0;
+    }
     c.w_bound = cfg->w_bound;
     c.temperature = cfg->temperature;
     c.lik_temp = cfg->lik_temp;
@@ -1015,12 +1027,74 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (out_loglik_prop) HIP_TRY(ctx, hipMemcpyAsync(out_loglik_prop, ctx->d_llp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
     if (out_logprior_prop) HIP_TRY(ctx, hipMemcpyAsync(out_logprior_prop, ctx->d_lpp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (d_stamps) {
+        std::vector<unsigned long long> hs(1024 * 8);
+        (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_stamps);
+        double acc[8] = {0};
+        int n = 0;
+        for (int r = 1; r < 1024; ++r) {
+            const unsigned long long* q = &hs[(size_t)r * 8];
+            if (!q[0] || !q[6]) continue;
+            for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;   // 100 MHz wall clock -> us
+            ++n;
+        }
+        if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
+                       acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
+    }
     result->loglik = fin.logLik;
     result->logprior = fin.logPrior;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) result->sigma[j] = fin.sigma[j];
     result->n_accepted = fin.n_accepted;
     result->n_passes = n_passes;
     result->n_candidates = D;
+    return NPBNN_OK;
+}
+
+int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, int iters, double* ms_kernel, int* used_candidates) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (iters < 1 || !ms_kernel || !W_packed) return fail(ctx, NPBNN_E_ARG, "time_pass: bad arguments");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "time_pass: call npbnn_set_arch first");
+    const int lik = ctx->net.lik_kind;
+    Dataset& d = ctx->ds[0];
+    int rc = check_dataset_for_lik(ctx, d, lik);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchPlan lp;
+    rc = plan_launch(ctx, 0, &lp, 0, n_candidates < 1 ? kMaxCand : n_candidates);
+    if (rc) return rc;
+    rc = ensure_work_buffers(ctx, lp.n_waves);
+    if (rc) return rc;
+    rc = stage_weights(ctx, W_packed, nullptr, nullptr);
+    if (rc) return rc;
+    if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, sizeof(PassDesc)));
+    PassDesc pd{};
+    pd.t0 = 0;
+    pd.n_cand = lp.n_cand;          // every candidate = the staged weights (empty patch lists): same work as a chain pass
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pass, &pd, sizeof(PassDesc), hipMemcpyHostToDevice, ctx->stream));
+    EvalParams p = make_params(ctx, d);
+    p.partials = ctx->d_partials;
+    p.inst_w = d.inst_w;
+    p.use_classw = ctx->n_classw > 0 ? 1 : 0;
+    p.pass = ctx->d_pass;
+    p.pv = nullptr;
+    p.pos = nullptr;
+    p.pscale = nullptr;
+    p.M = 0;
+    rc = push_eval_params(ctx, p);
+    if (rc) return rc;
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    *ms_kernel = (double)ms / iters;
+    if (used_candidates) *used_candidates = lp.n_cand;
     return NPBNN_OK;
 }
 

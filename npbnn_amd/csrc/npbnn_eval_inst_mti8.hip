@@ -1,4 +1,4 @@
-// Explicit instantiations of eval_kernel<MT0, MTI=8, F16, D=1> (one translation unit per group so they build in parallel).
+// Explicit instantiations of eval_kernel<MT0, MTI=8, F16, D=1, GEN=false> (one translation unit per group so they build in parallel).
 #include "npbnn_kernels.hip.h"
 
 namespace npbnn {
@@ -6,14 +6,14 @@ namespace npbnn {
 template <bool F16>
 static eval_fn_t pick_mt0(int mt0) {
     switch (mt0) {
-        case 1: return eval_kernel<1, 8, F16, 1>;
-        case 2: return eval_kernel<2, 8, F16, 1>;
-        case 3: return eval_kernel<3, 8, F16, 1>;
-        case 4: return eval_kernel<4, 8, F16, 1>;
-        case 5: return eval_kernel<5, 8, F16, 1>;
-        case 6: return eval_kernel<6, 8, F16, 1>;
-        case 7: return eval_kernel<7, 8, F16, 1>;
-        default: return eval_kernel<8, 8, F16, 1>;
+        case 1: return eval_kernel<1, 8, F16, 1, false>;
+        case 2: return eval_kernel<2, 8, F16, 1, false>;
+        case 3: return eval_kernel<3, 8, F16, 1, false>;
+        case 4: return eval_kernel<4, 8, F16, 1, false>;
+        case 5: return eval_kernel<5, 8, F16, 1, false>;
+        case 6: return eval_kernel<6, 8, F16, 1, false>;
+        case 7: return eval_kernel<7, 8, F16, 1, false>;
+        default: return eval_kernel<8, 8, F16, 1, false>;
     }
 }
 

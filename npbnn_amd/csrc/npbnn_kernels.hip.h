@@ -35,7 +35,7 @@ namespace npbnn {
 constexpr int kMaxLayers = NPBNN_MAX_LAYERS;
 constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
 #ifndef NPBNN_RING
-#define NPBNN_RING 6
+#define NPBNN_RING 4
 #endif
 constexpr int kRing = NPBNN_RING;              // X ring slots (1 KiB each) per wave; kRing-1 pieces stay in flight
 constexpr int kMaxWavesPerBlock = 16;
@@ -393,6 +393,7 @@ __device__ __forceinline__ void dma4(const void* g, char* l) {
 //         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
 //   F16 : fp16-split layer 0
 //   D   : weight sets ("candidates") evaluated against one streaming read of X (speculative chain passes; 1 otherwise)
+//   GEN : build with the float64 row-wise likelihoods (predicted sigma, Poisson, negative binomial)
 // ------------------------------------------------------------------------------------------------
 typedef void (*eval_fn_t)(const EvalParams*);
 
@@ -402,7 +403,7 @@ struct TileAcc {            // per-candidate float64 accumulators of one wave
 };
 
 // layers 1..L-1 and the likelihood epilogue of one 16-row tile for one candidate (weight image `img` in LDS)
-template <int MT0, int MTI>
+template <int MT0, int MTI, bool GEN>
 __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img, const f32x4 (&acc0)[MT0], int lane, int n, int kq,
                                           const char* a_slot, float* row_scratch, long long row, bool row_ok, bool primary,
                                           TileAcc& A) {
@@ -509,7 +510,8 @@ __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img,
             if (p.confusion && primary && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
         }
         A.ll += (double)term;
-    } else if (lik_needs_row_scratch(lik_kind)) {
+    } else if (GEN && lik_needs_row_scratch(lik_kind)) {
+        // (GEN builds only: the float64 lgamma / log / exp below would otherwise cost the hot kernels their registers)
         // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
         // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
         *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[0];
@@ -581,8 +583,11 @@ __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img,
     }
 }
 
-template <int MT0, int MTI, bool F16, int D>
-__global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const EvalParams* __restrict__ pp) {
+// waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive
+__host__ __device__ constexpr int max_waves_for(int mti, int d) { return mti == 1 ? (d == 1 ? 16 : d == 2 ? 14 : 11) : 8; }
+
+template <int MT0, int MTI, bool F16, int D, bool GEN>
+__global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const EvalParams* __restrict__ pp) {
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
@@ -814,7 +819,7 @@ __global__ void __launch_bounds__((MTI == 1 ? 16 : 8) * 64) eval_kernel(const Ev
 #pragma unroll
         for (int j = 0; j < D; ++j)
             if (j < n_cand)
-                tile_tail<MT0, MTI>(p, reinterpret_cast<const float*>(smem + j * IB), acc0[j], lane, n, kq, a_slot, row_scratch, row,
+                tile_tail<MT0, MTI, GEN>(p, reinterpret_cast<const float*>(smem + j * IB), acc0[j], lane, n, kq, a_slot, row_scratch, row,
                                     row_ok, j == 0, A[j]);
     }
 
@@ -974,6 +979,7 @@ struct ChainParams {
     int K, M, D, n_blocks;
     int prior_kind;
     double prior_scale[kMaxLayers];
+    double half_inv_s2[kMaxLayers];   // 0.5 / scale^2 (normal prior)
     double w_bound;
     double temperature, lik_temp;
     int sigma_given;           // Gaussian: 1 = use sigma_fixed, 0 = empirical
@@ -1058,10 +1064,13 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     __shared__ double red[16];
     __shared__ npbnn_eval_out o;
     __shared__ int s_accepted, s_t;
+    __shared__ double s_lp;             // log prior of the state the next candidates start from
     const int tid = threadIdx.x;
     ChainDev* st = c.st;
     const int lik_kind = c.net.lik_kind;
-#define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)(c.pass->t0 & 1023) * 8 + (k)] = wall_clock64(); } while (0)
+    const int stamp_row = first_launch ? 0 : (c.pass->t0 & 1023);
+#define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)stamp_row * 8 + (k)] = wall_clock64(); } while (0)
+    NPBNN_STAMP(0);
 
     // at the start of a batch the prior of the current state is summed in full (proposals then update it
     // incrementally from the touched entries, so rounding drift cannot accumulate across batches)
@@ -1087,6 +1096,31 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     // ---- 1. decide the pending candidates ----
     const int t0 = first_launch ? 0 : c.pass->t0;
     const int n_pend = first_launch ? 0 : c.pass->n_cand;
+    double prefetch_sink = 0.0;
+    {   // whichever candidate wins, the next pass starts at t0+1 .. t0+n_pend: pull those rows of the pre-drawn arrays
+        // towards the L2 now, while the partial sums are being reduced (the values are not used here)
+        const int r_lo = t0 + (first_launch ? 0 : 1), r_hi = min(c.K, t0 + n_pend + c.D);
+        double sink = 0.0;
+        for (int r = r_lo; r < r_hi; ++r)
+            if (tid < c.M) sink += (double)c.idx[(size_t)r * c.M + tid] + c.delta[(size_t)r * c.M + tid] + (double)c.pos[(size_t)r * c.M + tid];
+        prefetch_sink = sink;
+    }
+    // decision operands, fetched now by the deciding thread so that they are in registers when the sums arrive
+    double d_cand[kMaxCand], d_logu[kMaxCand], d_h[kMaxCand], d_ll = 0.0, d_lp = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMaxCand; ++j) { d_cand[j] = 0.0; d_logu[j] = 0.0; d_h[j] = 0.0; }
+    if (tid == 0 && n_pend > 0) {
+        d_ll = st->logLik;
+        d_lp = st->logPrior;
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j)
+            if (j < n_pend) {
+                d_cand[j] = st->cand_logPrior[j];
+                d_logu[j] = c.log_u[t0 + j];
+                d_h[j] = c.hastings ? c.hastings[t0 + j] : 0.0;
+            }
+    }
+    NPBNN_STAMP(1);
     if (n_pend > 0) {
         const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
         {   // wave w sums items w, w+nw, ... (item = candidate * nvals + value): lanes add workgroups lane, lane+64, ... in order
@@ -1102,34 +1136,39 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
             }
         }
         __syncthreads();
+        NPBNN_STAMP(2);
         if (tid == 0) {
             int accepted = -1, n_done = n_pend;
-            for (int j = 0; j < n_pend; ++j) {
-                const int t = t0 + j;
-                loglik_from_totals(tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
-                const double lp = st->cand_logPrior[j];
-                const double h = c.hastings ? c.hastings[t] : 0.0;
-                const double post_new = o.loglik + lp, post_old = st->logLik + st->logPrior;
-                const int a = ((post_new - post_old) * c.temperature + h >= c.log_u[t]) ? 1 : 0;
-                c.out_acc[t] = (unsigned char)a;
-                c.out_ll[t] = o.loglik;
-                c.out_lp[t] = lp;
-                if (a) {
-                    st->logLik = o.loglik;
-                    st->logPrior = lp;
-                    st->n_accepted += 1;
-                    if (lik_kind == NPBNN_LIK_GAUSS)
-                        for (int q = 0; q < c.net.k_targets; ++q) st->sigma[q] = o.sigma[q];
-                    accepted = j;
-                    n_done = j + 1;
-                    break;
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                if (j < n_pend && accepted < 0) {
+                    const int t = t0 + j;
+                    loglik_from_totals(tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &o);
+                    const double lp = d_cand[j];
+                    const double post_new = o.loglik + lp, post_old = d_ll + d_lp;
+                    const int a = ((post_new - post_old) * c.temperature + d_h[j] >= d_logu[j]) ? 1 : 0;
+                    c.out_acc[t] = (unsigned char)a;
+                    c.out_ll[t] = o.loglik;
+                    c.out_lp[t] = lp;
+                    if (a) {
+                        st->logLik = o.loglik;
+                        st->logPrior = lp;
+                        st->n_accepted += 1;
+                        if (lik_kind == NPBNN_LIK_GAUSS)
+                            for (int q = 0; q < c.net.k_targets; ++q) st->sigma[q] = o.sigma[q];
+                        accepted = j;
+                        n_done = j + 1;
+                        s_lp = lp;
+                    }
                 }
             }
+            if (accepted < 0) s_lp = d_lp;
             st->t = t0 + n_done;
             s_accepted = accepted;
             s_t = t0 + n_done;
         }
         __syncthreads();
+        NPBNN_STAMP(3);
         const int a = s_accepted;
         if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
             const size_t row = (size_t)(t0 + a) * c.M;
@@ -1147,51 +1186,102 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     } else if (tid == 0) {
         s_t = first_launch ? 0 : st->t;
         if (first_launch) st->t = 0;
+        s_lp = st->logPrior;
     }
     __syncthreads();
 
-    // ---- 2. prepare the next candidates: each is the current state plus its own iteration's perturbation ----
+    NPBNN_STAMP(4);
+    // ---- 2. prepare the next candidates: each is the current state plus its own iteration's perturbation.  Work items
+    //      are (candidate, entry) pairs spread over the whole workgroup; the three prior sums share one reduction. ----
     const int t_new = s_t;
     int n_new = c.K - t_new;
     if (n_new > c.D) n_new = c.D;
     if (n_new < 0) n_new = 0;
-    double cand_lp[kMaxCand];
+    double dlp[kMaxCand];
+    {
+        // staged so that the loads of all candidates are in flight together: (1) the pre-drawn entry, (2) the weight it
+        // touches, (3) arithmetic and stores.  One entry per thread and candidate; wider proposals loop.
+        const double* __restrict__ wcur = c.w_cur;
+        const double* __restrict__ mask = c.mask;
+        int woff[kMaxLayers];
+        double half_inv_s2[kMaxLayers];
 #pragma unroll
-    for (int j = 0; j < kMaxCand; ++j) {
-        cand_lp[j] = 0.0;
-        if (j < n_new) {
-            const size_t row = (size_t)(t_new + j) * c.M;
-            const int n = c.cnt[t_new + j];
-            double dlp = 0.0;
-            for (int e = tid; e < n; e += blockDim.x) {
-                const int i = c.idx[row + e];
-                if (i < 0) continue;
-                const double base = c.w_cur[i];
-                double v = base + c.delta[row + e];
-                if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
-                if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
-                if (c.mask) v *= c.mask[i];
-                c.pv[(size_t)j * c.M + e] = v;
-                if (c.pscale && c.pos[row + e] < 0 && !(fabs(v * (double)c.pscale[row + e]) <= (double)kF16Safe)) *c.overflow = 1;
-                if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
-                    int l = 0;
-                    while (l + 1 < c.net.n_layers && i >= c.net.L[l + 1].w_off) ++l;
-                    dlp += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
+        for (int q = 0; q < kMaxLayers; ++q) {
+            woff[q] = q < c.net.n_layers ? c.net.L[q].w_off : 0x7fffffff;
+            half_inv_s2[q] = c.half_inv_s2[q];
+        }
+        int ii[kMaxCand], pp[kMaxCand];
+        double dd[kMaxCand], bb[kMaxCand], mm[kMaxCand];
+        float ss[kMaxCand];
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+            dlp[j] = 0.0;
+            ii[j] = -1; pp[j] = 0; dd[j] = 0.0; ss[j] = 1.0f;
+            if (j < n_new && tid < c.cnt[t_new + j]) {
+                const size_t k = (size_t)(t_new + j) * c.M + tid;
+                ii[j] = c.idx[k];
+                dd[j] = c.delta[k];
+                pp[j] = c.pos[k];
+                if (c.pscale) ss[j] = c.pscale[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+            bb[j] = ii[j] >= 0 ? wcur[ii[j]] : 0.0;
+            mm[j] = (ii[j] >= 0 && mask) ? mask[ii[j]] : 1.0;
+        }
+        auto make = [&](int j, int e, int i, double base, double d, double m, int pos, float sc) {
+            double v = base + d;
+            if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
+            if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
+            v *= m;
+            c.pv[(size_t)j * c.M + e] = v;
+            if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) *c.overflow = 1;
+            if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+                int l = 0;
+#pragma unroll
+                for (int q = 1; q < kMaxLayers; ++q) l += (i >= woff[q]) ? 1 : 0;
+                if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * half_inv_s2[l];
+                else dlp[j] += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+            if (ii[j] >= 0) make(j, tid, ii[j], bb[j], dd[j], mm[j], pp[j], ss[j]);
+            if (j < n_new) {
+                const size_t row = (size_t)(t_new + j) * c.M;
+                for (int e = tid + blockDim.x; e < c.cnt[t_new + j]; e += blockDim.x) {
+                    const int i = c.idx[row + e];
+                    if (i >= 0) make(j, e, i, wcur[i], c.delta[row + e], mask ? mask[i] : 1.0, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f);
                 }
             }
-            cand_lp[j] = block_sum(dlp, red);
         }
     }
+    NPBNN_STAMP(5);
+    __shared__ double red3[kMaxCand][16];
+#pragma unroll
+    for (int j = 0; j < kMaxCand; ++j) {
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) dlp[j] += shfl_xor_f64(dlp[j], sh);
+        if ((tid & 63) == 0) red3[j][tid >> 6] = dlp[j];
+    }
+    __syncthreads();
     if (tid == 0) {
-        const double base_lp = st->logPrior;
-        for (int j = 0; j < n_new; ++j) st->cand_logPrior[j] = base_lp + cand_lp[j];
+        const double base_lp = s_lp;
         PassDesc d;
         d.t0 = t_new;
         d.n_cand = n_new;
-        for (int j = 0; j < kMaxCand; ++j) d.cnt[j] = j < n_new ? c.cnt[t_new + j] : 0;
+        for (int j = 0; j < kMaxCand; ++j) {
+            double sj = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sj += red3[j][w];
+            if (j < n_new) st->cand_logPrior[j] = base_lp + sj;
+            d.cnt[j] = j < n_new ? c.cnt[t_new + j] : 0;
+        }
         d.pad[0] = d.pad[1] = d.pad[2] = 0;
         *c.pass = d;
     }
+    if (prefetch_sink == 1.2345e300) c.out_lp[0] = prefetch_sink;      // keeps the prefetch loads alive; never true
+    NPBNN_STAMP(6);
 }
 #endif  // NPBNN_KERNELS_MAIN
 

@@ -329,6 +329,44 @@ __device__ __forceinline__ float softplus_f(float z) {   // np.logaddexp(0, z), 
     return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z)));
 }
 
+// Reductions over the 4 lanes {l, l^16, l^32, l^48} that hold one data row's units, without LDS traffic:
+// v_permlane16_swap exchanges odd and even 16-lane rows, v_permlane32_swap the two 32-lane halves; after a swap of two
+// copies of v the pair (r[0], r[1]) holds v[l] and v[l^16] (resp. v[l^32]) in every lane.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quad_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// arg-max over the quad: larger value wins, ties go to the smaller index (np.argmax takes the first maximum)
+__device__ __forceinline__ void quad_argmax(float& bv, int& bi) {
+    u32x2 rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    u32x2 ri = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+    {
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int i0 = (int)ri[0], i1 = (int)ri[1];
+        const bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+    }
+    rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+    {
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int i0 = (int)ri[0], i1 = (int)ri[1];
+        const bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+    }
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_xor(lo, m);
@@ -466,8 +504,7 @@ __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img,
                         if (h[mt][i] > bv) { bv = h[mt][i]; bi = o; }
                     }
                 }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+        m = quad_max(m);
         float se = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt)
@@ -475,16 +512,10 @@ __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img,
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (16 * mt + 4 * kq + i < C) se += __expf(h[mt][i] - m);
-        se += __shfl_xor(se, 16);
-        se += __shfl_xor(se, 32);
+        se = quad_sum(se);
         lse = m + __logf(se);
         if (p.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207)
-#pragma unroll
-            for (int sh = 16; sh <= 32; sh <<= 1) {
-                const float ov = __shfl_xor(bv, sh);
-                const int oi = __shfl_xor(bi, sh);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            quad_argmax(bv, bi);
             best_i = bi;
         }
     }

@@ -23,6 +23,7 @@
 #ifndef NPBNN_HIP_H
 #define NPBNN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -230,6 +231,12 @@ void npbnn_comm_destroy(npbnn_comm* comm);
 /* timing hook for a speculative chain pass: the evaluation kernel with n_candidates weight sets (0 = as many as fit),
  * `iters` back-to-back launches between one pair of HIP events on the ctx stream; mean milliseconds per launch */
 int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, int iters, double* ms_kernel, int* used_candidates);
+
+/* page-locked host memory for the per-batch inputs of npbnn_chain_run (idx / delta / cnt / log_u): arrays drawn straight into
+ * such memory are uploaded asynchronously at link speed instead of through the driver's bounce buffer.  (The reference has no
+ * counterpart: its draws never leave the host, np_bnn/BNN_mcmc.py:57-69.) */
+int npbnn_pinned_alloc(size_t bytes, void** out);
+void npbnn_pinned_free(void* ptr);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,8 @@ SIGNATURES = {
     "npbnn_predict": (C.c_int, [_P, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),
     "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
     "npbnn_time_pass": (C.c_int, [_P, _DP, C.c_int, C.c_int, _DP, C.POINTER(C.c_int)]),
+    "npbnn_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "npbnn_pinned_free": (None, [C.c_void_p]),
     "npbnn_chain_run": (C.c_int, [_P, C.POINTER(ChainCfg), _DP, _DP, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _DP,
                                   C.POINTER(C.c_int32), _DP, C.POINTER(C.c_uint8), _DP, _DP, C.POINTER(ChainResult)]),
     "npbnn_op_activation": (C.c_int, [C.c_int, C.c_int, C.c_double, _DP, C.c_int64]),

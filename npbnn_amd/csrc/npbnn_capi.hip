@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -95,7 +96,13 @@ struct npbnn_ctx {
     npbnn_eval_out* h_out = nullptr;
     unsigned* h_conf = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    // device-resident chain
+    // device-resident chain.  d_res / h_res: one block [ChainDev | overflow flag | W_cur | accepted | logLik' | logPrior'] so that a
+    // single copy brings the whole outcome of a batch to the (pinned) host side; d_chain, d_wcur, d_acc, d_llp, d_lpp point into it
+    char* d_res = nullptr;
+    char* h_res = nullptr;
+    size_t res_cap = 0, res_k = 0, res_nw = 0;
+    int* d_chain_ovf = nullptr;
+    double its_per_pass = 0.0;     // iterations a pass decided on average in the previous batch (0: unknown)
     double* d_wcur = nullptr;
     double* d_pv = nullptr;        // [kMaxCand][M] proposed values of the candidates in flight
     size_t pv_cap = 0;
@@ -116,6 +123,8 @@ struct npbnn_ctx {
 };
 
 namespace {
+
+constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 
 int fail(npbnn_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -610,10 +619,10 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_wcur, c->d_pv, c->d_pass, c->d_mask, c->d_chain, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu,
-                          c->d_acc, c->d_llp, c->d_lpp};
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_pass, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
+    if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
     if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -860,13 +869,19 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (!cfg || !W_inout || !result || K < 1 || M < 1 || !idx || !delta || !cnt || !log_u || !out_accepted)
         return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
     if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run: call npbnn_set_arch first");
+    static const bool timing = getenv("NPBNN_CHAIN_TIMING") != nullptr;     // diagnostics: host wall clock per phase
+    const auto wall = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tw0 = wall();
     const int lik = ctx->net.lik_kind;
     if (lik == NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_STATE, "chain_run: the architecture has no likelihood");
     if (cfg->prior_kind < 0 || cfg->prior_kind > NPBNN_PRIOR_LAPLACE) return fail(ctx, NPBNN_E_ARG, "chain_run: prior_kind=%d", cfg->prior_kind);
     for (int t = 0; t < K; ++t)
         if (cnt[t] < 0 || cnt[t] > M) return fail(ctx, NPBNN_E_ARG, "chain_run: cnt[%d]=%d outside 0..%d", t, cnt[t], M);
-    for (size_t i = 0; i < (size_t)K * M; ++i)
-        if (idx[i] >= ctx->n_weights) return fail(ctx, NPBNN_E_ARG, "chain_run: weight index %d out of range", idx[i]);
+    {
+        int32_t idx_max = -1;                          // branch-free so that it vectorises: this is K*M entries per batch
+        for (size_t i = 0; i < (size_t)K * M; ++i) idx_max = idx[i] > idx_max ? idx[i] : idx_max;
+        if (idx_max >= ctx->n_weights) return fail(ctx, NPBNN_E_ARG, "chain_run: weight index %d out of range", idx_max);
+    }
     Dataset& d = ctx->ds[0];
     int rc = check_dataset_for_lik(ctx, d, lik);
     if (rc) return rc;
@@ -880,10 +895,30 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (rc) return rc;
     const int D = lp.n_cand;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
-    if (!ctx->d_wcur) HIP_TRY(ctx, hipMalloc(&ctx->d_wcur, wb));
-    if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
-    if (!ctx->d_chain) HIP_TRY(ctx, hipMalloc(&ctx->d_chain, sizeof(ChainDev)));
     if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, sizeof(PassDesc)));
+    const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    if ((size_t)K > ctx->res_k || (size_t)ctx->n_weights != ctx->res_nw) {
+        size_t kc = (size_t)K > ctx->res_k ? (size_t)K : ctx->res_k;
+        if (kc < kChainMinCapacity) kc = kChainMinCapacity;
+        const size_t total = 512 + up256(wb) + up256(kc) + 2 * up256(kc * sizeof(double));
+        if (ctx->d_res) (void)hipFree(ctx->d_res);
+        if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+        if (ctx->d_mask) (void)hipFree(ctx->d_mask);        // sized by the number of weights as well
+        ctx->d_mask = nullptr;
+        ctx->d_res = nullptr; ctx->h_res = nullptr; ctx->res_cap = 0; ctx->res_k = 0; ctx->res_nw = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_res, total));
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_res, total));
+        ctx->res_cap = total; ctx->res_k = kc; ctx->res_nw = (size_t)ctx->n_weights;
+        char* b = ctx->d_res;
+        ctx->d_chain = reinterpret_cast<ChainDev*>(b);
+        ctx->d_chain_ovf = reinterpret_cast<int*>(b + 256);
+        ctx->d_wcur = reinterpret_cast<double*>(b + 512);
+        ctx->d_acc = reinterpret_cast<unsigned char*>(b + 512 + up256(wb));
+        ctx->d_llp = reinterpret_cast<double*>(b + 512 + up256(wb) + up256(kc));
+        ctx->d_lpp = reinterpret_cast<double*>(b + 512 + up256(wb) + up256(kc) + up256(kc * sizeof(double)));
+    }
+    static_assert(sizeof(ChainDev) <= 256, "ChainDev must fit its slot of the result block");
+    if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
     if ((size_t)M > ctx->pv_cap) {
         if (ctx->d_pv) (void)hipFree(ctx->d_pv);
         ctx->d_pv = nullptr; ctx->pv_cap = 0;
@@ -892,29 +927,27 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     }
     const size_t need = (size_t)K * M;
     if (need > ctx->draw_cap) {
+        const size_t cap = need > (size_t)kChainMinCapacity * M ? need : (size_t)kChainMinCapacity * M;
         if (ctx->d_idx) (void)hipFree(ctx->d_idx);
         if (ctx->d_delta) (void)hipFree(ctx->d_delta);
         if (ctx->d_pos) (void)hipFree(ctx->d_pos);
         if (ctx->d_pscale) (void)hipFree(ctx->d_pscale);
         ctx->d_idx = nullptr; ctx->d_delta = nullptr; ctx->d_pos = nullptr; ctx->d_pscale = nullptr; ctx->draw_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_idx, need * sizeof(int)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_delta, need * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_pos, need * sizeof(int)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_pscale, need * sizeof(float)));
-        ctx->draw_cap = need;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_idx, cap * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_delta, cap * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pos, cap * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pscale, cap * sizeof(float)));
+        ctx->draw_cap = cap;
     }
     if ((size_t)K > ctx->iter_cap) {
-        void* olds[] = {ctx->d_cnt, ctx->d_logu, ctx->d_acc, ctx->d_llp, ctx->d_lpp};
-        for (void* b : olds)
-            if (b) (void)hipFree(b);
-        ctx->d_cnt = nullptr; ctx->d_logu = nullptr; ctx->d_acc = nullptr; ctx->d_llp = nullptr; ctx->d_lpp = nullptr;
+        const size_t kcap = (size_t)K > kChainMinCapacity ? (size_t)K : kChainMinCapacity;
+        if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
+        if (ctx->d_logu) (void)hipFree(ctx->d_logu);
+        ctx->d_cnt = nullptr; ctx->d_logu = nullptr;
         ctx->iter_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_cnt, (size_t)K * sizeof(int)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_logu, (size_t)K * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_acc, (size_t)K));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_llp, (size_t)K * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_lpp, (size_t)K * sizeof(double)));
-        ctx->iter_cap = (size_t)K;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_cnt, kcap * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_logu, kcap * sizeof(double)));
+        ctx->iter_cap = kcap;
     }
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wcur, W_inout, wb, hipMemcpyHostToDevice, st));
@@ -934,14 +967,18 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) init.sigma[j] = cfg->cur_sigma[j];
     init.t = 0;
     init.n_accepted = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chain, &init, sizeof(ChainDev), hipMemcpyHostToDevice, st));
+    init.n_passes = 0;
+    {   // initial chain state and the overflow flag travel together (first 512 bytes of the result block)
+        memset(ctx->h_res, 0, 512);
+        memcpy(ctx->h_res, &init, sizeof(ChainDev));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_res, ctx->h_res, 512, hipMemcpyHostToDevice, st));
+    }
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
     {   // weight image of the current state; accepted candidates are committed to it entry by entry
         const int total = pack_item_count(ctx->net, true);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), st));
         hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ctx->d_wcur, (const double*)nullptr,
                            ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net,
-                           f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
+                           f16 ? ctx->d_wscale : nullptr, ctx->d_chain_ovf);
     }
     ChainParams c{};
     c.st = ctx->d_chain;
@@ -961,7 +998,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.pos = ctx->d_pos;
     c.pscale = f16 ? ctx->d_pscale : nullptr;
     c.pv = ctx->d_pv;
-    c.overflow = ctx->d_overflow;
+    c.overflow = ctx->d_chain_ovf;
     unsigned long long* d_stamps = nullptr;
     if (getenv("NPBNN_STEP_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the step kernel
         HIP_TRY(ctx, hipMalloc(&d_stamps, 1024 * 8 * sizeof(unsigned long long)));
@@ -1000,33 +1037,45 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     // step (prepare candidates) -> [eval -> step (decide + prepare)]* ; a pass consumes 1..D iterations, so the number of
     // passes is only known on the device: launch the least number that can finish, look at the counter, repeat
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
-    int t_done = 0, n_passes = 0;
+    const double tw1 = wall();
+    int t_done = 0, n_passes = 0, n_rounds = 0;
+    const size_t res_used = 512 + up256(wb) + up256(ctx->res_k) + 2 * up256(ctx->res_k * sizeof(double));
+    const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
     while (t_done < K) {
-        const int n = (K - t_done + D - 1) / D;
+        ++n_rounds;
+        // a pass decides between 1 and D iterations: launch what the previous batch's average says is needed plus a small
+        // margin (passes launched after the last iteration return at once), look at the counter, launch again if short
+        const int rem = K - t_done;
+        int n = (rem + D - 1) / D;
+        if (ctx->its_per_pass >= 1.0) {
+            const int est = (int)std::ceil((double)rem / ctx->its_per_pass);
+            if (est > n) n = est;
+            n += 1 + n / 64;
+        }
         for (int i = 0; i < n; ++i) {
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams);
             hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
         }
-        n_passes += n;
         HIP_TRY(ctx, hipGetLastError());
-        ChainDev now{};
-        HIP_TRY(ctx, hipMemcpyAsync(&now, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used, hipMemcpyDeviceToHost, st));   // state + results, one copy
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (now.t <= t_done) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now.t);
-        t_done = now.t;
+        if (now->t <= t_done) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now->t);
+        t_done = now->t;
     }
-    ChainDev fin{};
-    HIP_TRY(ctx, hipMemcpyAsync(&fin, ctx->d_chain, sizeof(ChainDev), hipMemcpyDeviceToHost, st));
-    int ovf = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (ctx->net.l0_f16 && ovf)     // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
+    const double tw2 = wall();
+    const ChainDev fin = *now;
+    n_passes = fin.n_passes;
+    if (n_passes > 0) ctx->its_per_pass = (double)K / n_passes;
+    if (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 256))     // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
         return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
-    HIP_TRY(ctx, hipMemcpyAsync(W_inout, ctx->d_wcur, wb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(out_accepted, ctx->d_acc, (size_t)K, hipMemcpyDeviceToHost, st));
-    if (out_loglik_prop) HIP_TRY(ctx, hipMemcpyAsync(out_loglik_prop, ctx->d_llp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (out_logprior_prop) HIP_TRY(ctx, hipMemcpyAsync(out_logprior_prop, ctx->d_lpp, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    {
+        const char* b = ctx->h_res;
+        memcpy(W_inout, b + 512, wb);
+        memcpy(out_accepted, b + 512 + up256(wb), (size_t)K);
+        if (out_loglik_prop) memcpy(out_loglik_prop, b + 512 + up256(wb) + up256(ctx->res_k), (size_t)K * sizeof(double));
+        if (out_logprior_prop)
+            memcpy(out_logprior_prop, b + 512 + up256(wb) + up256(ctx->res_k) + up256(ctx->res_k * sizeof(double)), (size_t)K * sizeof(double));
+    }
     if (d_stamps) {
         std::vector<unsigned long long> hs(1024 * 8);
         (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
@@ -1048,7 +1097,21 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     result->n_accepted = fin.n_accepted;
     result->n_passes = n_passes;
     result->n_candidates = D;
+    if (timing)
+        fprintf(stderr, "[npbnn chain timing] K=%d passes=%d rounds=%d: setup %.0f us, passes %.0f us (%.2f us/pass), results %.0f us\n", K,
+                n_passes, n_rounds, tw1 - tw0, tw2 - tw1, (tw2 - tw1) / n_passes, wall() - tw2);
     return NPBNN_OK;
+}
+
+int npbnn_pinned_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(nullptr, NPBNN_E_ARG, "pinned_alloc: bad arguments");
+    *out = nullptr;
+    HIP_TRY(nullptr, hipHostMalloc(out, bytes));
+    return NPBNN_OK;
+}
+
+void npbnn_pinned_free(void* ptr) {
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, int iters, double* ms_kernel, int* used_candidates) {

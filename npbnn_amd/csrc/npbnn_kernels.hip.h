@@ -984,6 +984,8 @@ struct ChainDev {          // device-resident chain state
     double cand_logPrior[kMaxCand];
     int t;                  // iterations decided so far in this batch
     int n_accepted;
+    int n_passes;           // evaluation passes that decided at least one iteration
+    int pad_;
 };
 
 struct ChainParams {
@@ -1098,6 +1100,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     __shared__ double s_lp;             // log prior of the state the next candidates start from
     const int tid = threadIdx.x;
     ChainDev* st = c.st;
+    if (!first_launch && c.pass->n_cand == 0) return;      // launched past the end of the batch
     const int lik_kind = c.net.lik_kind;
     const int stamp_row = first_launch ? 0 : (c.pass->t0 & 1023);
 #define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)stamp_row * 8 + (k)] = wall_clock64(); } while (0)
@@ -1195,6 +1198,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
             }
             if (accepted < 0) s_lp = d_lp;
             st->t = t0 + n_done;
+            st->n_passes += 1;
             s_accepted = accepted;
             s_t = t0 + n_done;
         }

@@ -71,6 +71,14 @@ class HipBackend:
         self._shapes = None
         self._act = bnn._act_fun
         self._configure(bnn._w_layers)
+        self._pinned = None
+
+    def host_empty(self, shape, dtype):
+        """Page-locked host array for data on its way to the device (pre-drawn proposals)."""
+        if self._pinned is None:
+            from .pinned import PinnedPool
+            self._pinned = PinnedPool(self.ctx._lib)
+        return self._pinned.empty(shape, dtype)
 
     def _configure(self, weights):
         shapes = tuple(w.shape for w in weights)

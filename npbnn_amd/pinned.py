@@ -1,0 +1,56 @@
+"""Page-locked host arrays for the per-batch inputs of the device-resident chain (npbnn_pinned_alloc).
+
+A pre-drawn batch is K x M indices and deviates (5 KB per iteration on BASELINE config 2); drawn straight into
+page-locked memory it is uploaded asynchronously at link speed.  Blocks are recycled through a small pool, because
+locking pages costs far more than a batch upload."""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _capi as capi
+
+
+class _Block:
+    __slots__ = ("pool", "ptr", "nbytes", "__weakref__")
+
+    def __init__(self, pool, ptr, nbytes):
+        self.pool, self.ptr, self.nbytes = pool, ptr, nbytes
+
+    def __del__(self):
+        pool = self.pool
+        if pool is not None:
+            pool._give_back(self.ptr, self.nbytes)
+
+
+class PinnedPool:
+    def __init__(self, lib=None):
+        self._lib = lib if lib is not None else capi.load_library()
+        self._free = {}
+        self._lock = threading.Lock()
+
+    def _give_back(self, ptr, nbytes):
+        try:
+            with self._lock:
+                self._free.setdefault(nbytes, []).append(ptr)
+        except Exception:       # interpreter shutdown
+            pass
+
+    def empty(self, shape, dtype):
+        """An uninitialised C-contiguous array in page-locked memory (returned to the pool when the last view dies)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        nbytes = 1 << max(12, (max(n, 1) - 1).bit_length())
+        with self._lock:
+            lst = self._free.get(nbytes)
+            ptr = lst.pop() if lst else None
+        if ptr is None:
+            out = C.c_void_p()
+            rc = self._lib.npbnn_pinned_alloc(nbytes, C.byref(out))
+            if rc != 0 or not out.value:
+                msg = self._lib.npbnn_last_error(None)
+                raise capi.NpbnnError(rc, "npbnn_pinned_alloc(%d): %s" % (nbytes, msg.decode() if msg else "?"))
+            ptr = out.value
+        raw = (C.c_char * nbytes).from_address(ptr)
+        raw._npbnn_block = _Block(self, ptr, nbytes)       # lives as long as any array built on `raw`
+        return np.ndarray(shape, dtype=dtype, buffer=raw)

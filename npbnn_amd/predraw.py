@@ -36,9 +36,13 @@ def load_host_library():
     return _lib
 
 
-def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, update_ws, freq_layer_update):
+def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, update_ws, freq_layer_update, empty=None):
     """Draw K iterations' proposals.  ``rs`` is the chain's numpy Generator (advanced in place unless
-    ``randomize_seed``).  Returns (idx [K,M] int32, delta [K,M] float64, cnt [K], u [K], layer_mask [K])."""
+    ``randomize_seed``).  Returns (idx [K,M] int32, delta [K,M] float64, cnt [K], u [K], layer_mask [K]).
+    ``empty(shape, dtype)`` allocates the four arrays that travel to the device (page-locked memory, pinned.py);
+    default numpy."""
+    if empty is None:
+        empty = np.empty
     lib = load_host_library()
     spec = ProposalSpec()
     n_layers = len(weights)
@@ -54,10 +58,12 @@ def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, 
         spec.update_ws[i] = ws.ctypes.data_as(C.POINTER(C.c_double))
         spec.freq_layer_update[i] = float(freq_layer_update[i])
     M = int(sum(int(n) for n in update_n))
-    idx = np.full((K, M), -1, dtype=np.int32)
-    delta = np.zeros((K, M), dtype=np.float64)
-    cnt = np.empty(K, dtype=np.int32)
-    u = np.empty(K, dtype=np.float64)
+    idx = empty((K, M), np.int32)
+    idx.fill(-1)
+    delta = empty((K, M), np.float64)
+    delta.fill(0.0)
+    cnt = empty((K,), np.int32)
+    u = empty((K,), np.float64)
     lmask = np.empty(K, dtype=np.int32)
     bitgen = None
     if not randomize_seed:

@@ -231,17 +231,22 @@ class MCMC():
             getattr(self, name)
 
     def __getstate__(self):
+        self._cancel_speculation()
         self._materialize()
         state = dict(self.__dict__)
         state.pop("_backend", None)
         return state
 
     def __setstate__(self, state):
+        state = dict(state)
+        if "_rs" in state:
+            state["_gen"] = state.pop("_rs")
         self.__dict__.update(state)
         self.__dict__.setdefault("_backend", None)
 
     def __deepcopy__(self, memo):
         import copy
+        self._cancel_speculation()
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
@@ -278,6 +283,7 @@ class MCMC():
     # one Metropolis-Hastings iteration (reference: BNN_env.py:381-532)
     # ------------------------------------------------------------------------------------------
     def mh_step(self, bnn_obj, additional_prob=0, return_bnn=False):
+        self._cancel_speculation()
         self._bnn = bnn_obj
         if self._backend is None:
             self._backend = get_backend(bnn_obj, self._likelihood_f)
@@ -400,6 +406,8 @@ class MCMC():
         return True
 
     def _next_adapt_boundary(self):
+        if self._adapt_f <= 0 and self._adapt_fM >= 1:
+            return None             # _adapt can never fire: the acceptance rate lies in [0, 1]
         it = self._current_iteration
         nxt = (it // self._adapt_freq + 1) * self._adapt_freq
         return nxt if nxt < self._adapt_stop else None
@@ -407,9 +415,10 @@ class MCMC():
     def run_steps(self, bnn_obj, n_steps):
         """Advance the chain by ``n_steps`` iterations: exactly ``n_steps`` calls of :meth:`mh_step` (same random
         stream, same adaptation points, same bookkeeping), executed where possible as a device-resident chain
-        with the random numbers pre-drawn on the host (the draws of the next sub-batch are produced by a helper
-        thread while the GPU runs the current one)."""
-        from . import predraw as pd
+        with the random numbers pre-drawn on the host.  The draws of the next sub-batch are produced by a helper
+        thread while the GPU runs the current one - also across calls: the last sub-batch of a call leaves the
+        draws of the probable next call in flight (:meth:`_cancel_speculation` rewinds the generator when something
+        else wants the stream first)."""
         self._bnn = bnn_obj
         if self._backend is None:
             self._backend = get_backend(bnn_obj, self._likelihood_f)
@@ -424,23 +433,75 @@ class MCMC():
                 remaining -= 1
                 continue
             self._adapt(bnn_obj)
-            shapes = [np.empty(w.shape) for w in bnn_obj._w_layers]      # predraw only needs the shapes
-
-            def draw(first_it, k):
-                return pd.predraw(self._rs, self._randomize_seed, first_it, self._mcmc_id, k, shapes, self._update_n,
-                                  self._update_ws, self._freq_layer_update)
-
             sizes = self._sub_batches(seg)
-            pool = _draw_pool()
             it = self._current_iteration
-            pending = pool.submit(draw, it, sizes[0])
+            pending = self._claim_draw(bnn_obj, it, sizes[0])
             for n, k in enumerate(sizes):
-                idx, delta, cnt, u, _ = pending.result()
+                idx, delta, cnt, log_u = pending.result()
                 it += k
                 if n + 1 < len(sizes):
-                    pending = pool.submit(draw, it, sizes[n + 1])
-                self._run_device_batch(bnn_obj, idx, delta, cnt, u)
+                    pending = self._submit_draw(bnn_obj, it, sizes[n + 1])[1]
+                elif remaining == seg:            # last sub-batch of this call: draw ahead for the next call
+                    self._speculation = self._submit_draw(bnn_obj, it, min(self.SUB_BATCH, int(n_steps)), rewindable=True)
+                self._run_device_batch(bnn_obj, idx, delta, cnt, log_u)
             remaining -= seg
+
+    _speculation = None      # (key, future, generator state before the draw) of draws made ahead of the next run_steps call
+
+    def _draw_key(self, bnn_obj, first_it, k):
+        return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id), tuple(int(n) for n in self._update_n),
+                tuple(hash(np.asarray(w).tobytes()) for w in self._update_ws), tuple(float(f) for f in self._freq_layer_update),
+                tuple(w.shape for w in bnn_obj._w_layers))
+
+    def _submit_draw(self, bnn_obj, first_it, k, rewindable=False):
+        """Start the pre-draw of iterations first_it .. first_it+k-1 on the helper thread."""
+        from . import predraw as pd
+        shapes = [np.empty(w.shape) for w in bnn_obj._w_layers]      # predraw only needs the shapes
+        rs, randomize, mcmc_id = self._gen, self._randomize_seed, self._mcmc_id
+        update_n, update_ws = [int(n) for n in self._update_n], list(self._update_ws)
+        freq = [float(f) for f in self._freq_layer_update]
+        empty = getattr(self._backend, "host_empty", None)
+        saved = rs.bit_generator.state if (rewindable and not randomize) else None
+
+        def draw():
+            idx, delta, cnt, u, _ = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty)
+            np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
+            return idx, delta, cnt, u
+
+        return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved
+
+    def _claim_draw(self, bnn_obj, first_it, k):
+        """The draws for iterations first_it .. first_it+k-1: the ones made ahead by the previous call when they
+        are exactly these, else fresh ones."""
+        spec = self._speculation
+        if spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k):
+            self._speculation = None
+            return spec[1]
+        self._cancel_speculation()
+        return self._submit_draw(bnn_obj, first_it, k)[1]
+
+    def _cancel_speculation(self):
+        """Drop draws made ahead and put the generator back where the chain left it."""
+        spec, self._speculation = self._speculation, None
+        if spec is None:
+            return
+        try:
+            spec[1].result()
+        finally:
+            if spec[2] is not None:
+                self._gen.bit_generator.state = spec[2]
+
+    @property
+    def _rs(self):
+        """The chain's numpy Generator (BNN_env.py:352).  Reading it first takes back any draws made ahead, so
+        callers always see the stream exactly where the iterations done so far left it."""
+        self._cancel_speculation()
+        return self._gen
+
+    @_rs.setter
+    def _rs(self, value):
+        self._cancel_speculation()
+        self._gen = value
 
     n_candidates = 0         # proposals evaluated per pass over the data by the device chain: 0 = as many as fit (<= 3)
     _device_passes = 0
@@ -457,7 +518,7 @@ class MCMC():
             k = min(2 * k, self.SUB_BATCH_MAX)
         return sizes
 
-    def _run_device_batch(self, bnn_obj, idx, delta, cnt, u):
+    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u):
         k = len(cnt)
         regression = bnn_obj._estimation_mode == "regression"
         sigma = None
@@ -467,7 +528,7 @@ class MCMC():
             if not bnn_obj._empirical_error:
                 sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
         w_new, acc, _, _, res = self._backend.run_chain(
-            bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=np.log(u),
+            bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u,
             prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
             w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
             cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma, mask=bnn_obj._mask,
@@ -486,13 +547,13 @@ class MCMC():
                 bnn_obj.reset_error_prm(res["sigma"])
             self._accepted_override = None
             self._invalidate()
-        history = self._last_accepted_mem + [int(a) for a in acc]
+        history = self._last_accepted_mem + acc.tolist()
         self._last_accepted = int(acc[-1])
         self._acceptance_rate = np.mean(history[-101:]) if len(history) > 100 else np.mean(history)
         self._last_accepted_mem = history[-100:] if len(history) > 100 else history
         self._current_iteration += k
-        if self._randomize_seed:
-            self._rs = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
+        if self._randomize_seed:        # (assigning _gen, not _rs: draws made ahead for the next call stay valid)
+            self._gen = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
 
     def gibbs_step(self, bnn_obj):
         bnn_obj.sample_prior_scale()

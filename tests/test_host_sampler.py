@@ -156,3 +156,46 @@ def test_run_steps_batching_equals_mh_step_loop_on_cpu(name, randomize_seed):
         np.testing.assert_array_equal(wa, wb)
     np.testing.assert_array_equal(mcmc_a._update_n, mcmc_b._update_n)
     assert mcmc_a._acceptance_rate == mcmc_b._acceptance_rate
+
+
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_draws_made_ahead_of_the_next_call_are_used_or_rewound(randomize_seed):
+    """run_steps leaves the draws of the probable next call in flight.  Whatever comes next - the same call again
+    (draws used), a different batch size, a plain mh_step, a deep copy (generator rewound) - the chain is the one
+    the mh_step loop produces."""
+    import copy
+    from oracle_backend import OracleChainBackend
+    cfg = dict(cases.TRACES["cfg1"])
+    cfg["mcmc"] = dict(cfg["mcmc"], randomize_seed=randomize_seed, mcmc_id=2)
+    bnn_a, mcmc_a, _ = build(cfg)
+    bnn_b, mcmc_b, _ = build(cfg)
+    mcmc_b._backend = OracleChainBackend(bnn_b, 0)
+    mcmc_b.run_steps(bnn_b, 40)
+    assert mcmc_b._speculation is not None
+    key = mcmc_b._speculation[0]
+    mcmc_b.run_steps(bnn_b, 40)                   # hit: same size again
+    assert mcmc_b._speculation is not None and mcmc_b._speculation[0] != key
+    mcmc_b.run_steps(bnn_b, 25)                   # miss: other size -> rewind and draw afresh
+    mcmc_b.mh_step(bnn_b)                         # the host path wants the stream: rewind
+    assert mcmc_b._speculation is None
+    mcmc_b.run_steps(bnn_b, 30)
+    clone = copy.deepcopy(mcmc_b)                 # copies must not carry draws in flight
+    assert clone._speculation is None and mcmc_b._speculation is None
+    mcmc_b.run_steps(bnn_b, 14)
+    n = 40 + 40 + 25 + 1 + 30 + 14
+    for _ in range(n):
+        mcmc_a.mh_step(bnn_a)
+    assert mcmc_a._current_iteration == mcmc_b._current_iteration == n
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+
+
+def test_no_adaptation_boundaries_when_adaptation_cannot_fire():
+    cfg = dict(cases.TRACES["cfg1"])
+    _, mcmc, _ = build(cfg)
+    mcmc._adapt_f, mcmc._adapt_fM, mcmc._adapt_freq, mcmc._adapt_stop = 0, 1, 10, 10 ** 6
+    assert mcmc._next_adapt_boundary() is None
+    mcmc._adapt_f = 0.1
+    assert mcmc._next_adapt_boundary() == 10

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rows", type=int, default=0)
+ap.add_argument("--cand", type=int, default=1, help="proposals evaluated per launch (chain pass kernel when > 1)")
 a = ap.parse_args()
 rs = np.random.default_rng(0)
 np.random.seed(1234)
@@ -43,6 +44,11 @@ else:
     w = init_weight_prm(hidden, f, c, bias_node=2)
     ctx.set_arch_from_weights(w, f, capi.ACT_TANH, capi.OUT_SOFTMAX, capi.LIK_CATEGORICAL)
     alg = 4.0 * n * f + 4.0 * n
+if a.cand > 1:
+    ms_k, cand = ctx.time_pass(w, n_candidates=a.cand, iters=a.iters)
+    print("config %d: pass kernel with %d candidates %.2f us" % (a.config, cand, ms_k * 1e3))
+    ctx.close()
+    sys.exit(0)
 ms_k, ms_t = ctx.time_eval(w, iters=a.iters)
 print("config %d: eval kernel %.2f us (%.0f GB/s algorithmic, %.1f%% of 8 TB/s); kernel+finalize %.2f us"
       % (a.config, ms_k * 1e3, alg / ms_k / 1e6, 100 * alg / (ms_k * 1e-3) / 8e12, ms_t * 1e3))

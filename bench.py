@@ -24,9 +24,9 @@ sys.path.insert(0, ROOT)
 
 N_ROWS, N_FEATURES, N_CLASSES, HIDDEN = 100_000, 256, 10, [32, 8]
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
-# HBM bytes per evaluation measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this workload
-# (profiles/r01_eval_pmc_*.csv): (2 x 50619.6 KiB [gfx950 reports half of a wide streaming read] + 8 KiB)
-MEASURED_TRAFFIC_BYTES = (2 * 50619.625 + 8.0) * 1024
+# HBM bytes per launch of the 3-candidate pass kernel measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
+# on this workload (profiles/r01_pass3_pmc_*.csv): (2 x 50728.0 KiB [gfx950 reports half of a wide streaming read] + 24 KiB)
+MEASURED_TRAFFIC_BYTES = (2 * 50728.01 + 24.0) * 1024
 
 
 def synthetic_config2():
@@ -173,7 +173,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES,
-                         "traffic_source": "profiles/r01_eval_pmc_FETCH_SIZE.csv + r01_eval_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, "
+                         "traffic_source": "profiles/r01_pass3_pmc_FETCH_SIZE.csv + r01_pass3_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, "
                                            "separate passes): one streaming read of X per launch, whatever the number of candidates",
                          "kernel": "eval_kernel<MT0=2,MTI=1,%s,D=%d>" % ("fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand),
                          "kernel_ms": ms_kernel, "proposals_per_launch": cand, "bytes_per_proposal": bytes_per_proposal,

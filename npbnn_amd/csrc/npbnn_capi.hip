@@ -20,19 +20,27 @@ using namespace npbnn;
 
 // the evaluation-kernel instantiations live in npbnn_eval_inst_*.hip (compiled in parallel)
 namespace npbnn {
-eval_fn_t pick_eval_mti8(int mt0, int f16);
-eval_fn_t pick_eval_mti8gen(int mt0, int f16);
-eval_fn_t pick_eval_d1(int mt0, int f16);
-eval_fn_t pick_eval_d1gen(int mt0, int f16);
-eval_fn_t pick_eval_d2(int mt0, int f16);
-eval_fn_t pick_eval_d3(int mt0, int f16);
+eval_fn_t pick_eval_mti8_cat(int mt0, int f16);
+eval_fn_t pick_eval_mti8_gauss(int mt0, int f16);
+eval_fn_t pick_eval_mti8_gen(int mt0, int f16);
+eval_fn_t pick_eval_d1_cat(int mt0, int f16);
+eval_fn_t pick_eval_d1_gauss(int mt0, int f16);
+eval_fn_t pick_eval_d1_gen(int mt0, int f16);
+eval_fn_t pick_eval_d2_cat(int mt0, int f16);
+eval_fn_t pick_eval_d2_gauss(int mt0, int f16);
+eval_fn_t pick_eval_d3_cat(int mt0, int f16);
+eval_fn_t pick_eval_d3_gauss(int mt0, int f16);
 }
 
-static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int gen) {
-    if (mti != 1) return gen ? pick_eval_mti8gen(mt0, f16) : pick_eval_mti8(mt0, f16);
-    if (gen) return pick_eval_d1gen(mt0, f16);
-    if (n_cand <= 1) return pick_eval_d1(mt0, f16);
-    return n_cand == 2 ? pick_eval_d2(mt0, f16) : pick_eval_d3(mt0, f16);
+// lk: likelihood class of the build (npbnn::lik_class); the float64 row-wise class has single-candidate builds only
+static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk) {
+    using namespace npbnn;
+    if (mti != 1) return lk == kLikGen ? pick_eval_mti8_gen(mt0, f16) : lk == kLikGauss ? pick_eval_mti8_gauss(mt0, f16) : pick_eval_mti8_cat(mt0, f16);
+    if (lk == kLikGen) return pick_eval_d1_gen(mt0, f16);
+    const bool g = lk == kLikGauss;
+    if (n_cand <= 1) return g ? pick_eval_d1_gauss(mt0, f16) : pick_eval_d1_cat(mt0, f16);
+    if (n_cand == 2) return g ? pick_eval_d2_gauss(mt0, f16) : pick_eval_d2_cat(mt0, f16);
+    return g ? pick_eval_d3_gauss(mt0, f16) : pick_eval_d3_cat(mt0, f16);
 }
 
 namespace {
@@ -291,8 +299,7 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand = 1
 
 
 eval_fn_t pick_kernel(const NetMeta& net, int n_cand) {
-    return npbnn_pick_eval_kernel(net.L[0].mt, max_inner_tiles(net) == 1 ? 1 : 8, net.l0_f16, n_cand,
-                                  lik_needs_row_scratch(net.lik_kind) ? 1 : 0);
+    return npbnn_pick_eval_kernel(net.L[0].mt, max_inner_tiles(net) == 1 ? 1 : 8, net.l0_f16, n_cand, lik_class(net.lik_kind));
 }
 
 // ---- fp16-split data: scales from the training matrix, split copies built on the device ----

@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "npbnn_hip.h"
 
 namespace npbnn {
@@ -431,171 +432,265 @@ __device__ __forceinline__ void dma4(const void* g, char* l) {
 //         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
 //   F16 : fp16-split layer 0
 //   D   : weight sets ("candidates") evaluated against one streaming read of X (speculative chain passes; 1 otherwise)
-//   GEN : build with the float64 row-wise likelihoods (predicted sigma, Poisson, negative binomial)
+//   LK  : likelihood class the epilogue is built for - kLikCat (categorical / none), kLikGauss (residual moments) or
+//         kLikGen (float64 row-wise likelihoods: predicted sigma, Poisson, negative binomial).  Separate builds because
+//         each class keeps different per-lane accumulators alive through the whole kernel (and lgamma is register hungry).
 // ------------------------------------------------------------------------------------------------
 typedef void (*eval_fn_t)(const EvalParams*);
+constexpr int kLikCat = 0, kLikGauss = 1, kLikGen = 2;
+__host__ __device__ inline int lik_class(int lik_kind) {
+    return lik_needs_row_scratch(lik_kind) ? kLikGen : (lik_kind == NPBNN_LIK_GAUSS ? kLikGauss : kLikCat);
+}
 
-struct TileAcc {            // per-candidate float64 accumulators of one wave
+template <int LK>
+struct TileAcc {            // per-candidate float64 accumulators of one wave: sum of the per-row log-likelihood terms ...
     double ll;
+};
+template <>
+struct TileAcc<kLikGauss> { // ... or, for the Gaussian likelihood, residual moments of the 4 target columns this lane owns
     double s1[4], s2[4];
 };
 
-// layers 1..L-1 and the likelihood epilogue of one 16-row tile for one candidate (weight image `img` in LDS)
-template <int MT0, int MTI, bool GEN>
-__device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img, const f32x4 (&acc0)[MT0], int lane, int n, int kq,
-                                          const char* a_slot, float* row_scratch, long long row, bool row_ok, bool primary,
-                                          TileAcc& A) {
-    constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
-    const NetMeta& net = p.net;
-    const int n_layers = net.n_layers;
-    const int C = net.n_out;
-    const int MTL = net.L[n_layers - 1].mt;
-    const int lik_kind = net.lik_kind;
-    const int k_targets = net.k_targets;
-    const bool need_softmax = (lik_kind == NPBNN_LIK_CATEGORICAL) || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
-    // ---------------- layers 1..L-1 chained through the accumulators ----------------
-    f32x4 h[HT];
+// Launch-invariant scalars of the parameter block, copied once so that they stay in SGPRs: the counted s_waitcnt
+// statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
+// after each of them.
+struct HotParams {
+    const int* labels;
+    const float* targets;
+    const float* inst_w;
+    unsigned* confusion;
+    float* y_out;
+    long long n_rows;
+    int use_classw, predict_mode;
+    int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off;
+};
+
+template <int KIND, int HT, int D>
+__device__ __forceinline__ void act_tiles_all(f32x4 (&h)[D][HT], int live, float prm) {
 #pragma unroll
-    for (int mt = 0; mt < HT; ++mt) h[mt] = mt < MT0 ? acc0[mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < HT; ++mt)
+        if (mt < live)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) h[j][mt][i] = act_apply(h[j][mt][i], KIND, prm);
+}
+// activation on the first `live` tiles of every candidate (wave-uniform kind and count; candidates innermost so that
+// their independent exp / rcp chains interleave)
+template <int HT, int D>
+__device__ __forceinline__ void act_live_all(f32x4 (&h)[D][HT], int live, int kind, float prm) {
+    switch (kind) {
+        case NPBNN_ACT_RELU: act_tiles_all<NPBNN_ACT_RELU>(h, live, prm); break;
+        case NPBNN_ACT_LEAKY: act_tiles_all<NPBNN_ACT_LEAKY>(h, live, prm); break;
+        case NPBNN_ACT_SWISH: act_tiles_all<NPBNN_ACT_SWISH>(h, live, prm); break;
+        default: act_tiles_all<NPBNN_ACT_TANH>(h, live, prm); break;
+    }
+}
+
+// layers 1..L-1 and the likelihood epilogue of one 16-row tile for the D candidates of the pass (weight images
+// `imgs + j*image_floats` in LDS).  Every stage loops over the candidates innermost: their chains (dependent MFMAs,
+// exp / rcp / log) are independent, so the wave always has three of them to interleave.
+// Handles candidates J0 .. J0+D-1 of the DA the pass holds (all of them when the registers allow, else one at a time).
+template <int MT0, int MTI, int LK, int D, int DA, int J0>
+__device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& hp, const float* imgs0, int image_floats,
+                                          const f32x4 (&acc0_all)[DA][MT0], int lane, int n, int kq, const char* a_slot, float* row_scratch,
+                                          long long row, bool row_ok, TileAcc<LK> (&A_all)[DA]) {
+    static_assert(J0 + D <= DA, "candidate range");
+    constexpr bool primary = J0 == 0;              // statistics and predictions come from the first candidate
+    const float* const imgs = imgs0 + (size_t)J0 * image_floats;
+    auto A = [&](int j) -> TileAcc<LK>& { return A_all[J0 + j]; };
+    constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
+    const int n_layers = hp.n_layers;
+    const int C = hp.C;
+    const int MTL = hp.MTL;
+    const int lik_kind = hp.lik_kind;
+    const int k_targets = hp.k_targets;
+    const bool need_softmax = LK == kLikCat && ((lik_kind == NPBNN_LIK_CATEGORICAL) || (hp.predict_mode == 2 && hp.out_kind == NPBNN_OUT_SOFTMAX));
+    // ---------------- layers 1..L-1 chained through the accumulators ----------------
+    f32x4 h[D][HT];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) h[j][mt] = mt < MT0 ? acc0_all[J0 + j][mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int l = 1; l < n_layers; ++l) {
         const LayerMeta& L = net.L[l];
         const int lkt = L.kt, lmt = L.mt;
-        act_live(h, lkt, net.act_kind, net.act_prm[l - 1]);
-        const float* frag = img + L.frag_off + lane * 4;
-        const float* bias = img + L.bias_off + 4 * kq;
-        f32x4 acc[MTI];
+        act_live_all(h, lkt, hp.act_kind, net.act_prm[l - 1]);
+        const float* frag = imgs + L.frag_off + lane * 4;
+        const float* bias = imgs + L.bias_off + 4 * kq;
+        f32x4 acc[D][MTI];
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt) {
-            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (mt < lmt) {
-                acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
+#pragma unroll
+                for (int j = 0; j < D; ++j) acc[j][mt] = *reinterpret_cast<const f32x4*>(bias + (size_t)j * image_floats + 16 * mt);
 #pragma unroll
                 for (int ct = 0; ct < HT; ++ct) {
                     if (ct < lkt) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * lmt + mt) * 256);
+                        f32x4 a[D];
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                            a[j] = *reinterpret_cast<const f32x4*>(frag + (size_t)j * image_floats + (size_t)(ct * lmt + mt) * 256);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], h[ct][s], acc[mt], 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < D; ++j)
+                                acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], h[j][ct][s], acc[j][mt], 0, 0, 0);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int mt = 0; mt < MTI; ++mt) h[mt] = acc[mt];
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt) h[j][mt] = acc[j][mt];
     }
-    if (net.final_act) act_live(h, MTL, net.act_kind, net.act_prm[n_layers - 1]);
-    // h[mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
+    if (hp.final_act) act_live_all(h, MTL, hp.act_kind, net.act_prm[n_layers - 1]);
+    // h[j][mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
 
     // ---------------- epilogue ----------------
-
-    float lse = 0.f;
+    float lse[D];
     int best_i = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) lse[j] = 0.f;
     if (need_softmax) {
-        float m = -INFINITY, bv = -INFINITY;
-        int bi = 0x7fffffff;
+        float m[D], se[D];
 #pragma unroll
-        for (int mt = 0; mt < MTI; ++mt)
-            if (mt < MTL)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int o = 16 * mt + 4 * kq + i;
-                    if (o < C) {
-                        m = fmaxf(m, h[mt][i]);
-                        if (h[mt][i] > bv) { bv = h[mt][i]; bi = o; }
-                    }
-                }
-        m = quad_max(m);
-        float se = 0.f;
+        for (int j = 0; j < D; ++j) { m[j] = -INFINITY; se[j] = 0.f; }
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt)
             if (mt < MTL)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (16 * mt + 4 * kq + i < C) se += __expf(h[mt][i] - m);
-        se = quad_sum(se);
-        lse = m + __logf(se);
-        if (p.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207)
+                    if (16 * mt + 4 * kq + i < C)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) m[j] = fmaxf(m[j], h[j][mt][i]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * mt + 4 * kq + i < C)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) se[j] += __expf(h[j][mt][i] - m[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) se[j] = quad_sum(se[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) lse[j] = m[j] + __logf(se[j]);
+        if (hp.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207); statistics of the first candidate only
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 16 * mt + 4 * kq + i;
+                        if (o < C && h[0][mt][i] > bv) { bv = h[0][mt][i]; bi = o; }
+                    }
             quad_argmax(bv, bi);
             best_i = bi;
         }
     }
 
-    if (lik_kind == NPBNN_LIK_CATEGORICAL) {
+    if constexpr (LK == kLikCat) {
+      if (lik_kind == NPBNN_LIK_CATEGORICAL) {
         const int lab = *reinterpret_cast<const int*>(a_slot + n * 4);
-        float zl = 0.f;
+        float zl[D];
         bool own = false;
+#pragma unroll
+        for (int j = 0; j < D; ++j) zl[j] = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt)
             if (mt < MTL)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (16 * mt + 4 * kq + i == lab) { zl = h[mt][i]; own = true; }
-        float term = 0.f;
+                    if (16 * mt + 4 * kq + i == lab) {
+                        own = true;
+#pragma unroll
+                        for (int j = 0; j < D; ++j) zl[j] = h[j][mt][i];
+                    }
         if (lab >= 0) {
-            if (own) term += zl;
-            if (kq == 0) term -= lse;
             float wgt = 1.f;
-            if (p.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
-            if (p.use_classw) wgt *= img[net.classw_off + lab];
-            term *= wgt;
-            if (p.confusion && primary && kq == 0 && best_i < C) atomicAdd(p.confusion + lab * C + best_i, 1u);
+            if (hp.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
+            if (hp.use_classw) wgt *= imgs[hp.classw_off + lab];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float term = 0.f;
+                if (own) term += zl[j];
+                if (kq == 0) term -= lse[j];
+                term *= wgt;
+                A(j).ll += (double)term;
+            }
+            if (hp.confusion && primary && kq == 0 && best_i < C) atomicAdd(hp.confusion + lab * C + best_i, 1u);
         }
-        A.ll += (double)term;
-    } else if (GEN && lik_needs_row_scratch(lik_kind)) {
-        // (GEN builds only: the float64 lgamma / log / exp below would otherwise cost the hot kernels their registers)
+      }
+    } else if constexpr (LK == kLikGen) {
+        // (kLikGen builds only: the float64 lgamma / log / exp below would otherwise cost the hot kernels their registers)
         // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
         // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
-        *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[0];
         const float* tg = reinterpret_cast<const float*>(a_slot + 128);
-        double term = 0.0;
-        if (row_ok) {
-            for (int j = kq; j < k_targets; j += 4) {
-                const double y = (double)tg[n * k_targets + j];
-                if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
-                    const double mu = (double)row_scratch[n * 16 + j];
-                    const double zs = (double)row_scratch[n * 16 + k_targets + j];
-                    const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));      // softplus, BNN_lib.py:172,181
-                    const double r = (y - mu) / sg;
-                    term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
-                } else if (lik_kind == NPBNN_LIK_POISSON) {
-                    if (j == 0) {
-                        const double eta = (double)row_scratch[n * 16];
-                        term += y * eta - exp(eta) - lgamma(y + 1.0);             // poisson.logpmf(k, exp(eta))
-                    }
-                } else {
-                    const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
-                    if (one_col && j > 0) continue;
-                    const int jp = one_col ? 1 : k_targets + j;
-                    const double e0 = (double)row_scratch[n * 16 + j], e1 = (double)row_scratch[n * 16 + jp];
-                    double mean, pr;
-                    if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
-                        mean = exp(2.302585092994046 * e0);
-                        pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[c][0];
+            double term = 0.0;
+            if (row_ok) {
+                for (int j = kq; j < k_targets; j += 4) {
+                    const double y = (double)tg[n * k_targets + j];
+                    if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
+                        const double mu = (double)row_scratch[n * 16 + j];
+                        const double zs = (double)row_scratch[n * 16 + k_targets + j];
+                        const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));      // softplus, BNN_lib.py:172,181
+                        const double r = (y - mu) / sg;
+                        term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
+                    } else if (lik_kind == NPBNN_LIK_POISSON) {
+                        if (j == 0) {
+                            const double eta = (double)row_scratch[n * 16];
+                            term += y * eta - exp(eta) - lgamma(y + 1.0);             // poisson.logpmf(k, exp(eta))
+                        }
                     } else {
-                        mean = exp(e0);
-                        pr = 1.0 / (1.0 + exp(-e1));
+                        const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
+                        if (one_col && j > 0) continue;
+                        const int jp = one_col ? 1 : k_targets + j;
+                        const double e0 = (double)row_scratch[n * 16 + j], e1 = (double)row_scratch[n * 16 + jp];
+                        double mean, pr;
+                        if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
+                            mean = exp(2.302585092994046 * e0);
+                            pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+                        } else {
+                            mean = exp(e0);
+                            pr = 1.0 / (1.0 + exp(-e1));
+                        }
+                        const double nn = pr * mean / (1.0 - pr);
+                        // nbinom.logpmf(k; n, p) = lgamma(k+n) - lgamma(k+1) - lgamma(n) + n log p + k log(1-p)
+                        term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
                     }
-                    const double nn = pr * mean / (1.0 - pr);
-                    // nbinom.logpmf(k; n, p) = lgamma(k+n) - lgamma(k+1) - lgamma(n) + n log p + k log(1-p)
-                    term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
                 }
             }
+            A(c).ll += term;
         }
-        A.ll += term;
-    } else if (lik_kind == NPBNN_LIK_GAUSS) {
+    } else {
         const float* tg = reinterpret_cast<const float*>(a_slot + 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = 4 * kq + i;
             if (o < k_targets && row_ok) {
-                const float r = tg[n * k_targets + o] - h[0][i];
-                A.s1[i] += (double)r;
-                A.s2[i] += (double)r * (double)r;
+                const float y = tg[n * k_targets + o];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float r = y - h[j][0][i];
+                    A(j).s1[i] += (double)r;
+                    A(j).s2[i] += (double)r * (double)r;
+                }
             }
         }
     }
 
-    if (p.predict_mode && primary && row_ok) {
+    if (hp.predict_mode && primary && row_ok) {       // predictions of the first candidate (plain evaluations have only one)
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt)
             if (mt < MTL)
@@ -603,12 +698,12 @@ __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img,
                 for (int i = 0; i < 4; ++i) {
                     const int o = 16 * mt + 4 * kq + i;
                     if (o < C) {
-                        float v = h[mt][i];
-                        if (p.predict_mode == 2) {
-                            if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
-                            else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+                        float v = h[0][mt][i];
+                        if (hp.predict_mode == 2) {
+                            if (hp.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse[0]);
+                            else if (hp.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
                         }
-                        p.y_out[row * C + o] = v;
+                        hp.y_out[row * C + o] = v;
                     }
                 }
     }
@@ -616,13 +711,21 @@ __device__ __forceinline__ void tile_tail(const EvalParams& p, const float* img,
 
 // waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive
 __host__ __device__ constexpr int max_waves_for(int mti, int d) { return mti == 1 ? (d == 1 ? 16 : d == 2 ? 14 : 11) : 8; }
+// software-pipelined layer 0 (the fragments of K-step s+1 are read from LDS while the MFMAs of step s run): builds whose two
+// fragment sets fit the register budget of their launch bounds
+__host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int d) {
+    return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && mt0 <= 1) || (d == 1 && mt0 <= 3));
+}
 
-template <int MT0, int MTI, bool F16, int D, bool GEN>
+#define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int MT0, int MTI, bool F16, int D, int LK>
 __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const EvalParams* __restrict__ pp) {
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
+    constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -630,35 +733,46 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     const int n = lane & 15, kq = lane >> 4;
     const NetMeta& net = p.net;
     const int wpb = blockDim.x >> 6;
-    const int k_targets = net.k_targets;
-    const int aux_sz = aux_bytes(k_targets);
-    const size_t IB = (size_t)net.image_floats * 4;                 // bytes of one weight image
+    const int image_floats = net.image_floats;
+    const size_t IB = (size_t)image_floats * 4;                     // bytes of one weight image
 
-    // ---- which candidates does this pass evaluate? ----
-    int n_cand = 1, t0 = 0;
+    HotParams hp;
+    hp.labels = p.labels; hp.targets = p.targets; hp.inst_w = p.inst_w; hp.confusion = p.confusion; hp.y_out = p.y_out;
+    hp.n_rows = p.n_rows; hp.use_classw = p.use_classw; hp.predict_mode = p.predict_mode;
+    hp.n_layers = net.n_layers; hp.C = net.n_out; hp.MTL = net.L[net.n_layers - 1].mt; hp.lik_kind = net.lik_kind;
+    hp.k_targets = net.k_targets; hp.act_kind = net.act_kind; hp.out_kind = net.out_kind; hp.final_act = net.final_act;
+    hp.classw_off = net.classw_off;
+    const int k_targets = hp.k_targets;
+    const int aux_sz = aux_bytes(k_targets);
+    const float* const Xg = p.X;
+    const int Fp = p.Fp;
+    const int n_tiles = p.n_tiles;
+
+    // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
+    //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
+    int t0 = 0;
     int cnt[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) cnt[j] = 0;
-    if (p.pass) {
-        n_cand = p.pass->n_cand;
-        if (n_cand == 0) return;                                    // the chain batch is finished
-        if (n_cand > D) n_cand = D;
-        t0 = p.pass->t0;
+    const PassDesc* const pass = p.pass;
+    if (pass) {
+        if (pass->n_cand == 0) return;                              // the chain batch is finished
+        t0 = pass->t0;
 #pragma unroll
-        for (int j = 0; j < D; ++j) cnt[j] = p.pass->cnt[j];
+        for (int j = 0; j < D; ++j) cnt[j] = pass->cnt[j < kMaxCand ? j : 0];
     }
 
-    char* const ring = smem + D * IB + (size_t)wave * wave_lds_bytes(k_targets, net.lik_kind);
+    char* const ring = smem + D * IB + (size_t)wave * wave_lds_bytes(k_targets, hp.lik_kind);
     char* const aux = ring + kRing * 1024;
     float* const row_scratch = reinterpret_cast<float*>(aux + kAuxSlots * aux_sz);   // [16 rows][16 outputs], generic likelihoods
 
     // ---- stage the weight image of the current state into LDS, once per candidate: lane-linear DMA copies ----
     {
-        const int n_pieces = net.image_floats >> 8;   // 1-KiB pieces
+        const int n_pieces = image_floats >> 8;   // 1-KiB pieces
+        const float* const image = p.image;
 #pragma unroll
         for (int j = 0; j < D; ++j)
-            if (j < n_cand)
-                for (int i = wave; i < n_pieces; i += wpb) dma16(p.image + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+            for (int i = wave; i < n_pieces; i += wpb) dma16(image + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
     }
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
@@ -667,29 +781,29 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     const int G = gridDim.x;
     const int first_tile = blockIdx.x + G * wave;
     const int stride = G * wpb;
-    const int my_tiles = first_tile < p.n_tiles ? (p.n_tiles - first_tile + stride - 1) / stride : 0;
+    const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
-    int Dp = DEPTH;                                     // prefetch distance in pieces
+    int Dp = PIPE ? kRing : DEPTH;                      // prefetch distance in pieces
     if (Dp > 2 * KT0) Dp = 2 * KT0;                     // at most 3 tiles in flight (aux slots)
     const bool full_depth = (Dp == DEPTH);
 
     // prefetch cursor: a per-lane running source pointer and a scalar ring offset
-    const float* pf_ptr = p.X + ((size_t)first_tile * 16 + n) * (size_t)p.Fp + 4 * kq;
-    const size_t tile_jump = (size_t)stride * 16 * (size_t)p.Fp - (size_t)KT0 * 16;
+    const float* pf_ptr = Xg + ((size_t)first_tile * 16 + n) * (size_t)Fp + 4 * kq;
+    const size_t tile_jump = (size_t)stride * 16 * (size_t)Fp - (size_t)KT0 * 16;
     int pf_q = 0, pf_kt = 0, pf_tile = first_tile, pf_seq = 0, pf_slot = 0;
     auto issue_aux = [&]() {   // row-aux data of a tile travels ahead of its first X piece
         char* a = aux + (pf_seq & (kAuxSlots - 1)) * aux_sz;
         const size_t r0 = (size_t)pf_tile * 16;
         if (lane < 16) {
-            if (p.labels) dma4(p.labels + r0 + lane, a);
-            if (p.inst_w) dma4(p.inst_w + r0 + lane, a + 64);
+            if (hp.labels) dma4(hp.labels + r0 + lane, a);
+            if (hp.inst_w) dma4(hp.inst_w + r0 + lane, a + 64);
         }
-        if (p.targets) {
+        if (hp.targets) {
             const int total = 16 * k_targets;           // contiguous floats of this tile's targets
             for (int e = 0; e < total; e += 64) {
                 int idx = e + lane;
                 if (idx >= total) idx = total - 1;      // duplicate the last element, never read
-                dma4(p.targets + r0 * k_targets + idx, a + 128 + e * 4);
+                dma4(hp.targets + r0 * k_targets + idx, a + 128 + e * 4);
             }
         }
     };
@@ -712,7 +826,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
-        if (p.pass && j < n_cand && tid < cnt[j]) {
+        if (pass && tid < cnt[j]) {
             const size_t k = (size_t)(t0 + j) * p.M + tid;
             ppos[j] = p.pos[k];
             pval[j] = p.pv[(size_t)j * p.M + tid];
@@ -720,7 +834,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
         }
     }
     __syncthreads();
-    if (p.pass) {
+    if (pass) {
         auto patch = [&](int j, int pos, double v, float sc) {
             if (pos == 0x7fffffff) return;                  // superseded entry (a later draw of the same position wins)
             float* imgj = reinterpret_cast<float*>(smem + j * IB);
@@ -736,38 +850,148 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
             }
         };
 #pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (j < n_cand) {
-                if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
-                for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
-                    const size_t k = (size_t)(t0 + j) * p.M + e;
-                    patch(j, p.pos[k], p.pv[(size_t)j * p.M + e], p.pscale ? p.pscale[k] : 1.0f);
-                }
+        for (int j = 0; j < D; ++j) {
+            if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
+            for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
+                const size_t k = (size_t)(t0 + j) * p.M + e;
+                patch(j, p.pos[k], p.pv[(size_t)j * p.M + e], p.pscale ? p.pscale[k] : 1.0f);
             }
+        }
         __syncthreads();
     }
 
-    TileAcc A[D];
+    TileAcc<LK> A[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        A[j].ll = 0.0;
+        if constexpr (LK == kLikGauss) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { A[j].s1[i] = 0.0; A[j].s2[i] = 0.0; }
+            for (int i = 0; i < 4; ++i) { A[j].s1[i] = 0.0; A[j].s2[i] = 0.0; }
+        } else {
+            A[j].ll = 0.0;
+        }
     }
 
+    const float* const imgs = reinterpret_cast<const float*>(smem);
     const int frag0_off = net.L[0].frag_off + lane * 4;            // float offsets inside an image
     const int bias0_off = net.L[0].bias_off + 4 * kq;
-    const int lik_kind = net.lik_kind;
+    auto load_bias0 = [&](f32x4 (&acc0)[D][MT0]) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt)
+                acc0[j][mt] = *reinterpret_cast<const f32x4*>(imgs + (size_t)j * image_floats + bias0_off + 16 * mt);
+    };
+    auto run_tail = [&](const f32x4 (&acc0)[D][MT0], int tseq, int tile) {
+        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
+        const long long row = (long long)tile * 16 + n;
+        // the candidates go through the tail together (their independent chains interleave) while the registers allow
+        constexpr int HT = MT0 > MTI ? MT0 : MTI;
+        constexpr int DT = (D * HT <= 6 && LK != kLikGen) ? D : 1;
+        if constexpr (DT == D) {
+            tile_tail<MT0, MTI, LK, D, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+        } else {
+            tile_tail<MT0, MTI, LK, 1, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            static_assert(D <= 3, "add a call per candidate");
+        }
+    };
+
+    if constexpr (PIPE) {
+        // ---------------- fp16-split layer 0, software pipelined over the K-steps of ALL tiles of this wave ----------------
+        // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high parts)
+        // and 2(kg&1)+1 (low parts); three MFMAs per unit tile and candidate: wh.xh + wl.xh + wh.xl.
+        // Ring = 2 steps.  Per step s: the fragments of step s are in registers (so its two slots are free) -> DMA of step
+        // s+2 into them -> wait for step s+1 -> read its fragments -> MFMAs of step s (the LDS reads complete underneath).
+        // Work unit = (K-step s, candidate j): 3*MT0 MFMAs on the x fragments of the step and the weight fragments of the
+        // candidate.  While unit u computes, the fragments of unit u+1 are read from LDS into the other register set.
+        struct WFrag { f16x8 wh[MT0], wl[MT0]; };
+        struct XFrag { f16x8 xh, xl; };
+        const int KS = KT0 >> 1;                          // K-steps per tile
+        const int S = my_tiles * KS;
+        if (S > 0) {
+            WFrag Wb[2];
+            XFrag Xb[2];
+            f32x4 acc0[D][MT0];
+            int ld_slot = 0;                              // ring offset of the next step to read
+            int s = 0, ks = 0;                            // current step: global index, index inside its tile
+            auto load_x = [&](XFrag& x) {
+                const int slot_b = ring_next(ld_slot);
+                const char* px = ring + ((kq >> 1) ? slot_b : ld_slot) + ((2 * (kq & 1)) * 16 + n) * 16;
+                x.xh = *reinterpret_cast<const f16x8*>(px);
+                x.xl = *reinterpret_cast<const f16x8*>(px + 256);
+                ld_slot = ring_next(slot_b);
+            };
+            auto load_w = [&](WFrag& w, int kstep, int j) {
+                const float* fr = imgs + (size_t)j * image_floats + frag0_off + kstep * (MT0 * 512);
+#pragma unroll
+                for (int mt = 0; mt < MT0; ++mt) {
+                    w.wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
+                    w.wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
+                }
+            };
+            NPBNN_WAIT_VMCNT(0);                          // (the barriers above already drained this wave's loads)
+            load_x(Xb[0]);
+            load_w(Wb[0], 0, 0);
+            load_bias0(acc0);
+            // one K-step; PAR = which x set holds it.  Unit j reads its weights from Wb[(PAR*D + j) & 1].
+            auto step = [&](auto par_tag) {
+                constexpr int PAR = decltype(par_tag)::value;
+                const int ks_next = (ks + 1 == KS) ? 0 : ks + 1;
+                bool issued = false;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const WFrag& wc = Wb[(PAR * D + j) & 1];
+                    WFrag& wn = Wb[(PAR * D + j + 1) & 1];
+                    NPBNN_WAIT_LGKM0();                   // this unit's fragments are complete
+                    if (j == 0 && pf_q < Q) {             // the x fragments of step s are in registers: refill its slots (step s+2)
+                        issue_next();
+                        issue_next();
+                        issued = true;
+                    }
+                    if (j == D - 1) {
+                        if (s + 1 < S) {
+                            if (issued) wait_depth<2>();  // step s+1 has landed
+                            else NPBNN_WAIT_VMCNT(0);
+                            load_x(Xb[PAR ^ 1]);
+                            load_w(wn, ks_next, 0);
+                        }
+                    } else {
+                        load_w(wn, ks, j + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);    // keep the LDS reads of the next unit ahead of this unit's MFMAs
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wl[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xl, acc0[j][mt], 0, 0, 0);
+                }
+                ++s;
+                ks = ks_next;
+            };
+            int tile = first_tile;
+            for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
+                for (int kp = 0; kp + 1 < KS; kp += 2) { // the register sets alternate, no copies
+                    step(std::integral_constant<int, 0>{});
+                    step(std::integral_constant<int, 1>{});
+                }
+                if (KS & 1) {                             // odd number of steps per tile: put the next tile's first fragments
+                    step(std::integral_constant<int, 0>{});   // back into set 0 (once per tile)
+                    Xb[0] = Xb[1];
+                    if (D & 1) Wb[0] = Wb[1];
+                }
+                run_tail(acc0, tseq, tile);              // (the first fragments of the next tile arrive underneath)
+                load_bias0(acc0);
+            }
+        }
+    } else {
     int q = 0, cs_slot = 0;
     int tile = first_tile;
     for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
         // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring, every candidate on the same X piece ----------------
         f32x4 acc0[D][MT0];
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT0; ++mt)
-                acc0[j][mt] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + j * IB) + bias0_off + 16 * mt);
+        load_bias0(acc0);
         int fr_off = frag0_off;
         auto consume = [&]() {
             if constexpr (F16) {
@@ -780,21 +1004,19 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                 cs_slot = ring_next(slot_b);
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    if (j < n_cand) {
-                        const float* fr = reinterpret_cast<const float*>(smem + j * IB) + fr_off;
-                        f16x8 wh[MT0], wl[MT0];
+                    const float* fr = imgs + (size_t)j * image_floats + fr_off;
+                    f16x8 wh[MT0], wl[MT0];
 #pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) {
-                            wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
-                            wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
-                        }
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[j][mt], 0, 0, 0);
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[j][mt], 0, 0, 0);
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt) {
+                        wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
+                        wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
                     }
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
                 }
                 fr_off += MT0 * 512;
             } else {
@@ -802,17 +1024,15 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                 cs_slot = ring_next(cs_slot);
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    if (j < n_cand) {
-                        const float* fr = reinterpret_cast<const float*>(smem + j * IB) + fr_off;
-                        f32x4 a[MT0];
+                    const float* fr = imgs + (size_t)j * image_floats + fr_off;
+                    f32x4 a[MT0];
 #pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
+                    for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int mt = 0; mt < MT0; ++mt)
-                                acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[j][mt], 0, 0, 0);
-                    }
+                        for (int mt = 0; mt < MT0; ++mt)
+                            acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[j][mt], 0, 0, 0);
                 }
                 fr_off += MT0 * 256;
             }
@@ -843,25 +1063,17 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
             }
         }
 
-        // ---------------- layers 1..L-1 + likelihood terms, candidate by candidate ----------------
-        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
-        const long long row = (long long)tile * 16 + n;
-        const bool row_ok = row < p.n_rows;
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (j < n_cand)
-                tile_tail<MT0, MTI, GEN>(p, reinterpret_cast<const float*>(smem + j * IB), acc0[j], lane, n, kq, a_slot, row_scratch, row,
-                                    row_ok, j == 0, A[j]);
+        // ---------------- layers 1..L-1 + likelihood terms of every candidate ----------------
+        run_tail(acc0, tseq, tile);
+    }
     }
 
     // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
     if (p.partials) {
-        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+        constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-#pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) A[j].ll += shfl_xor_f64(A[j].ll, sh);
-            if (lik_kind == NPBNN_LIK_GAUSS) {
+            if constexpr (LK == kLikGauss) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -869,6 +1081,9 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                         A[j].s1[i] += shfl_xor_f64(A[j].s1[i], sh);
                         A[j].s2[i] += shfl_xor_f64(A[j].s2[i], sh);
                     }
+            } else {
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) A[j].ll += shfl_xor_f64(A[j].ll, sh);
             }
         }
         __syncthreads();                                   // every wave is done with its ring: reuse the rings as scratch
@@ -876,17 +1091,21 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             double* ws = wsum + ((size_t)j * wpb + wave) * kPartialStride;
-            if (lane == 0) ws[0] = A[j].ll;
-            if (lik_kind == NPBNN_LIK_GAUSS && n == 0) {
+            if constexpr (LK == kLikGauss) {
+                if (lane == 0) ws[0] = 0.0;
+                if (n == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ws[1 + 4 * kq + i] = A[j].s1[i];
-                    ws[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = A[j].s2[i];
+                    for (int i = 0; i < 4; ++i) {
+                        ws[1 + 4 * kq + i] = A[j].s1[i];
+                        ws[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = A[j].s2[i];
+                    }
                 }
+            } else {
+                if (lane == 0) ws[0] = A[j].ll;
             }
         }
         __syncthreads();
-        for (int item = tid; item < n_cand * nvals; item += blockDim.x) {
+        for (int item = tid; item < D * nvals; item += blockDim.x) {
             const int j = item / nvals, v = item % nvals;
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];

@@ -183,7 +183,14 @@ typedef struct {
     int32_t n_candidates;                      /* proposals evaluated per pass over X (speculative Metropolis-Hastings: iteration t and
                                                   t+1.. assuming the earlier ones are rejected; the chain is unchanged); 0 = as many
                                                   as fit (<= 3), 1 = strictly one evaluation per iteration */
+    int32_t schedule;                          /* NPBNN_SCHED_AUTO / _SERIAL (evaluate a pass, decide it, evaluate the next) / _OVERLAP
+                                                  (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
+                                                  pass L-1 rejects; a pass overtaken by an accept is dropped).  Same chain either way. */
+    int32_t reserved_;
 } npbnn_chain_cfg;
+#define NPBNN_SCHED_AUTO 0
+#define NPBNN_SCHED_SERIAL 1
+#define NPBNN_SCHED_OVERLAP 2
 
 typedef struct {
     double loglik, logprior;                   /* state after the K iterations */
@@ -191,6 +198,8 @@ typedef struct {
     int64_t n_accepted;
     int32_t n_passes;                          /* passes over X used for the K iterations */
     int32_t n_candidates;                      /* candidates per pass actually used */
+    int32_t n_void_passes;                     /* overlapped schedule: passes dropped because the pass before them accepted */
+    int32_t schedule;                          /* schedule actually used (NPBNN_SCHED_SERIAL / NPBNN_SCHED_OVERLAP) */
 } npbnn_chain_result;
 
 int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed,

@@ -55,12 +55,17 @@ class ChainCfg(C.Structure):
     _fields_ = [("prior_kind", C.c_int32), ("prior_scale", C.c_double * MAX_LAYERS), ("w_bound", C.c_double),
                 ("temperature", C.c_double), ("lik_temp", C.c_double), ("sigma_given", C.c_int32),
                 ("sigma", C.c_double * MAX_TARGETS), ("cur_loglik", C.c_double), ("cur_logprior", C.c_double),
-                ("cur_sigma", C.c_double * MAX_TARGETS), ("force_f32", C.c_int32), ("n_candidates", C.c_int32)]
+                ("cur_sigma", C.c_double * MAX_TARGETS), ("force_f32", C.c_int32), ("n_candidates", C.c_int32),
+                ("schedule", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class ChainResult(C.Structure):
     _fields_ = [("loglik", C.c_double), ("logprior", C.c_double), ("sigma", C.c_double * MAX_TARGETS),
-                ("n_accepted", C.c_int64), ("n_passes", C.c_int32), ("n_candidates", C.c_int32)]
+                ("n_accepted", C.c_int64), ("n_passes", C.c_int32), ("n_candidates", C.c_int32),
+                ("n_void_passes", C.c_int32), ("schedule", C.c_int32)]
+
+
+SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP = 0, 1, 2
 
 
 _P = C.c_void_p

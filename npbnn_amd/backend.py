@@ -180,7 +180,7 @@ class HipContext:
         return ms.value, used.value
 
     def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
-                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0):
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0):
         """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
         (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
         w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
@@ -202,6 +202,7 @@ class HipContext:
                 cfg.cur_sigma[j] = float(v)
         cfg.cur_loglik, cfg.cur_logprior = float(cur_loglik), float(cur_logprior)
         cfg.n_candidates = int(n_candidates)
+        cfg.schedule = int(schedule)
         m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         delta = capi.as_f64(delta)
@@ -221,4 +222,5 @@ class HipContext:
             self._chk(rc)
             break
         return w, acc, llp, lpp, dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]),
-                                      n_accepted=res.n_accepted, n_passes=res.n_passes, n_candidates=res.n_candidates)
+                                      n_accepted=res.n_accepted, n_passes=res.n_passes, n_candidates=res.n_candidates,
+                                      n_void_passes=res.n_void_passes, schedule=res.schedule)

@@ -110,7 +110,8 @@ struct npbnn_ctx {
     char* h_res = nullptr;
     size_t res_cap = 0, res_k = 0, res_nw = 0;
     int* d_chain_ovf = nullptr;
-    double its_per_pass = 0.0;     // iterations a pass decided on average in the previous batch (0: unknown)
+    double its_per_pass = 0.0;     // iterations a launch decided on average in the previous batch (0: unknown)
+    double accept_rate = -1.0;     // acceptance rate of the previous batch (< 0: unknown)
     double* d_wcur = nullptr;
     double* d_pv = nullptr;        // [kMaxCand][M] proposed values of the candidates in flight
     size_t pv_cap = 0;
@@ -409,7 +410,7 @@ int ensure_work_buffers(npbnn_ctx* ctx, int n_waves) {
     if (n_waves > ctx->partial_waves) {
         if (ctx->d_partials) (void)hipFree(ctx->d_partials);
         ctx->d_partials = nullptr;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_partials, (size_t)kMaxCand * n_waves * kPartialStride * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_partials, (size_t)2 * kMaxCand * n_waves * kPartialStride * sizeof(double)));   // two pass parities
         ctx->partial_waves = n_waves;
     }
     return NPBNN_OK;
@@ -769,7 +770,7 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     }
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
     HIP_TRY(ctx, hipGetLastError());
     FinalizeParams f{};
     f.partials = ctx->d_partials;
@@ -856,7 +857,7 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     p.predict_mode = apply_out_fn ? 2 : 1;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     int ovf = 0;
@@ -898,11 +899,25 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
     rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand);
     if (rc) return rc;
+    const int D = lp.n_cand;
+    // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
+    int schedule = cfg->schedule;
+    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP) {
+        const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
+        schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
+    }
+    const bool overlap = schedule == NPBNN_SCHED_OVERLAP;
+    if (overlap) {                      // one workgroup of the launch runs the step: the others share the tiles
+        int g = lp.grid;
+        if (g > ctx->n_cu - 1) g = ctx->n_cu - 1;
+        if (g < 1) g = 1;
+        lp.grid = g;
+        lp.n_waves = g;
+    }
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
-    const int D = lp.n_cand;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
-    if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, sizeof(PassDesc)));
+    if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, 2 * sizeof(PassDesc)));
     const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
     if ((size_t)K > ctx->res_k || (size_t)ctx->n_weights != ctx->res_nw) {
         size_t kc = (size_t)K > ctx->res_k ? (size_t)K : ctx->res_k;
@@ -929,7 +944,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if ((size_t)M > ctx->pv_cap) {
         if (ctx->d_pv) (void)hipFree(ctx->d_pv);
         ctx->d_pv = nullptr; ctx->pv_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_pv, (size_t)kMaxCand * M * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pv, (size_t)2 * kMaxCand * M * sizeof(double)));
         ctx->pv_cap = (size_t)M;
     }
     const size_t need = (size_t)K * M;
@@ -975,6 +990,8 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     init.t = 0;
     init.n_accepted = 0;
     init.n_passes = 0;
+    init.void_launch = -2;
+    init.n_void = 0;
     {   // initial chain state and the overflow flag travel together (first 512 bytes of the result block)
         memset(ctx->h_res, 0, 512);
         memcpy(ctx->h_res, &init, sizeof(ChainDev));
@@ -1037,6 +1054,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     p.pos = ctx->d_pos;
     p.pscale = f16 ? ctx->d_pscale : nullptr;
     p.M = M;
+    p.chain = overlap ? ctx->d_cparams : nullptr;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     rc = push_chain_params(ctx, c);
@@ -1045,7 +1063,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     // passes is only known on the device: launch the least number that can finish, look at the counter, repeat
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
     const double tw1 = wall();
-    int t_done = 0, n_passes = 0, n_rounds = 0;
+    int t_done = 0, n_passes = 0, n_rounds = 0, launch = 0;
     const size_t res_used = 512 + up256(wb) + up256(ctx->res_k) + 2 * up256(ctx->res_k * sizeof(double));
     const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
     while (t_done < K) {
@@ -1059,20 +1077,29 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
             if (est > n) n = est;
             n += 1 + n / 64;
         }
-        for (int i = 0; i < n; ++i) {
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams);
-            hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
+        if (overlap) {
+            n += 1;                             // the last pass is decided by the launch after it
+            for (int i = 0; i < n; ++i, ++launch)
+                hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, launch);
+        } else {
+            for (int i = 0; i < n; ++i) {
+                hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0);
+                hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
+            }
         }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used, hipMemcpyDeviceToHost, st));   // state + results, one copy
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (now->t <= t_done) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now->t);
+        if (now->t < t_done || (now->t == t_done && !overlap))
+            return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now->t);
+        if (now->t == t_done && n_rounds > 64) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain is stuck at t=%d", now->t);
         t_done = now->t;
     }
     const double tw2 = wall();
     const ChainDev fin = *now;
     n_passes = fin.n_passes;
-    if (n_passes > 0) ctx->its_per_pass = (double)K / n_passes;
+    if (n_passes + fin.n_void > 0) ctx->its_per_pass = (double)K / (n_passes + fin.n_void);
+    ctx->accept_rate = (double)fin.n_accepted / K;
     if (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 256))     // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
         return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
     {
@@ -1104,9 +1131,11 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     result->n_accepted = fin.n_accepted;
     result->n_passes = n_passes;
     result->n_candidates = D;
+    result->n_void_passes = fin.n_void;
+    result->schedule = schedule;
     if (timing)
-        fprintf(stderr, "[npbnn chain timing] K=%d passes=%d rounds=%d: setup %.0f us, passes %.0f us (%.2f us/pass), results %.0f us\n", K,
-                n_passes, n_rounds, tw1 - tw0, tw2 - tw1, (tw2 - tw1) / n_passes, wall() - tw2);
+        fprintf(stderr, "[npbnn chain timing] K=%d passes=%d (+%d void, %s) rounds=%d: setup %.0f us, passes %.0f us (%.2f us/pass), results %.0f us\n", K,
+                n_passes, fin.n_void, overlap ? "overlapped" : "serial", n_rounds, tw1 - tw0, tw2 - tw1, (tw2 - tw1) / n_passes, wall() - tw2);
     return NPBNN_OK;
 }
 
@@ -1151,13 +1180,19 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     p.pos = nullptr;
     p.pscale = nullptr;
     p.M = 0;
+    unsigned long long* d_stamps = nullptr;
+    if (getenv("NPBNN_EVAL_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the last launch
+        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)lp.grid * 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)lp.grid * 8 * sizeof(unsigned long long)));
+        p.stamps = d_stamps;
+    }
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
@@ -1165,6 +1200,26 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     *ms_kernel = (double)ms / iters;
     if (used_candidates) *used_candidates = lp.n_cand;
+    if (d_stamps) {
+        std::vector<unsigned long long> hs((size_t)lp.grid * 8);
+        (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_stamps);
+        unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
+        double acc[8] = {0};
+        for (int b = 0; b < lp.grid; ++b) {
+            const unsigned long long* q = &hs[(size_t)b * 8];
+            if (q[0] < first) first = q[0];
+            if (q[6] > last) last = q[6];
+            if (q[6] < first_end) first_end = q[6];
+            for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;      // 100 MHz wall clock -> us
+        }
+        double late = 0;
+        for (int b = 0; b < lp.grid; ++b) late += (double)(hs[(size_t)b * 8] - first) * 0.01;
+        fprintf(stderr, "[npbnn eval stamps] wave 0 of a workgroup, mean us: start skew %.2f | issue %.2f  barrier1 %.2f  patch %.2f  tiles %.2f  "
+                        "barrier2 %.2f  partials %.2f | first start -> first end %.2f, -> last end %.2f\n",
+                late / lp.grid, acc[1] / lp.grid, acc[2] / lp.grid, acc[3] / lp.grid, acc[4] / lp.grid, acc[5] / lp.grid, acc[6] / lp.grid,
+                (double)(first_end - first) * 0.01, (double)(last - first) * 0.01);
+    }
     return NPBNN_OK;
 }
 
@@ -1204,10 +1259,10 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     //     would add ~4 us of command-processor overhead to each 20 us kernel); includes the ~1.5 us launch boundary
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     float burst = 0.f;
@@ -1216,7 +1271,7 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     // (2) evaluation = eval kernel + finalize
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i) {
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, (const FinalizeParams*)ctx->d_fparams);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

@@ -504,7 +504,9 @@ class MCMC():
         self._gen = value
 
     n_candidates = 0         # proposals evaluated per pass over the data by the device chain: 0 = as many as fit (<= 3)
+    device_schedule = 0      # 0 auto, 1 serial (evaluate, decide, evaluate ...), 2 overlapped (decide pass L-1 while pass L is evaluated)
     _device_passes = 0
+    _device_void_passes = 0
     _device_iterations = 0
     SUB_BATCH = 128          # first sub-batch of a segment (its pre-draw is not overlapped); later ones double
     SUB_BATCH_MAX = 2048
@@ -532,8 +534,9 @@ class MCMC():
             prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
             w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
             cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma, mask=bnn_obj._mask,
-            n_candidates=self.n_candidates)
+            n_candidates=self.n_candidates, schedule=self.device_schedule)
         self._device_passes += res.get("n_passes", k)
+        self._device_void_passes += res.get("n_void_passes", 0)
         self._device_iterations += k
         if res["n_accepted"] > 0:
             layers, off = [], 0

@@ -61,7 +61,7 @@ class OracleChainBackend(OracleBackend):
     bookkeeping) can be tested on CPU against the plain mh_step loop."""
 
     def run_chain(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
-                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0):
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0):
         shapes = [w.shape for w in weights]
         cur = np.concatenate([np.asarray(w, dtype=float).ravel() for w in weights])
         m = None if mask is None else np.concatenate([np.asarray(x, dtype=float).ravel() for x in mask])

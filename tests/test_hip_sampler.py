@@ -172,20 +172,29 @@ def test_rccl_communicator_single_rank():
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg4s"])
 def test_speculative_passes_do_not_change_the_chain(name):
-    """1, 2 or 3 candidates per pass over the data: identical accept/reject sequence, weights and log-likelihood
-    (the speculative evaluation only changes how many passes the same chain needs)."""
+    """1, 2 or 3 candidates per pass over the data, decided between the passes (serial schedule) or inside the launch
+    that already evaluates the next pass (overlapped schedule): identical accept/reject sequence, weights and
+    log-likelihood - the speculation only changes how many passes the same chain needs."""
     cfg = cases.TRACES[name]
     out = []
-    for d in (1, 2, 3):
+    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0)):
         bnn, mcmc = build(cfg)
         mcmc.n_candidates = d
+        mcmc.device_schedule = sched
+        mcmc.SUB_BATCH = 64
         mcmc.run_steps(bnn, 300)
-        out.append((bnn, mcmc))
-    (b1, m1) = out[0]
+        out.append((bnn, mcmc, d, sched))
+    (b1, m1, _, _) = out[0]
     assert m1._device_passes == 300
-    for b, m in out[1:]:
+    assert sum(m1._last_accepted_mem) > 0
+    for b, m, d, sched in out[1:]:
         assert m._last_accepted_mem == m1._last_accepted_mem
         assert m._logLik == m1._logLik and m._logPrior == m1._logPrior
         for wa, wb in zip(b1._w_layers, b._w_layers):
             np.testing.assert_array_equal(wa, wb)
+        if sched == 2:
+            assert m._device_void_passes > 0                # accepts happened, so passes were dropped ...
+        if d == 1:
+            assert m._device_passes == 300                  # ... and never counted
+            continue
         assert m._device_passes < 300                       # fewer passes over the data for the same 300 iterations

@@ -302,6 +302,9 @@ __global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ 
 // helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float z, int kind, float prm) {
+#ifdef NPBNN_EXP_NO_ACT      // timing experiment only: activation = identity
+    return z;
+#endif
     switch (kind) {
         case NPBNN_ACT_RELU: return fmaxf(z, 0.f);                                  // BNN_lib.py:51
         case NPBNN_ACT_LEAKY: return z < 0.f ? prm * z : z;                         // BNN_lib.py:55
@@ -948,6 +951,20 @@ struct TileAcc<kLikGauss> { // ... or, for the Gaussian likelihood, residual mom
     double s1[4], s2[4];
 };
 
+// A value every lane of the wave holds identically, moved to scalar registers.  The kernel reads its launch-invariant
+// parameters through pointers that other code inlined into it (the chain step) writes through, and its first branch is
+// lane dependent (the diagnostic stamps), so the compiler no longer proves them uniform by itself - and a loop bound it
+// believes divergent turns every branch of the main loop into exec-mask bookkeeping.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ long long uni(long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T* uni(T* ptr) { return reinterpret_cast<T*>(uni((long long)reinterpret_cast<unsigned long long>(ptr))); }
+
 // Launch-invariant scalars of the parameter block, copied once so that they stay in SGPRs: the counted s_waitcnt
 // statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
 // after each of them.
@@ -1011,10 +1028,10 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         for (int mt = 0; mt < HT; ++mt) h[j][mt] = mt < MT0 ? acc0_all[J0 + j][mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int l = 1; l < n_layers; ++l) {
         const LayerMeta& L = net.L[l];
-        const int lkt = L.kt, lmt = L.mt;
-        act_live_all(h, lkt, hp.act_kind, net.act_prm[l - 1]);
-        const float* frag = imgs + L.frag_off + lane * 4;
-        const float* bias = imgs + L.bias_off + 4 * kq;
+        const int lkt = uni(L.kt), lmt = uni(L.mt);
+        act_live_all(h, lkt, hp.act_kind, uni(net.act_prm[l - 1]));
+        const float* frag = imgs + uni(L.frag_off) + lane * 4;
+        const float* bias = imgs + uni(L.bias_off) + 4 * kq;
         f32x4 acc[D][MTI];
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt) {
@@ -1044,7 +1061,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 #pragma unroll
             for (int mt = 0; mt < MTI; ++mt) h[j][mt] = acc[j][mt];
     }
-    if (hp.final_act) act_live_all(h, MTL, hp.act_kind, net.act_prm[n_layers - 1]);
+    if (hp.final_act) act_live_all(h, MTL, hp.act_kind, uni(net.act_prm[n_layers - 1]));
     // h[j][mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
 
     // ---------------- epilogue ----------------
@@ -1221,17 +1238,18 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
-    unsigned long long* const stamps = p.stamps;
-#define NPBNN_ESTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+    const int bid = uni((int)blockIdx.x);      // (pinned to a scalar register before the first lane-dependent branch)
+    unsigned long long* const stamps = uni(p.stamps);
+#define NPBNN_ESTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + (k)] = wall_clock64(); } while (0)
     NPBNN_ESTAMP(0);
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
     constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
-    const ChainParams* const chain = p.chain;
+    const ChainParams* const chain = uni(p.chain);
     const int G = (int)gridDim.x - (chain ? 1 : 0);     // workgroups that evaluate
-    if (chain && (int)blockIdx.x == G) {
+    if (chain && bid == G) {
         chain_step(*chain, overlapped_plan(launch), *reinterpret_cast<StepShared*>(smem));
         return;
     }
@@ -1242,20 +1260,26 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     const int n = lane & 15, kq = lane >> 4;
     const NetMeta& net = p.net;
     const int wpb = blockDim.x >> 6;
-    const int image_floats = net.image_floats;
+    const int image_floats = uni(net.image_floats);
     const size_t IB = (size_t)image_floats * 4;                     // bytes of one weight image
 
     HotParams hp;
-    hp.labels = p.labels; hp.targets = p.targets; hp.inst_w = p.inst_w; hp.confusion = p.confusion; hp.y_out = p.y_out;
-    hp.n_rows = p.n_rows; hp.use_classw = p.use_classw; hp.predict_mode = p.predict_mode;
-    hp.n_layers = net.n_layers; hp.C = net.n_out; hp.MTL = net.L[net.n_layers - 1].mt; hp.lik_kind = net.lik_kind;
-    hp.k_targets = net.k_targets; hp.act_kind = net.act_kind; hp.out_kind = net.out_kind; hp.final_act = net.final_act;
-    hp.classw_off = net.classw_off;
+    hp.labels = uni(p.labels); hp.targets = uni(p.targets); hp.inst_w = uni(p.inst_w); hp.confusion = uni(p.confusion);
+    hp.y_out = uni(p.y_out);
+    hp.n_rows = uni(p.n_rows); hp.use_classw = uni(p.use_classw); hp.predict_mode = uni(p.predict_mode);
+    hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out); hp.MTL = uni(net.L[hp.n_layers - 1].mt); hp.lik_kind = uni(net.lik_kind);
+    hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind); hp.out_kind = uni(net.out_kind);
+    hp.final_act = uni(net.final_act);
+    hp.classw_off = uni(net.classw_off);
     const int k_targets = hp.k_targets;
     const int aux_sz = aux_bytes(k_targets);
-    const float* const Xg = p.X;
-    const int Fp = p.Fp;
-    const int n_tiles = p.n_tiles;
+    const float* const Xg = uni(p.X);
+    const int Fp = uni(p.Fp);
+    const int n_tiles = uni(p.n_tiles);
+    const int M = uni(p.M);
+    const int* const g_pos = uni(p.pos);
+    const float* const g_pscale = uni(p.pscale);
+    double* const g_partials = uni(p.partials);
 
     // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
     //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
@@ -1263,13 +1287,14 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     int cnt[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) cnt[j] = 0;
-    const PassDesc* const pass = p.pass ? p.pass + par : nullptr;
-    const double* const pv = p.pv + (size_t)par * kMaxCand * p.M;
+    const PassDesc* const pass0 = uni(p.pass);
+    const PassDesc* const pass = pass0 ? pass0 + par : nullptr;
+    const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
     if (pass) {
-        if (pass->n_cand == 0) return;                              // the chain batch is finished
-        t0 = pass->t0;
+        if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
+        t0 = uni(pass->t0);
 #pragma unroll
-        for (int j = 0; j < D; ++j) cnt[j] = pass->cnt[j < kMaxCand ? j : 0];
+        for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
     }
 
     char* const ring = smem + D * IB + (size_t)wave * wave_lds_bytes(k_targets, hp.lik_kind);
@@ -1279,7 +1304,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     // ---- stage the weight image of the current state into LDS, once per candidate: lane-linear DMA copies ----
     {
         const int n_pieces = image_floats >> 8;   // 1-KiB pieces
-        const float* const image = p.image;
+        const float* const image = uni(p.image);
 #pragma unroll
         for (int j = 0; j < D; ++j)
             for (int i = wave; i < n_pieces; i += wpb) dma16(image + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
@@ -1287,8 +1312,8 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
     //      tile counts of the waves (and SIMDs) of one CU differ by at most one ----
-    const int KT0 = net.L[0].kt;
-    const int first_tile = blockIdx.x + G * wave;
+    const int KT0 = uni(net.L[0].kt);
+    const int first_tile = bid + G * wave;
     const int stride = G * wpb;
     const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
@@ -1336,10 +1361,10 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     for (int j = 0; j < D; ++j) {
         ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
         if (pass && tid < cnt[j]) {
-            const size_t k = (size_t)(t0 + j) * p.M + tid;
-            ppos[j] = p.pos[k];
-            pval[j] = pv[(size_t)j * p.M + tid];
-            if (p.pscale) psc[j] = p.pscale[k];
+            const size_t k = (size_t)(t0 + j) * M + tid;
+            ppos[j] = g_pos[k];
+            pval[j] = pv[(size_t)j * M + tid];
+            if (g_pscale) psc[j] = g_pscale[k];
         }
     }
     NPBNN_ESTAMP(1);
@@ -1364,8 +1389,8 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
         for (int j = 0; j < D; ++j) {
             if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
             for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
-                const size_t k = (size_t)(t0 + j) * p.M + e;
-                patch(j, p.pos[k], pv[(size_t)j * p.M + e], p.pscale ? p.pscale[k] : 1.0f);
+                const size_t k = (size_t)(t0 + j) * M + e;
+                patch(j, g_pos[k], pv[(size_t)j * M + e], g_pscale ? g_pscale[k] : 1.0f);
             }
         }
         __syncthreads();
@@ -1384,8 +1409,8 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     }
 
     const float* const imgs = reinterpret_cast<const float*>(smem);
-    const int frag0_off = net.L[0].frag_off + lane * 4;            // float offsets inside an image
-    const int bias0_off = net.L[0].bias_off + 4 * kq;
+    const int frag0_off = uni(net.L[0].frag_off) + lane * 4;       // float offsets inside an image
+    const int bias0_off = uni(net.L[0].bias_off) + 4 * kq;
     auto load_bias0 = [&](f32x4 (&acc0)[D][MT0]) {
 #pragma unroll
         for (int j = 0; j < D; ++j)
@@ -1394,6 +1419,13 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                 acc0[j][mt] = *reinterpret_cast<const f32x4*>(imgs + (size_t)j * image_floats + bias0_off + 16 * mt);
     };
     auto run_tail = [&](const f32x4 (&acc0)[D][MT0], int tseq, int tile) {
+#ifdef NPBNN_EXP_NO_TAIL      // timing experiment only: keep the layer-0 result alive, skip layers 1.. and the likelihood
+        if constexpr (LK != kLikGauss) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) A[j].ll += (double)acc0[j][0][0];
+        }
+        return;
+#endif
         const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
         const long long row = (long long)tile * 16 + n;
         // the candidates go through the tail together (their independent chains interleave) while the registers allow
@@ -1472,12 +1504,16 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                         load_w(wn, ks, j + 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);    // keep the LDS reads of the next unit ahead of this unit's MFMAs
+#ifndef NPBNN_EXP_NO_L0       // (timing experiment only: without the layer-0 MFMAs)
 #pragma unroll
                     for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wl[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xl, acc0[j][mt], 0, 0, 0);
+#else
+                    acc0[j][0][0] += (float)wc.wh[0][0] + (float)wc.wl[MT0 - 1][7] + (float)Xb[PAR].xh[0] + (float)Xb[PAR].xl[7];
+#endif
                 }
                 ++s;
                 ks = ks_next;
@@ -1582,7 +1618,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
 
     NPBNN_ESTAMP(4);
     // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
-    if (p.partials) {
+    if (g_partials) {
         constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -1623,7 +1659,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
             const int j = item / nvals, v = item % nvals;
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
-            p.partials[(((size_t)par * kMaxCand + j) * kPartialStride + v) * G + blockIdx.x] = s;
+            g_partials[(((size_t)par * kMaxCand + j) * kPartialStride + v) * G + bid] = s;
         }
     }
     NPBNN_ESTAMP(6);

@@ -62,6 +62,22 @@ def cpu_baseline(x, y, budget_s=15.0):
                        "%d BLAS threads of %d host CPUs" % (n, blas_threads, os.cpu_count()))
 
 
+def parity_readout(x, y, bnn, mcmc):
+    """State of the timed chain against the float64 oracle (same leg as the CPU baseline: rank 0, one GPU): relative error
+    of the device log-likelihood of the chain's current weights and max abs error of its class probabilities on a row sample."""
+    import oracle as orc
+    w = [np.array(v, dtype=np.float64) for v in bnn._w_layers]
+    xs = x.astype(np.float32).astype(np.float64)
+    pred = orc.forward(xs, w, orc.Act("tanh"), orc.out_softmax)
+    ll = orc.lik_categorical(pred, y, np.arange(len(y)))
+    dev = mcmc._backend.evaluate(bnn._w_layers, None)["loglik"] if hasattr(mcmc._backend, "evaluate") else float("nan")
+    rows = np.arange(0, len(y), 97)
+    y_dev = np.asarray(mcmc._y)[rows]
+    return dict(loglik_oracle=float(ll), loglik_device=float(dev), loglik_rel_err=float(abs(dev - ll) / abs(ll)),
+                chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)),
+                prediction_max_abs_err=float(np.max(np.abs(y_dev - pred[rows]))), tolerance="1e-4 relative (BASELINE.json)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,12 +106,30 @@ def main():
     comm = None
     swap_frequency = 100
     if world > 1:
+        import torch
         from npbnn_amd.comm import RcclComm, TorchDistComm
-        try:
-            comm = RcclComm(rank=rank, world_size=world, device=local_rank)
+
+        # the launcher's process group carries the 128-byte RCCL unique id; every rank takes part in every collective
+        # below whatever happens, so a failure anywhere cannot leave the others waiting
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = RcclComm.make_unique_id()
+            except Exception as e:
+                print("[rank 0] cannot create an RCCL unique id (%s)" % e, flush=True)
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local_rank))
+        ok = 1 if box[0] else 0
+        if ok:
+            try:
+                comm = RcclComm(rank=rank, world_size=world, device=local_rank, uid=box[0])
+            except Exception as e:
+                print("[rank %d] native RCCL communicator unavailable (%s)" % (rank, e), flush=True)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
             comm_kind = "rccl (C ABI)"
-        except Exception as e:                      # RCCL via torch.distributed is still RCCL over xGMI
-            print("[rank %d] native RCCL communicator unavailable (%s); using torch.distributed nccl" % (rank, e), flush=True)
+        else:                                       # every rank falls back together; torch.distributed "nccl" is RCCL over xGMI too
             comm = TorchDistComm()
             comm_kind = "rccl (torch.distributed)"
     else:
@@ -187,8 +221,16 @@ def main():
             "accept_rate": float(mcmc._acceptance_rate),
             "loglik": float(mcmc._logLik),
         }
+        passes, voids = max(1, mcmc._device_passes), mcmc._device_void_passes
+        line["config"]["schedule"] = ("overlapped: the launch that evaluates pass L also decides pass L-1 (one workgroup); a pass "
+                                      "overtaken by an accept is dropped and re-evaluated")
+        line["config"]["void_pass_fraction"] = voids / (passes + voids)
+        line["roofline"]["useful_iterations_per_launch"] = mcmc._device_iterations / (passes + voids)
+        if cand != 3:
+            line["roofline"]["traffic"] = None      # the PMC figure was collected on the 3-candidate kernel
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(x, y)
+            line["parity"] = parity_readout(x, y, bnn, mcmc)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

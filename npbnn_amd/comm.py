@@ -110,7 +110,20 @@ class RcclComm:
     """RCCL communicator owned by the C library: ncclAllGather of the per-chain scalars and
     ncclBroadcast of the decision, on this rank's GPU stream (over xGMI inside a node)."""
 
-    def __init__(self, rank=None, world_size=None, device=None, addr=None, port=None):
+    @staticmethod
+    def make_unique_id():
+        """A fresh 128-byte RCCL unique id (rank 0 creates it, every rank passes it to the constructor)."""
+        import ctypes as C
+        from . import _capi as capi
+        lib = capi.load_library()
+        uid = (C.c_char * 128)()
+        capi.check(lib, None, lib.npbnn_comm_unique_id(uid))
+        return bytes(uid.raw)
+
+    def __init__(self, rank=None, world_size=None, device=None, addr=None, port=None, uid=None):
+        """``uid``: the unique id from :meth:`make_unique_id` when the launcher already offers a channel to share it (e.g. a
+        torch.distributed broadcast); default: rank 0 creates one and hands it out over a TCP socket on
+        MASTER_ADDR:MASTER_PORT+17."""
         import ctypes as C
         from . import _capi as capi
         from .backend import default_device
@@ -121,11 +134,14 @@ class RcclComm:
         dev = default_device() if device is None else device
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = port or (int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        raw = uid
+        if raw is None:
+            raw = self.make_unique_id() if self.rank == 0 else b""
+            if self.world_size > 1:
+                raw = _exchange_unique_id(self.rank, self.world_size, raw, addr, port)
+        if len(raw) != 128:
+            raise ValueError("RCCL unique id must be 128 bytes")
         uid = (C.c_char * 128)()
-        if self.rank == 0:
-            capi.check(self._lib, None, self._lib.npbnn_comm_unique_id(uid))
-        raw = bytes(uid.raw) if self.rank == 0 else b""
-        raw = _exchange_unique_id(self.rank, self.world_size, raw, addr, port) if self.world_size > 1 else raw
         C.memmove(uid, raw, 128)
         self._comm = C.c_void_p()
         capi.check(self._lib, None, self._lib.npbnn_comm_init(dev, self.rank, self.world_size, uid, C.byref(self._comm)))

@@ -446,19 +446,19 @@ class MCMC():
                 self._run_device_batch(bnn_obj, idx, delta, cnt, log_u)
             remaining -= seg
 
-    _speculation = None      # (key, future, generator state before the draw) of draws made ahead of the next run_steps call
+    _speculation = None      # (key, future, generator state before the draw, step sizes used) of draws made ahead of the next call
 
     def _draw_key(self, bnn_obj, first_it, k):
         return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id), tuple(int(n) for n in self._update_n),
-                tuple(hash(np.asarray(w).tobytes()) for w in self._update_ws), tuple(float(f) for f in self._freq_layer_update),
-                tuple(w.shape for w in bnn_obj._w_layers))
+                tuple(float(f) for f in self._freq_layer_update), tuple(w.shape for w in bnn_obj._w_layers))
 
     def _submit_draw(self, bnn_obj, first_it, k, rewindable=False):
         """Start the pre-draw of iterations first_it .. first_it+k-1 on the helper thread."""
         from . import predraw as pd
         shapes = [np.empty(w.shape) for w in bnn_obj._w_layers]      # predraw only needs the shapes
         rs, randomize, mcmc_id = self._gen, self._randomize_seed, self._mcmc_id
-        update_n, update_ws = [int(n) for n in self._update_n], list(self._update_ws)
+        update_n = [int(n) for n in self._update_n]
+        update_ws = [np.array(w, dtype=np.float64) for w in self._update_ws]      # private copies: the draw runs later
         freq = [float(f) for f in self._freq_layer_update]
         empty = getattr(self._backend, "host_empty", None)
         saved = rs.bit_generator.state if (rewindable and not randomize) else None
@@ -468,13 +468,14 @@ class MCMC():
             np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
             return idx, delta, cnt, u
 
-        return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved
+        return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved, update_ws
 
     def _claim_draw(self, bnn_obj, first_it, k):
         """The draws for iterations first_it .. first_it+k-1: the ones made ahead by the previous call when they
         are exactly these, else fresh ones."""
         spec = self._speculation
-        if spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k):
+        if (spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k) and len(spec[3]) == len(self._update_ws)
+                and all(np.array_equal(a, np.broadcast_to(b, a.shape)) for a, b in zip(spec[3], self._update_ws))):
             self._speculation = None
             return spec[1]
         self._cancel_speculation()

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Throughput of run_steps when the chain is advanced in short segments (the MC3 pattern: a temperature-swap point
+every `seg` iterations), against one long call.  Config 2, one GPU."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench_support import build_config2  # noqa: E402
+
+rs = np.random.default_rng(0)
+x = rs.standard_normal((100_000, 256)).astype(np.float32)
+y = rs.integers(0, 10, 100_000)
+seg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+total = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+for randomize in (False, True):
+    bnn, mcmc = build_config2(x, y, [32, 8], randomize_seed=randomize, mcmc_id=1)
+    mcmc.run_steps(bnn, 200)
+    t0 = time.perf_counter()
+    for _ in range(total // seg):
+        mcmc.run_steps(bnn, seg)
+    el = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    mcmc.run_steps(bnn, total)
+    el1 = time.perf_counter() - t1
+    print("randomize_seed=%s: segments of %d: %.0f it/s (%.1f us per segment beyond compute); one call: %.0f it/s"
+          % (randomize, seg, total / el, (el - el1) / (total // seg) * 1e6, total / el1))

@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 N_ROWS, N_FEATURES, N_CLASSES, HIDDEN = 100_000, 256, 10, [32, 8]
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the 3-candidate pass kernel measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# on this workload (profiles/r01_pass3_pmc_*.csv): (2 x 50728.0 KiB [gfx950 reports half of a wide streaming read] + 24 KiB)
-MEASURED_TRAFFIC_BYTES = (2 * 50728.01 + 24.0) * 1024
+# on this workload (profiles/r01_pass3_pmc_*.csv): (2 x 50679 KiB [gfx950 reports half of a wide streaming read] + 24 KiB)
+MEASURED_TRAFFIC_BYTES = (2 * 50679.0 + 24.0) * 1024
 
 
 def synthetic_config2():
@@ -209,7 +209,7 @@ def main():
                          "traffic": MEASURED_TRAFFIC_BYTES,
                          "traffic_source": "profiles/r01_pass3_pmc_FETCH_SIZE.csv + r01_pass3_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, "
                                            "separate passes): one streaming read of X per launch, whatever the number of candidates",
-                         "kernel": "eval_kernel<MT0=2,MTI=1,%s,D=%d>" % ("fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand),
+                         "kernel": "eval_kernel<MT0=2,MTI=1,%s,D=%d,LK=categorical>" % ("fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand),
                          "kernel_ms": ms_kernel, "proposals_per_launch": cand, "bytes_per_proposal": bytes_per_proposal,
                          "algorithmic_bytes": alg_bytes,
                          "note": "algorithmic bytes = reference bytes per proposal evaluation (SURVEY 8d) x proposals evaluated per "

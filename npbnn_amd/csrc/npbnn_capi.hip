@@ -1212,12 +1212,13 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
             if (q[6] > last) last = q[6];
             if (q[6] < first_end) first_end = q[6];
             for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;      // 100 MHz wall clock -> us
+            acc[7] += (double)q[7] * 0.01;
         }
         double late = 0;
         for (int b = 0; b < lp.grid; ++b) late += (double)(hs[(size_t)b * 8] - first) * 0.01;
         fprintf(stderr, "[npbnn eval stamps] wave 0 of a workgroup, mean us: start skew %.2f | issue %.2f  barrier1 %.2f  patch %.2f  tiles %.2f  "
-                        "barrier2 %.2f  partials %.2f | first start -> first end %.2f, -> last end %.2f\n",
-                late / lp.grid, acc[1] / lp.grid, acc[2] / lp.grid, acc[3] / lp.grid, acc[4] / lp.grid, acc[5] / lp.grid, acc[6] / lp.grid,
+                        "barrier2 %.2f  partials %.2f | tails within tiles %.2f | first start -> first end %.2f, -> last end %.2f\n",
+                late / lp.grid, acc[1] / lp.grid, acc[2] / lp.grid, acc[3] / lp.grid, acc[4] / lp.grid, acc[5] / lp.grid, acc[6] / lp.grid, acc[7] / lp.grid,
                 (double)(first_end - first) * 0.01, (double)(last - first) * 0.01);
     }
     return NPBNN_OK;

@@ -1519,6 +1519,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                 ks = ks_next;
             };
             int tile = first_tile;
+            unsigned long long tail_ticks = 0;
             for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
                 for (int kp = 0; kp + 1 < KS; kp += 2) { // the register sets alternate, no copies
                     step(std::integral_constant<int, 0>{});
@@ -1529,9 +1530,12 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
                     Xb[0] = Xb[1];
                     if (D & 1) Wb[0] = Wb[1];
                 }
+                const unsigned long long tk = stamps ? wall_clock64() : 0;
                 run_tail(acc0, tseq, tile);              // (the first fragments of the next tile arrive underneath)
                 load_bias0(acc0);
+                if (stamps) tail_ticks += wall_clock64() - tk;
             }
+            if (stamps && tid == 0) stamps[(size_t)bid * 8 + 7] = tail_ticks;      // diagnostics: time this wave spent in tails
         }
     } else {
     int q = 0, cs_slot = 0;

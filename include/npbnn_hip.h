@@ -154,6 +154,13 @@ int npbnn_eval(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
 int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
                   const double* col_override, int which, int apply_out_fn, double* out_y);
 
+/* Posterior prediction: n_sets stored weight vectors (W_sets [n_sets][n_weights], act_prm_sets [n_sets][n_layers-1] or NULL)
+ * against the resident matrix `which`; up to three sets share one streaming read of X.  out_y: [n_sets][n_rows][out_dim].
+ * Replaces the loop over RunPredict of get_posterior_cat_prob (np_bnn/BNN_lib.py:375-381; also predictBNN :430, feature_importance
+ * :504-597, get_posterior_est :715-748), which copies and re-reads the feature matrix once per posterior sample. */
+int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_prm_sets, int32_t n_sets, int which, int apply_out_fn,
+                       double* out_y);
+
 /* ---- timing hook for bench.py: launches the evaluation kernels `iters` times on the ctx stream
  * with weights already resident and returns the mean duration of the dominant kernel (HIP events
  * around each launch) and of the whole evaluation, in milliseconds. */

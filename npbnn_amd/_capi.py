@@ -89,6 +89,7 @@ SIGNATURES = {
     "npbnn_eval": (C.c_int, [_P, _DP, _DP, _DP, C.c_double, _DP, C.c_int, C.POINTER(EvalOut),
                              C.POINTER(C.c_int64)]),
     "npbnn_predict": (C.c_int, [_P, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),
+    "npbnn_predict_sets": (C.c_int, [_P, _DP, _DP, C.c_int32, C.c_int, C.c_int, _DP]),
     "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
     "npbnn_time_pass": (C.c_int, [_P, _DP, C.c_int, C.c_int, _DP, C.POINTER(C.c_int)]),
     "npbnn_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -166,6 +166,21 @@ class HipContext:
                                           1 if apply_out_fn else 0, capi.dptr(y)))
         return y
 
+    def predict_sets(self, weight_sets, act_prm_sets=None, which=capi.TRAIN, apply_out_fn=True):
+        """Predictions of several weight sets on the resident matrix (npbnn_predict_sets): [n_sets, n_rows, n_out].
+        ``weight_sets``: list of per-layer lists (or packed vectors); ``act_prm_sets``: per set the activation slopes
+        of the hidden layers, or None."""
+        packed = np.stack([pack_weights(w) if isinstance(w, (list, tuple)) else capi.as_f64(w).ravel() for w in weight_sets])
+        packed = capi.as_f64(packed)
+        n_sets = packed.shape[0]
+        ap = None
+        if act_prm_sets is not None and self.arch.n_layers > 1:
+            ap = capi.as_f64(np.stack([np.asarray(a, dtype=np.float64).ravel()[: self.arch.n_layers - 1] for a in act_prm_sets]))
+        out = np.empty((n_sets, self.n_rows[which], self.n_out), dtype=np.float64)
+        self._chk(self._lib.npbnn_predict_sets(self._ctx, capi.dptr(packed), capi.dptr(ap), n_sets, which,
+                                               1 if apply_out_fn else 0, capi.dptr(out)))
+        return out
+
     def time_eval(self, weights, iters=20):
         w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights)
         a, b = C.c_double(0), C.c_double(0)

@@ -369,7 +369,7 @@ struct LaunchPlan {
     int n_waves;
 };
 
-int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1) {
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false) {
     Dataset& d = ctx->ds[which];
     bool want_f16 = false;
     if (!force_f32 && ctx->l0_option != NPBNN_L0_F32) {
@@ -386,7 +386,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     }
     size_t lds = 0;
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
-    int n_cand = (max_inner_tiles(ctx->net) == 1 && !lik_needs_row_scratch(ctx->net.lik_kind)) ? want_cand : 1;
+    int n_cand = (max_inner_tiles(ctx->net) == 1 && (predict_only || !lik_needs_row_scratch(ctx->net.lik_kind))) ? want_cand : 1;
     if (n_cand > kMaxCand) n_cand = kMaxCand;
     while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand) < 8) --n_cand;
     lp->n_cand = n_cand;
@@ -394,7 +394,8 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
-    lp->fn = pick_kernel(ctx->net, n_cand);
+    lp->fn = predict_only ? npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand, kLikCat)
+                          : pick_kernel(ctx->net, n_cand);
     lp->wpb = wpb;
     lp->lds = lds;
     int grid = (d.n_tiles + wpb - 1) / wpb;
@@ -500,8 +501,9 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
     if (pick_waves_per_block(ctx, &lds) == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
-    HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)ctx->net.image_floats * sizeof(float)));
-    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)ctx->net.image_floats * sizeof(float)));
+    // (room for kMaxCand independent images: npbnn_predict_sets stages that many weight sets per pass)
+    HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)kMaxCand * ctx->net.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)kMaxCand * ctx->net.image_floats * sizeof(float)));
     // where each packed weight lives in the image (bias column -> bias slot, else its MFMA fragment slot)
     std::vector<int> map((size_t)ctx->n_weights);
     std::vector<float> scale;
@@ -723,7 +725,7 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
     if (ctx->d_wcur) { (void)hipFree(ctx->d_wcur); ctx->d_wcur = nullptr; }
     if (ctx->d_mask) { (void)hipFree(ctx->d_mask); ctx->d_mask = nullptr; }
-    HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)ctx->n_weights * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)kMaxCand * ctx->n_weights * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_w, ((size_t)ctx->n_weights + arch->in_dim) * sizeof(double)));
     ctx->arch_set = true;
@@ -867,6 +869,80 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     if (ctx->l0_option == NPBNN_L0_F16) return fail(ctx, NPBNN_E_RANGE, "predict: a layer-0 weight left the fp16 range");
     }
     for (size_t i = 0; i < n_el; ++i) out_y[i] = (double)tmp[i];
+    return NPBNN_OK;
+}
+
+int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_prm_sets, int32_t n_sets, int which, int apply_out_fn,
+                       double* out_y) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!W_sets || !out_y || n_sets < 1) return fail(ctx, NPBNN_E_ARG, "predict_sets: bad arguments");
+    if (which != 0 && which != 1) return fail(ctx, NPBNN_E_ARG, "predict_sets: which must be 0 or 1");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "predict_sets: call npbnn_set_arch first");
+    Dataset& d = ctx->ds[which];
+    int rc = check_dataset_for_lik(ctx, d, NPBNN_LIK_NONE);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int C = ctx->net.n_out;
+    const int n_act = ctx->net.n_layers - 1;
+    const size_t per_set = (size_t)d.n_rows * C;
+    const size_t wn = (size_t)ctx->n_weights;
+    if (kMaxCand * per_set > ctx->d_y_cap) {
+        if (ctx->d_y) (void)hipFree(ctx->d_y);
+        ctx->d_y = nullptr;
+        ctx->d_y_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_y, kMaxCand * per_set * sizeof(float)));
+        ctx->d_y_cap = kMaxCand * per_set;
+    }
+    std::vector<float> tmp(kMaxCand * per_set);
+    std::vector<double> wstage(kMaxCand * wn);
+    int s0 = 0;
+    while (s0 < n_sets) {
+        // sets that share their activation slopes travel together, up to kMaxCand per streaming read of X
+        int g = 1;
+        while (s0 + g < n_sets && g < kMaxCand &&
+               (!act_prm_sets || n_act == 0 ||
+                memcmp(act_prm_sets + (size_t)(s0 + g) * n_act, act_prm_sets + (size_t)s0 * n_act, (size_t)n_act * sizeof(double)) == 0))
+            ++g;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            LaunchPlan lp;
+            rc = plan_launch(ctx, which, &lp, attempt, g, true);
+            if (rc) return rc;
+            if (lp.n_cand < g) g = lp.n_cand;          // (fewer images fit the LDS: the rest waits for the next round)
+            memcpy(wstage.data(), W_sets + (size_t)s0 * wn, (size_t)g * wn * sizeof(double));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wraw, wstage.data(), (size_t)g * wn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
+            if (act_prm_sets)
+                for (int l = 0; l < n_act; ++l) ctx->net.act_prm[l] = (float)act_prm_sets[(size_t)s0 * n_act + l];
+            const int total = pack_item_count(ctx->net, true);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), ctx->stream));
+            for (int j = 0; j < g; ++j)
+                hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wraw + (size_t)j * wn,
+                                   (const double*)nullptr, ctx->n_classw ? ctx->d_classw : nullptr,
+                                   ctx->d_image + (size_t)j * ctx->net.image_floats, ctx->net, ctx->net.l0_f16 ? ctx->d_wscale : nullptr,
+                                   ctx->d_overflow);
+            HIP_TRY(ctx, hipGetLastError());
+            EvalParams p = make_params(ctx, d);
+            p.labels = nullptr;
+            p.targets = nullptr;
+            p.net.lik_kind = NPBNN_LIK_NONE;
+            p.y_out = ctx->d_y;
+            p.predict_mode = apply_out_fn ? 2 : 1;
+            p.weight_sets = 1;
+            rc = push_eval_params(ctx, p);
+            if (rc) return rc;
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, (size_t)g * per_set * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            int ovf = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (!(ctx->net.l0_f16 && ovf)) break;
+            if (ctx->l0_option == NPBNN_L0_F16) return fail(ctx, NPBNN_E_RANGE, "predict_sets: a layer-0 weight left the fp16 range");
+        }
+        double* dst = out_y + (size_t)s0 * per_set;
+        for (size_t i = 0; i < (size_t)g * per_set; ++i) dst[i] = (double)tmp[i];
+        s0 += g;
+    }
     return NPBNN_OK;
 }
 

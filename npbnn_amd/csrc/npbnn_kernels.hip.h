@@ -105,6 +105,9 @@ struct EvalParams {
     int Fp;
     int use_classw;
     int predict_mode;         // 0 none, 1 raw last-layer values, 2 output function applied
+    int weight_sets;          // 0: the D candidates of a launch are patched copies of ONE image (chain pass); 1: D independent
+                              // weight sets, image j at image + j*image_floats, predictions of set j at y_out + j*n_rows*n_out
+                              // (posterior prediction: several stored samples per streaming read of X)
     // speculative multi-candidate pass of a device-resident chain (nullptr / unused for a plain evaluation):
     const PassDesc* pass;     // [2] which candidates this pass evaluates (entry = pass parity; parity 0 outside the overlapped schedule)
     const double* pv;         // [2][kMaxCand][M] proposed values of the touched entries of each candidate
@@ -975,7 +978,7 @@ struct HotParams {
     unsigned* confusion;
     float* y_out;
     long long n_rows;
-    int use_classw, predict_mode;
+    int use_classw, predict_mode, weight_sets;
     int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off;
 };
 
@@ -1204,22 +1207,27 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         }
     }
 
-    if (hp.predict_mode && primary && row_ok) {       // predictions of the first candidate (plain evaluations have only one)
+    if (hp.predict_mode && row_ok) {       // predictions: of the first candidate, or of every weight set of the launch
 #pragma unroll
-        for (int mt = 0; mt < MTI; ++mt)
-            if (mt < MTL)
+        for (int j = 0; j < D; ++j) {
+            if (!(hp.weight_sets || (primary && j == 0))) continue;
+            float* const yo = hp.y_out + (size_t)(J0 + j) * (size_t)hp.n_rows * C;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int o = 16 * mt + 4 * kq + i;
-                    if (o < C) {
-                        float v = h[0][mt][i];
-                        if (hp.predict_mode == 2) {
-                            if (hp.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse[0]);
-                            else if (hp.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 16 * mt + 4 * kq + i;
+                        if (o < C) {
+                            float v = h[j][mt][i];
+                            if (hp.predict_mode == 2) {
+                                if (hp.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse[j]);
+                                else if (hp.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+                            }
+                            yo[row * C + o] = v;
                         }
-                        hp.y_out[row * C + o] = v;
                     }
-                }
+        }
     }
 }
 
@@ -1267,6 +1275,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     hp.labels = uni(p.labels); hp.targets = uni(p.targets); hp.inst_w = uni(p.inst_w); hp.confusion = uni(p.confusion);
     hp.y_out = uni(p.y_out);
     hp.n_rows = uni(p.n_rows); hp.use_classw = uni(p.use_classw); hp.predict_mode = uni(p.predict_mode);
+    hp.weight_sets = uni(p.weight_sets);
     hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out); hp.MTL = uni(net.L[hp.n_layers - 1].mt); hp.lik_kind = uni(net.lik_kind);
     hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind); hp.out_kind = uni(net.out_kind);
     hp.final_act = uni(net.final_act);
@@ -1305,9 +1314,11 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     {
         const int n_pieces = image_floats >> 8;   // 1-KiB pieces
         const float* const image = uni(p.image);
+        const size_t set_stride = hp.weight_sets ? (size_t)image_floats : 0;
 #pragma unroll
         for (int j = 0; j < D; ++j)
-            for (int i = wave; i < n_pieces; i += wpb) dma16(image + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+            for (int i = wave; i < n_pieces; i += wpb)
+                dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
     }
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the

@@ -31,6 +31,7 @@ __all__ = [
     "propose_normal", "propose_normal_1d", "propose_fixed_normal",
     "propose_normal_normalized", "propose_multiplier_vector",
     "make_chain", "mh_step", "run_chain", "mc3_make", "mc3_run",
+    "posterior_cat_prob", "sample_from_categorical",
 ]
 
 
@@ -140,6 +141,62 @@ def forward_logits(data, weights, act, indicators=None, col_override=None):
 def forward(data, weights, act, out_fn, indicators=None, col_override=None):
     """RunPredict (BNN_lib.py:245-256) / RunPredictInd (:258-272)."""
     return out_fn(forward_logits(data, weights, act, indicators, col_override))
+
+
+# --------------------------------------------------------------------------
+# posterior prediction                          (np_bnn/BNN_lib.py:352-397, 682-713)
+# --------------------------------------------------------------------------
+def sample_from_categorical(post_probs):
+    """sample_from_categorical (BNN_lib.py:682-713): per instance, one categorical draw per posterior sample
+    (np.random.random, global stream); point estimate = class frequencies of the draws."""
+    n_samples, n_instances, n_classes = post_probs.shape
+    res = np.zeros((n_instances, n_samples))
+    point = np.zeros((n_instances, n_classes))
+    for j in range(n_instances):
+        p = np.cumsum(post_probs[:, j, :], axis=1)                   # :696
+        r = np.random.random(len(p))                                 # :697
+        q = p - r.reshape(len(r), 1)
+        q[q < 0] = 1                                                 # :699
+        cls = np.argmin(q, axis=1)                                   # :700
+        res[j, :] = cls
+        counts = np.bincount(cls, minlength=n_classes)
+        point[j, :] = counts / np.sum(counts)                        # :704
+    class_counts = np.zeros((n_samples, n_classes))
+    for i in range(res.shape[1]):
+        class_counts[i] = np.bincount(res[:, i].astype(int), minlength=n_classes)
+    return dict(predictions=point, class_counts=class_counts, post_predictions=res)
+
+
+def posterior_cat_prob(features, post_samples, act, out_fn, summary_mode=0, feature_index_to_shuffle=None,
+                       unlink_features_within_block=False):
+    """get_posterior_cat_prob (BNN_lib.py:352-397): every stored weight set (with its own activation slopes) is
+    run over the - optionally column-shuffled - feature matrix; summary 0 = frequency of the arg-max class over the
+    samples, 1 = mean class probabilities, 2 = posterior-predictive resampling."""
+    x = features.copy()                                              # :364
+    if feature_index_to_shuffle:                                     # :366-371 (np.random.permutation, global stream)
+        if unlink_features_within_block and type(feature_index_to_shuffle) == list:
+            for fi in feature_index_to_shuffle:
+                x[:, fi] = np.random.permutation(x[:, fi])
+        else:
+            x[:, feature_index_to_shuffle] = np.random.permutation(x[:, feature_index_to_shuffle])
+    probs = []
+    for smp in post_samples:                                         # :376-380
+        a = Act(act.fun, smp["alphas"], act.trainable)
+        probs.append(forward(x, smp["weights"], a, out_fn))
+    probs = np.array(probs)
+    if summary_mode == 0:                                            # :382-390
+        calls = np.argmax(probs, axis=2).T
+        n_s, n_i, n_c = probs.shape
+        summary = np.zeros((n_i, n_c))
+        for i, row in enumerate(calls):
+            cls, cnt = np.unique(row, return_counts=True)
+            summary[i, cls] = cnt
+        summary = summary / n_s
+    elif summary_mode == 1:                                          # :391-392
+        summary = np.mean(probs, axis=0)
+    else:                                                            # :393-395
+        summary = sample_from_categorical(probs)["predictions"]
+    return probs, summary
 
 
 # --------------------------------------------------------------------------

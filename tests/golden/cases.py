@@ -134,3 +134,23 @@ BLOCK_LAYOUTS = [
     # config-5 layout: 512 features in 8 blocks of 64, 4 nodes per block
     (512, [32, 8], 1, [list(np.repeat(np.arange(8), 64)), [], []], [[4] * 8, [], []]),
 ]
+
+
+# ---- G7: posterior prediction (get_posterior_cat_prob) ----------------------
+def posterior_inputs(seed=77, n_rows=97, n_features=11, n_nodes=(6, 5), n_classes=4, n_samples=7, fun="tanh", bias=2):
+    """S stored weight sets against one feature matrix.  genReLU runs carry a different slope vector per sample
+    (trainable activations are logged per posterior sample, BNN_env.py:642-658)."""
+    rs = np.random.default_rng(seed)
+    x = rs.standard_normal((n_rows, n_features))
+    shapes = layer_shapes(n_features, list(n_nodes), n_classes, bias)
+    samples = []
+    for i in range(n_samples):
+        w = [rs.normal(0, 0.6, s) for s in shapes]
+        alphas = rs.uniform(0.0, 0.3, len(n_nodes)) if fun == "genReLU" else np.zeros(1)
+        samples.append(dict(weights=w, alphas=alphas, mcmc_it=100 * i))
+    labels = rs.integers(0, n_classes, n_rows)
+    return dict(x=x, samples=samples, labels=labels, fun=fun)
+
+
+POSTERIOR_CASES = [dict(name="tanh", fun="tanh", seed=77), dict(name="genrelu", fun="genReLU", seed=78),
+                   dict(name="swish_bias3", fun="swish", seed=79, bias=3)]

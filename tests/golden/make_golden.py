@@ -13,6 +13,7 @@ Groups:
   G4 trace_*.npz     Metropolis-Hastings traces (per-proposal logLik', logPrior', accept)
   G5 mc3.npz         MC3 (4 chains) swap sequence and final chain states
   G6 masks.npz       create_mask block layouts
+  G7 posterior.npz   get_posterior_cat_prob: per-sample class probabilities and the three summaries
 """
 import contextlib
 import io
@@ -226,6 +227,27 @@ def g6_masks():
     print("masks.npz")
 
 
+def g7_posterior():
+    out = {}
+    for case in cases.POSTERIOR_CASES:
+        kw = {k: v for k, v in case.items() if k != "name"}
+        inp = cases.posterior_inputs(**kw)
+        act = bn.ActFun(fun=inp["fun"], prm=np.zeros(2)) if inp["fun"] == "genReLU" else bn.ActFun(fun=inp["fun"])
+        for mode in (0, 1, 2):
+            np.random.seed(4321)
+            probs, summary = quiet(bn.get_posterior_cat_prob, inp["x"], post_samples=inp["samples"], post_summary_mode=mode,
+                                   actFun=act, output_act_fun=bn.SoftMax)
+            out["%s_summary%d" % (case["name"], mode)] = summary
+        out["%s_probs" % case["name"]] = probs
+        np.random.seed(99)
+        probs_sh, summary_sh = quiet(bn.get_posterior_cat_prob, inp["x"], post_samples=inp["samples"], post_summary_mode=1,
+                                     feature_index_to_shuffle=[1, 4], unlink_features_within_block=True, actFun=act,
+                                     output_act_fun=bn.SoftMax)
+        out["%s_shuffled_summary1" % case["name"]] = summary_sh
+    np.savez_compressed(os.path.join(HERE, "posterior.npz"), **out)
+    print("posterior.npz")
+
+
 if __name__ == "__main__":
     print("reference np_bnn", bn.__version__, "numpy", np.__version__)
     g1_grid()
@@ -234,3 +256,4 @@ if __name__ == "__main__":
     g4_traces()
     g5_mc3()
     g6_masks()
+    g7_posterior()

@@ -1,0 +1,86 @@
+"""Posterior prediction on the GPU (npbnn_predict_sets / get_posterior_cat_prob) against the reference's golden
+vectors (tests/golden/posterior.npz, G7) and the float64 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5      # class probabilities, float32 forward pass vs float64
+
+
+def _setup(case):
+    import npbnn_amd as bn
+    inp = cases.posterior_inputs(**{k: v for k, v in case.items() if k != "name"})
+    act = bn.ActFun(fun=inp["fun"], prm=np.zeros(2)) if inp["fun"] == "genReLU" else bn.ActFun(fun=inp["fun"])
+    return bn, inp, act
+
+
+@pytest.mark.parametrize("case", cases.POSTERIOR_CASES, ids=lambda c: c["name"])
+def test_get_posterior_cat_prob_matches_reference(case, golden_dir):
+    bn, inp, act = _setup(case)
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    k = case["name"]
+    for mode in (0, 1, 2):
+        np.random.seed(4321)
+        probs, summary = bn.get_posterior_cat_prob(inp["x"], post_samples=inp["samples"], post_summary_mode=mode, actFun=act,
+                                                   output_act_fun=bn.SoftMax)
+        assert probs.shape == g[k + "_probs"].shape
+        np.testing.assert_allclose(probs, g[k + "_probs"], atol=TOL, rtol=0)
+        ref = g["%s_summary%d" % (k, mode)]
+        if mode == 1:
+            np.testing.assert_allclose(summary, ref, atol=TOL, rtol=0)
+        else:       # counts of arg-max calls / categorical draws: a float32 near-tie may move a single call
+            assert np.mean(np.abs(summary - ref)) < 2e-3
+            assert np.mean(np.all(summary == ref, axis=1)) > 0.97
+    np.random.seed(99)
+    _, summary = bn.get_posterior_cat_prob(inp["x"], post_samples=inp["samples"], post_summary_mode=1,
+                                           feature_index_to_shuffle=[1, 4], unlink_features_within_block=True, actFun=act,
+                                           output_act_fun=bn.SoftMax)
+    np.testing.assert_allclose(summary, g[k + "_shuffled_summary1"], atol=TOL, rtol=0)
+
+
+def test_predict_sets_groups_and_single_predict_agree():
+    """Seven sets go through as groups of three, three and one; every set must equal its own single prediction bit for
+    bit (same kernel arithmetic per weight set, whatever shares the pass) and the oracle within tolerance."""
+    from npbnn_amd import HipContext, _capi as capi
+    rs = np.random.default_rng(5)
+    n, f, c = 1000, 40, 6
+    x = rs.standard_normal((n, f))
+    shapes = cases.layer_shapes(f, [12, 7], c, 2)
+    sets = [[rs.normal(0, 0.5, s) for s in shapes] for _ in range(7)]
+    ctx = HipContext(0)
+    ctx.set_data(x)
+    ctx.set_arch_from_weights(sets[0], f, capi.ACT_TANH, capi.OUT_SOFTMAX, capi.LIK_NONE)
+    y = ctx.predict_sets(sets)
+    assert y.shape == (7, n, c)
+    for i, w in enumerate(sets):
+        np.testing.assert_array_equal(y[i], ctx.predict(w))
+        ref = orc.forward(x.astype(np.float32).astype(np.float64), w, orc.Act("tanh"), orc.out_softmax)
+        np.testing.assert_allclose(y[i], ref, atol=TOL, rtol=0)
+    ctx.close()
+
+
+def test_predictbnn_writes_the_reference_files(tmp_path):
+    import npbnn_amd as bn
+    inp = cases.posterior_inputs(seed=31, n_rows=120, n_samples=5)
+    dat = dict(data=inp["x"], labels=inp["labels"], test_data=np.zeros((0, inp["x"].shape[1])), test_labels=np.zeros(0))
+    np.random.seed(1234)
+    bnn = bn.npBNN(dat, n_nodes=[6, 5], actFun=bn.ActFun(fun="tanh"), use_bias_node=2)
+    mcmc = bn.MCMC(bnn, n_iteration=50, sampling_f=10, print_f=1000, n_post_samples=5)
+    logger = bn.postLogger(bnn, wdir=str(tmp_path), filename="run", log_all_weights=0)
+    logger._post_weight_samples = inp["samples"]
+    pkl = os.path.join(str(tmp_path), "run.pkl")
+    bn.SaveObject([bnn, mcmc, logger], pkl)
+    res = bn.predictBNN(inp["x"], pkl, test_labels=inp["labels"], post_summary_mode=1, verbose=0)
+    probs = np.load(os.path.join(str(tmp_path), "run_pred_pr.npy"))
+    assert probs.shape == (5, 120, 4)
+    ref_probs, ref_summary = orc.posterior_cat_prob(inp["x"], inp["samples"], orc.Act("tanh"), orc.out_softmax, summary_mode=1)
+    np.testing.assert_allclose(probs, ref_probs, atol=TOL, rtol=0)
+    np.testing.assert_allclose(res["post_prob_predictions"], ref_summary, atol=TOL, rtol=0)
+    assert os.path.exists(os.path.join(str(tmp_path), "run_pred_mean_pr.txt"))
+    assert res["confusion_matrix"].sum() == 120

@@ -197,3 +197,22 @@ def test_g6_block_masks(golden_dir):
         m = orc.block_mask([np.ones(s) for s in shapes], idx, npf)
         for li, mm in enumerate(m):
             np.testing.assert_array_equal(mm.astype(np.int8), g["m%d_%d" % (bi, li)])
+
+
+@pytest.mark.parametrize("case", cases.POSTERIOR_CASES, ids=lambda c: c["name"])
+def test_g7_posterior_prediction(case, golden_dir):
+    """get_posterior_cat_prob: per-sample class probabilities and the three summaries (incl. the consumption of the
+    global numpy stream by the column shuffle and by the posterior-predictive resampling)."""
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    inp = cases.posterior_inputs(**{k: v for k, v in case.items() if k != "name"})
+    act = orc.Act(inp["fun"], np.zeros(2)) if inp["fun"] == "genReLU" else orc.Act(inp["fun"])
+    k = case["name"]
+    for mode in (0, 1, 2):
+        np.random.seed(4321)
+        probs, summary = orc.posterior_cat_prob(inp["x"], inp["samples"], act, orc.out_softmax, summary_mode=mode)
+        np.testing.assert_allclose(probs, g[k + "_probs"], rtol=RTOL, atol=1e-15)
+        np.testing.assert_allclose(summary, g["%s_summary%d" % (k, mode)], rtol=RTOL, atol=1e-15)
+    np.random.seed(99)
+    _, summary = orc.posterior_cat_prob(inp["x"], inp["samples"], act, orc.out_softmax, summary_mode=1,
+                                        feature_index_to_shuffle=[1, 4], unlink_features_within_block=True)
+    np.testing.assert_allclose(summary, g[k + "_shuffled_summary1"], rtol=RTOL, atol=1e-15)

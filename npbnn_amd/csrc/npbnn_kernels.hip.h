@@ -1346,9 +1346,9 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
         if (hp.targets) {
             const int total = 16 * k_targets;           // contiguous floats of this tile's targets
             for (int e = 0; e < total; e += 64) {
-                int idx = e + lane;
-                if (idx >= total) idx = total - 1;      // duplicate the last element, never read
-                dma4(hp.targets + r0 * k_targets + idx, a + 128 + e * 4);
+                const int idx = e + lane;               // (only the lanes with an element take part: an LDS-DMA writes
+                if (idx < total)                        //  lane*4 bytes past its base whatever it loaded, and the slot ends at `total`)
+                    dma4(hp.targets + r0 * k_targets + idx, a + 128 + e * 4);
             }
         }
     };

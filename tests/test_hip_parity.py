@@ -249,6 +249,75 @@ def test_config2_full_size(hip):
     assert abs(parts - r1["loglik"]) / abs(r1["loglik"]) < 1e-9
 
 
+def test_config4_full_size_regression(hip):
+    """BASELINE.json config 4 (1e6 x 64 -> 2 targets, [16,4], tanh, bias 2, empirical sigma): oracle comparison at
+    full size, determinism, and the closed form of the empirical-sigma likelihood recomputed from the returned moments."""
+    rs = np.random.default_rng(0)
+    n, f, k = 1_000_000, 64, 2
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    np.random.seed(1234)
+    teacher = orc.init_weights([16, 4], f, k, bias_node=2)
+    teacher = [t * 3 for t in teacher]
+    act = orc.Act("tanh")
+    x64 = x.astype(np.float64)
+    targets = orc.forward(x64, teacher, act, orc.out_identity) + 0.5 * rs.standard_normal((n, k))
+    w = orc.init_weights([16, 4], f, k, bias_node=2)
+    ctx = make_ctx(hip, x, w, act, 1, 1, targets=targets, n_targets=k)
+    r1 = ctx.eval(w)
+    r2 = ctx.eval(w)
+    assert r1["loglik"] == r2["loglik"]
+    pred = orc.forward(x64, w, act, orc.out_identity)
+    t32 = targets.astype(np.float32).astype(np.float64)
+    want, _ = orc.closed_gaussian_empirical(pred, t32)
+    assert abs(r1["loglik"] - want) / abs(want) < 1e-7
+    res = t32 - pred
+    np.testing.assert_allclose(r1["sigma"], np.std(res, axis=0), rtol=1e-6)
+    s1, s2 = r1["sum_r"], r1["sum_r2"]
+    sg = np.sqrt(s2 / n - (s1 / n) ** 2)
+    closed = np.sum(-n * (0.5 * np.log(2 * np.pi) + np.log(sg)) - s2 / (2 * sg ** 2))
+    assert abs(closed - r1["loglik"]) / abs(closed) < 1e-12
+    # fixed sigma vector
+    sig = np.array([0.7, 1.3])
+    want = orc.lik_gaussian(pred, t32, sig2=sig)
+    assert abs(ctx.eval(w, sigma=sig)["loglik"] - want) / abs(want) < 1e-6
+    ctx.close()
+
+
+def test_config5_block_masked_network(hip):
+    """BASELINE.json config 5 (5e4 x 512, 8 blocks of 64 inputs with 4 nodes each, [32,8] -> 1 target, bias -1): the
+    block mask zeroes 7/8 of the first layer; masked weights must behave exactly like structural zeros."""
+    rs = np.random.default_rng(0)
+    n, f, k = 50_000, 512, 1
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    np.random.seed(1234)
+    w = orc.init_weights([32, 8], f, k, bias_node=-1)
+    mask = orc.block_mask(w, [np.repeat(np.arange(8), 64), [], []], [[4] * 8, [], []])
+    assert mask[0].sum() == 32 * 64
+    wm = [wi * mi for wi, mi in zip(w, mask)]
+    act = orc.Act("tanh")
+    x64 = x.astype(np.float64)
+    targets = rs.standard_normal((n, k))
+    ctx = make_ctx(hip, x, wm, act, 1, 1, targets=targets, n_targets=k)
+    r = ctx.eval(wm)
+    pred = orc.forward(x64, wm, act, orc.out_identity)
+    t32 = targets.astype(np.float32).astype(np.float64)
+    want, _ = orc.closed_gaussian_empirical(pred, t32)
+    assert abs(r["loglik"] - want) / abs(want) < 1e-6
+    # the masked-out entries are irrelevant: garbage there, times the mask, gives the same bits
+    junk = [wi + (1 - mi) * 123.0 for wi, mi in zip(wm, mask)]
+    assert ctx.eval([j * m for j, m in zip(junk, mask)])["loglik"] == r["loglik"]
+    # block structure: with every later block's second-layer inputs cut, the prediction must ignore inputs 64..511
+    w_cut = [wm[0], wm[1].copy(), wm[2]]
+    w_cut[1][:, 4:] = 0.0                                              # keep only the 4 nodes of block 0
+    y = ctx.predict(w_cut, apply_out_fn=False)
+    x2 = x.copy()
+    x2[:, 64:] = rs.standard_normal((n, f - 64)).astype(np.float32)
+    c2 = make_ctx(hip, x2, wm, act, 1, 1, targets=targets, n_targets=k)
+    np.testing.assert_array_equal(c2.predict(w_cut, apply_out_fn=False), y)
+    c2.close()
+    ctx.close()
+
+
 # ---- layer-0 precision modes -------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 def test_l0_modes_against_oracle(mode, hip):

@@ -198,3 +198,36 @@ def test_speculative_passes_do_not_change_the_chain(name):
             assert m._device_passes == 300                  # ... and never counted
             continue
         assert m._device_passes < 300                       # fewer passes over the data for the same 300 iterations
+
+
+@pytest.mark.parametrize("kind", ["regression", "classification"])
+def test_device_chain_with_many_tiles_per_wave(kind):
+    """200k rows (a dozen tiles per wavefront, every row-aux slot in rotation, three candidates per pass in the overlapped
+    schedule) against the host loop (one single-candidate evaluation per proposal): same decisions, same state."""
+    n, f = 200_000, 48
+    if kind == "regression":
+        dat = cases.regression_data(5, n, f, 3, 0)
+        extra = dict(estimation_mode="regression", empirical_error=True)
+        kw = dict(update_f=[0.02, 0.02, 0.05], estimate_error=False)
+    else:
+        dat = cases.classification_data(5, n, f, 7, 0)
+        dat["instance_weights"] = None
+        extra = {}
+        kw = dict(update_f=[0.02, 0.02, 0.05])
+    out = []
+    for _ in range(2):
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, {k: v for k, v in dat.items() if k != "instance_weights"}, n_nodes=[24, 6],
+                    actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1, **extra)
+        out.append((bnn, bn.MCMC(bnn, **kw)))
+    (ba, ma), (bb, mb) = out
+    steps = 90
+    for _ in range(steps):
+        ma.mh_step(ba)
+    mb.run_steps(bb, steps)
+    assert mb._device_void_passes + mb._device_passes > 0
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    assert sum(ma._last_accepted_mem) > 0
+    np.testing.assert_allclose(mb._logLik, ma._logLik, rtol=1e-11)
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)

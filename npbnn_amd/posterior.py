@@ -15,26 +15,48 @@ from .layers import ActFun, SoftMax, output_kind
 from .likelihoods import CalcAccuracy
 
 
-def _predict_samples(features, post_samples, actFun, output_act_fun):
-    """[n_samples, n_rows, n_out] predictions of every stored sample on ``features``."""
-    from .backend import HipContext
-    weights = [s["weights"] for s in post_samples]
-    kind = output_kind(output_act_fun)
-    ctx = HipContext()
-    try:
-        ctx.set_data(features)
-        ctx.set_arch_from_weights(weights[0], features.shape[1], actFun.device_kind(),
-                                  capi.OUT_IDENTITY if kind is None else kind, capi.LIK_NONE)
-        slopes = None
+class _SamplePredictor:
+    """One device context for a set of stored samples: the feature matrix can be replaced (column shuffles of
+    feature_importance) while network description and packed weight sets stay."""
+
+    def __init__(self, n_features, post_samples, actFun, output_act_fun):
+        from .backend import HipContext, pack_weights
+        self._weights = [s["weights"] for s in post_samples]
+        self._packed = np.stack([pack_weights(w) for w in self._weights])
+        self._kind = output_kind(output_act_fun)
+        self._out_fn = output_act_fun
+        self._act = actFun
+        self._n_features = n_features
+        self._slopes = None
         if actFun._function == "genReLU":
-            n_hidden = len(weights[0]) - 1
-            slopes = [np.asarray(s["alphas"], dtype=float)[:n_hidden] for s in post_samples]
-        y = ctx.predict_sets(weights, act_prm_sets=slopes, apply_out_fn=kind is not None)
+            n_hidden = len(self._weights[0]) - 1
+            self._slopes = [np.asarray(s["alphas"], dtype=float)[:n_hidden] for s in post_samples]
+        self._ctx = HipContext()
+        self._arch_set = False
+
+    def predict(self, features):
+        """[n_samples, n_rows, n_out] predictions of every stored sample on ``features``."""
+        ctx = self._ctx
+        ctx.set_data(features)
+        if not self._arch_set:
+            ctx.set_arch_from_weights(self._weights[0], self._n_features, self._act.device_kind(),
+                                      capi.OUT_IDENTITY if self._kind is None else self._kind, capi.LIK_NONE)
+            self._arch_set = True
+        y = ctx.predict_sets(list(self._packed), act_prm_sets=self._slopes, apply_out_fn=self._kind is not None)
+        if self._kind is None and self._out_fn is not None:      # custom output callable: host side, sample by sample
+            y = np.array([self._out_fn(yi) for yi in y])
+        return y
+
+    def close(self):
+        self._ctx.close()
+
+
+def _predict_samples(features, post_samples, actFun, output_act_fun):
+    pred = _SamplePredictor(features.shape[1], post_samples, actFun, output_act_fun)
+    try:
+        return pred.predict(features)
     finally:
-        ctx.close()
-    if kind is None and output_act_fun is not None:      # custom output callable: host side, sample by sample
-        y = np.array([output_act_fun(yi) for yi in y])
-    return y
+        pred.close()
 
 
 def sample_from_categorical(posterior_weights=None, post_prob_file=None, verbose=False):
@@ -67,7 +89,7 @@ def sample_from_categorical(posterior_weights=None, post_prob_file=None, verbose
 
 
 def get_posterior_cat_prob(pred_features, post_samples=None, feature_index_to_shuffle=None, post_summary_mode=0,
-                           unlink_features_within_block=False, actFun=None, output_act_fun=None):
+                           unlink_features_within_block=False, actFun=None, output_act_fun=None, _predictor=None):
     """Class probabilities of every posterior sample and their summary (reference: BNN_lib.py:352-397):
     mode 0 frequency of the arg-max class over the samples, 1 mean probabilities, 2 posterior-predictive resampling."""
     if len(pred_features) == 0:
@@ -84,7 +106,10 @@ def get_posterior_cat_prob(pred_features, post_samples=None, feature_index_to_sh
         actFun = ActFun()
     if len(post_samples):
         actFun.reset_prm(post_samples[-1]['alphas'])          # the reference leaves the last sample's slopes installed
-    post_softmax_probs = _predict_samples(predict_features, post_samples, actFun, output_act_fun)
+    if _predictor is not None:
+        post_softmax_probs = _predictor.predict(predict_features)
+    else:
+        post_softmax_probs = _predict_samples(predict_features, post_samples, actFun, output_act_fun)
     if post_summary_mode == 0:
         class_call_posterior = np.argmax(post_softmax_probs, axis=2).T
         n_posterior_samples, n_instances, n_classes = post_softmax_probs.shape
@@ -141,3 +166,78 @@ def predictBNN(predict_features, pickle_file, test_labels=[], instance_id=[], po
         print('   ', out_file_post_pr)
         print('   ', out_file_mean_pr, "\n")
     return {'post_prob_predictions': post_prob_predictions, 'mean_accuracy': mean_accuracy, 'confusion_matrix': cm_out}
+
+
+def feature_importance(input_features, weights_pkl=None, weights_posterior=None, true_labels=[], fname_stem='',
+                       feature_names=[], verbose=False, post_summary_mode=0, n_permutations=100, feature_blocks=dict(),
+                       write_to_file=True, predictions_outdir='', unlink_features_within_block=True, actFun=None,
+                       output_act_fun=None):
+    """Accuracy lost when a feature (or block of features) is shuffled between the instances, ``n_permutations`` times
+    per block (reference: BNN_lib.py:504-597).  Every permutation is one upload of the shuffled matrix and one
+    ``npbnn_predict_sets`` over all stored samples; the permutations themselves come from numpy's global stream as in
+    the reference.  Returns the reference's data frame, sorted by decreasing mean accuracy loss."""
+    import pandas as pd
+    features = np.asarray(input_features)
+    feature_indices = np.arange(features.shape[1])
+    if len(feature_names) == 0:
+        feature_names = feature_indices.astype(str)
+    if type(feature_blocks) is dict:
+        if len(feature_blocks.keys()) > 0:
+            selected_features = list(feature_blocks.values())
+            feature_block_names = list(feature_blocks.keys())
+        else:
+            selected_features = [[i] for i in feature_indices]
+            feature_block_names = [i for i in feature_names]
+    else:
+        selected_features = feature_blocks
+        feature_block_names = ['block_' + str(i) for i in range(len(feature_blocks))]
+    if weights_pkl:
+        bnn_obj, mcmc_obj, logger_obj = load_obj(weights_pkl)
+        weights_posterior = logger_obj._post_weight_samples
+        actFun = bnn_obj._act_fun
+        output_act_fun = bnn_obj._output_act_fun
+    if actFun is None:
+        actFun = ActFun()
+    predictor = _SamplePredictor(features.shape[1], weights_posterior, actFun, output_act_fun)
+    try:
+        _, post_prob_predictions = get_posterior_cat_prob(features, weights_posterior, post_summary_mode=post_summary_mode,
+                                                          actFun=actFun, output_act_fun=output_act_fun, _predictor=predictor)
+        ref_accuracy = CalcAccuracy(post_prob_predictions, true_labels)
+        if verbose:
+            print("Reference accuracy (mean):", np.mean(ref_accuracy))
+        accuracies_wo_feature = []
+        for block_id, feature_block in enumerate(selected_features):
+            if verbose:
+                print('Processing feature block %i', block_id + 1)
+            n_accuracies = []
+            for _ in np.arange(n_permutations):
+                _, post_prob_predictions = get_posterior_cat_prob(
+                    features, weights_posterior, feature_index_to_shuffle=feature_block, post_summary_mode=post_summary_mode,
+                    unlink_features_within_block=unlink_features_within_block, actFun=actFun, output_act_fun=output_act_fun,
+                    _predictor=predictor)
+                n_accuracies.append(CalcAccuracy(post_prob_predictions, true_labels))
+            accuracies_wo_feature.append(n_accuracies)
+    finally:
+        predictor.close()
+    accuracies_wo_feature = np.array(accuracies_wo_feature)
+    delta_accs = ref_accuracy - accuracies_wo_feature
+    df = pd.DataFrame(np.array([np.arange(0, len(selected_features)), feature_block_names,
+                                np.mean(delta_accs, axis=1), np.std(delta_accs, axis=1),
+                                np.mean(accuracies_wo_feature, axis=1), np.std(accuracies_wo_feature, axis=1)]).T,
+                      columns=['feature_block_index', 'feature_name', 'delta_acc_mean', 'delta_acc_std',
+                               'acc_with_feature_randomized_mean', 'acc_with_feature_randomized_std'])
+    df.iloc[:, 2:] = df.iloc[:, 2:].astype(float)
+    df_sorted = df.sort_values('delta_acc_mean', ascending=False)
+    df_sorted['delta_acc_mean'] = pd.to_numeric(df_sorted['delta_acc_mean'])
+    df_sorted['acc_with_feature_randomized_mean'] = pd.to_numeric(df_sorted['acc_with_feature_randomized_mean'])
+    if write_to_file:
+        if predictions_outdir == "":
+            predictions_outdir = os.path.dirname(weights_pkl)
+        if not os.path.exists(predictions_outdir) and predictions_outdir != "":
+            os.makedirs(predictions_outdir)
+        if fname_stem != "":
+            fname_stem = fname_stem + "_"
+        out_name = os.path.join(predictions_outdir, fname_stem + 'feature_importance.txt')
+        df_sorted.to_csv(out_name, sep='\t', index=False, header=True, float_format='%.6f')
+        print("Output saved in: %s" % out_name)
+    return df_sorted

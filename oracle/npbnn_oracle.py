@@ -31,7 +31,7 @@ __all__ = [
     "propose_normal", "propose_normal_1d", "propose_fixed_normal",
     "propose_normal_normalized", "propose_multiplier_vector",
     "make_chain", "mh_step", "run_chain", "mc3_make", "mc3_run",
-    "posterior_cat_prob", "sample_from_categorical",
+    "posterior_cat_prob", "sample_from_categorical", "feature_importance",
 ]
 
 
@@ -197,6 +197,39 @@ def posterior_cat_prob(features, post_samples, act, out_fn, summary_mode=0, feat
     else:                                                            # :393-395
         summary = sample_from_categorical(probs)["predictions"]
     return probs, summary
+
+
+def feature_importance(features, post_samples, act, out_fn, true_labels, n_permutations=100, feature_blocks=None,
+                       summary_mode=0, unlink_features_within_block=True, feature_names=()):
+    """feature_importance (BNN_lib.py:504-597): accuracy of the posterior prediction with all features, then with each
+    feature (block) shuffled between the instances, ``n_permutations`` times each.  Returns (block order, names, table)
+    sorted by decreasing mean accuracy loss like the reference's data frame; table columns: delta_acc mean / std,
+    accuracy-with-feature-randomised mean / std."""
+    idx_all = np.arange(features.shape[1])
+    names = list(feature_names) if len(feature_names) else list(idx_all.astype(str))
+    if isinstance(feature_blocks, dict) and len(feature_blocks):                        # :525-531
+        blocks, block_names = list(feature_blocks.values()), list(feature_blocks.keys())
+    elif feature_blocks is None or isinstance(feature_blocks, dict):                    # :532-534
+        blocks, block_names = [[i] for i in idx_all], names
+    else:                                                                               # :536-538
+        blocks, block_names = feature_blocks, ["block_" + str(i) for i in range(len(feature_blocks))]
+    _, pred = posterior_cat_prob(features, post_samples, act, out_fn, summary_mode)     # :546-549
+    ref_acc = acc_classification(pred, true_labels)
+    acc = []
+    for block in blocks:                                                                # :555-569
+        row = []
+        for _ in range(n_permutations):
+            _, pred = posterior_cat_prob(features, post_samples, act, out_fn, summary_mode, feature_index_to_shuffle=block,
+                                         unlink_features_within_block=unlink_features_within_block)
+            row.append(acc_classification(pred, true_labels))
+        acc.append(row)
+    acc = np.array(acc)
+    delta = ref_acc - acc                                                               # :571
+    table = np.stack([np.mean(delta, axis=1), np.std(delta, axis=1), np.mean(acc, axis=1), np.std(acc, axis=1)], axis=1)
+    # DataFrame.sort_values('delta_acc_mean', ascending=False) (:583): quicksort on the reversed column, reversed back
+    key = table[:, 0]
+    order = np.arange(len(key))[::-1][key[::-1].argsort(kind="quicksort")][::-1]
+    return order, [block_names[i] for i in order], table[order]
 
 
 # --------------------------------------------------------------------------

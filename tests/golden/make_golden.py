@@ -244,6 +244,16 @@ def g7_posterior():
                                      feature_index_to_shuffle=[1, 4], unlink_features_within_block=True, actFun=act,
                                      output_act_fun=bn.SoftMax)
         out["%s_shuffled_summary1" % case["name"]] = summary_sh
+    # feature importance: accuracy lost when a feature (or a block of features) is shuffled between the instances
+    inp = cases.posterior_inputs(**{k: v for k, v in cases.POSTERIOR_CASES[0].items() if k != "name"})
+    act = bn.ActFun(fun=inp["fun"])
+    for tag, blocks in (("single", dict()), ("blocks", {"a": [0, 1, 2], "b": [3, 4], "c": [5, 6, 7, 8, 9, 10]})):
+        np.random.seed(7)
+        df = quiet(bn.feature_importance, inp["x"], weights_posterior=inp["samples"], true_labels=inp["labels"], n_permutations=4,
+                   feature_blocks=blocks, write_to_file=False, post_summary_mode=1, actFun=act, output_act_fun=bn.SoftMax)
+        out["fi_%s_index" % tag] = df["feature_block_index"].to_numpy().astype(np.int64)
+        out["fi_%s_values" % tag] = df.iloc[:, 2:].to_numpy().astype(np.float64)
+        out["fi_%s_names" % tag] = df["feature_name"].to_numpy().astype(str)
     np.savez_compressed(os.path.join(HERE, "posterior.npz"), **out)
     print("posterior.npz")
 

@@ -84,3 +84,23 @@ def test_predictbnn_writes_the_reference_files(tmp_path):
     np.testing.assert_allclose(res["post_prob_predictions"], ref_summary, atol=TOL, rtol=0)
     assert os.path.exists(os.path.join(str(tmp_path), "run_pred_mean_pr.txt"))
     assert res["confusion_matrix"].sum() == 120
+
+
+@pytest.mark.parametrize("tag,blocks", [("single", dict()), ("blocks", {"a": [0, 1, 2], "b": [3, 4], "c": [5, 6, 7, 8, 9, 10]})])
+def test_feature_importance_matches_reference(tag, blocks, golden_dir):
+    """Same permutations (numpy's global stream), same table as the reference's data frame; accuracies are multiples of
+    1/N, so a float32 near-tie could move one by a single instance."""
+    bn, inp, act = _setup(cases.POSTERIOR_CASES[0])
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    np.random.seed(7)
+    df = bn.feature_importance(inp["x"], weights_posterior=inp["samples"], true_labels=inp["labels"], n_permutations=4,
+                               feature_blocks=blocks, write_to_file=False, post_summary_mode=1, actFun=act, output_act_fun=bn.SoftMax)
+    assert list(df.columns) == ['feature_block_index', 'feature_name', 'delta_acc_mean', 'delta_acc_std',
+                                'acc_with_feature_randomized_mean', 'acc_with_feature_randomized_std']
+    values = df.iloc[:, 2:].to_numpy().astype(float)
+    order = df["feature_block_index"].to_numpy().astype(int)
+    want = g["fi_%s_values" % tag]
+    if np.array_equal(order, g["fi_%s_index" % tag]):
+        np.testing.assert_allclose(values, want, atol=1.5 / len(inp["labels"]), rtol=0)
+    else:       # a one-instance difference may swap two neighbours of the ranking
+        np.testing.assert_allclose(np.sort(values[:, 0]), np.sort(want[:, 0]), atol=1.5 / len(inp["labels"]), rtol=0)

@@ -216,3 +216,16 @@ def test_g7_posterior_prediction(case, golden_dir):
     _, summary = orc.posterior_cat_prob(inp["x"], inp["samples"], act, orc.out_softmax, summary_mode=1,
                                         feature_index_to_shuffle=[1, 4], unlink_features_within_block=True)
     np.testing.assert_allclose(summary, g[k + "_shuffled_summary1"], rtol=RTOL, atol=1e-15)
+
+
+@pytest.mark.parametrize("tag,blocks", [("single", None), ("blocks", {"a": [0, 1, 2], "b": [3, 4], "c": [5, 6, 7, 8, 9, 10]})])
+def test_g7_feature_importance(tag, blocks, golden_dir):
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    case = cases.POSTERIOR_CASES[0]
+    inp = cases.posterior_inputs(**{k: v for k, v in case.items() if k != "name"})
+    np.random.seed(7)
+    order, names, table = orc.feature_importance(inp["x"], inp["samples"], orc.Act(inp["fun"]), orc.out_softmax, inp["labels"],
+                                                 n_permutations=4, feature_blocks=blocks, summary_mode=1)
+    np.testing.assert_array_equal(order, g["fi_%s_index" % tag])
+    assert [str(n) for n in names] == [str(n) for n in g["fi_%s_names" % tag]]
+    np.testing.assert_allclose(table, g["fi_%s_values" % tag], rtol=1e-12, atol=1e-15)

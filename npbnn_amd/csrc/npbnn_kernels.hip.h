@@ -385,6 +385,31 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     return __hiloint2double(hi, lo);
 }
 
+// float64 sums across lanes without LDS traffic (the ds_bpermute behind __shfl_xor costs ~100 cycles per step, two per
+// double): rotations inside a 16-lane row by DPP, rows combined with the permlane swaps.  Every lane ends with the sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum_f64(double v) {      // over the 16 lanes of a row (row_ror:8, 4, 2, 1)
+    v += dpp_f64<0x128>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x122>(v);
+    v += dpp_f64<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {     // over all 64 lanes
+    v = row_sum_f64(v);
+    u32x2 rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    u32x2 rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    rl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    rh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
 #define NPBNN_WAIT_VMCNT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define NPBNN_WAIT_VMCNT(n) NPBNN_WAIT_VMCNT_(n)
 #define NPBNN_DEPTH (NPBNN_RING - 1)
@@ -1639,15 +1664,12 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
         for (int j = 0; j < D; ++j) {
             if constexpr (LK == kLikGauss) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int sh = 1; sh < 16; sh <<= 1) {
-                        A[j].s1[i] += shfl_xor_f64(A[j].s1[i], sh);
-                        A[j].s2[i] += shfl_xor_f64(A[j].s2[i], sh);
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    A[j].s1[i] = row_sum_f64(A[j].s1[i]);
+                    A[j].s2[i] = row_sum_f64(A[j].s2[i]);
+                }
             } else {
-#pragma unroll
-                for (int sh = 1; sh < 64; sh <<= 1) A[j].ll += shfl_xor_f64(A[j].ll, sh);
+                A[j].ll = wave_sum_f64(A[j].ll);
             }
         }
         __syncthreads();                                   // every wave is done with its ring: reuse the rings as scratch

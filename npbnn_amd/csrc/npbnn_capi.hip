@@ -115,7 +115,6 @@ struct npbnn_ctx {
     double* d_wcur = nullptr;
     double* d_pv = nullptr;        // [kMaxCand][M] proposed values of the candidates in flight
     size_t pv_cap = 0;
-    PassDesc* d_pass = nullptr;
     double* d_mask = nullptr;
     ChainDev* d_chain = nullptr;
     int* d_idx = nullptr;
@@ -470,7 +469,7 @@ EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
     p.image = ctx->d_image;
     p.n_rows = d.n_rows;
     p.n_tiles = d.n_tiles;
-    p.pass = nullptr;
+    p.has_pass = 0;
     p.Fp = ctx->net.l0_f16 ? d.Fp16 : d.Fp;
     p.net = ctx->net;
     return p;
@@ -629,7 +628,7 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_pass, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu};
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -993,7 +992,6 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
-    if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, 2 * sizeof(PassDesc)));
     const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
     if ((size_t)K > ctx->res_k || (size_t)ctx->n_weights != ctx->res_nw) {
         size_t kc = (size_t)K > ctx->res_k ? (size_t)K : ctx->res_k;
@@ -1082,7 +1080,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     }
     ChainParams c{};
     c.st = ctx->d_chain;
-    c.pass = ctx->d_pass;
+    c.pass = reinterpret_cast<PassDesc*>(reinterpret_cast<char*>(ctx->d_eparams) + offsetof(EvalParams, pass_desc));   // inside the evaluation's block
     c.w_cur = ctx->d_wcur;
     c.mask = mask_packed ? ctx->d_mask : nullptr;
     c.idx = ctx->d_idx;
@@ -1125,7 +1123,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
-    p.pass = ctx->d_pass;
+    p.has_pass = 1;
     p.pv = ctx->d_pv;
     p.pos = ctx->d_pos;
     p.pscale = f16 ? ctx->d_pscale : nullptr;
@@ -1242,16 +1240,15 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     if (rc) return rc;
     rc = stage_weights(ctx, W_packed, nullptr, nullptr);
     if (rc) return rc;
-    if (!ctx->d_pass) HIP_TRY(ctx, hipMalloc(&ctx->d_pass, sizeof(PassDesc)));
     PassDesc pd{};
     pd.t0 = 0;
     pd.n_cand = lp.n_cand;          // every candidate = the staged weights (empty patch lists): same work as a chain pass
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pass, &pd, sizeof(PassDesc), hipMemcpyHostToDevice, ctx->stream));
     EvalParams p = make_params(ctx, d);
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
-    p.pass = ctx->d_pass;
+    p.has_pass = 1;
+    p.pass_desc[0] = pd;
     p.pv = nullptr;
     p.pos = nullptr;
     p.pscale = nullptr;

@@ -109,7 +109,9 @@ struct EvalParams {
                               // weight sets, image j at image + j*image_floats, predictions of set j at y_out + j*n_rows*n_out
                               // (posterior prediction: several stored samples per streaming read of X)
     // speculative multi-candidate pass of a device-resident chain (nullptr / unused for a plain evaluation):
-    const PassDesc* pass;     // [2] which candidates this pass evaluates (entry = pass parity; parity 0 outside the overlapped schedule)
+    int has_pass;             // chain pass: pass_desc[parity] says which candidates this launch evaluates (parity 0 outside the
+    int pad_pass_;            // overlapped schedule).  The descriptors live INSIDE this block - the step writes them here - so the
+    PassDesc pass_desc[2];    // evaluation reads them with the rest of its parameters instead of through one more dependent load
     const double* pv;         // [2][kMaxCand][M] proposed values of the touched entries of each candidate
     const int* pos;           // [K][M] image position of every pre-drawn entry (w2img gather)
     const float* pscale;      // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
@@ -1321,8 +1323,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     int cnt[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) cnt[j] = 0;
-    const PassDesc* const pass0 = uni(p.pass);
-    const PassDesc* const pass = pass0 ? pass0 + par : nullptr;
+    const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
     const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
     if (pass) {
         if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished

@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 N_ROWS, N_FEATURES, N_CLASSES, HIDDEN = 100_000, 256, 10, [32, 8]
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the 3-candidate pass kernel measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# on this workload (profiles/r01_pass3_pmc_*.csv): (2 x 50679 KiB [gfx950 reports half of a wide streaming read] + 24 KiB)
-MEASURED_TRAFFIC_BYTES = (2 * 50679.0 + 24.0) * 1024
+# on this workload (profiles/r01_pass3_pmc_*.csv): (2 x 50701 KiB [gfx950 reports half of a wide streaming read] + 24 KiB)
+MEASURED_TRAFFIC_BYTES = (2 * 50701.0 + 24.0) * 1024
 
 
 def synthetic_config2():

@@ -27,6 +27,7 @@ from .files import SaveObject, load_obj  # noqa: F401
 from .logger import init_output_files, postLogger  # noqa: F401
 from .mc3 import MC3  # noqa: F401
 from .posterior import feature_importance, get_posterior_cat_prob, predictBNN, sample_from_categorical  # noqa: F401
+from .pdp import get_feature_summary, get_pdp, make_pdp_features, pdp  # noqa: F401
 from . import comm  # noqa: F401
 
 BNN = npBNN                       # BASELINE.json's wording

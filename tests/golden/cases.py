@@ -154,3 +154,15 @@ def posterior_inputs(seed=77, n_rows=97, n_features=11, n_nodes=(6, 5), n_classe
 
 POSTERIOR_CASES = [dict(name="tanh", fun="tanh", seed=77), dict(name="genrelu", fun="genReLU", seed=78),
                    dict(name="swish_bias3", fun="swish", seed=79, bias=3)]
+
+
+def pdp_inputs():
+    """Feature matrix for the partial-dependence vectors: column 0 continuous, column 3 ordinal, columns 8-10 one-hot."""
+    inp = posterior_inputs(**{k: v for k, v in POSTERIOR_CASES[0].items() if k != "name"})
+    xp = inp["x"].copy()
+    xp[:, 3] = np.round(np.abs(xp[:, 3]) * 2)
+    xp[:, 8:11] = np.eye(3)[np.random.default_rng(3).integers(0, 3, len(xp))]
+    return inp, xp
+
+
+PDP_FOCAL = (("cont", [0]), ("ord", [3]), ("ohe", [8, 9, 10]))

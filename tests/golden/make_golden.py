@@ -254,6 +254,14 @@ def g7_posterior():
         out["fi_%s_index" % tag] = df["feature_block_index"].to_numpy().astype(np.int64)
         out["fi_%s_values" % tag] = df.iloc[:, 2:].to_numpy().astype(np.float64)
         out["fi_%s_names" % tag] = df["feature_name"].to_numpy().astype(str)
+    # partial dependence: continuous focal feature (100 steps), an ordinal one, a one-hot block
+    inp, xp = cases.pdp_inputs()
+    weights = [s["weights"] for s in inp["samples"]]
+    alphas = [s["alphas"] for s in inp["samples"]]
+    for tag, focal in cases.PDP_FOCAL:
+        res = quiet(bn.get_pdp, xp, focal, "classification", 4, bn.ActFun(fun=inp["fun"]), bn.SoftMax, weights, alphas, None)
+        out["pdp_%s_feature" % tag] = res["feature"]
+        out["pdp_%s_pdp" % tag] = res["pdp"]
     np.savez_compressed(os.path.join(HERE, "posterior.npz"), **out)
     print("posterior.npz")
 

@@ -104,3 +104,14 @@ def test_feature_importance_matches_reference(tag, blocks, golden_dir):
         np.testing.assert_allclose(values, want, atol=1.5 / len(inp["labels"]), rtol=0)
     else:       # a one-instance difference may swap two neighbours of the ranking
         np.testing.assert_allclose(np.sort(values[:, 0]), np.sort(want[:, 0]), atol=1.5 / len(inp["labels"]), rtol=0)
+
+
+@pytest.mark.parametrize("tag,focal", cases.PDP_FOCAL)
+def test_partial_dependence_matches_reference(tag, focal, golden_dir):
+    import npbnn_amd as bn
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    inp, xp = cases.pdp_inputs()
+    res = bn.get_pdp(xp, focal, "classification", 4, bn.ActFun(fun=inp["fun"]), bn.SoftMax,
+                     [s["weights"] for s in inp["samples"]], [s["alphas"] for s in inp["samples"]], None)
+    np.testing.assert_array_equal(res["feature"], g["pdp_%s_feature" % tag])
+    np.testing.assert_allclose(res["pdp"], g["pdp_%s_pdp" % tag], atol=TOL, rtol=0)

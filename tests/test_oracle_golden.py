@@ -229,3 +229,12 @@ def test_g7_feature_importance(tag, blocks, golden_dir):
     np.testing.assert_array_equal(order, g["fi_%s_index" % tag])
     assert [str(n) for n in names] == [str(n) for n in g["fi_%s_names" % tag]]
     np.testing.assert_allclose(table, g["fi_%s_values" % tag], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("tag,focal", cases.PDP_FOCAL)
+def test_g7_partial_dependence_gradient(tag, focal, golden_dir):
+    """The host half of get_pdp (feature gradients) is pure numpy in the product; pin it here without a GPU."""
+    from npbnn_amd.pdp import make_pdp_features
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    _, xp = cases.pdp_inputs()
+    np.testing.assert_array_equal(make_pdp_features(xp, focal), g["pdp_%s_feature" % tag])

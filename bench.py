@@ -135,6 +135,10 @@ def main():
     else:
         comm_kind = "none"
 
+    # the swap proposal (which two chains, the uniform of the accept test: BNN_mc3.py:99,110) comes from a stream every rank
+    # seeds identically, so one all-gather of [logPost, temperature] is the whole exchange: each rank reaches the same decision
+    swap_rs = np.random.RandomState(4321)
+
     def advance(n):
         """n iterations of every chain; with several chains, a temperature-swap exchange every swap_frequency."""
         done = 0
@@ -144,13 +148,9 @@ def main():
             done += k
             if world > 1 and done % swap_frequency == 0:
                 scal = comm.allgather_f64(np.array([mcmc._logPost, mcmc._temperature]))
-                dec = np.zeros(3, dtype=np.int64)
-                if rank == 0:
-                    j, k2 = np.random.choice(range(world), 2, replace=False)
-                    r = (scal[k2, 0] - scal[j, 0]) * scal[j, 1] + (scal[j, 0] - scal[k2, 0]) * scal[k2, 1]
-                    dec[:] = (j, k2, 1 if r >= np.log(np.random.random()) else 0)
-                j, k2, ok = (int(v) for v in comm.bcast_i64(dec, root=0))
-                if ok:
+                j, k2 = swap_rs.choice(range(world), 2, replace=False)
+                r = (scal[k2, 0] - scal[j, 0]) * scal[j, 1] + (scal[j, 0] - scal[k2, 0]) * scal[k2, 1]
+                if r >= np.log(swap_rs.random_sample()):
                     if rank == j:
                         mcmc.reset_temperature(scal[k2, 1])
                     elif rank == k2:

@@ -200,7 +200,10 @@ class HipContext:
         (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
         w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
         K, M = idx.shape
-        cfg = capi.ChainCfg()
+        cfg = self.__dict__.get("_chain_cfg")
+        if cfg is None:
+            cfg = self._chain_cfg = capi.ChainCfg()
+            self._chain_res = capi.ChainResult()
         cfg.prior_kind = int(prior_kind)
         for i, s in enumerate(prior_scale):
             cfg.prior_scale[i] = float(s)
@@ -219,18 +222,21 @@ class HipContext:
         cfg.n_candidates = int(n_candidates)
         cfg.schedule = int(schedule)
         m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
-        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if idx.dtype != np.int32 or not idx.flags.c_contiguous:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if cnt.dtype != np.int32 or not cnt.flags.c_contiguous:
+            cnt = np.ascontiguousarray(cnt, dtype=np.int32)
         delta = capi.as_f64(delta)
-        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
         log_u = capi.as_f64(log_u)
         acc = np.empty(K, dtype=np.uint8)
         llp, lpp = np.empty(K), np.empty(K)
-        res = capi.ChainResult()
+        res = self._chain_res
+        i32p = C.POINTER(C.c_int32)
         for attempt in (0, 1):
             cfg.force_f32 = attempt
             rc = self._lib.npbnn_chain_run(
-                self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(C.POINTER(C.c_int32)),
-                capi.dptr(delta), cnt.ctypes.data_as(C.POINTER(C.c_int32)), capi.dptr(log_u),
+                self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(i32p),
+                capi.dptr(delta), cnt.ctypes.data_as(i32p), capi.dptr(log_u),
                 acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res))
             if rc == capi.E_RANGE and attempt == 0:
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)

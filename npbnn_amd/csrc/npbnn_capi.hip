@@ -628,7 +628,7 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_cnt, c->d_logu};
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -993,26 +993,43 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (rc) return rc;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
     const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    // one block, device and page-locked host twin: [ChainDev | overflow | W | cnt | log u || accepted | logLik' | logPrior'];
+    // everything before `||` goes up in ONE copy at the start of a batch, the whole block comes back in one at its end
+    struct ResLayout { size_t w, cnt, logu, acc, llp, lpp, total; };
+    const auto layout = [&](size_t kc) {
+        ResLayout L;
+        L.w = 512;
+        L.cnt = L.w + up256(wb);
+        L.logu = L.cnt + up256(kc * sizeof(int));
+        L.acc = L.logu + up256(kc * sizeof(double));
+        L.llp = L.acc + up256(kc);
+        L.lpp = L.llp + up256(kc * sizeof(double));
+        L.total = L.lpp + up256(kc * sizeof(double));
+        return L;
+    };
     if ((size_t)K > ctx->res_k || (size_t)ctx->n_weights != ctx->res_nw) {
         size_t kc = (size_t)K > ctx->res_k ? (size_t)K : ctx->res_k;
         if (kc < kChainMinCapacity) kc = kChainMinCapacity;
-        const size_t total = 512 + up256(wb) + up256(kc) + 2 * up256(kc * sizeof(double));
+        const ResLayout L = layout(kc);
         if (ctx->d_res) (void)hipFree(ctx->d_res);
         if (ctx->h_res) (void)hipHostFree(ctx->h_res);
         if (ctx->d_mask) (void)hipFree(ctx->d_mask);        // sized by the number of weights as well
         ctx->d_mask = nullptr;
         ctx->d_res = nullptr; ctx->h_res = nullptr; ctx->res_cap = 0; ctx->res_k = 0; ctx->res_nw = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_res, total));
-        HIP_TRY(ctx, hipHostMalloc(&ctx->h_res, total));
-        ctx->res_cap = total; ctx->res_k = kc; ctx->res_nw = (size_t)ctx->n_weights;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_res, L.total));
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_res, L.total));
+        ctx->res_cap = L.total; ctx->res_k = kc; ctx->res_nw = (size_t)ctx->n_weights;
         char* b = ctx->d_res;
         ctx->d_chain = reinterpret_cast<ChainDev*>(b);
         ctx->d_chain_ovf = reinterpret_cast<int*>(b + 256);
-        ctx->d_wcur = reinterpret_cast<double*>(b + 512);
-        ctx->d_acc = reinterpret_cast<unsigned char*>(b + 512 + up256(wb));
-        ctx->d_llp = reinterpret_cast<double*>(b + 512 + up256(wb) + up256(kc));
-        ctx->d_lpp = reinterpret_cast<double*>(b + 512 + up256(wb) + up256(kc) + up256(kc * sizeof(double)));
+        ctx->d_wcur = reinterpret_cast<double*>(b + L.w);
+        ctx->d_cnt = reinterpret_cast<int*>(b + L.cnt);
+        ctx->d_logu = reinterpret_cast<double*>(b + L.logu);
+        ctx->d_acc = reinterpret_cast<unsigned char*>(b + L.acc);
+        ctx->d_llp = reinterpret_cast<double*>(b + L.llp);
+        ctx->d_lpp = reinterpret_cast<double*>(b + L.lpp);
     }
+    const ResLayout RL = layout(ctx->res_k);
     static_assert(sizeof(ChainDev) <= 256, "ChainDev must fit its slot of the result block");
     if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
     if ((size_t)M > ctx->pv_cap) {
@@ -1035,18 +1052,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         HIP_TRY(ctx, hipMalloc(&ctx->d_pscale, cap * sizeof(float)));
         ctx->draw_cap = cap;
     }
-    if ((size_t)K > ctx->iter_cap) {
-        const size_t kcap = (size_t)K > kChainMinCapacity ? (size_t)K : kChainMinCapacity;
-        if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
-        if (ctx->d_logu) (void)hipFree(ctx->d_logu);
-        ctx->d_cnt = nullptr; ctx->d_logu = nullptr;
-        ctx->iter_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_cnt, kcap * sizeof(int)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_logu, kcap * sizeof(double)));
-        ctx->iter_cap = kcap;
-    }
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wcur, W_inout, wb, hipMemcpyHostToDevice, st));
     if (mask_packed) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mask, mask_packed, wb, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_idx, idx, need * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_delta, delta, need * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1055,8 +1061,6 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     hipLaunchKernelGGL(gather_pos_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, (const int*)ctx->d_idx, (long long)need,
                        (const int*)ctx->d_w2img, (const float*)(f16 ? ctx->d_w2scale : nullptr), ctx->d_pos,
                        f16 ? ctx->d_pscale : (float*)nullptr);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cnt, cnt, (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_logu, log_u, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
     ChainDev init{};
     init.logLik = cfg->cur_loglik;
     init.logPrior = cfg->cur_logprior;
@@ -1066,10 +1070,13 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     init.n_passes = 0;
     init.void_launch = -2;
     init.n_void = 0;
-    {   // initial chain state and the overflow flag travel together (first 512 bytes of the result block)
+    {   // initial chain state, overflow flag, weights and the per-iteration scalars travel together (head of the block)
         memset(ctx->h_res, 0, 512);
         memcpy(ctx->h_res, &init, sizeof(ChainDev));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_res, ctx->h_res, 512, hipMemcpyHostToDevice, st));
+        memcpy(ctx->h_res + RL.w, W_inout, wb);
+        memcpy(ctx->h_res + RL.cnt, cnt, (size_t)K * sizeof(int));
+        memcpy(ctx->h_res + RL.logu, log_u, (size_t)K * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_res, ctx->h_res, RL.acc, hipMemcpyHostToDevice, st));
     }
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
     {   // weight image of the current state; accepted candidates are committed to it entry by entry
@@ -1138,7 +1145,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
     const double tw1 = wall();
     int t_done = 0, n_passes = 0, n_rounds = 0, launch = 0;
-    const size_t res_used = 512 + up256(wb) + up256(ctx->res_k) + 2 * up256(ctx->res_k * sizeof(double));
+    const size_t res_used = RL.total;
     const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
     while (t_done < K) {
         ++n_rounds;
@@ -1178,11 +1185,11 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
     {
         const char* b = ctx->h_res;
-        memcpy(W_inout, b + 512, wb);
-        memcpy(out_accepted, b + 512 + up256(wb), (size_t)K);
-        if (out_loglik_prop) memcpy(out_loglik_prop, b + 512 + up256(wb) + up256(ctx->res_k), (size_t)K * sizeof(double));
+        memcpy(W_inout, b + RL.w, wb);
+        memcpy(out_accepted, b + RL.acc, (size_t)K);
+        if (out_loglik_prop) memcpy(out_loglik_prop, b + RL.llp, (size_t)K * sizeof(double));
         if (out_logprior_prop)
-            memcpy(out_logprior_prop, b + 512 + up256(wb) + up256(ctx->res_k) + up256(ctx->res_k * sizeof(double)), (size_t)K * sizeof(double));
+            memcpy(out_logprior_prop, b + RL.lpp, (size_t)K * sizeof(double));
     }
     if (d_stamps) {
         std::vector<unsigned long long> hs(1024 * 8);

@@ -1,0 +1,491 @@
+// Partial-sum reduction, log-likelihood from the sums, and the device-resident Metropolis-Hastings chain step
+// (part of the device code of the npBNN hot path, see npbnn_kernels.hip.h)
+#pragma once
+#include "npbnn_common.hip.h"
+#include "npbnn_pack.hip.h"
+
+namespace npbnn {
+
+// ------------------------------------------------------------------------------------------------
+// finalize: reduce the per-wave partials in a fixed order and form the log-likelihood
+// ------------------------------------------------------------------------------------------------
+struct FinalizeParams {
+    const double* partials;
+    int n_waves;
+    int lik_kind;
+    int k_targets;
+    long long n_rows;
+    double lik_temp;
+    int sigma_given;
+    double sigma[NPBNN_MAX_TARGETS];
+    npbnn_eval_out* out;   // device
+};
+
+// Sum value v of every wave's partial record: wave (threadIdx>>6) of the block takes values v = wave, wave+nw, ...;
+// lane l adds records l, l+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int nvals, double* tot /*LDS*/) {
+    // partials are laid out [value][workgroup]; wave w of this block sums values w, w+nw, ...: each lane adds workgroups
+    // lane, lane+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int v = wave; v < nvals; v += nw) {
+        double s = 0.0;
+        for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)v * n_blocks + b];
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
+        if (lane == 0) tot[v] = s;
+    }
+    __syncthreads();
+}
+
+// log-likelihood (and sigma / residual moments) from the reduced totals; one thread.
+__device__ __forceinline__ void loglik_from_totals(const double* tot, int lik_kind, int k_targets, long long n_rows, double lik_temp,
+                                                   int sigma_given, const double* sigma_in, npbnn_eval_out* o) {
+    o->n_rows = n_rows;
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { o->sigma[j] = 0; o->sum_r[j] = 0; o->sum_r2[j] = 0; }
+    if (lik_kind == NPBNN_LIK_GAUSS) {
+        // sum_j [ -N (0.5 log 2pi + log s_j) - S2_j / (2 s_j^2) ];  empirical s_j = population std of the residuals
+        // (np.std, BNN_env.py:475-476; scipy.stats.norm.logpdf, BNN_lib.py:131)
+        const double N = (double)n_rows;
+        double ll = 0.0;
+        for (int j = 0; j < k_targets; ++j) {
+            const double S1 = tot[1 + j], S2 = tot[1 + NPBNN_MAX_TARGETS + j];
+            double sg;
+            if (sigma_given) sg = sigma_in[j];
+            else {
+                const double mean = S1 / N;
+                sg = sqrt(S2 / N - mean * mean);
+            }
+            o->sigma[j] = sg; o->sum_r[j] = S1; o->sum_r2[j] = S2;
+            ll += -N * (0.9189385332046727418 + log(sg)) - S2 / (2.0 * sg * sg);
+        }
+        o->loglik = lik_temp * ll;
+    } else {
+        // the plug-in count likelihoods ignore lik_temp (BNN_lik.py:5-66)
+        o->loglik = (lik_kind >= NPBNN_LIK_POISSON && lik_kind <= NPBNN_LIK_NEGBIN_BASE10 ? 1.0 : lik_temp) * tot[0];
+    }
+}
+
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams* __restrict__ fp) {
+    const FinalizeParams& f = *fp;
+    __shared__ double tot[kPartialStride];
+    const int nvals = (f.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+    reduce_partials(f.partials, f.n_waves, nvals, tot);
+    if (threadIdx.x == 0) loglik_from_totals(tot, f.lik_kind, f.k_targets, f.n_rows, f.lik_temp, f.sigma_given, f.sigma, f.out);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+// ------------------------------------------------------------------------------------------------
+// device-resident Metropolis-Hastings chain: state and parameter blocks (the step itself is chain_step, below)
+// ------------------------------------------------------------------------------------------------
+struct ChainDev {          // device-resident chain state
+    double logLik, logPrior;
+    double sigma[NPBNN_MAX_TARGETS];
+    double cand_logPrior[2][kMaxCand];   // log priors of the candidates of the two passes in the pipeline (by pass parity)
+    int t;                  // iterations decided so far in this batch
+    int n_accepted;
+    int n_passes;           // evaluation passes that decided at least one iteration
+    int void_launch;        // overlapped mode: launch whose pass was evaluated from a state that an accept has since replaced
+    int n_void;             // such passes in this batch
+    int pad_;
+};
+
+struct ChainParams {
+    ChainDev* st;
+    PassDesc* pass;            // [2] candidates of the passes in the pipeline, by pass parity (read by the evaluation kernel)
+    double* w_cur;             // float64 master copy of the current weights
+    const double* mask;        // or nullptr
+    const int* idx;            // [K][M] pre-drawn packed-weight indices (-1: superseded entry)
+    const double* delta;       // [K][M]
+    const int* cnt;            // [K]
+    const double* log_u;       // [K]
+    const double* hastings;    // [K] or nullptr
+    unsigned char* out_acc;    // [K]
+    double* out_ll;            // [K] proposed logLik
+    double* out_lp;            // [K] proposed logPrior
+    const double* partials;    // [2][candidate][kPartialStride][n_blocks], by pass parity
+    float* image;              // fragment image of the current weights, read by the evaluation kernel
+    const int* pos;            // [K][M] image position of every pre-drawn entry; bit 31 set: fp16-split layer-0 entry (the
+                               // low bits are the half index of the high part, low part 512 halfs later); kSkipPos: none
+    const float* pscale;       // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
+    double* pv;                // [2][kMaxCand][M] proposed values of the candidates of the passes in the pipeline
+    int* overflow;             // set when a scaled weight leaves the fp16 range
+    unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1), else nullptr
+    int K, M, D, n_blocks;
+    int prior_kind;
+    double prior_scale[kMaxLayers];
+    double half_inv_s2[kMaxLayers];   // 0.5 / scale^2 (normal prior)
+    double w_bound;
+    double temperature, lik_temp;
+    int sigma_given;           // Gaussian: 1 = use sigma_fixed, 0 = empirical
+    double sigma_fixed[NPBNN_MAX_TARGETS];
+    long long n_rows;
+    NetMeta net;
+};
+
+constexpr int kSkipPos = 0x7fffffff;
+
+__device__ __forceinline__ double log_prior_density(int kind, double w, double scale) {
+    if (kind == NPBNN_PRIOR_CAUCHY) return -log(3.14159265358979323846 * scale * (1.0 + (w / scale) * (w / scale)));
+    if (kind == NPBNN_PRIOR_LAPLACE) return -log(2.0 * scale) - fabs(w) / scale;
+    return -0.5 * (w / scale) * (w / scale) - log(scale) - 0.9189385332046727418;
+}
+
+// change of the log prior density when an entry moves from `b` to `v` (scale sc); the normal prior needs no
+// transcendental: -(v^2 - b^2) / (2 sc^2)
+__device__ __forceinline__ double prior_delta(int kind, double v, double b, double sc) {
+    if (kind == NPBNN_PRIOR_NORMAL) return -0.5 * (v * v - b * b) / (sc * sc);
+    if (kind == NPBNN_PRIOR_LAPLACE) return -(fabs(v) - fabs(b)) / sc;
+    return log((sc * sc + b * b) / (sc * sc + v * v));                  // Cauchy
+}
+
+// image position / fp16-split scale of every pre-drawn entry, gathered once per batch
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__ idx, long long n, const int* __restrict__ w2img,
+                                                         const float* __restrict__ w2scale, int* __restrict__ pos, float* __restrict__ pscale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int w = idx[i];
+    pos[i] = w >= 0 ? w2img[w] : kSkipPos;
+    if (pscale) pscale[i] = (w >= 0 && w2scale) ? w2scale[w] : 1.0f;
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+__device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) {
+    if (pos < 0) {                                   // fp16-split layer-0 entry
+        const float wv = (float)(v * (double)scale);
+        _Float16 hi, lo;
+        split_f16(wv, hi, lo);
+        _Float16* img16 = reinterpret_cast<_Float16*>(c.image);
+        const int h = pos & 0x7fffffff;
+        img16[h] = hi;
+        img16[h + 512] = lo;
+    } else {
+        c.image[pos] = (float)v;
+    }
+}
+
+// block-wide sum of one double per thread, fixed order; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 doubles*/) {
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) v += shfl_xor_f64(v, sh);
+    __syncthreads();                                  // `red` may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident Metropolis-Hastings chain, speculative over D candidates per pass
+//
+// K iterations of MCMC.mh_step (BNN_env.py:381-532, default path: UpdateNormal proposals, BNN_mcmc.py:57-69); the host
+// pre-draws the random numbers of the K iterations (npbnn_host.c), so the proposals are the reference's.  chain_step (one
+// workgroup):
+//   1. decide the candidates of an evaluated pass, in iteration order (fixed-order reduction of the per-workgroup partials
+//      -> logLik', accept test (logPost' - logPost) * temperature + hastings >= log u, BNN_env.py:493-494) and stop at the first
+//      accepted one: it is committed to W_cur and to the weight image; later candidates of the pass were computed from a
+//      state that no longer exists and are simply dropped (their iterations are evaluated again);
+//   2. prepare the next candidates: for j < D, W_cur[idx] + delta of iteration t+j, reflected at +-bound and masked
+//      (BNN_mcmc.py:64-67, BNN_env.py:461-462), stored as a patch list (the evaluation kernel applies it to its LDS image);
+//      logPrior' = logPrior + sum of per-entry prior changes (npBNN.calc_prior, BNN_env.py:180-194; full sum at batch start).
+//
+// Two schedules (StepPlan):
+//   serial      eval(L) -> step(L) -> eval(L+1) ...: the step decides the pass just evaluated and prepares the next one.
+//   overlapped  one launch per pass; the last workgroup of launch L runs the step for pass L-1 WHILE the other workgroups
+//               evaluate pass L, whose candidates were prepared one launch earlier on the assumption that pass L-1 rejects
+//               everything (true for ~91 % of the passes at the 3 % acceptance rate of config 2).  The step prepares pass
+//               L+1.  When pass L-1 does accept, pass L was evaluated from a state that no longer exists: it is marked void,
+//               never decided, and pass L+1 restarts right after the accepted iteration.  Either way every decision is made
+//               in iteration order on sums computed from the true current state: the chain is the sequential one.
+// ------------------------------------------------------------------------------------------------
+struct StepPlan {
+    int first;     // first launch of a batch: full prior of the current state, no pass to decide
+    int dec;       // parity of the pass to decide, or -1
+    int fly;       // parity of the pass being evaluated while this step runs (overlapped schedule), or -1
+    int out;       // parity of the pass to prepare
+    int launch;    // launch index within the batch (overlapped schedule)
+};
+__device__ __forceinline__ StepPlan overlapped_plan(int launch) {
+    StepPlan pl;
+    pl.first = 0;
+    pl.dec = launch >= 1 ? ((launch - 1) & 1) : -1;
+    pl.fly = launch & 1;
+    pl.out = (launch + 1) & 1;
+    pl.launch = launch;
+    return pl;
+}
+
+struct StepShared {            // LDS scratch of chain_step
+    double tot[kMaxCand][kPartialStride];
+    double red[16];
+    double red3[kMaxCand][16];
+    npbnn_eval_out o;
+    double s_lp;               // log prior of the state the next candidates start from
+    int s_accepted, s_t, s_start;
+};
+
+__device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan pl, StepShared& sh) {
+    const int tid = threadIdx.x;
+    ChainDev* st = c.st;
+    const int lik_kind = c.net.lik_kind;
+    const size_t pv_stride = (size_t)kMaxCand * c.M;
+    const size_t part_stride = (size_t)kMaxCand * kPartialStride * c.n_blocks;
+    const int stamp_row = pl.first ? 0 : (c.pass[pl.dec >= 0 ? pl.dec : 0].t0 & 1023);
+#define NPBNN_STAMP(k) do { if (c.stamps && threadIdx.x == 0) c.stamps[(size_t)stamp_row * 8 + (k)] = wall_clock64(); } while (0)
+    NPBNN_STAMP(0);
+
+    // at the start of a batch the prior of the current state is summed in full (proposals then update it
+    // incrementally from the touched entries, so rounding drift cannot accumulate across batches)
+    if (pl.first && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+        double lp = 0.0;
+        for (int l = 0; l < c.net.n_layers; ++l) {
+            const LayerMeta& L = c.net.L[l];
+            const int n = L.out_dim * (L.in_dim + L.has_bias);
+            const double sc = c.prior_scale[l];
+            if (c.prior_kind == NPBNN_PRIOR_NORMAL) {
+                double q = 0.0;
+                for (int i = tid; i < n; i += blockDim.x) { const double w = c.w_cur[L.w_off + i]; q += w * w; }
+                lp += -0.5 * q / (sc * sc);
+                if (tid == 0) lp -= (double)n * (log(sc) + 0.9189385332046727418);
+            } else {
+                for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_cur[L.w_off + i], sc);
+            }
+        }
+        const double s = block_sum(lp, sh.red);
+        if (tid == 0) st->logPrior = s;
+    }
+
+    // ---- 1. decide the pending candidates ----
+    int t0 = 0, n_pend = 0;
+    if (pl.dec >= 0) {
+        t0 = c.pass[pl.dec].t0;
+        n_pend = c.pass[pl.dec].n_cand;
+        if (pl.fly >= 0 && st->void_launch == pl.launch - 1) n_pend = 0;     // that pass saw a state that an accept replaced
+    }
+    double prefetch_sink = 0.0;
+    if (pl.fly < 0) {   // serial schedule: whichever candidate wins, the next pass starts at t0+1 .. t0+n_pend: pull those rows of
+        // the pre-drawn arrays towards the L2 now, while the partial sums are being reduced (the values are not used here)
+        const int r_lo = t0 + (pl.first ? 0 : 1), r_hi = min(c.K, t0 + n_pend + c.D);
+        double sink = 0.0;
+        for (int r = r_lo; r < r_hi; ++r)
+            if (tid < c.M) sink += (double)c.idx[(size_t)r * c.M + tid] + c.delta[(size_t)r * c.M + tid] + (double)c.pos[(size_t)r * c.M + tid];
+        prefetch_sink = sink;
+    }
+    // decision operands, fetched now by the deciding thread so that they are in registers when the sums arrive
+    double d_cand[kMaxCand], d_logu[kMaxCand], d_h[kMaxCand], d_ll = 0.0, d_lp = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMaxCand; ++j) { d_cand[j] = 0.0; d_logu[j] = 0.0; d_h[j] = 0.0; }
+    if (tid == 0 && n_pend > 0) {
+        d_ll = st->logLik;
+        d_lp = st->logPrior;
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j)
+            if (j < n_pend) {
+                d_cand[j] = st->cand_logPrior[pl.dec][j];
+                d_logu[j] = c.log_u[t0 + j];
+                d_h[j] = c.hastings ? c.hastings[t0 + j] : 0.0;
+            }
+    }
+    NPBNN_STAMP(1);
+    if (n_pend > 0) {
+        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+        {   // wave w sums items w, w+nw, ... (item = candidate * nvals + value): lanes add workgroups lane, lane+64, ... in order
+            const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+            const double* part = c.partials + (size_t)pl.dec * part_stride;
+            for (int item = wave; item < n_pend * nvals; item += nw) {
+                const int j = item / nvals, v = item % nvals;
+                const double* src = part + ((size_t)j * kPartialStride + v) * c.n_blocks;
+                double s = 0.0;
+                for (int b = lane; b < c.n_blocks; b += 64) s += src[b];
+#pragma unroll
+                for (int shf = 32; shf > 0; shf >>= 1) s += shfl_xor_f64(s, shf);
+                if (lane == 0) sh.tot[j][v] = s;
+            }
+        }
+        __syncthreads();
+        NPBNN_STAMP(2);
+        if (tid == 0) {
+            int accepted = -1, n_done = n_pend;
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                if (j < n_pend && accepted < 0) {
+                    const int t = t0 + j;
+                    loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &sh.o);
+                    const double lp = d_cand[j];
+                    const double post_new = sh.o.loglik + lp, post_old = d_ll + d_lp;
+                    const int a = ((post_new - post_old) * c.temperature + d_h[j] >= d_logu[j]) ? 1 : 0;
+                    c.out_acc[t] = (unsigned char)a;
+                    c.out_ll[t] = sh.o.loglik;
+                    c.out_lp[t] = lp;
+                    if (a) {
+                        st->logLik = sh.o.loglik;
+                        st->logPrior = lp;
+                        st->n_accepted += 1;
+                        if (lik_kind == NPBNN_LIK_GAUSS)
+                            for (int q = 0; q < c.net.k_targets; ++q) st->sigma[q] = sh.o.sigma[q];
+                        accepted = j;
+                        n_done = j + 1;
+                        sh.s_lp = lp;
+                    }
+                }
+            }
+            if (accepted < 0) sh.s_lp = d_lp;
+            st->t = t0 + n_done;
+            st->n_passes += 1;
+            sh.s_accepted = accepted;
+            sh.s_t = t0 + n_done;
+            // where the next candidates start: right after the decided iterations - unless a pass is being evaluated right now
+            // and is still good (nothing accepted): it covers the iterations after these, the new candidates follow it
+            int start = t0 + n_done;
+            if (pl.fly >= 0) {
+                if (accepted >= 0) {
+                    st->void_launch = pl.launch;
+                    if (c.pass[pl.fly].n_cand > 0) st->n_void += 1;
+                } else {
+                    start = c.pass[pl.fly].t0 + c.pass[pl.fly].n_cand;
+                }
+            }
+            sh.s_start = start;
+        }
+        __syncthreads();
+        NPBNN_STAMP(3);
+        const int a = sh.s_accepted;
+        if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
+            const size_t row = (size_t)(t0 + a) * c.M;
+            const int n = c.cnt[t0 + a];
+            const double* pv = c.pv + (size_t)pl.dec * pv_stride;
+            for (int e = tid; e < n; e += blockDim.x) {
+                const int i = c.idx[row + e];
+                if (i >= 0) {
+                    const double v = pv[(size_t)a * c.M + e];
+                    c.w_cur[i] = v;
+                    patch_global_image(c, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, v);
+                }
+            }
+        }
+        __syncthreads();
+    } else if (tid == 0) {
+        const int t_now = pl.first ? 0 : st->t;
+        if (pl.first) st->t = 0;
+        sh.s_t = t_now;
+        sh.s_lp = st->logPrior;
+        // nothing decided (start of a batch, or the pending pass was void): the pass in flight, if any, is good
+        sh.s_start = pl.fly >= 0 ? c.pass[pl.fly].t0 + c.pass[pl.fly].n_cand : t_now;
+    }
+    __syncthreads();
+
+    NPBNN_STAMP(4);
+    // ---- 2. prepare the next candidates: each is the current state plus its own iteration's perturbation.  Work items
+    //      are (candidate, entry) pairs spread over the whole workgroup; the three prior sums share one reduction. ----
+    const int t_new = sh.s_start;
+    int n_new = c.K - t_new;
+    if (n_new > c.D) n_new = c.D;
+    if (n_new < 0) n_new = 0;
+    double dlp[kMaxCand];
+    {
+        // staged so that the loads of all candidates are in flight together: (1) the pre-drawn entry, (2) the weight it
+        // touches, (3) arithmetic and stores.  One entry per thread and candidate; wider proposals loop.
+        const double* __restrict__ wcur = c.w_cur;
+        const double* __restrict__ mask = c.mask;
+        double* __restrict__ pv_out = c.pv + (size_t)pl.out * pv_stride;
+        int woff[kMaxLayers];
+        double half_inv_s2[kMaxLayers];
+#pragma unroll
+        for (int q = 0; q < kMaxLayers; ++q) {
+            woff[q] = q < c.net.n_layers ? c.net.L[q].w_off : 0x7fffffff;
+            half_inv_s2[q] = c.half_inv_s2[q];
+        }
+        int ii[kMaxCand], pp[kMaxCand];
+        double dd[kMaxCand], bb[kMaxCand], mm[kMaxCand];
+        float ss[kMaxCand];
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+            dlp[j] = 0.0;
+            ii[j] = -1; pp[j] = 0; dd[j] = 0.0; ss[j] = 1.0f;
+            if (j < n_new && tid < c.cnt[t_new + j]) {
+                const size_t k = (size_t)(t_new + j) * c.M + tid;
+                ii[j] = c.idx[k];
+                dd[j] = c.delta[k];
+                pp[j] = c.pos[k];
+                if (c.pscale) ss[j] = c.pscale[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+            bb[j] = ii[j] >= 0 ? wcur[ii[j]] : 0.0;
+            mm[j] = (ii[j] >= 0 && mask) ? mask[ii[j]] : 1.0;
+        }
+        auto make = [&](int j, int e, int i, double base, double d, double m, int pos, float sc) {
+            double v = base + d;
+            if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
+            if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
+            v *= m;
+            pv_out[(size_t)j * c.M + e] = v;
+            if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) *c.overflow = 1;
+            if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+                int l = 0;
+#pragma unroll
+                for (int q = 1; q < kMaxLayers; ++q) l += (i >= woff[q]) ? 1 : 0;
+                if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * half_inv_s2[l];
+                else dlp[j] += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) {
+            if (ii[j] >= 0) make(j, tid, ii[j], bb[j], dd[j], mm[j], pp[j], ss[j]);
+            if (j < n_new) {
+                const size_t row = (size_t)(t_new + j) * c.M;
+                for (int e = tid + blockDim.x; e < c.cnt[t_new + j]; e += blockDim.x) {
+                    const int i = c.idx[row + e];
+                    if (i >= 0) make(j, e, i, wcur[i], c.delta[row + e], mask ? mask[i] : 1.0, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f);
+                }
+            }
+        }
+    }
+    NPBNN_STAMP(5);
+#pragma unroll
+    for (int j = 0; j < kMaxCand; ++j) {
+#pragma unroll
+        for (int shf = 32; shf > 0; shf >>= 1) dlp[j] += shfl_xor_f64(dlp[j], shf);
+        if ((tid & 63) == 0) sh.red3[j][tid >> 6] = dlp[j];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double base_lp = sh.s_lp;
+        PassDesc d;
+        d.t0 = t_new;
+        d.n_cand = n_new;
+        for (int j = 0; j < kMaxCand; ++j) {
+            double sj = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sj += sh.red3[j][w];
+            if (j < n_new) st->cand_logPrior[pl.out][j] = base_lp + sj;
+            d.cnt[j] = j < n_new ? c.cnt[t_new + j] : 0;
+        }
+        d.pad[0] = d.pad[1] = d.pad[2] = 0;
+        c.pass[pl.out] = d;
+    }
+    if (prefetch_sink == 1.2345e300) c.out_lp[0] = prefetch_sink;      // keeps the prefetch loads alive; never true
+    NPBNN_STAMP(6);
+#undef NPBNN_STAMP
+}
+
+#ifdef NPBNN_KERNELS_MAIN
+// serial schedule: the step as a kernel of its own, between two evaluation kernels (and as the first launch of every batch)
+__global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int first_launch) {
+    const ChainParams& c = *cp;           // device-resident parameter block; only the per-launch scalar travels as an argument
+    __shared__ StepShared sh;
+    if (!first_launch && c.pass[0].n_cand == 0) return;      // launched past the end of the batch
+    StepPlan pl;
+    pl.first = first_launch;
+    pl.dec = first_launch ? -1 : 0;
+    pl.fly = -1;
+    pl.out = 0;
+    pl.launch = 0;
+    chain_step(c, pl, sh);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+}  // namespace npbnn

@@ -1,0 +1,258 @@
+// Shared definitions: layout constants, parameter blocks, lane-level helpers
+// (part of the device code of the npBNN hot path, see npbnn_kernels.hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "npbnn_hip.h"
+
+namespace npbnn {
+
+constexpr int kMaxLayers = NPBNN_MAX_LAYERS;
+constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
+#ifndef NPBNN_RING
+#define NPBNN_RING 4
+#endif
+constexpr int kRing = NPBNN_RING;              // X ring slots (1 KiB each) per wave; kRing-1 pieces stay in flight
+constexpr int kMaxWavesPerBlock = 16;
+constexpr int kAuxSlots = 4;                   // per-wave row-aux buffers (labels / weights / targets)
+// per-wave aux slot: labels (64 B) + instance weights (64 B) + 16 x k targets; sized per network
+__host__ __device__ inline int aux_bytes(int k_targets) { return 128 + 64 * k_targets; }
+// likelihoods that combine several outputs of one row (predicted sigma, count data) exchange them through 1 KiB of LDS
+__host__ __device__ inline bool lik_needs_row_scratch(int lik_kind) {
+    return lik_kind >= NPBNN_LIK_GAUSS_PRED_SIGMA && lik_kind <= NPBNN_LIK_NEGBIN_BASE10;
+}
+__host__ __device__ inline int wave_lds_bytes(int k_targets, int lik_kind) {
+    return kRing * 1024 + kAuxSlots * aux_bytes(k_targets) + (lik_needs_row_scratch(lik_kind) ? 1024 : 0);
+}
+constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct LayerMeta {
+    int kt;        // 16-wide k tiles of the input dimension
+    int mt;        // 16-wide tiles of the output dimension
+    int frag_off;  // float offset of the fragment block in the image
+    int bias_off;  // float offset of the padded bias (16*mt floats)
+    int in_dim, out_dim, has_bias;
+    int w_off;     // double offset of the layer matrix in the packed weights
+};
+
+struct NetMeta {
+    int n_layers;
+    int image_floats;   // total floats of the image (multiple of 256)
+    int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats)
+    int act_kind, out_kind, lik_kind, n_out, k_targets;
+    int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
+    int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)
+    LayerMeta L[kMaxLayers];
+    float act_prm[kMaxLayers];
+};
+
+constexpr int kMaxCand = 3;    // candidates evaluated per pass over X by a speculative chain
+
+// One pass of a device-resident chain evaluates, against a single streaming read of X, the proposal of iteration t0 and
+// the proposals of iterations t0+1 .. t0+n_cand-1 *under the assumption that the earlier ones are rejected* (each is the
+// current state plus its own pre-drawn perturbation).  The step kernel then decides them in order and stops at the first
+// accepted one: the chain is exactly the sequential Metropolis-Hastings chain ("prefetching" / speculative MH).
+struct PassDesc {
+    int t0;                   // first iteration evaluated by the pass
+    int n_cand;               // candidates in the pass (0: the batch is finished, the evaluation kernel exits at once)
+    int cnt[kMaxCand];        // touched entries per candidate
+    int pad[3];
+};
+
+struct ChainParams;
+
+struct EvalParams {
+    const float* X;           // [n_tiles*16][Fp] zero padded; in fp16-split mode the same bytes hold, per 8 features,
+                              // 8 x fp16 high parts then 8 x fp16 low parts of the column-scaled values
+    const int* labels;        // [n_tiles*16], -1 on padding rows
+    const float* targets;     // [n_tiles*16][k] (k = k_targets), 0 on padding rows
+    const float* inst_w;      // [n_tiles*16] or nullptr
+    const float* image;       // float32 fragment image of the weights (global), DMA-copied into LDS
+    double* partials;         // [2][candidate][kPartialStride][n_workgroups] (pass parity first)
+    unsigned* confusion;      // [n_out*n_out] or nullptr
+    float* y_out;             // [n_rows][n_out] or nullptr
+    long long n_rows;
+    int n_tiles;
+    int Fp;
+    int use_classw;
+    int predict_mode;         // 0 none, 1 raw last-layer values, 2 output function applied
+    int weight_sets;          // 0: the D candidates of a launch are patched copies of ONE image (chain pass); 1: D independent
+                              // weight sets, image j at image + j*image_floats, predictions of set j at y_out + j*n_rows*n_out
+                              // (posterior prediction: several stored samples per streaming read of X)
+    // speculative multi-candidate pass of a device-resident chain (nullptr / unused for a plain evaluation):
+    int has_pass;             // chain pass: pass_desc[parity] says which candidates this launch evaluates (parity 0 outside the
+    int pad_pass_;            // overlapped schedule).  The descriptors live INSIDE this block - the step writes them here - so the
+    PassDesc pass_desc[2];    // evaluation reads them with the rest of its parameters instead of through one more dependent load
+    const double* pv;         // [2][kMaxCand][M] proposed values of the touched entries of each candidate
+    const int* pos;           // [K][M] image position of every pre-drawn entry (w2img gather)
+    const float* pscale;      // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
+    int M;
+    const ChainParams* chain;  // overlapped chain schedule: the last workgroup of the launch runs chain_step (else nullptr)
+    unsigned long long* stamps;   // diagnostics only (NPBNN_EVAL_STAMPS=1 in npbnn_time_pass): [workgroup][8] wall-clock stamps, else nullptr
+    NetMeta net;
+};
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float z, int kind, float prm) {
+#ifdef NPBNN_EXP_NO_ACT      // timing experiment only: activation = identity
+    return z;
+#endif
+    switch (kind) {
+        case NPBNN_ACT_RELU: return fmaxf(z, 0.f);                                  // BNN_lib.py:51
+        case NPBNN_ACT_LEAKY: return z < 0.f ? prm * z : z;                         // BNN_lib.py:55
+        case NPBNN_ACT_SWISH: return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));   // BNN_lib.py:60
+        default: return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f);   // BNN_lib.py:65 (exp-form tanh)
+    }
+}
+
+template <int KIND, int HT>
+__device__ __forceinline__ void act_tiles(f32x4 (&h)[HT], int live, float prm) {
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt)
+        if (mt < live)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[mt][i] = act_apply(h[mt][i], KIND, prm);
+}
+
+// activation on the first `live` tiles only (wave-uniform kind and count)
+template <int HT>
+__device__ __forceinline__ void act_live(f32x4 (&h)[HT], int live, int kind, float prm) {
+    switch (kind) {
+        case NPBNN_ACT_RELU: act_tiles<NPBNN_ACT_RELU>(h, live, prm); break;
+        case NPBNN_ACT_LEAKY: act_tiles<NPBNN_ACT_LEAKY>(h, live, prm); break;
+        case NPBNN_ACT_SWISH: act_tiles<NPBNN_ACT_SWISH>(h, live, prm); break;
+        default: act_tiles<NPBNN_ACT_TANH>(h, live, prm); break;
+    }
+}
+
+__device__ __forceinline__ float softplus_f(float z) {   // np.logaddexp(0, z), BNN_lib.py:172
+    return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z)));
+}
+
+// Reductions over the 4 lanes {l, l^16, l^32, l^48} that hold one data row's units, without LDS traffic:
+// v_permlane16_swap exchanges odd and even 16-lane rows, v_permlane32_swap the two 32-lane halves; after a swap of two
+// copies of v the pair (r[0], r[1]) holds v[l] and v[l^16] (resp. v[l^32]) in every lane.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quad_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// arg-max over the quad: larger value wins, ties go to the smaller index (np.argmax takes the first maximum)
+__device__ __forceinline__ void quad_argmax(float& bv, int& bi) {
+    u32x2 rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    u32x2 ri = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+    {
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int i0 = (int)ri[0], i1 = (int)ri[1];
+        const bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+    }
+    rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+    {
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int i0 = (int)ri[0], i1 = (int)ri[1];
+        const bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+    }
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+
+// float64 sums across lanes without LDS traffic (the ds_bpermute behind __shfl_xor costs ~100 cycles per step, two per
+// double): rotations inside a 16-lane row by DPP, rows combined with the permlane swaps.  Every lane ends with the sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum_f64(double v) {      // over the 16 lanes of a row (row_ror:8, 4, 2, 1)
+    v += dpp_f64<0x128>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x122>(v);
+    v += dpp_f64<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {     // over all 64 lanes
+    v = row_sum_f64(v);
+    u32x2 rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    u32x2 rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    rl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    rh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
+#define NPBNN_WAIT_VMCNT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define NPBNN_WAIT_VMCNT(n) NPBNN_WAIT_VMCNT_(n)
+#define NPBNN_DEPTH (NPBNN_RING - 1)
+#if NPBNN_RING == 4
+#define NPBNN_DEPTH_LIT 3
+#elif NPBNN_RING == 6
+#define NPBNN_DEPTH_LIT 5
+#elif NPBNN_RING == 8
+#define NPBNN_DEPTH_LIT 7
+#else
+#error "NPBNN_RING must be 4, 6 or 8"
+#endif
+
+__device__ __forceinline__ void wait_younger(int younger) {   // wave-uniform argument; tail / shallow-ring path only
+    if (younger >= 7) NPBNN_WAIT_VMCNT(7);
+    else if (younger == 6) NPBNN_WAIT_VMCNT(6);
+    else if (younger == 5) NPBNN_WAIT_VMCNT(5);
+    else if (younger == 4) NPBNN_WAIT_VMCNT(4);
+    else if (younger == 3) NPBNN_WAIT_VMCNT(3);
+    else if (younger == 2) NPBNN_WAIT_VMCNT(2);
+    else if (younger == 1) NPBNN_WAIT_VMCNT(1);
+    else NPBNN_WAIT_VMCNT(0);
+}
+template <int N>
+__device__ __forceinline__ void wait_depth() {
+    static_assert(N >= 0 && N <= 7, "ring depth");
+    if constexpr (N == 7) NPBNN_WAIT_VMCNT(7);
+    else if constexpr (N == 6) NPBNN_WAIT_VMCNT(6);
+    else if constexpr (N == 5) NPBNN_WAIT_VMCNT(5);
+    else if constexpr (N == 4) NPBNN_WAIT_VMCNT(4);
+    else if constexpr (N == 3) NPBNN_WAIT_VMCNT(3);
+    else if constexpr (N == 2) NPBNN_WAIT_VMCNT(2);
+    else if constexpr (N == 1) NPBNN_WAIT_VMCNT(1);
+    else NPBNN_WAIT_VMCNT(0);
+}
+__device__ __forceinline__ int ring_next(int slot) {            // byte offset of the next 1-KiB ring slot
+    slot += 1024;
+    return slot == kRing * 1024 ? 0 : slot;
+}
+
+typedef __attribute__((address_space(1))) const void gvoid;
+typedef __attribute__((address_space(3))) void lvoid;
+
+__device__ __forceinline__ void dma16(const float* g, char* l) {
+    __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* g, char* l) {
+    __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 4, 0, 0);
+}
+
+}  // namespace npbnn

@@ -1,0 +1,758 @@
+// eval_kernel: fused forward pass + likelihood (the dominant kernel)
+// (part of the device code of the npBNN hot path, see npbnn_kernels.hip.h)
+#pragma once
+#include "npbnn_common.hip.h"
+#include "npbnn_chain.hip.h"
+
+namespace npbnn {
+
+// ------------------------------------------------------------------------------------------------
+// fused forward + likelihood
+//   MT0 : 16-unit tiles of layer 0's output (accumulators of the streamed GEMM)
+//   MTI : max 16-unit tiles of any later layer's output (1 covers every net whose hidden layers after the first
+//         and whose output have <= 16 nodes - all BASELINE configs; 8 is the general case)
+//   F16 : fp16-split layer 0
+//   D   : weight sets ("candidates") evaluated against one streaming read of X (speculative chain passes; 1 otherwise)
+//   LK  : likelihood class the epilogue is built for - kLikCat (categorical / none), kLikGauss (residual moments) or
+//         kLikGen (float64 row-wise likelihoods: predicted sigma, Poisson, negative binomial).  Separate builds because
+//         each class keeps different per-lane accumulators alive through the whole kernel (and lgamma is register hungry).
+// ------------------------------------------------------------------------------------------------
+typedef void (*eval_fn_t)(const EvalParams*, int);
+constexpr int kLikCat = 0, kLikGauss = 1, kLikGen = 2;
+__host__ __device__ inline int lik_class(int lik_kind) {
+    return lik_needs_row_scratch(lik_kind) ? kLikGen : (lik_kind == NPBNN_LIK_GAUSS ? kLikGauss : kLikCat);
+}
+
+template <int LK>
+struct TileAcc {            // per-candidate float64 accumulators of one wave: sum of the per-row log-likelihood terms ...
+    double ll;
+};
+template <>
+struct TileAcc<kLikGauss> { // ... or, for the Gaussian likelihood, residual moments of the 4 target columns this lane owns
+    double s1[4], s2[4];
+};
+
+// A value every lane of the wave holds identically, moved to scalar registers.  The kernel reads its launch-invariant
+// parameters through pointers that other code inlined into it (the chain step) writes through, and its first branch is
+// lane dependent (the diagnostic stamps), so the compiler no longer proves them uniform by itself - and a loop bound it
+// believes divergent turns every branch of the main loop into exec-mask bookkeeping.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ long long uni(long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T* uni(T* ptr) { return reinterpret_cast<T*>(uni((long long)reinterpret_cast<unsigned long long>(ptr))); }
+
+// Launch-invariant scalars of the parameter block, copied once so that they stay in SGPRs: the counted s_waitcnt
+// statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
+// after each of them.
+struct HotParams {
+    const int* labels;
+    const float* targets;
+    const float* inst_w;
+    unsigned* confusion;
+    float* y_out;
+    long long n_rows;
+    int use_classw, predict_mode, weight_sets;
+    int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off;
+};
+
+template <int KIND, int HT, int D>
+__device__ __forceinline__ void act_tiles_all(f32x4 (&h)[D][HT], int live, float prm) {
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt)
+        if (mt < live)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) h[j][mt][i] = act_apply(h[j][mt][i], KIND, prm);
+}
+// activation on the first `live` tiles of every candidate (wave-uniform kind and count; candidates innermost so that
+// their independent exp / rcp chains interleave)
+template <int HT, int D>
+__device__ __forceinline__ void act_live_all(f32x4 (&h)[D][HT], int live, int kind, float prm) {
+    switch (kind) {
+        case NPBNN_ACT_RELU: act_tiles_all<NPBNN_ACT_RELU>(h, live, prm); break;
+        case NPBNN_ACT_LEAKY: act_tiles_all<NPBNN_ACT_LEAKY>(h, live, prm); break;
+        case NPBNN_ACT_SWISH: act_tiles_all<NPBNN_ACT_SWISH>(h, live, prm); break;
+        default: act_tiles_all<NPBNN_ACT_TANH>(h, live, prm); break;
+    }
+}
+
+// layers 1..L-1 and the likelihood epilogue of one 16-row tile for the D candidates of the pass (weight images
+// `imgs + j*image_floats` in LDS).  Every stage loops over the candidates innermost: their chains (dependent MFMAs,
+// exp / rcp / log) are independent, so the wave always has three of them to interleave.
+// Handles candidates J0 .. J0+D-1 of the DA the pass holds (all of them when the registers allow, else one at a time).
+template <int MT0, int MTI, int LK, int D, int DA, int J0>
+__device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& hp, const float* imgs0, int image_floats,
+                                          const f32x4 (&acc0_all)[DA][MT0], int lane, int n, int kq, const char* a_slot, float* row_scratch,
+                                          long long row, bool row_ok, TileAcc<LK> (&A_all)[DA]) {
+    static_assert(J0 + D <= DA, "candidate range");
+    constexpr bool primary = J0 == 0;              // statistics and predictions come from the first candidate
+    const float* const imgs = imgs0 + (size_t)J0 * image_floats;
+    auto A = [&](int j) -> TileAcc<LK>& { return A_all[J0 + j]; };
+    constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
+    const int n_layers = hp.n_layers;
+    const int C = hp.C;
+    const int MTL = hp.MTL;
+    const int lik_kind = hp.lik_kind;
+    const int k_targets = hp.k_targets;
+    const bool need_softmax = LK == kLikCat && ((lik_kind == NPBNN_LIK_CATEGORICAL) || (hp.predict_mode == 2 && hp.out_kind == NPBNN_OUT_SOFTMAX));
+    // ---------------- layers 1..L-1 chained through the accumulators ----------------
+    f32x4 h[D][HT];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) h[j][mt] = mt < MT0 ? acc0_all[J0 + j][mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 1; l < n_layers; ++l) {
+        const LayerMeta& L = net.L[l];
+        const int lkt = uni(L.kt), lmt = uni(L.mt);
+        act_live_all(h, lkt, hp.act_kind, uni(net.act_prm[l - 1]));
+        const float* frag = imgs + uni(L.frag_off) + lane * 4;
+        const float* bias = imgs + uni(L.bias_off) + 4 * kq;
+        f32x4 acc[D][MTI];
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mt < lmt) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) acc[j][mt] = *reinterpret_cast<const f32x4*>(bias + (size_t)j * image_floats + 16 * mt);
+#pragma unroll
+                for (int ct = 0; ct < HT; ++ct) {
+                    if (ct < lkt) {
+                        f32x4 a[D];
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                            a[j] = *reinterpret_cast<const f32x4*>(frag + (size_t)j * image_floats + (size_t)(ct * lmt + mt) * 256);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int j = 0; j < D; ++j)
+                                acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], h[j][ct][s], acc[j][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt) h[j][mt] = acc[j][mt];
+    }
+    if (hp.final_act) act_live_all(h, MTL, hp.act_kind, uni(net.act_prm[n_layers - 1]));
+    // h[j][mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
+
+    // ---------------- epilogue ----------------
+    float lse[D];
+    int best_i = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) lse[j] = 0.f;
+    if (need_softmax) {
+        float m[D], se[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { m[j] = -INFINITY; se[j] = 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * mt + 4 * kq + i < C)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) m[j] = fmaxf(m[j], h[j][mt][i]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * mt + 4 * kq + i < C)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) se[j] += __expf(h[j][mt][i] - m[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) se[j] = quad_sum(se[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) lse[j] = m[j] + __logf(se[j]);
+        if (hp.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207); statistics of the first candidate only
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 16 * mt + 4 * kq + i;
+                        if (o < C && h[0][mt][i] > bv) { bv = h[0][mt][i]; bi = o; }
+                    }
+            quad_argmax(bv, bi);
+            best_i = bi;
+        }
+    }
+
+    if constexpr (LK == kLikCat) {
+      if (lik_kind == NPBNN_LIK_CATEGORICAL) {
+        const int lab = *reinterpret_cast<const int*>(a_slot + n * 4);
+        float zl[D];
+        bool own = false;
+#pragma unroll
+        for (int j = 0; j < D; ++j) zl[j] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTI; ++mt)
+            if (mt < MTL)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * mt + 4 * kq + i == lab) {
+                        own = true;
+#pragma unroll
+                        for (int j = 0; j < D; ++j) zl[j] = h[j][mt][i];
+                    }
+        if (lab >= 0) {
+            float wgt = 1.f;
+            if (hp.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
+            if (hp.use_classw) wgt *= imgs[hp.classw_off + lab];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float term = 0.f;
+                if (own) term += zl[j];
+                if (kq == 0) term -= lse[j];
+                term *= wgt;
+                A(j).ll += (double)term;
+            }
+            if (hp.confusion && primary && kq == 0 && best_i < C) atomicAdd(hp.confusion + lab * C + best_i, 1u);
+        }
+      }
+    } else if constexpr (LK == kLikGen) {
+        // (kLikGen builds only: the float64 lgamma / log / exp below would otherwise cost the hot kernels their registers)
+        // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
+        // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
+        const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[c][0];
+            double term = 0.0;
+            if (row_ok) {
+                for (int j = kq; j < k_targets; j += 4) {
+                    const double y = (double)tg[n * k_targets + j];
+                    if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
+                        const double mu = (double)row_scratch[n * 16 + j];
+                        const double zs = (double)row_scratch[n * 16 + k_targets + j];
+                        const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));      // softplus, BNN_lib.py:172,181
+                        const double r = (y - mu) / sg;
+                        term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
+                    } else if (lik_kind == NPBNN_LIK_POISSON) {
+                        if (j == 0) {
+                            const double eta = (double)row_scratch[n * 16];
+                            term += y * eta - exp(eta) - lgamma(y + 1.0);             // poisson.logpmf(k, exp(eta))
+                        }
+                    } else {
+                        const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
+                        if (one_col && j > 0) continue;
+                        const int jp = one_col ? 1 : k_targets + j;
+                        const double e0 = (double)row_scratch[n * 16 + j], e1 = (double)row_scratch[n * 16 + jp];
+                        double mean, pr;
+                        if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
+                            mean = exp(2.302585092994046 * e0);
+                            pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+                        } else {
+                            mean = exp(e0);
+                            pr = 1.0 / (1.0 + exp(-e1));
+                        }
+                        const double nn = pr * mean / (1.0 - pr);
+                        // nbinom.logpmf(k; n, p) = lgamma(k+n) - lgamma(k+1) - lgamma(n) + n log p + k log(1-p)
+                        term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
+                    }
+                }
+            }
+            A(c).ll += term;
+        }
+    } else {
+        const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 4 * kq + i;
+            if (o < k_targets && row_ok) {
+                const float y = tg[n * k_targets + o];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float r = y - h[j][0][i];
+                    A(j).s1[i] += (double)r;
+                    A(j).s2[i] += (double)r * (double)r;
+                }
+            }
+        }
+    }
+
+    if (hp.predict_mode && row_ok) {       // predictions: of the first candidate, or of every weight set of the launch
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (!(hp.weight_sets || (primary && j == 0))) continue;
+            float* const yo = hp.y_out + (size_t)(J0 + j) * (size_t)hp.n_rows * C;
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 16 * mt + 4 * kq + i;
+                        if (o < C) {
+                            float v = h[j][mt][i];
+                            if (hp.predict_mode == 2) {
+                                if (hp.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse[j]);
+                                else if (hp.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+                            }
+                            yo[row * C + o] = v;
+                        }
+                    }
+        }
+    }
+}
+
+// waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive
+__host__ __device__ constexpr int max_waves_for(int mti, int d) { return mti == 1 ? (d == 1 ? 16 : d == 2 ? 14 : 11) : 8; }
+// software-pipelined layer 0 (the fragments of K-step s+1 are read from LDS while the MFMAs of step s run): builds whose two
+// fragment sets fit the register budget of their launch bounds
+__host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int d) {
+    return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && mt0 <= 1) || (d == 1 && mt0 <= 3));
+}
+
+#define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int MT0, int MTI, bool F16, int D, int LK>
+__global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch) {
+    // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
+    // kernel argument of this size costs several microseconds of cold scalar loads per launch
+    const EvalParams& p = *pp;
+    const int bid = uni((int)blockIdx.x);      // (pinned to a scalar register before the first lane-dependent branch)
+    unsigned long long* const stamps = uni(p.stamps);
+#define NPBNN_ESTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + (k)] = wall_clock64(); } while (0)
+    NPBNN_ESTAMP(0);
+    constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
+    constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
+    // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
+    const ChainParams* const chain = uni(p.chain);
+    const int G = (int)gridDim.x - (chain ? 1 : 0);     // workgroups that evaluate
+    if (chain && bid == G) {
+        chain_step(*chain, overlapped_plan(launch), *reinterpret_cast<StepShared*>(smem));
+        return;
+    }
+    const int par = chain ? (launch & 1) : 0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const NetMeta& net = p.net;
+    const int wpb = blockDim.x >> 6;
+    const int image_floats = uni(net.image_floats);
+    const size_t IB = (size_t)image_floats * 4;                     // bytes of one weight image
+
+    HotParams hp;
+    hp.labels = uni(p.labels); hp.targets = uni(p.targets); hp.inst_w = uni(p.inst_w); hp.confusion = uni(p.confusion);
+    hp.y_out = uni(p.y_out);
+    hp.n_rows = uni(p.n_rows); hp.use_classw = uni(p.use_classw); hp.predict_mode = uni(p.predict_mode);
+    hp.weight_sets = uni(p.weight_sets);
+    hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out); hp.MTL = uni(net.L[hp.n_layers - 1].mt); hp.lik_kind = uni(net.lik_kind);
+    hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind); hp.out_kind = uni(net.out_kind);
+    hp.final_act = uni(net.final_act);
+    hp.classw_off = uni(net.classw_off);
+    const int k_targets = hp.k_targets;
+    const int aux_sz = aux_bytes(k_targets);
+    const float* const Xg = uni(p.X);
+    const int Fp = uni(p.Fp);
+    const int n_tiles = uni(p.n_tiles);
+    const int M = uni(p.M);
+    const int* const g_pos = uni(p.pos);
+    const float* const g_pscale = uni(p.pscale);
+    double* const g_partials = uni(p.partials);
+
+    // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
+    //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
+    int t0 = 0;
+    int cnt[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) cnt[j] = 0;
+    const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
+    const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
+    if (pass) {
+        if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
+        t0 = uni(pass->t0);
+#pragma unroll
+        for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
+    }
+
+    char* const ring = smem + D * IB + (size_t)wave * wave_lds_bytes(k_targets, hp.lik_kind);
+    char* const aux = ring + kRing * 1024;
+    float* const row_scratch = reinterpret_cast<float*>(aux + kAuxSlots * aux_sz);   // [16 rows][16 outputs], generic likelihoods
+
+    // ---- stage the weight image of the current state into LDS, once per candidate: lane-linear DMA copies ----
+    {
+        const int n_pieces = image_floats >> 8;   // 1-KiB pieces
+        const float* const image = uni(p.image);
+        const size_t set_stride = hp.weight_sets ? (size_t)image_floats : 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            for (int i = wave; i < n_pieces; i += wpb)
+                dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+    }
+
+    // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
+    //      tile counts of the waves (and SIMDs) of one CU differ by at most one ----
+    const int KT0 = uni(net.L[0].kt);
+    const int first_tile = bid + G * wave;
+    const int stride = G * wpb;
+    const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
+    const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
+    int Dp = PIPE ? kRing : DEPTH;                      // prefetch distance in pieces
+    if (Dp > 2 * KT0) Dp = 2 * KT0;                     // at most 3 tiles in flight (aux slots)
+    const bool full_depth = (Dp == DEPTH);
+
+    // prefetch cursor: a per-lane running source pointer and a scalar ring offset
+    const float* pf_ptr = Xg + ((size_t)first_tile * 16 + n) * (size_t)Fp + 4 * kq;
+    const size_t tile_jump = (size_t)stride * 16 * (size_t)Fp - (size_t)KT0 * 16;
+    int pf_q = 0, pf_kt = 0, pf_tile = first_tile, pf_seq = 0, pf_slot = 0;
+    auto issue_aux = [&]() {   // row-aux data of a tile travels ahead of its first X piece
+        char* a = aux + (pf_seq & (kAuxSlots - 1)) * aux_sz;
+        const size_t r0 = (size_t)pf_tile * 16;
+        if (lane < 16) {
+            if (hp.labels) dma4(hp.labels + r0 + lane, a);
+            if (hp.inst_w) dma4(hp.inst_w + r0 + lane, a + 64);
+        }
+        if (hp.targets) {
+            const int total = 16 * k_targets;           // contiguous floats of this tile's targets
+            for (int e = 0; e < total; e += 64) {
+                const int idx = e + lane;               // (only the lanes with an element take part: an LDS-DMA writes
+                if (idx < total)                        //  lane*4 bytes past its base whatever it loaded, and the slot ends at `total`)
+                    dma4(hp.targets + r0 * k_targets + idx, a + 128 + e * 4);
+            }
+        }
+    };
+    auto issue_next = [&]() {
+        if (pf_kt == 0) issue_aux();
+        dma16(pf_ptr, ring + pf_slot);
+        pf_ptr += 16;
+        pf_slot = ring_next(pf_slot);
+        ++pf_q;
+        if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
+    };
+    for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
+
+    // ---- candidates = current state + their own touched entries: fetch the first entry per thread now (its latency
+    //      hides under the image copy), meet, patch the LDS images, meet again.  The first barrier also waits for this
+    //      wave's image pieces and first X pieces (needed next anyway). ----
+    int ppos[D];
+    double pval[D];
+    float psc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
+        if (pass && tid < cnt[j]) {
+            const size_t k = (size_t)(t0 + j) * M + tid;
+            ppos[j] = g_pos[k];
+            pval[j] = pv[(size_t)j * M + tid];
+            if (g_pscale) psc[j] = g_pscale[k];
+        }
+    }
+    NPBNN_ESTAMP(1);
+    __syncthreads();
+    NPBNN_ESTAMP(2);
+    if (pass) {
+        auto patch = [&](int j, int pos, double v, float sc) {
+            if (pos == 0x7fffffff) return;                  // superseded entry (a later draw of the same position wins)
+            float* imgj = reinterpret_cast<float*>(smem + j * IB);
+            if (pos < 0) {                               // fp16-split layer-0 entry
+                _Float16 hi, lo;
+                split_f16((float)(v * (double)sc), hi, lo);
+                _Float16* i16 = reinterpret_cast<_Float16*>(imgj);
+                const int hpos = pos & 0x7fffffff;
+                i16[hpos] = hi;
+                i16[hpos + 512] = lo;
+            } else {
+                imgj[pos] = (float)v;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
+            for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
+                const size_t k = (size_t)(t0 + j) * M + e;
+                patch(j, g_pos[k], pv[(size_t)j * M + e], g_pscale ? g_pscale[k] : 1.0f);
+            }
+        }
+        __syncthreads();
+    }
+    NPBNN_ESTAMP(3);
+
+    TileAcc<LK> A[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if constexpr (LK == kLikGauss) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { A[j].s1[i] = 0.0; A[j].s2[i] = 0.0; }
+        } else {
+            A[j].ll = 0.0;
+        }
+    }
+
+    const float* const imgs = reinterpret_cast<const float*>(smem);
+    const int frag0_off = uni(net.L[0].frag_off) + lane * 4;       // float offsets inside an image
+    const int bias0_off = uni(net.L[0].bias_off) + 4 * kq;
+    auto load_bias0 = [&](f32x4 (&acc0)[D][MT0]) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt)
+                acc0[j][mt] = *reinterpret_cast<const f32x4*>(imgs + (size_t)j * image_floats + bias0_off + 16 * mt);
+    };
+    auto run_tail = [&](const f32x4 (&acc0)[D][MT0], int tseq, int tile) {
+#ifdef NPBNN_EXP_NO_TAIL      // timing experiment only: keep the layer-0 result alive, skip layers 1.. and the likelihood
+        if constexpr (LK != kLikGauss) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) A[j].ll += (double)acc0[j][0][0];
+        }
+        return;
+#endif
+        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
+        const long long row = (long long)tile * 16 + n;
+        // the candidates go through the tail together (their independent chains interleave) while the registers allow
+        constexpr int HT = MT0 > MTI ? MT0 : MTI;
+        constexpr int DT = (D * HT <= 6 && LK != kLikGen) ? D : 1;
+        if constexpr (DT == D) {
+            tile_tail<MT0, MTI, LK, D, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+        } else {
+            tile_tail<MT0, MTI, LK, 1, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            static_assert(D <= 3, "add a call per candidate");
+        }
+    };
+
+    if constexpr (PIPE) {
+        // ---------------- fp16-split layer 0, software pipelined over the K-steps of ALL tiles of this wave ----------------
+        // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high parts)
+        // and 2(kg&1)+1 (low parts); three MFMAs per unit tile and candidate: wh.xh + wl.xh + wh.xl.
+        // Ring = 2 steps.  Per step s: the fragments of step s are in registers (so its two slots are free) -> DMA of step
+        // s+2 into them -> wait for step s+1 -> read its fragments -> MFMAs of step s (the LDS reads complete underneath).
+        // Work unit = (K-step s, candidate j): 3*MT0 MFMAs on the x fragments of the step and the weight fragments of the
+        // candidate.  While unit u computes, the fragments of unit u+1 are read from LDS into the other register set.
+        struct WFrag { f16x8 wh[MT0], wl[MT0]; };
+        struct XFrag { f16x8 xh, xl; };
+        const int KS = KT0 >> 1;                          // K-steps per tile
+        const int S = my_tiles * KS;
+        if (S > 0) {
+            WFrag Wb[2];
+            XFrag Xb[2];
+            f32x4 acc0[D][MT0];
+            int ld_slot = 0;                              // ring offset of the next step to read
+            int s = 0, ks = 0;                            // current step: global index, index inside its tile
+            auto load_x = [&](XFrag& x) {
+                const int slot_b = ring_next(ld_slot);
+                const char* px = ring + ((kq >> 1) ? slot_b : ld_slot) + ((2 * (kq & 1)) * 16 + n) * 16;
+                x.xh = *reinterpret_cast<const f16x8*>(px);
+                x.xl = *reinterpret_cast<const f16x8*>(px + 256);
+                ld_slot = ring_next(slot_b);
+            };
+            auto load_w = [&](WFrag& w, int kstep, int j) {
+                const float* fr = imgs + (size_t)j * image_floats + frag0_off + kstep * (MT0 * 512);
+#pragma unroll
+                for (int mt = 0; mt < MT0; ++mt) {
+                    w.wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
+                    w.wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
+                }
+            };
+            NPBNN_WAIT_VMCNT(0);                          // (the barriers above already drained this wave's loads)
+            load_x(Xb[0]);
+            load_w(Wb[0], 0, 0);
+            load_bias0(acc0);
+            // one K-step; PAR = which x set holds it.  Unit j reads its weights from Wb[(PAR*D + j) & 1].
+            auto step = [&](auto par_tag) {
+                constexpr int PAR = decltype(par_tag)::value;
+                const int ks_next = (ks + 1 == KS) ? 0 : ks + 1;
+                bool issued = false;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const WFrag& wc = Wb[(PAR * D + j) & 1];
+                    WFrag& wn = Wb[(PAR * D + j + 1) & 1];
+                    NPBNN_WAIT_LGKM0();                   // this unit's fragments are complete
+                    if (j == 0 && pf_q < Q) {             // the x fragments of step s are in registers: refill its slots (step s+2)
+                        issue_next();
+                        issue_next();
+                        issued = true;
+                    }
+                    if (j == D - 1) {
+                        if (s + 1 < S) {
+                            if (issued) wait_depth<2>();  // step s+1 has landed
+                            else NPBNN_WAIT_VMCNT(0);
+                            load_x(Xb[PAR ^ 1]);
+                            load_w(wn, ks_next, 0);
+                        }
+                    } else {
+                        load_w(wn, ks, j + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);    // keep the LDS reads of the next unit ahead of this unit's MFMAs
+#ifndef NPBNN_EXP_NO_L0       // (timing experiment only: without the layer-0 MFMAs)
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wl[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xl, acc0[j][mt], 0, 0, 0);
+#else
+                    acc0[j][0][0] += (float)wc.wh[0][0] + (float)wc.wl[MT0 - 1][7] + (float)Xb[PAR].xh[0] + (float)Xb[PAR].xl[7];
+#endif
+                }
+                ++s;
+                ks = ks_next;
+            };
+            int tile = first_tile;
+            unsigned long long tail_ticks = 0;
+            for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
+                for (int kp = 0; kp + 1 < KS; kp += 2) { // the register sets alternate, no copies
+                    step(std::integral_constant<int, 0>{});
+                    step(std::integral_constant<int, 1>{});
+                }
+                if (KS & 1) {                             // odd number of steps per tile: put the next tile's first fragments
+                    step(std::integral_constant<int, 0>{});   // back into set 0 (once per tile)
+                    Xb[0] = Xb[1];
+                    if (D & 1) Wb[0] = Wb[1];
+                }
+                const unsigned long long tk = stamps ? wall_clock64() : 0;
+                run_tail(acc0, tseq, tile);              // (the first fragments of the next tile arrive underneath)
+                load_bias0(acc0);
+                if (stamps) tail_ticks += wall_clock64() - tk;
+            }
+            if (stamps && tid == 0) stamps[(size_t)bid * 8 + 7] = tail_ticks;      // diagnostics: time this wave spent in tails
+        }
+    } else {
+    int q = 0, cs_slot = 0;
+    int tile = first_tile;
+    for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
+        // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring, every candidate on the same X piece ----------------
+        f32x4 acc0[D][MT0];
+        load_bias0(acc0);
+        int fr_off = frag0_off;
+        auto consume = [&]() {
+            if constexpr (F16) {
+                // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high
+                // parts) and 2(kg&1)+1 (low parts); three MFMAs per tile: wh.xh + wl.xh + wh.xl
+                const int slot_b = ring_next(cs_slot);
+                const char* px = ring + ((kq >> 1) ? slot_b : cs_slot) + ((2 * (kq & 1)) * 16 + n) * 16;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(px);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(px + 256);
+                cs_slot = ring_next(slot_b);
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float* fr = imgs + (size_t)j * image_floats + fr_off;
+                    f16x8 wh[MT0], wl[MT0];
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) {
+                        wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
+                        wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[j][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
+                }
+                fr_off += MT0 * 512;
+            } else {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);
+                cs_slot = ring_next(cs_slot);
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float* fr = imgs + (size_t)j * image_floats + fr_off;
+                    f32x4 a[MT0];
+#pragma unroll
+                    for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int mt = 0; mt < MT0; ++mt)
+                            acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[j][mt], 0, 0, 0);
+                }
+                fr_off += MT0 * 256;
+            }
+        };
+        constexpr int STEP = F16 ? 2 : 1;               // pieces per consume()
+        if (full_depth) {
+            // steady part: every step consumed is replaced by one issued -> exactly DEPTH younger pieces in flight;
+            // once the wave's last piece has been issued, drain once and consume what is left without waiting
+            int n_issue = Q - pf_q;
+            if (n_issue > KT0) n_issue = KT0;
+            for (int kt = 0; kt < n_issue; kt += STEP) {
+                issue_next();                           // targets the slot(s) consumed one step ago
+                if constexpr (F16) issue_next();
+                wait_depth<DEPTH>();
+                consume();
+            }
+            if (n_issue < KT0) {
+                NPBNN_WAIT_VMCNT(0);
+                for (int kt = n_issue; kt < KT0; kt += STEP) consume();
+            }
+            q += KT0;
+        } else {
+            for (int kt = 0; kt < KT0; kt += STEP, q += STEP) {
+                for (int i = 0; i < STEP; ++i)
+                    if (pf_q < Q) issue_next();
+                wait_younger(pf_q - q - STEP);
+                consume();
+            }
+        }
+
+        // ---------------- layers 1..L-1 + likelihood terms of every candidate ----------------
+        run_tail(acc0, tseq, tile);
+    }
+    }
+
+    NPBNN_ESTAMP(4);
+    // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
+    if (g_partials) {
+        constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if constexpr (LK == kLikGauss) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A[j].s1[i] = row_sum_f64(A[j].s1[i]);
+                    A[j].s2[i] = row_sum_f64(A[j].s2[i]);
+                }
+            } else {
+                A[j].ll = wave_sum_f64(A[j].ll);
+            }
+        }
+        __syncthreads();                                   // every wave is done with its ring: reuse the rings as scratch
+        NPBNN_ESTAMP(5);
+        double* wsum = reinterpret_cast<double*>(smem + D * IB);    // [candidate][wave][kPartialStride]
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double* ws = wsum + ((size_t)j * wpb + wave) * kPartialStride;
+            if constexpr (LK == kLikGauss) {
+                if (lane == 0) ws[0] = 0.0;
+                if (n == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ws[1 + 4 * kq + i] = A[j].s1[i];
+                        ws[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = A[j].s2[i];
+                    }
+                }
+            } else {
+                if (lane == 0) ws[0] = A[j].ll;
+            }
+        }
+        __syncthreads();
+        for (int item = tid; item < D * nvals; item += blockDim.x) {
+            const int j = item / nvals, v = item % nvals;
+            double s = 0.0;
+            for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
+            g_partials[(((size_t)par * kMaxCand + j) * kPartialStride + v) * G + bid] = s;
+        }
+    }
+    NPBNN_ESTAMP(6);
+#undef NPBNN_ESTAMP
+}
+
+}  // namespace npbnn

@@ -1,0 +1,190 @@
+// Weight image packing and the one-off fp16-split copy of the feature matrix
+// (part of the device code of the npBNN hot path, see npbnn_kernels.hip.h)
+#pragma once
+#include "npbnn_common.hip.h"
+
+namespace npbnn {
+
+// ------------------------------------------------------------------------------------------------
+// pack: float64 packed weights -> fragment image
+//   frag_l[((kt*MT + mt)*64 + lane)*4 + s] = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + s]
+//   (bias column excluded, zero outside the matrix); bias_l[o] = W_l[o][0] when the layer has a bias.
+//   Layer 0 with a column override (data_transform_obj, BNN_env.py:14-17): an overridden feature column
+//   is the constant v_c for every row, so its contribution v_c*W0[o][c] moves into the bias and the
+//   fragment entry becomes 0 - no extra pass over X.
+// ------------------------------------------------------------------------------------------------
+// fp16 split of a float: hi = fp16(v), lo = fp16(v - hi); hi + lo carries ~22 significant bits of v
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+constexpr float kF16Safe = 60000.0f;   // |value| above this does not survive fp16 (max 65504)
+
+// One item of the weight image.  Layer-l fragment layouts (16-byte entries, one per lane):
+//   float32 : entry ((kt*MT + mt)*64 + lane) = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + 0..3]
+//   fp16-split layer 0 : entry (((ks*MT + mt)*2 + part)*64 + lane) = part (0 high, 1 low) of
+//                        W_0[o][c = 32ks + 8(lane>>4) + 0..7] * w_scale[c]
+//   (bias column excluded, zero outside the matrix); bias_l[o] = W_l[o][0] when the layer has a bias.
+// Layer 0 with a column override (data_transform_obj, BNN_env.py:14-17): an overridden feature column is the
+// constant v_c for every row, so its contribution v_c*W0[o][c] moves into the bias and the fragment entry
+// becomes 0 - no extra pass over X.
+__device__ __forceinline__ void pack_item(int item, const double* __restrict__ w, const double* __restrict__ col_override,
+                                          const double* __restrict__ class_w, float* __restrict__ image, const NetMeta& net,
+                                          bool with_classw, const float* __restrict__ w_scale = nullptr, int* overflow = nullptr) {
+    int piece = item;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerMeta& L = net.L[l];
+        const int n_pieces = L.kt * L.mt * 64;
+        if (piece < n_pieces) {
+            const int lane = piece & 63;
+            const int tile = piece >> 6;
+            const int ld = L.in_dim + L.has_bias;
+            if (l == 0 && net.l0_f16) {
+                const int part = tile & 1, rest = tile >> 1;
+                const int mt = rest % L.mt, ks = rest / L.mt;
+                const int o = 16 * mt + (lane & 15);
+                const int c0 = 32 * ks + 8 * (lane >> 4);
+                f16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+                if (o < L.out_dim) {
+                    const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = c0 + j;
+                        if (c < L.in_dim) {
+                            const bool overridden = (col_override != nullptr && !isnan(col_override[c]));
+                            const float wv = overridden ? 0.f : (float)(row[c] * (double)w_scale[c]);
+                            if (overflow && !(fabsf(wv) <= kF16Safe)) *overflow = 1;
+                            _Float16 hi, lo;
+                            split_f16(wv, hi, lo);
+                            v[j] = part ? lo : hi;
+                        }
+                    }
+                }
+                *reinterpret_cast<f16x8*>(image + L.frag_off + (long long)piece * 4) = v;
+                return;
+            }
+            const int mt = tile % L.mt, kt = tile / L.mt;
+            const int o = 16 * mt + (lane & 15);
+            const int c0 = 16 * kt + 4 * (lane >> 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (o < L.out_dim) {
+                const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
+                for (int s = 0; s < 4; ++s) {
+                    const int c = c0 + s;
+                    if (c < L.in_dim) {
+                        bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
+                        v[s] = overridden ? 0.f : (float)row[c];
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(image + L.frag_off + (long long)piece * 4) = v;
+            return;
+        }
+        piece -= n_pieces;
+    }
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerMeta& L = net.L[l];
+        const int nb = 16 * L.mt;
+        if (piece < nb) {
+            const int o = piece;
+            double b = 0.0;
+            if (o < L.out_dim) {
+                const int ld = L.in_dim + L.has_bias;
+                const double* row = w + L.w_off + (long long)o * ld;
+                if (L.has_bias) b = row[0];
+                if (l == 0 && col_override != nullptr) {
+                    for (int c = 0; c < L.in_dim; ++c) {
+                        const double ov = col_override[c];
+                        if (!isnan(ov)) b += ov * row[L.has_bias + c];
+                    }
+                }
+            }
+            image[L.bias_off + o] = (float)b;
+            return;
+        }
+        piece -= nb;
+    }
+    if (with_classw && piece < NPBNN_MAX_WIDTH) {
+        image[net.classw_off + piece] = (class_w != nullptr && piece < net.n_out) ? (float)class_w[piece] : 1.0f;
+    }
+}
+
+__host__ __device__ inline int pack_item_count(const NetMeta& net, bool with_classw) {
+    int total = with_classw ? NPBNN_MAX_WIDTH : 0;
+    for (int l = 0; l < net.n_layers; ++l) total += net.L[l].kt * net.L[l].mt * 64 + 16 * net.L[l].mt;
+    return total;
+}
+
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) pack_weights_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
+                                                           const double* __restrict__ class_w, float* __restrict__ image,
+                                                           NetMeta net, const float* __restrict__ w_scale, int* overflow) {
+    pack_item(blockIdx.x * 256 + threadIdx.x, w, col_override, class_w, image, net, true, w_scale, overflow);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+// ------------------------------------------------------------------------------------------------
+// fp16-split copy of the feature matrix (built once per data set, on the device)
+//   col_absmax_kernel : per-column max |x| (atomic max on the bit pattern of the non-negative floats)
+//   col_scale_kernel  : x_scale[c] = 2^-e, w_scale[c] = 2^e with 2^(e-1) <= max|x_c| < 2^e  (exact powers of two)
+//   split_x_kernel    : per row and per 8 features: 8 x fp16 high parts, then 8 x fp16 low parts of x * x_scale
+// ------------------------------------------------------------------------------------------------
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) col_absmax_kernel(const float* __restrict__ X, long long n_rows, int Fp, unsigned* __restrict__ absmax) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Fp) return;
+    const long long r0 = (long long)blockIdx.y * 1024;
+    long long r1 = r0 + 1024;
+    if (r1 > n_rows) r1 = n_rows;
+    float m = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        const float a = fabsf(X[r * Fp + c]);
+        m = (a > m || isnan(a)) ? a : m;
+    }
+    atomicMax(absmax + c, __float_as_uint(m));     // NaN / inf bit patterns compare above every finite value
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) col_scale_kernel(const unsigned* __restrict__ absmax, int Fp, float* __restrict__ x_scale,
+                                                        float* __restrict__ w_scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Fp) return;
+    const float m = __uint_as_float(absmax[c]);
+    int e = 0;
+    if (m > 0.f && isfinite(m)) (void)frexpf(m, &e);
+    x_scale[c] = ldexpf(1.f, -e);
+    w_scale[c] = ldexpf(1.f, e);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ X, long long n_rows_pad, int Fp, int Fp16,
+                                                      const float* __restrict__ x_scale, float* __restrict__ X16,
+                                                      unsigned* __restrict__ absmax_scaled) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per (row, group of 8 features)
+    const int groups = Fp16 >> 3;
+    if (g >= n_rows_pad * groups) return;
+    const long long r = g / groups;
+    const int c0 = (int)(g % groups) * 8;
+    f16x8 hi, lo;
+    float m = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const float v = c < Fp ? X[r * Fp + c] * x_scale[c] : 0.f;
+        _Float16 h, l;
+        split_f16(v, h, l);
+        hi[j] = h;
+        lo[j] = l;
+        const float a = fabsf(v);
+        m = (a > m || isnan(a)) ? a : m;
+    }
+    f16x8* dst = reinterpret_cast<f16x8*>(X16 + r * Fp16 + c0);
+    dst[0] = hi;
+    dst[1] = lo;
+    if (m > 1.0f || isnan(m)) atomicMax(absmax_scaled, __float_as_uint(m));   // only a test set scaled by the training scales
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+}  // namespace npbnn

@@ -253,9 +253,13 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         net.L[l].bias_off = off;
         off += 16 * net.L[l].mt;
     }
-    net.classw_off = off;
-    off += NPBNN_MAX_WIDTH;
-    net.image_floats = round_up(off, 256);
+    if (ctx->n_classw > 0) {            // class weights ride in the image only when there are any
+        net.classw_off = off;
+        off += NPBNN_MAX_WIDTH;
+    } else {
+        net.classw_off = -1;
+    }
+    net.image_floats = round_up(off, 64);   // a multiple of 256 B (the LDS copies of several candidates sit back to back)
     net.n_out = a->out_dim[a->n_layers - 1];
     if (a->lik_kind == NPBNN_LIK_GAUSS) {
         if (a->n_targets < 1 || a->n_targets > NPBNN_MAX_TARGETS || a->n_targets > net.n_out)
@@ -285,10 +289,16 @@ int max_inner_tiles(const NetMeta& net) {
     return mti;
 }
 
-int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand = 1) {
-    const int top = max_waves_for(max_inner_tiles(ctx->net) == 1 ? 1 : 8, n_cand);     // launch bound of the kernel build in use
+WaveLayout layout_for(const npbnn_ctx* ctx, const Dataset& d, bool predict_only = false) {
+    return make_wave_layout(d.labels != nullptr, d.inst_w != nullptr, d.targets ? ctx->net.k_targets : 0, ctx->net.L[0].kt,
+                            predict_only ? NPBNN_LIK_NONE : ctx->net.lik_kind);
+}
+
+int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand, const WaveLayout& lay, bool predict_only = false) {
+    const int lk = predict_only ? kLikCat : lik_class(ctx->net.lik_kind);
+    const int top = max_waves_for(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16 != 0, n_cand, lk);   // launch bound of the build in use
     for (int w = top; w >= 1; --w) {
-        const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)w * wave_lds_bytes(ctx->net.k_targets, ctx->net.lik_kind);
+        const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)w * lay.wave_lds;
         if (need <= ctx->lds_limit) {
             *lds_bytes = need;
             return w;
@@ -387,9 +397,10 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
     int n_cand = (max_inner_tiles(ctx->net) == 1 && (predict_only || !lik_needs_row_scratch(ctx->net.lik_kind))) ? want_cand : 1;
     if (n_cand > kMaxCand) n_cand = kMaxCand;
-    while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand) < 8) --n_cand;
+    const WaveLayout lay = layout_for(ctx, d, predict_only);
+    while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only) < 8) --n_cand;
     lp->n_cand = n_cand;
-    const int wpb = pick_waves_per_block(ctx, &lds, n_cand);
+    const int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only);
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
@@ -472,6 +483,7 @@ EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
     p.has_pass = 0;
     p.Fp = ctx->net.l0_f16 ? d.Fp16 : d.Fp;
     p.net = ctx->net;
+    p.lay = layout_for(ctx, d);
     return p;
 }
 
@@ -497,7 +509,7 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
     if (ctx->d_w2img) { (void)hipFree(ctx->d_w2img); ctx->d_w2img = nullptr; }
     if (ctx->d_w2scale) { (void)hipFree(ctx->d_w2scale); ctx->d_w2scale = nullptr; }
     size_t lds = 0;
-    if (pick_waves_per_block(ctx, &lds) == 0)
+    if (pick_waves_per_block(ctx, &lds, 1, make_wave_layout(true, false, ctx->net.k_targets, ctx->net.L[0].kt, ctx->net.lik_kind)) == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
     // (room for kMaxCand independent images: npbnn_predict_sets stages that many weight sets per pass)
@@ -704,6 +716,8 @@ int npbnn_set_row_weights(npbnn_ctx* ctx, const double* instance_w, int64_t n_ro
     } else {
         ctx->n_classw = 0;
     }
+    if (ctx->arch_set && (ctx->n_classw > 0) != (ctx->net.classw_off >= 0))      // the image gains / loses its class-weight block
+        return rebuild_net(ctx, ctx->net.l0_f16 != 0);
     return NPBNN_OK;
 }
 
@@ -744,7 +758,7 @@ int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
 int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (!ctx || !out) return fail(ctx, NPBNN_E_ARG, "get_info: bad arguments");
     if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
-    if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds); return NPBNN_OK; }
+    if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds, 1, layout_for(ctx, ctx->ds[0])); return NPBNN_OK; }
     if (what == NPBNN_INFO_N_CU) { *out = ctx->n_cu; return NPBNN_OK; }
     return fail(ctx, NPBNN_E_ARG, "get_info: unknown item %d", what);
 }
@@ -927,6 +941,7 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
             p.y_out = ctx->d_y;
             p.predict_mode = apply_out_fn ? 2 : 1;
             p.weight_sets = 1;
+            p.lay = layout_for(ctx, d, true);
             rc = push_eval_params(ctx, p);
             if (rc) return rc;
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);

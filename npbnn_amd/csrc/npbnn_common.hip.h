@@ -15,15 +15,28 @@ constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
 #endif
 constexpr int kRing = NPBNN_RING;              // X ring slots (1 KiB each) per wave; kRing-1 pieces stay in flight
 constexpr int kMaxWavesPerBlock = 16;
-constexpr int kAuxSlots = 4;                   // per-wave row-aux buffers (labels / weights / targets)
-// per-wave aux slot: labels (64 B) + instance weights (64 B) + 16 x k targets; sized per network
-__host__ __device__ inline int aux_bytes(int k_targets) { return 128 + 64 * k_targets; }
+// Per-wave row-aux slots (labels / instance weights / targets of a 16-row tile, fetched ahead of the tile's X pieces).  Their
+// number and size depend on the data set and the network: the host lays them out (WaveLayout) and hands the numbers to the
+// kernel, so that nothing is reserved that a run does not use - at config 2 this is what lets a 13th wave fit the LDS.
+struct WaveLayout {
+    int aux_slots;   // 2 when the ring never holds pieces of more than the next tile, else 4 (a power of two)
+    int aux_sz;      // bytes per slot
+    int off_w;       // instance weights inside a slot (labels, when present, sit at 0)
+    int off_t;       // targets inside a slot
+    int wave_lds;    // bytes of LDS per wave: ring + slots (+ row scratch of the float64 row-wise likelihoods)
+};
 // likelihoods that combine several outputs of one row (predicted sigma, count data) exchange them through 1 KiB of LDS
 __host__ __device__ inline bool lik_needs_row_scratch(int lik_kind) {
     return lik_kind >= NPBNN_LIK_GAUSS_PRED_SIGMA && lik_kind <= NPBNN_LIK_NEGBIN_BASE10;
 }
-__host__ __device__ inline int wave_lds_bytes(int k_targets, int lik_kind) {
-    return kRing * 1024 + kAuxSlots * aux_bytes(k_targets) + (lik_needs_row_scratch(lik_kind) ? 1024 : 0);
+__host__ __device__ inline WaveLayout make_wave_layout(bool labels, bool inst_w, int k_targets, int kt0, int lik_kind) {
+    WaveLayout L;
+    L.off_w = labels ? 64 : 0;
+    L.off_t = L.off_w + (inst_w ? 64 : 0);
+    L.aux_sz = L.off_t + 64 * k_targets;
+    L.aux_slots = kt0 >= kRing ? 2 : 4;
+    L.wave_lds = kRing * 1024 + L.aux_slots * L.aux_sz + (lik_needs_row_scratch(lik_kind) ? 1024 : 0);
+    return L;
 }
 constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]
 
@@ -42,7 +55,7 @@ struct LayerMeta {
 struct NetMeta {
     int n_layers;
     int image_floats;   // total floats of the image (multiple of 256)
-    int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats)
+    int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats; only present when class weights are set, else -1)
     int act_kind, out_kind, lik_kind, n_out, k_targets;
     int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
     int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)
@@ -91,6 +104,8 @@ struct EvalParams {
     const int* pos;           // [K][M] image position of every pre-drawn entry (w2img gather)
     const float* pscale;      // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
     int M;
+    WaveLayout lay;           // per-wave LDS layout of this launch (host-computed)
+    int pad_lay_;
     const ChainParams* chain;  // overlapped chain schedule: the last workgroup of the launch runs chain_step (else nullptr)
     unsigned long long* stamps;   // diagnostics only (NPBNN_EVAL_STAMPS=1 in npbnn_time_pass): [workgroup][8] wall-clock stamps, else nullptr
     NetMeta net;

@@ -57,6 +57,7 @@ struct HotParams {
     float* y_out;
     long long n_rows;
     int use_classw, predict_mode, weight_sets;
+    int aux_off_w, aux_off_t;
     int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off;
 };
 
@@ -211,7 +212,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
                     }
         if (lab >= 0) {
             float wgt = 1.f;
-            if (hp.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + 64 + n * 4);
+            if (hp.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + hp.aux_off_w + n * 4);
             if (hp.use_classw) wgt *= imgs[hp.classw_off + lab];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -228,7 +229,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         // (kLikGen builds only: the float64 lgamma / log / exp below would otherwise cost the hot kernels their registers)
         // likelihoods pairing output j with output k+j of the same row (BNN_lib.py:134-143, BNN_lik.py:5-66): the 16
         // outputs of a row meet through LDS; lane (n, kq) then owns target columns j = kq, kq+4, ...; float64 terms
-        const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+        const float* tg = reinterpret_cast<const float*>(a_slot + hp.aux_off_t);
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             *reinterpret_cast<f32x4*>(row_scratch + n * 16 + 4 * kq) = h[c][0];
@@ -269,7 +270,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
             A(c).ll += term;
         }
     } else {
-        const float* tg = reinterpret_cast<const float*>(a_slot + 128);
+        const float* tg = reinterpret_cast<const float*>(a_slot + hp.aux_off_t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = 4 * kq + i;
@@ -309,18 +310,21 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
     }
 }
 
-// waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive
-__host__ __device__ constexpr int max_waves_for(int mti, int d) { return mti == 1 ? (d == 1 ? 16 : d == 2 ? 14 : 11) : 8; }
 // software-pipelined layer 0 (the fragments of K-step s+1 are read from LDS while the MFMAs of step s run): builds whose two
 // fragment sets fit the register budget of their launch bounds
 __host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int d) {
     return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && mt0 <= 1) || (d == 1 && mt0 <= 3));
 }
-
+// waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive.  The
+// three-candidate categorical build of the narrow networks (the chain kernel of config 2) fits 128 VGPRs, i.e. 13 waves:
+// with 24-25 tiles per workgroup that is two rounds of tiles per wave instead of three for some.
+__host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int d, int lk) {
+    return mti != 1 ? 8 : d == 1 ? 16 : d == 2 ? 14 : (lk == kLikCat && pipelined_l0(mt0, mti, f16, d)) ? 13 : 11;
+}
 #define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int MT0, int MTI, bool F16, int D, int LK>
-__global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch) {
+__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch) {
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
@@ -359,7 +363,9 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     hp.final_act = uni(net.final_act);
     hp.classw_off = uni(net.classw_off);
     const int k_targets = hp.k_targets;
-    const int aux_sz = aux_bytes(k_targets);
+    const int aux_sz = uni(p.lay.aux_sz), aux_mask = uni(p.lay.aux_slots) - 1;
+    hp.aux_off_w = uni(p.lay.off_w);
+    hp.aux_off_t = uni(p.lay.off_t);
     const float* const Xg = uni(p.X);
     const int Fp = uni(p.Fp);
     const int n_tiles = uni(p.n_tiles);
@@ -383,19 +389,20 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
         for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
     }
 
-    char* const ring = smem + D * IB + (size_t)wave * wave_lds_bytes(k_targets, hp.lik_kind);
+    char* const ring = smem + D * IB + (size_t)wave * uni(p.lay.wave_lds);
     char* const aux = ring + kRing * 1024;
-    float* const row_scratch = reinterpret_cast<float*>(aux + kAuxSlots * aux_sz);   // [16 rows][16 outputs], generic likelihoods
+    float* const row_scratch = reinterpret_cast<float*>(aux + (aux_mask + 1) * aux_sz);   // [16 rows][16 outputs], generic likelihoods
 
     // ---- stage the weight image of the current state into LDS, once per candidate: lane-linear DMA copies ----
     {
-        const int n_pieces = image_floats >> 8;   // 1-KiB pieces
+        const int n_pieces = (image_floats + 255) >> 8;   // 1-KiB pieces; the last one may be partial (the image is a multiple of 256 B)
         const float* const image = uni(p.image);
         const size_t set_stride = hp.weight_sets ? (size_t)image_floats : 0;
 #pragma unroll
         for (int j = 0; j < D; ++j)
             for (int i = wave; i < n_pieces; i += wpb)
-                dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                if (i * 256 + lane * 4 < image_floats)      // (an LDS-DMA writes only its active lanes' 16 bytes)
+                    dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
     }
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
@@ -414,18 +421,18 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
     const size_t tile_jump = (size_t)stride * 16 * (size_t)Fp - (size_t)KT0 * 16;
     int pf_q = 0, pf_kt = 0, pf_tile = first_tile, pf_seq = 0, pf_slot = 0;
     auto issue_aux = [&]() {   // row-aux data of a tile travels ahead of its first X piece
-        char* a = aux + (pf_seq & (kAuxSlots - 1)) * aux_sz;
+        char* a = aux + (pf_seq & aux_mask) * aux_sz;
         const size_t r0 = (size_t)pf_tile * 16;
         if (lane < 16) {
             if (hp.labels) dma4(hp.labels + r0 + lane, a);
-            if (hp.inst_w) dma4(hp.inst_w + r0 + lane, a + 64);
+            if (hp.inst_w) dma4(hp.inst_w + r0 + lane, a + hp.aux_off_w);
         }
         if (hp.targets) {
             const int total = 16 * k_targets;           // contiguous floats of this tile's targets
             for (int e = 0; e < total; e += 64) {
                 const int idx = e + lane;               // (only the lanes with an element take part: an LDS-DMA writes
                 if (idx < total)                        //  lane*4 bytes past its base whatever it loaded, and the slot ends at `total`)
-                    dma4(hp.targets + r0 * k_targets + idx, a + 128 + e * 4);
+                    dma4(hp.targets + r0 * k_targets + idx, a + hp.aux_off_t + e * 4);
             }
         }
     };
@@ -514,7 +521,7 @@ __global__ void __launch_bounds__(max_waves_for(MTI, D) * 64) eval_kernel(const 
         }
         return;
 #endif
-        const char* a_slot = aux + (tseq & (kAuxSlots - 1)) * aux_sz;
+        const char* a_slot = aux + (tseq & aux_mask) * aux_sz;
         const long long row = (long long)tile * 16 + n;
         // the candidates go through the tail together (their independent chains interleave) while the registers allow
         constexpr int HT = MT0 > MTI ? MT0 : MTI;

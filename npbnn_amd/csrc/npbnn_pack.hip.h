@@ -105,7 +105,7 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
         }
         piece -= nb;
     }
-    if (with_classw && piece < NPBNN_MAX_WIDTH) {
+    if (with_classw && net.classw_off >= 0 && piece < NPBNN_MAX_WIDTH) {
         image[net.classw_off + piece] = (class_w != nullptr && piece < net.n_out) ? (float)class_w[piece] : 1.0f;
     }
 }

@@ -185,7 +185,7 @@ int upload_matrix(npbnn_ctx* ctx, const T* X, int64_t n_rows, int32_t F, int whi
     d.F = F;
     d.Fp = round_up(F, 16);
     d.n_tiles = (int)((n_rows + 15) / 16);
-    const size_t n_pad = (size_t)round_up(d.n_tiles, 2) * 16;   // rows padded to a whole 32-row tile
+    const size_t n_pad = (size_t)d.n_tiles * 16;
     const size_t bytes = n_pad * d.Fp * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&d.X, bytes));
     // convert + pad on the host in slabs, so the staging buffer stays small
@@ -231,7 +231,6 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     net.k_targets = a->n_targets;
     net.final_act = a->final_act ? 1 : 0;
     net.l0_f16 = f16 ? 1 : 0;
-    net.l0_tile32 = 0;
     int in = a->in_dim, off = 0, woff = 0;
     for (int l = 0; l < a->n_layers; ++l) {
         const int out = a->out_dim[l];
@@ -275,11 +274,6 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
             return fail(ctx, NPBNN_E_ARG, "set_arch: likelihood kind %d needs 1..8 target columns and %d..16 outputs (got %d targets, %d outputs)",
                         a->lik_kind, need_out, k, net.n_out);
     }
-    {   // 32-row tiles (v_mfma_f32_32x32x16_f16): fp16-split layer 0 of exactly 32 units feeding narrow later layers
-        int mti = 1;
-        for (int l = 1; l < net.n_layers; ++l) mti = net.L[l].mt > mti ? net.L[l].mt : mti;
-        net.l0_tile32 = (f16 && net.n_layers >= 2 && mti == 1 && net.L[0].mt == 2 && getenv("NPBNN_TILE32") != nullptr) ? 1 : 0;
-    }
     ctx->net = net;
     ctx->n_weights = woff;
     ctx->mt0_template = net.L[0].mt;
@@ -295,14 +289,9 @@ int max_inner_tiles(const NetMeta& net) {
     return mti;
 }
 
-// tiles (16 or 32 rows) of a data set under the current network description
-int tiles_of(const npbnn_ctx* ctx, const Dataset& d) { return ctx->net.l0_tile32 ? (d.n_tiles + 1) / 2 : d.n_tiles; }
-
-WaveLayout layout_for(const npbnn_ctx* ctx, const Dataset& d, bool predict_only = false, bool one_tile = false) {
-    const bool t32 = ctx->net.l0_tile32 != 0;
-    return make_wave_layout(d.labels != nullptr, d.inst_w != nullptr, d.targets ? ctx->net.k_targets : 0,
-                            t32 ? 2 * ctx->net.L[0].kt : ctx->net.L[0].kt, predict_only ? NPBNN_LIK_NONE : ctx->net.lik_kind,
-                            t32 ? 32 : 16, one_tile);
+WaveLayout layout_for(const npbnn_ctx* ctx, const Dataset& d, bool predict_only = false) {
+    return make_wave_layout(d.labels != nullptr, d.inst_w != nullptr, d.targets ? ctx->net.k_targets : 0, ctx->net.L[0].kt,
+                            predict_only ? NPBNN_LIK_NONE : ctx->net.lik_kind);
 }
 
 int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand, const WaveLayout& lay, bool predict_only = false) {
@@ -362,7 +351,7 @@ int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
     Dataset& d = ctx->ds[which];
     if (d.f16_state == 0) {
         d.Fp16 = round_up(d.F, 32);
-        const size_t n_pad = (size_t)round_up(d.n_tiles, 2) * 16;   // rows padded to a whole 32-row tile
+        const size_t n_pad = (size_t)d.n_tiles * 16;
         if (!d.X16) HIP_TRY(ctx, hipMalloc(&d.X16, n_pad * d.Fp16 * sizeof(float)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), ctx->stream));
         const long long items = (long long)n_pad * (d.Fp16 / 8);
@@ -382,7 +371,6 @@ int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
 int rebuild_net(npbnn_ctx* ctx, bool f16);
 
 struct LaunchPlan {
-    WaveLayout lay;
     eval_fn_t fn;
     int n_cand;
     int grid, wpb;
@@ -390,8 +378,7 @@ struct LaunchPlan {
     int n_waves;
 };
 
-int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false,
-                bool chain_overlap = false) {
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false) {
     Dataset& d = ctx->ds[which];
     bool want_f16 = false;
     if (!force_f32 && ctx->l0_option != NPBNN_L0_F32) {
@@ -410,18 +397,10 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
     int n_cand = (max_inner_tiles(ctx->net) == 1 && (predict_only || !lik_needs_row_scratch(ctx->net.lik_kind))) ? want_cand : 1;
     if (n_cand > kMaxCand) n_cand = kMaxCand;
-    WaveLayout lay = layout_for(ctx, d, predict_only);
+    const WaveLayout lay = layout_for(ctx, d, predict_only);
     while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only) < 8) --n_cand;
     lp->n_cand = n_cand;
-    int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only);
-    {   // when no wave gets a second tile, the row-aux look-ahead slot is not needed: maybe one more wave fits
-        const WaveLayout lay1 = layout_for(ctx, d, predict_only, true);
-        size_t lds1 = 0;
-        const int w1 = pick_waves_per_block(ctx, &lds1, n_cand, lay1, predict_only);
-        const int cus = ctx->n_cu - (chain_overlap ? 1 : 0);
-        if (w1 > 0 && (long long)tiles_of(ctx, d) <= (long long)w1 * cus) { lay = lay1; lds = lds1; wpb = w1; }
-    }
-    lp->lay = lay;
+    const int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only);
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
@@ -429,7 +408,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
                           : pick_kernel(ctx->net, n_cand);
     lp->wpb = wpb;
     lp->lds = lds;
-    int grid = (tiles_of(ctx, d) + wpb - 1) / wpb;
+    int grid = (d.n_tiles + wpb - 1) / wpb;
     if (grid > ctx->n_cu) grid = ctx->n_cu;     // persistent: one workgroup per CU
     if (grid < 1) grid = 1;
     lp->grid = grid;
@@ -556,21 +535,13 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
                 else {
                     const int c = j - L.has_bias;
                     const int mt = o / 16, u = o % 16;
-                    if (l == 0 && f16 && ctx->net.l0_tile32) {
-                        // 32x32x16 A fragments: chunk of 16 features, lane = (feature group of 8) * 32 + unit
-                        const int ch = c / 16, kg = (c % 16) / 8, jj = c % 8;
-                        const int half_index = 2 * L.frag_off + ((ch * 2) * 64 + kg * 32 + o) * 8 + jj;
-                        pos = (int)(0x80000000u | (unsigned)half_index);
-                        scale[wi] = wscale[(size_t)c];
-                    } else if (l == 0 && f16) {
+                    if (l == 0 && f16) {
                         const int ks = c / 32, kg = (c % 32) / 8, jj = c % 8;
                         const int half_index = 2 * L.frag_off + ((((ks * L.mt + mt) * 2) * 64) + kg * 16 + u) * 8 + jj;
                         pos = (int)(0x80000000u | (unsigned)half_index);
                         scale[wi] = wscale[(size_t)c];
                     } else {
-                        const int kt = c / 16, sidx = c % 4;
-                        int kq = (c % 16) / 4;
-                        if (l == 1 && ctx->net.l0_tile32) kq = tile32_lane_row(kq);   // layer 1 sees layer 0's units in the order the 32x32 accumulators leave them
+                        const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4;
                         pos = L.frag_off + ((kt * L.mt + mt) * 64 + kq * 16 + u) * 4 + sidx;
                     }
                 }
@@ -692,7 +663,7 @@ int npbnn_set_labels_i64(npbnn_ctx* ctx, const int64_t* y, int64_t n_rows, int w
     if (rc) return rc;
     if (!y) return fail(ctx, NPBNN_E_ARG, "set_labels: null labels");
     Dataset& d = ctx->ds[which];
-    const size_t n_pad = (size_t)round_up(d.n_tiles, 2) * 16;   // rows padded to a whole 32-row tile
+    const size_t n_pad = (size_t)d.n_tiles * 16;
     std::vector<int> tmp(n_pad, -1);
     for (int64_t i = 0; i < n_rows; ++i) {
         if (y[i] < 0 || y[i] >= NPBNN_MAX_WIDTH)
@@ -710,7 +681,7 @@ int npbnn_set_targets_f64(npbnn_ctx* ctx, const double* Y, int64_t n_rows, int32
     if (rc) return rc;
     if (!Y || k < 1 || k > NPBNN_MAX_TARGETS) return fail(ctx, NPBNN_E_ARG, "set_targets: need 1..%d target columns, got %d", NPBNN_MAX_TARGETS, k);
     Dataset& d = ctx->ds[which];
-    const size_t n_pad = (size_t)round_up(d.n_tiles, 2) * 16;   // rows padded to a whole 32-row tile
+    const size_t n_pad = (size_t)d.n_tiles * 16;
     std::vector<float> tmp(n_pad * k, 0.0f);
     for (size_t i = 0; i < (size_t)n_rows * k; ++i) tmp[i] = (float)Y[i];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -728,7 +699,7 @@ int npbnn_set_row_weights(npbnn_ctx* ctx, const double* instance_w, int64_t n_ro
     if (instance_w) {
         int rc = check_rows(ctx, 0, n_rows, "set_row_weights");
         if (rc) return rc;
-        const size_t n_pad = (size_t)round_up(d.n_tiles, 2) * 16;   // rows padded to a whole 32-row tile
+        const size_t n_pad = (size_t)d.n_tiles * 16;
         std::vector<float> tmp(n_pad, 0.0f);
         for (int64_t i = 0; i < n_rows; ++i) tmp[i] = (float)instance_w[i];
         if (!d.inst_w) HIP_TRY(ctx, hipMalloc(&d.inst_w, n_pad * sizeof(float)));
@@ -804,7 +775,6 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     rc = stage_weights(ctx, W_packed, act_prm, col_override);
     if (rc) return rc;
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = (which == 0) ? d.inst_w : nullptr;
     p.use_classw = (which == 0 && ctx->n_classw > 0) ? 1 : 0;
@@ -895,7 +865,6 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
         ctx->d_y_cap = n_el;
     }
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.labels = nullptr;
     p.targets = nullptr;
     p.net.lik_kind = NPBNN_LIK_NONE;
@@ -966,14 +935,13 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
                                    ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
             EvalParams p = make_params(ctx, d);
-            p.lay = lp.lay;
-    p.lay = lp.lay;
             p.labels = nullptr;
             p.targets = nullptr;
             p.net.lik_kind = NPBNN_LIK_NONE;
             p.y_out = ctx->d_y;
             p.predict_mode = apply_out_fn ? 2 : 1;
             p.weight_sets = 1;
+            p.lay = layout_for(ctx, d, true);
             rc = push_eval_params(ctx, p);
             if (rc) return rc;
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
@@ -1019,15 +987,15 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     LaunchPlan lp;
     int want_cand = cfg->n_candidates;
     if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
+    rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand);
+    if (rc) return rc;
+    const int D = lp.n_cand;
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
     int schedule = cfg->schedule;
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
-        schedule = (1.0 - std::pow(1.0 - p_acc, want_cand < kMaxCand ? want_cand : kMaxCand)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
+        schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
     }
-    rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand, false, schedule == NPBNN_SCHED_OVERLAP);
-    if (rc) return rc;
-    const int D = lp.n_cand;
     const bool overlap = schedule == NPBNN_SCHED_OVERLAP;
     if (overlap) {                      // one workgroup of the launch runs the step: the others share the tiles
         int g = lp.grid;
@@ -1174,7 +1142,6 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.n_rows = d.n_rows;
     c.net = ctx->net;
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
@@ -1299,7 +1266,6 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     pd.t0 = 0;
     pd.n_cand = lp.n_cand;          // every candidate = the staged weights (empty patch lists): same work as a chain pass
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
@@ -1370,7 +1336,6 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     rc = stage_weights(ctx, W_packed, nullptr, nullptr);
     if (rc) return rc;
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;

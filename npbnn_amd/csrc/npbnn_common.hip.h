@@ -29,15 +29,12 @@ struct WaveLayout {
 __host__ __device__ inline bool lik_needs_row_scratch(int lik_kind) {
     return lik_kind >= NPBNN_LIK_GAUSS_PRED_SIGMA && lik_kind <= NPBNN_LIK_NEGBIN_BASE10;
 }
-// rows: 16 or 32 per tile; pieces_per_tile: 1-KiB X pieces of a tile; one_tile: no wave has more than one tile (no look-ahead)
-__host__ __device__ inline WaveLayout make_wave_layout(bool labels, bool inst_w, int k_targets, int pieces_per_tile, int lik_kind,
-                                                       int rows = 16, bool one_tile = false) {
+__host__ __device__ inline WaveLayout make_wave_layout(bool labels, bool inst_w, int k_targets, int kt0, int lik_kind) {
     WaveLayout L;
-    const int per = 4 * rows;                        // bytes of one float / int per row
-    L.off_w = labels ? per : 0;
-    L.off_t = L.off_w + (inst_w ? per : 0);
-    L.aux_sz = L.off_t + per * k_targets;
-    L.aux_slots = one_tile ? 1 : pieces_per_tile >= kRing ? 2 : 4;
+    L.off_w = labels ? 64 : 0;
+    L.off_t = L.off_w + (inst_w ? 64 : 0);
+    L.aux_sz = L.off_t + 64 * k_targets;
+    L.aux_slots = kt0 >= kRing ? 2 : 4;
     L.wave_lds = kRing * 1024 + L.aux_slots * L.aux_sz + (lik_needs_row_scratch(lik_kind) ? 1024 : 0);
     return L;
 }
@@ -62,8 +59,6 @@ struct NetMeta {
     int act_kind, out_kind, lik_kind, n_out, k_targets;
     int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
     int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)
-    int l0_tile32;      // ... on 32-row tiles with v_mfma_f32_32x32x16_f16 (layer 0 of exactly 32 units): layer-0 fragments are
-                        // laid out per 16-feature chunk, and layer 1 takes its inputs in the order tile32_lane_row gives
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
 };
@@ -74,10 +69,6 @@ constexpr int kMaxCand = 3;    // candidates evaluated per pass over X by a spec
 // the proposals of iterations t0+1 .. t0+n_cand-1 *under the assumption that the earlier ones are rejected* (each is the
 // current state plus its own pre-drawn perturbation).  The step kernel then decides them in order and stops at the first
 // accepted one: the chain is exactly the sequential Metropolis-Hastings chain ("prefetching" / speculative MH).
-// After a 32x32 accumulator has been split into two 16-row halves with v_permlane16_swap, lane row kq of a half holds the
-// units 4*tile32_lane_row(kq) + 0..3 of each 16-unit block (rows 1 and 2 trade places); layer 1's fragments follow suit.
-__host__ __device__ constexpr int tile32_lane_row(int kq) { return kq == 1 ? 2 : kq == 2 ? 1 : kq; }
-
 struct PassDesc {
     int t0;                   // first iteration evaluated by the pass
     int n_cand;               // candidates in the pass (0: the batch is finished, the evaluation kernel exits at once)

@@ -334,7 +334,6 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     NPBNN_ESTAMP(0);
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
     constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
-    constexpr bool T32 = F16 && MTI == 1 && MT0 == 2 && kRing == 4;      // 32-row tiles available in this build (NetMeta.l0_tile32 selects)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
@@ -408,34 +407,28 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
     //      tile counts of the waves (and SIMDs) of one CU differ by at most one ----
-    //      32-row builds (T32): a tile is two 16-row blocks; its X pieces alternate between them, 16 features at a time. ----
     const int KT0 = uni(net.L[0].kt);
-    const bool t32 = T32 && uni(net.l0_tile32) != 0;
-    const int RT = t32 ? 32 : 16;                       // rows per tile
-    const int PT = t32 ? 2 * KT0 : KT0;                 // 1-KiB X pieces per tile
-    const int tiles_total = t32 ? (n_tiles + 1) >> 1 : n_tiles;
     const int first_tile = bid + G * wave;
     const int stride = G * wpb;
-    const int my_tiles = first_tile < tiles_total ? (tiles_total - first_tile + stride - 1) / stride : 0;
-    const int Q = my_tiles * PT;                        // 1-KiB X pieces this wave consumes
-    int Dp = (PIPE || t32) ? kRing : DEPTH;             // prefetch distance in pieces
-    if (Dp > 2 * PT) Dp = 2 * PT;                       // at most 3 tiles in flight (aux slots)
+    const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
+    const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
+    int Dp = PIPE ? kRing : DEPTH;                      // prefetch distance in pieces
+    if (Dp > 2 * KT0) Dp = 2 * KT0;                     // at most 3 tiles in flight (aux slots)
     const bool full_depth = (Dp == DEPTH);
 
     // prefetch cursor: a per-lane running source pointer and a scalar ring offset
-    const float* pf_ptr = Xg + ((size_t)first_tile * RT + n) * (size_t)Fp + 4 * kq;
-    const size_t tile_jump = (size_t)stride * RT * (size_t)Fp - (size_t)KT0 * 16;
-    const size_t half_rows = (size_t)16 * (size_t)Fp;   // T32: from a piece of the upper 16 rows to the same features of the lower 16
+    const float* pf_ptr = Xg + ((size_t)first_tile * 16 + n) * (size_t)Fp + 4 * kq;
+    const size_t tile_jump = (size_t)stride * 16 * (size_t)Fp - (size_t)KT0 * 16;
     int pf_q = 0, pf_kt = 0, pf_tile = first_tile, pf_seq = 0, pf_slot = 0;
     auto issue_aux = [&]() {   // row-aux data of a tile travels ahead of its first X piece
         char* a = aux + (pf_seq & aux_mask) * aux_sz;
-        const size_t r0 = (size_t)pf_tile * RT;
-        if (lane < RT) {
+        const size_t r0 = (size_t)pf_tile * 16;
+        if (lane < 16) {
             if (hp.labels) dma4(hp.labels + r0 + lane, a);
             if (hp.inst_w) dma4(hp.inst_w + r0 + lane, a + hp.aux_off_w);
         }
         if (hp.targets) {
-            const int total = RT * k_targets;           // contiguous floats of this tile's targets
+            const int total = 16 * k_targets;           // contiguous floats of this tile's targets
             for (int e = 0; e < total; e += 64) {
                 const int idx = e + lane;               // (only the lanes with an element take part: an LDS-DMA writes
                 if (idx < total)                        //  lane*4 bytes past its base whatever it loaded, and the slot ends at `total`)
@@ -445,12 +438,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     };
     auto issue_next = [&]() {
         if (pf_kt == 0) issue_aux();
-        const bool lower = t32 && (pf_kt & 1);          // T32: odd pieces come from rows 16..31 of the tile
-        dma16(lower ? pf_ptr + half_rows : pf_ptr, ring + pf_slot);
-        if (!t32 || lower) pf_ptr += 16;
+        dma16(pf_ptr, ring + pf_slot);
+        pf_ptr += 16;
         pf_slot = ring_next(pf_slot);
         ++pf_q;
-        if (++pf_kt == PT) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
+        if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
     for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
 
@@ -544,123 +536,6 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         }
     };
 
-    bool tiles_done = false;
-    if constexpr (T32) {
-      if (t32) {
-        // ---------------- 32-row tiles: layer 0 on v_mfma_f32_32x32x16_f16 ----------------
-        // One K-step = one 16-feature chunk = two 1-KiB pieces (rows 0..15 and rows 16..31 of the tile).  Lane (row n32, feature
-        // group kg) takes its row's 8 high and 8 low parts from the piece of its half; the weight fragment of a chunk (32 units x
-        // 16 features, high and low) feeds 32 rows, half the LDS reads per row of the 16-row path.  The 32x32 accumulator (unit
-        // 8(i>>2) + 4(lane>>5) + (i&3) in register i, row lane&31) is then split into two 16-row halves in the 16x16 layout with
-        // v_permlane16_swap (lane rows 1 and 2 hold each other's units, which layer 1's fragments are packed for) and every half
-        // goes through the common tail.
-        typedef float f32x16 __attribute__((ext_vector_type(16)));
-        struct WF { f16x8 wh, wl; };
-        struct XF { f16x8 xh, xl; };
-        const int KS = KT0;                               // K-steps per tile (even: KT0 is)
-        const int S = my_tiles * KS;
-        if (S > 0) {
-            WF Wb[2];
-            XF Xb[2];
-            f32x16 acc[D];
-            const int n32 = lane & 31, kg = lane >> 5;
-            const int frag32 = uni(net.L[0].frag_off) + lane * 4;
-            const int bias32 = uni(net.L[0].bias_off) + 4 * kg;
-            int ld_slot = 0, s = 0, ks = 0;
-            auto load_x = [&](XF& x) {
-                const int slot_b = ring_next(ld_slot);
-                const char* px = ring + ((n32 >> 4) ? slot_b : ld_slot) + ((2 * kg) * 16 + (n32 & 15)) * 16;
-                x.xh = *reinterpret_cast<const f16x8*>(px);
-                x.xl = *reinterpret_cast<const f16x8*>(px + 256);
-                ld_slot = ring_next(slot_b);
-            };
-            auto load_w = [&](WF& w, int chunk, int j) {
-                const float* fr = imgs + (size_t)j * image_floats + frag32 + chunk * 512;
-                w.wh = *reinterpret_cast<const f16x8*>(fr);
-                w.wl = *reinterpret_cast<const f16x8*>(fr + 256);
-            };
-            auto load_bias = [&]() {
-#pragma unroll
-                for (int j = 0; j < D; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(imgs + (size_t)j * image_floats + bias32 + 8 * g);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[j][4 * g + i] = b[i];
-                    }
-            };
-            // (fragments are not carried across the tail: a tile starts by reading its first ones, which keeps 32 registers
-            //  free for the tails - most waves have a single tile anyway; the X pieces themselves do run ahead in the ring)
-            auto step = [&](auto par_tag) {
-                constexpr int PAR = decltype(par_tag)::value;
-                const int ks_next = ks + 1;
-                bool issued = false;
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    const WF& wc = Wb[(PAR * D + j) & 1];
-                    WF& wn = Wb[(PAR * D + j + 1) & 1];
-                    NPBNN_WAIT_LGKM0();                   // this unit's fragments are complete
-                    if (j == 0 && pf_q < Q) {             // the x fragments of step s are in registers: refill its slots (step s+2)
-                        issue_next();
-                        issue_next();
-                        issued = true;
-                    }
-                    if (j == D - 1) {
-                        if (ks_next < KS) {
-                            if (issued) wait_depth<2>();  // step s+1 has landed
-                            else NPBNN_WAIT_VMCNT(0);
-                            load_x(Xb[PAR ^ 1]);
-                            load_w(wn, ks_next, 0);
-                        }
-                    } else {
-                        load_w(wn, ks, j + 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);    // keep the LDS reads of the next unit ahead of this unit's MFMAs
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.wh, Xb[PAR].xh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.wl, Xb[PAR].xh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc.wh, Xb[PAR].xl, acc[j], 0, 0, 0);
-                }
-                ++s;
-                ks = ks_next;
-            };
-            HotParams hp_lower = hp;                      // rows 16..31: same slot, 64 bytes on; the targets of 16 rows further
-            hp_lower.aux_off_t = hp.aux_off_t + 64 * k_targets - 64;
-            int tile = first_tile;
-            for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
-                ks = 0;
-                wait_younger(pf_q - 2 * (s + 1));         // the tile's first step has landed
-                load_x(Xb[0]);
-                load_w(Wb[0], 0, 0);
-                load_bias();
-                for (int kp = 0; kp < KS; kp += 2) {      // the register sets alternate, no copies
-                    step(std::integral_constant<int, 0>{});
-                    step(std::integral_constant<int, 1>{});
-                }
-                // ---- split the accumulators into the two halves (16x16 layout), then layers 1.. + likelihood of each ----
-                f32x4 upper[D][MT0], lower[D][MT0];
-#pragma unroll
-                for (int j = 0; j < D; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[j][8 * mt + i]),
-                                                                             __float_as_uint(acc[j][8 * mt + 4 + i]), false, false);
-                            upper[j][mt][i] = __uint_as_float(r[0]);
-                            lower[j][mt][i] = __uint_as_float(r[1]);
-                        }
-                const char* a_slot = aux + (tseq & aux_mask) * aux_sz;
-                const long long row = (long long)tile * 32 + n;
-                tile_tail<MT0, MTI, LK, D, D, 0>(net, hp, imgs, image_floats, upper, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                tile_tail<MT0, MTI, LK, D, D, 0>(net, hp_lower, imgs, image_floats, lower, lane, n, kq, a_slot + 64, row_scratch, row + 16,
-                                                 row + 16 < hp.n_rows, A);
-            }
-        }
-        tiles_done = true;
-      }
-    }
-    if (tiles_done) {
-    } else
     if constexpr (PIPE) {
         // ---------------- fp16-split layer 0, software pipelined over the K-steps of ALL tiles of this wave ----------------
         // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high parts)

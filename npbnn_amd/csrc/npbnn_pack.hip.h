@@ -40,30 +40,6 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
             const int lane = piece & 63;
             const int tile = piece >> 6;
             const int ld = L.in_dim + L.has_bias;
-            if (l == 0 && net.l0_f16 && net.l0_tile32) {
-                // 32x32x16 A fragments: entry ((chunk*2 + part)*64 + lane) = part of W_0[o = lane&31][c = 16 chunk + 8(lane>>5) + 0..7] * w_scale[c]
-                const int part = tile & 1, chunk = tile >> 1;
-                const int o = lane & 31;
-                const int c0 = 16 * chunk + 8 * (lane >> 5);
-                f16x8 v;
-                for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
-                if (o < L.out_dim) {
-                    const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
-                    for (int j = 0; j < 8; ++j) {
-                        const int c = c0 + j;
-                        if (c < L.in_dim) {
-                            const bool overridden = (col_override != nullptr && !isnan(col_override[c]));
-                            const float wv = overridden ? 0.f : (float)(row[c] * (double)w_scale[c]);
-                            if (overflow && !(fabsf(wv) <= kF16Safe)) *overflow = 1;
-                            _Float16 hi, lo;
-                            split_f16(wv, hi, lo);
-                            v[j] = part ? lo : hi;
-                        }
-                    }
-                }
-                *reinterpret_cast<f16x8*>(image + L.frag_off + (long long)piece * 4) = v;
-                return;
-            }
             if (l == 0 && net.l0_f16) {
                 const int part = tile & 1, rest = tile >> 1;
                 const int mt = rest % L.mt, ks = rest / L.mt;
@@ -90,7 +66,7 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
             }
             const int mt = tile % L.mt, kt = tile / L.mt;
             const int o = 16 * mt + (lane & 15);
-            const int c0 = 16 * kt + 4 * ((l == 1 && net.l0_tile32) ? tile32_lane_row(lane >> 4) : (lane >> 4));
+            const int c0 = 16 * kt + 4 * (lane >> 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (o < L.out_dim) {
                 const double* row = w + L.w_off + (long long)o * ld + L.has_bias;

@@ -371,7 +371,6 @@ int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
 int rebuild_net(npbnn_ctx* ctx, bool f16);
 
 struct LaunchPlan {
-    WaveLayout lay;
     eval_fn_t fn;
     int n_cand;
     int grid, wpb;
@@ -405,7 +404,6 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
-    lp->lay = lay;
     lp->fn = predict_only ? npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand, kLikCat)
                           : pick_kernel(ctx->net, n_cand);
     lp->wpb = wpb;
@@ -413,23 +411,9 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     int grid = (d.n_tiles + wpb - 1) / wpb;
     if (grid > ctx->n_cu) grid = ctx->n_cu;     // persistent: one workgroup per CU
     if (grid < 1) grid = 1;
-    // producer / consumer mode of the three-candidate categorical build: worth it when a workgroup has many tiles
-    if (n_cand == 3 && !predict_only && ctx->net.l0_f16 && max_inner_tiles(ctx->net) == 1 && ctx->net.L[0].mt <= 2 &&
-        lik_class(ctx->net.lik_kind) == kLikCat && ctx->net.L[0].kt >= 8 && d.n_tiles >= 16 * ctx->n_cu && getenv("NPBNN_NO_PC") == nullptr) {
-        const int waves = 12, producers = 4;
-        const PcLayout pcl = make_pc_layout(waves, producers, lay.aux_sz, n_cand * ctx->net.L[0].mt * 1024);
-        const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)pcl.total;
-        if (need <= ctx->lds_limit && waves <= max_waves_for(ctx->net.L[0].mt, 1, true, n_cand, kLikCat)) {
-            lp->lay.pc_producers = producers;
-            lp->wpb = waves;
-            lp->lds = need;
-            grid = ctx->n_cu;                   // one workgroup per CU, each with many tiles
-            if (grid > d.n_tiles) grid = d.n_tiles;
-        }
-    }
     lp->grid = grid;
     lp->n_waves = grid;            // one partial record per workgroup
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp->lds));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return NPBNN_OK;
 }
 
@@ -791,7 +775,6 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     rc = stage_weights(ctx, W_packed, act_prm, col_override);
     if (rc) return rc;
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = (which == 0) ? d.inst_w : nullptr;
     p.use_classw = (which == 0 && ctx->n_classw > 0) ? 1 : 0;
@@ -882,7 +865,6 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
         ctx->d_y_cap = n_el;
     }
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.labels = nullptr;
     p.targets = nullptr;
     p.net.lik_kind = NPBNN_LIK_NONE;
@@ -953,14 +935,13 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
                                    ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
             EvalParams p = make_params(ctx, d);
-            p.lay = lp.lay;
-    p.lay = lp.lay;
             p.labels = nullptr;
             p.targets = nullptr;
             p.net.lik_kind = NPBNN_LIK_NONE;
             p.y_out = ctx->d_y;
             p.predict_mode = apply_out_fn ? 2 : 1;
             p.weight_sets = 1;
+            p.lay = layout_for(ctx, d, true);
             rc = push_eval_params(ctx, p);
             if (rc) return rc;
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
@@ -1161,7 +1142,6 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.n_rows = d.n_rows;
     c.net = ctx->net;
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
@@ -1286,7 +1266,6 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     pd.t0 = 0;
     pd.n_cand = lp.n_cand;          // every candidate = the staged weights (empty patch lists): same work as a chain pass
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
@@ -1357,7 +1336,6 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     rc = stage_weights(ctx, W_packed, nullptr, nullptr);
     if (rc) return rc;
     EvalParams p = make_params(ctx, d);
-    p.lay = lp.lay;
     p.partials = ctx->d_partials;
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;

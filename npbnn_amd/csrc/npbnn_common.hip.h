@@ -24,35 +24,7 @@ struct WaveLayout {
     int off_w;       // instance weights inside a slot (labels, when present, sit at 0)
     int off_t;       // targets inside a slot
     int wave_lds;    // bytes of LDS per wave: ring + slots (+ row scratch of the float64 row-wise likelihoods)
-    int pc_producers;  // > 0: producer / consumer mode (PcLayout below) with that many streaming waves; 0: every wave does whole tiles
 };
-
-// Producer / consumer mode of the three-candidate chain kernel.  P waves only stream X and run layer 0 (their rings are
-// twice as deep, since the other waves need none); the finished layer-0 accumulators of a tile travel through one of M
-// LDS mailboxes to one of the C other waves, which only run the tails (layers 1.., likelihood).  The X stream then never
-// stops for a tail, and the tails of one tile run while the next ones stream.  Tile t of the workgroup is produced by
-// wave t % P, passes through mailbox t % M and is consumed by wave P + t % C: a fixed assignment, so every sum is formed
-// in the same order on every run.
-struct PcLayout {
-    int P, C, M;
-    int ring_bytes;      // per producer
-    int off_rings, off_paux, off_mail, mail_sz, off_caux, off_ctrl, total;     // byte offsets behind the weight images
-};
-__host__ __device__ inline PcLayout make_pc_layout(int waves, int producers, int aux_sz, int acc_bytes) {
-    PcLayout L;
-    L.P = producers;
-    L.C = waves - producers;
-    L.M = 3;
-    L.ring_bytes = 8192;
-    L.off_rings = 0;
-    L.off_paux = L.off_rings + L.P * L.ring_bytes;
-    L.off_mail = L.off_paux + L.P * 2 * aux_sz;
-    L.mail_sz = acc_bytes + ((aux_sz + 255) / 256) * 256;
-    L.off_caux = L.off_mail + L.M * L.mail_sz;
-    L.off_ctrl = L.off_caux + L.C * aux_sz;
-    L.total = L.off_ctrl + 256;
-    return L;
-}
 // likelihoods that combine several outputs of one row (predicted sigma, count data) exchange them through 1 KiB of LDS
 __host__ __device__ inline bool lik_needs_row_scratch(int lik_kind) {
     return lik_kind >= NPBNN_LIK_GAUSS_PRED_SIGMA && lik_kind <= NPBNN_LIK_NEGBIN_BASE10;
@@ -64,7 +36,6 @@ __host__ __device__ inline WaveLayout make_wave_layout(bool labels, bool inst_w,
     L.aux_sz = L.off_t + 64 * k_targets;
     L.aux_slots = kt0 >= kRing ? 2 : 4;
     L.wave_lds = kRing * 1024 + L.aux_slots * L.aux_sz + (lik_needs_row_scratch(lik_kind) ? 1024 : 0);
-    L.pc_producers = 0;
     return L;
 }
 constexpr int kPartialStride = 1 + 2 * NPBNN_MAX_TARGETS;   // loglik, sum_r[16], sum_r2[16]

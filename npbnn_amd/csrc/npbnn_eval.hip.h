@@ -334,7 +334,6 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     NPBNN_ESTAMP(0);
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
     constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
-    constexpr bool PCB = PIPE && D == 3 && LK == kLikCat;      // builds that have the producer / consumer mode
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
@@ -445,43 +444,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         ++pf_q;
         if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
-    // ---- producer / consumer mode: its own LDS map and X stream (see PcLayout) ----
-    const int pc_P = PCB ? uni(p.lay.pc_producers) : 0;
-    const bool pc = pc_P > 0;
-    const PcLayout pcl = make_pc_layout(wpb, pc ? pc_P : 1, aux_sz, D * MT0 * 1024);
-    char* const pc_base = smem + D * IB;
-    char* const pc_ring = pc_base + pcl.off_rings + wave * pcl.ring_bytes;              // producers
-    char* const pc_paux = pc_base + pcl.off_paux + wave * 2 * aux_sz;
-    int* const pc_seq = reinterpret_cast<int*>(pc_base + pcl.off_ctrl);                // mailbox sequence numbers
-    const int pc_nt = bid < n_tiles ? (n_tiles - bid + G - 1) / G : 0;                  // tiles of this workgroup
-    const bool pc_prod = pc && wave < pcl.P;
-    const int pc_tiles = pc_prod ? (pc_nt - wave + pcl.P - 1) / pcl.P : 0;              // (wave < P <= pc_nt is not required: may be <= 0)
-    const int pcQ = (pc_tiles > 0 ? pc_tiles : 0) * KT0;
-    const float* pc_ptr = Xg + ((size_t)(bid + G * wave) * 16 + n) * (size_t)Fp + 4 * kq;
-    const size_t pc_jump = (size_t)G * pcl.P * 16 * (size_t)Fp - (size_t)KT0 * 16;
-    int pc_q = 0, pc_kt = 0, pc_sq = 0, pc_slot = 0;
-    auto pc_issue = [&]() {
-        if (pc_kt == 0) {                               // row-aux data of the tile, into this producer's own slot pair
-            char* a = pc_paux + (pc_sq & 1) * aux_sz;
-            const size_t r0 = (size_t)(bid + G * (wave + pc_sq * pcl.P)) * 16;
-            if (lane < 16) {
-                if (hp.labels) dma4(hp.labels + r0 + lane, a);
-                if (hp.inst_w) dma4(hp.inst_w + r0 + lane, a + hp.aux_off_w);
-            }
-        }
-        dma16(pc_ptr, pc_ring + pc_slot);
-        pc_ptr += 16;
-        pc_slot = (pc_slot + 1024) & (pcl.ring_bytes - 1);
-        ++pc_q;
-        if (++pc_kt == KT0) { pc_kt = 0; ++pc_sq; pc_ptr += pc_jump; }
-    };
-    if (pc) {
-        if (tid < pcl.M) pc_seq[tid] = tid;             // mailbox m first takes ticket m
-        if (pc_prod)
-            for (int i = 0; i < 8 && pc_q < pcQ; ++i) pc_issue();
-    } else {
-        for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
-    }
+    for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
 
     // ---- candidates = current state + their own touched entries: fetch the first entry per thread now (its latency
     //      hides under the image copy), meet, patch the LDS images, meet again.  The first barrier also waits for this
@@ -573,135 +536,6 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         }
     };
 
-    bool tiles_done = false;
-    if constexpr (PCB) {
-      if (pc) {
-        struct WFrag { f16x8 wh[MT0], wl[MT0]; };
-        struct XFrag { f16x8 xh, xl; };
-        const int KS = KT0 >> 1;
-        constexpr int kSpinLimit = 1 << 18;             // (a mailbox that never turns up ends the wait instead of hanging the GPU)
-        auto wait_seq = [&](int m, int want) {
-            int spins = 0;
-            while (uni(__hip_atomic_load(pc_seq + m, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != want) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > kSpinLimit) break;
-            }
-        };
-        if (pc_prod) {
-            // ---------------- producer: X stream + layer 0, tile after tile ----------------
-            const int S = pc_tiles * KS;
-            if (S > 0) {
-                WFrag Wb[2];
-                XFrag Xb[2];
-                f32x4 acc0[D][MT0];
-                int rd_slot = 0, s = 0, ks = 0;
-                auto load_x = [&](XFrag& x) {
-                    const int slot_b = (rd_slot + 1024) & (pcl.ring_bytes - 1);
-                    const char* px = pc_ring + ((kq >> 1) ? slot_b : rd_slot) + ((2 * (kq & 1)) * 16 + n) * 16;
-                    x.xh = *reinterpret_cast<const f16x8*>(px);
-                    x.xl = *reinterpret_cast<const f16x8*>(px + 256);
-                    rd_slot = (slot_b + 1024) & (pcl.ring_bytes - 1);
-                };
-                auto load_w = [&](WFrag& w, int kstep, int j) {
-                    const float* fr = imgs + (size_t)j * image_floats + frag0_off + kstep * (MT0 * 512);
-#pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) {
-                        w.wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
-                        w.wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
-                    }
-                };
-                NPBNN_WAIT_VMCNT(0);                      // (the barriers above already drained this wave's loads)
-                load_x(Xb[0]);
-                load_w(Wb[0], 0, 0);
-                load_bias0(acc0);
-                // one K-step: the ring holds four of them; step s+4 is requested as soon as the fragments of step s are in registers
-                auto step = [&](auto par_tag) {
-                    constexpr int PAR = decltype(par_tag)::value;
-                    const int ks_next = (ks + 1 == KS) ? 0 : ks + 1;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const WFrag& wc = Wb[(PAR * D + j) & 1];
-                        WFrag& wn = Wb[(PAR * D + j + 1) & 1];
-                        NPBNN_WAIT_LGKM0();
-                        if (j == 0 && pc_q < pcQ) {
-                            pc_issue();
-                            pc_issue();
-                        }
-                        if (j == D - 1) {
-                            if (s + 1 < S) {
-                                wait_younger(pc_q - 2 * (s + 2));     // step s+1 has landed
-                                load_x(Xb[PAR ^ 1]);
-                                load_w(wn, ks_next, 0);
-                            }
-                        } else {
-                            load_w(wn, ks, j + 1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wl[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xl, acc0[j][mt], 0, 0, 0);
-                    }
-                    ++s;
-                    ks = ks_next;
-                };
-                for (int tseq = 0; tseq < pc_tiles; ++tseq) {
-                    for (int kp = 0; kp + 1 < KS; kp += 2) {
-                        step(std::integral_constant<int, 0>{});
-                        step(std::integral_constant<int, 1>{});
-                    }
-                    if (KS & 1) {
-                        step(std::integral_constant<int, 0>{});
-                        Xb[0] = Xb[1];
-                        if (D & 1) Wb[0] = Wb[1];
-                    }
-                    // ---- hand the tile over: accumulators and row-aux data into mailbox t % M ----
-                    const int t = wave + tseq * pcl.P;
-                    const int m = t % pcl.M;
-                    wait_seq(m, t);                      // emptied by the consumer of ticket t - M
-                    char* mb = pc_base + pcl.off_mail + m * pcl.mail_sz;
-#pragma unroll
-                    for (int j = 0; j < D; ++j)
-#pragma unroll
-                        for (int mt = 0; mt < MT0; ++mt)
-                            *reinterpret_cast<f32x4*>(mb + ((j * MT0 + mt) * 64 + lane) * 16) = acc0[j][mt];
-                    {
-                        const char* a = pc_paux + (tseq & 1) * aux_sz;
-                        for (int b = lane * 4; b < aux_sz; b += 256)
-                            *reinterpret_cast<int*>(mb + D * MT0 * 1024 + b) = *reinterpret_cast<const int*>(a + b);
-                    }
-                    __hip_atomic_store(pc_seq + m, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    load_bias0(acc0);
-                }
-            }
-        } else {
-            // ---------------- consumer: layers 1.. + likelihood of the tiles t = c, c + C, ... ----------------
-            const int c = wave - pcl.P;
-            char* my_aux = pc_base + pcl.off_caux + c * aux_sz;
-            for (int t = c; t < pc_nt; t += pcl.C) {
-                const int m = t % pcl.M;
-                wait_seq(m, t + 1);
-                const char* mb = pc_base + pcl.off_mail + m * pcl.mail_sz;
-                f32x4 acc0[D][MT0];
-#pragma unroll
-                for (int j = 0; j < D; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = *reinterpret_cast<const f32x4*>(mb + ((j * MT0 + mt) * 64 + lane) * 16);
-                for (int b = lane * 4; b < aux_sz; b += 256)
-                    *reinterpret_cast<int*>(my_aux + b) = *reinterpret_cast<const int*>(mb + D * MT0 * 1024 + b);
-                __hip_atomic_store(pc_seq + m, t + pcl.M, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);    // free for ticket t + M
-                const int tile = bid + G * t;
-                const long long row = (long long)tile * 16 + n;
-                tile_tail<MT0, MTI, LK, D, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, my_aux, row_scratch, row, row < hp.n_rows, A);
-            }
-        }
-        tiles_done = true;
-      }
-    }
-    if (tiles_done) {
-    } else
     if constexpr (PIPE) {
         // ---------------- fp16-split layer 0, software pipelined over the K-steps of ALL tiles of this wave ----------------
         // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high parts)

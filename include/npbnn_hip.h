@@ -207,6 +207,10 @@ typedef struct {
     int32_t n_candidates;                      /* candidates per pass actually used */
     int32_t n_void_passes;                     /* overlapped schedule: passes dropped because the pass before them accepted */
     int32_t schedule;                          /* schedule actually used (NPBNN_SCHED_SERIAL / NPBNN_SCHED_OVERLAP) */
+    double temperature;                        /* MCMC._temperature after the iterations (changes in an exchange run only) */
+    int32_t iterations_done;                   /* K for npbnn_chain_run; an exchange run may stop a chain earlier (see below) */
+    int32_t overflow;                          /* exchange run: 1 = the chain stopped before a proposal that leaves the fp16 range of the
+                                                  layer-0 path (continue it with npbnn_chain_run, cfg->force_f32 = 1) */
 } npbnn_chain_result;
 
 int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed,
@@ -243,6 +247,47 @@ int npbnn_comm_init(int device_id, int rank, int nranks, const char id[128], npb
 int npbnn_comm_allgather_f64(npbnn_comm* comm, const double* send, int count, double* recv /* nranks*count */);
 int npbnn_comm_bcast_i64(npbnn_comm* comm, int64_t* buf, int count, int root);
 void npbnn_comm_destroy(npbnn_comm* comm);
+
+/* ---- exchange run: the chains of an MC3 run (np_bnn/BNN_mc3.py:87-126) advance n_seg swap intervals of seg_len iterations with
+ * the temperature swaps between them done on the GPU: replaces n_seg rounds of  pool.map(run_single_mcmc) -> read
+ * [logPost, temperature] of every chain -> swap the temperatures of chains j, k when
+ *   (logPost_k - logPost_j) * T_j + (logPost_j - logPost_k) * T_k >= log u           (BNN_mc3.py:99-112)
+ * Everything is enqueued on the chains' streams: after the launches of a segment every chain writes its record, the records
+ * are all-gathered in place (RCCL on the stream when `comm` spans several processes; chains of this process meet through
+ * events), every chain applies the decision to its own temperature and starts the next segment.  No host round trip per
+ * segment.  The swap proposals (swap_j, swap_k: chain ids; swap_logu) are pre-drawn by the caller from the stream the
+ * reference's parent process draws from, identically on every rank.
+ *   chain i lives on rank i % nranks as job i / nranks of that rank; n_chains = nranks * n_jobs; K = n_seg * seg_len rows per job.
+ * The number of passes a segment needs is only known on the device; each segment is given launch_slack (1.25 if <= 0) times
+ * the expected number.  If some chain has not finished a segment when it is exchanged (or stopped before an fp16 overflow), every
+ * chain on every rank sees it in the records and stops at that exchange: *out_segments_done < n_seg, each job's
+ * result->iterations_done says how far its chain got (its state and outputs are valid up to there), and the caller
+ * finishes that segment with npbnn_chain_run and a host-side swap.
+ *   out_records[s][i] = {logPost, temperature (before swap s), 1.0 if chain i had finished segment s, iterations done}
+ *   job.out_state[s]  = {logLik, logPrior, temperature, iterations done} of the chain after exchange s
+ *   job.out_cold_w[s] = its weights at exchange s if it is the cold chain (temperature 1) afterwards (the logger's sample,
+ *                       BNN_mc3.py:118-122); untouched otherwise */
+typedef struct {
+    npbnn_ctx* ctx;
+    const npbnn_chain_cfg* cfg;
+    double* W_inout;
+    const double* mask_packed;
+    int32_t M, chain_id;
+    const int32_t* idx;
+    const double* delta;
+    const int32_t* cnt;
+    const double* log_u;
+    uint8_t* out_accepted;
+    double* out_loglik_prop;                   /* or NULL */
+    double* out_logprior_prop;                 /* or NULL */
+    double* out_state;                         /* [n_seg][4] or NULL */
+    double* out_cold_w;                        /* [n_seg][n_weights] or NULL */
+    npbnn_chain_result* result;
+} npbnn_chain_job;
+int npbnn_chains_run_exchange(npbnn_comm* comm /* NULL: the chains of this process only */, npbnn_chain_job* jobs, int32_t n_jobs,
+                              int32_t n_chains, int32_t seg_len, int32_t n_seg, const int32_t* swap_j, const int32_t* swap_k,
+                              const double* swap_logu, double launch_slack, double* out_records /* [n_seg][n_chains][4] */,
+                              int32_t* out_segments_done);
 
 /* timing hook for a speculative chain pass: the evaluation kernel with n_candidates weight sets (0 = as many as fit),
  * `iters` back-to-back launches between one pair of HIP events on the ctx stream; mean milliseconds per launch */

@@ -62,8 +62,22 @@ class ChainCfg(C.Structure):
 class ChainResult(C.Structure):
     _fields_ = [("loglik", C.c_double), ("logprior", C.c_double), ("sigma", C.c_double * MAX_TARGETS),
                 ("n_accepted", C.c_int64), ("n_passes", C.c_int32), ("n_candidates", C.c_int32),
-                ("n_void_passes", C.c_int32), ("schedule", C.c_int32)]
+                ("n_void_passes", C.c_int32), ("schedule", C.c_int32), ("temperature", C.c_double),
+                ("iterations_done", C.c_int32), ("overflow", C.c_int32)]
 
+
+class ChainJob(C.Structure):
+    """One chain's share of npbnn_chains_run_exchange (npbnn_chain_job)."""
+    _fields_ = [("ctx", C.c_void_p), ("cfg", C.POINTER(ChainCfg)), ("W_inout", C.POINTER(C.c_double)),
+                ("mask_packed", C.POINTER(C.c_double)), ("M", C.c_int32), ("chain_id", C.c_int32),
+                ("idx", C.POINTER(C.c_int32)), ("delta", C.POINTER(C.c_double)), ("cnt", C.POINTER(C.c_int32)),
+                ("log_u", C.POINTER(C.c_double)), ("out_accepted", C.POINTER(C.c_uint8)),
+                ("out_loglik_prop", C.POINTER(C.c_double)), ("out_logprior_prop", C.POINTER(C.c_double)),
+                ("out_state", C.POINTER(C.c_double)), ("out_cold_w", C.POINTER(C.c_double)),
+                ("result", C.POINTER(ChainResult))]
+
+
+REC_DOUBLES = 4      # record of a chain at an exchange: logPost, temperature, finished-the-segment flag, iterations done
 
 SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP = 0, 1, 2
 
@@ -96,6 +110,9 @@ SIGNATURES = {
     "npbnn_pinned_free": (None, [C.c_void_p]),
     "npbnn_chain_run": (C.c_int, [_P, C.POINTER(ChainCfg), _DP, _DP, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _DP,
                                   C.POINTER(C.c_int32), _DP, C.POINTER(C.c_uint8), _DP, _DP, C.POINTER(ChainResult)]),
+    "npbnn_chains_run_exchange": (C.c_int, [_P, C.POINTER(ChainJob), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32), _DP, C.c_double, _DP,
+                                            C.POINTER(C.c_int32)]),
     "npbnn_op_activation": (C.c_int, [C.c_int, C.c_int, C.c_double, _DP, C.c_int64]),
     "npbnn_op_output": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.c_int32]),
     "npbnn_op_likelihood": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.POINTER(C.c_int64), _DP, C.c_int32, _DP, _DP,

@@ -194,16 +194,8 @@ class HipContext:
         self._chk(self._lib.npbnn_time_pass(self._ctx, capi.dptr(w), int(n_candidates), int(iters), C.byref(ms), C.byref(used)))
         return ms.value, used.value
 
-    def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
-                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0):
-        """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
-        (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
-        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
-        K, M = idx.shape
-        cfg = self.__dict__.get("_chain_cfg")
-        if cfg is None:
-            cfg = self._chain_cfg = capi.ChainCfg()
-            self._chain_res = capi.ChainResult()
+    def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
+                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0):
         cfg.prior_kind = int(prior_kind)
         for i, s in enumerate(prior_scale):
             cfg.prior_scale[i] = float(s)
@@ -221,6 +213,27 @@ class HipContext:
         cfg.cur_loglik, cfg.cur_logprior = float(cur_loglik), float(cur_logprior)
         cfg.n_candidates = int(n_candidates)
         cfg.schedule = int(schedule)
+        cfg.force_f32 = 0
+
+    def _result_dict(self, res):
+        k = self.arch.n_targets
+        return dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]),
+                    n_accepted=res.n_accepted, n_passes=res.n_passes, n_candidates=res.n_candidates,
+                    n_void_passes=res.n_void_passes, schedule=res.schedule, temperature=res.temperature,
+                    iterations_done=res.iterations_done, overflow=res.overflow)
+
+    def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0):
+        """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
+        (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
+        K, M = idx.shape
+        cfg = self.__dict__.get("_chain_cfg")
+        if cfg is None:
+            cfg = self._chain_cfg = capi.ChainCfg()
+            self._chain_res = capi.ChainResult()
+        self._fill_chain_cfg(cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
+                             cur_sigma, sigma, n_candidates, schedule)
         m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
         if idx.dtype != np.int32 or not idx.flags.c_contiguous:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
@@ -242,6 +255,74 @@ class HipContext:
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)
             self._chk(rc)
             break
-        return w, acc, llp, lpp, dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]),
-                                      n_accepted=res.n_accepted, n_passes=res.n_passes, n_candidates=res.n_candidates,
-                                      n_void_passes=res.n_void_passes, schedule=res.schedule)
+        return w, acc, llp, lpp, self._result_dict(res)
+
+
+def chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=None, launch_slack=1.25,
+                        want_cold_w=True):
+    """Several chains advance ``n_seg`` swap intervals of ``seg_len`` iterations with the temperature swaps done on the GPU
+    (npbnn_chains_run_exchange; reference loop: np_bnn/BNN_mc3.py:94-112).
+
+    ``jobs``: one dict per chain of this process - ``ctx`` (HipContext), ``chain_id``, ``weights``, ``idx``, ``delta``,
+    ``cnt``, ``log_u`` (K = n_seg * seg_len rows), ``mask`` and the keyword arguments of :meth:`HipContext.chain_run`
+    under ``cfg``.  ``comm``: the native communicator handle (``RcclComm._comm``) or None for the chains of this process.
+
+    Returns ``(outs, records, segments_done)``: per job ``dict(w, accepted, loglik_prop, logprior_prop, state, cold_w,
+    result)`` valid for the first ``result['iterations_done']`` iterations; ``records[s, i] = (logPost, temperature before
+    swap s, finished flag, iterations done)`` of chain i; ``segments_done < n_seg`` when some chain fell short."""
+    K = int(seg_len) * int(n_seg)
+    lib = jobs[0]["ctx"]._lib
+    arr = (capi.ChainJob * len(jobs))()
+    keep, outs = [], []
+    i32p = C.POINTER(C.c_int32)
+    for q, job in enumerate(jobs):
+        ctx = job["ctx"]
+        weights = job["weights"]
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
+        idx, cnt = job["idx"], job["cnt"]
+        if idx.shape[0] != K or len(cnt) != K:
+            raise ValueError("job %d: %d rows of draws for %d x %d iterations" % (q, idx.shape[0], n_seg, seg_len))
+        if idx.dtype != np.int32 or not idx.flags.c_contiguous:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if cnt.dtype != np.int32 or not cnt.flags.c_contiguous:
+            cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+        delta, log_u = capi.as_f64(job["delta"]), capi.as_f64(job["log_u"])
+        mask = job.get("mask")
+        m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
+        cfg, res = capi.ChainCfg(), capi.ChainResult()
+        ctx._fill_chain_cfg(cfg, **job["cfg"])
+        acc = np.zeros(K, dtype=np.uint8)
+        llp, lpp = np.zeros(K), np.zeros(K)
+        state = np.zeros((n_seg, 4))
+        cold = np.zeros((n_seg, w.size)) if want_cold_w else None
+        J = arr[q]
+        J.ctx = ctx._ctx
+        J.cfg = C.pointer(cfg)
+        J.W_inout = capi.dptr(w)
+        J.mask_packed = capi.dptr(m)
+        J.M = idx.shape[1]
+        J.chain_id = int(job["chain_id"])
+        J.idx = idx.ctypes.data_as(i32p)
+        J.delta = capi.dptr(delta)
+        J.cnt = cnt.ctypes.data_as(i32p)
+        J.log_u = capi.dptr(log_u)
+        J.out_accepted = acc.ctypes.data_as(C.POINTER(C.c_uint8))
+        J.out_loglik_prop = capi.dptr(llp)
+        J.out_logprior_prop = capi.dptr(lpp)
+        J.out_state = capi.dptr(state)
+        J.out_cold_w = capi.dptr(cold)
+        J.result = C.pointer(res)
+        keep.append((w, idx, cnt, delta, log_u, m, cfg, res))
+        outs.append(dict(w=w, accepted=acc, loglik_prop=llp, logprior_prop=lpp, state=state, cold_w=cold, _res=res, _ctx=ctx))
+    sj = np.ascontiguousarray(swap_j, dtype=np.int32)
+    sk = np.ascontiguousarray(swap_k, dtype=np.int32)
+    su = capi.as_f64(swap_logu)
+    records = np.zeros((n_seg, n_chains, capi.REC_DOUBLES))
+    done = C.c_int32(0)
+    rc = lib.npbnn_chains_run_exchange(comm, arr, len(jobs), int(n_chains), int(seg_len), int(n_seg), sj.ctypes.data_as(i32p),
+                                       sk.ctypes.data_as(i32p), capi.dptr(su), float(launch_slack), capi.dptr(records),
+                                       C.byref(done))
+    capi.check(lib, None, rc)
+    for o in outs:
+        o["result"] = o.pop("_ctx")._result_dict(o.pop("_res"))
+    return outs, records, int(done.value)

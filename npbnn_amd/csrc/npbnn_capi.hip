@@ -128,6 +128,11 @@ struct npbnn_ctx {
     double* d_llp = nullptr;
     double* d_lpp = nullptr;
     size_t iter_cap = 0;        // K capacity
+    // exchange run (npbnn_chains_run_exchange): [ExchangeParams | swap_j | swap_k | swap_logu || state | records | cold weights]
+    char* d_xbuf = nullptr;
+    char* h_xbuf = nullptr;
+    size_t xbuf_cap = 0;
+    hipEvent_t ev_x = nullptr;
 };
 
 namespace {
@@ -629,6 +634,9 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (c->d_eparams) (void)hipFree(c->d_eparams);
     if (c->d_fparams) (void)hipFree(c->d_fparams);
     if (c->d_cparams) (void)hipFree(c->d_cparams);
+    if (c->d_xbuf) (void)hipFree(c->d_xbuf);
+    if (c->h_xbuf) (void)hipHostFree(c->h_xbuf);
+    if (c->ev_x) (void)hipEventDestroy(c->ev_x);
     if (c->h_params) (void)hipHostFree(c->h_params);
     if (c->d_w2scale) (void)hipFree(c->d_w2scale);
     if (c->d_image) (void)hipFree(c->d_image);
@@ -960,16 +968,50 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
     return NPBNN_OK;
 }
 
-int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed, int32_t K, int32_t M,
-                    const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, uint8_t* out_accepted,
-                    double* out_loglik_prop, double* out_logprior_prop, npbnn_chain_result* result) {
+}  // extern "C"
+
+extern "C" int npbnn_comm_allgather_inplace_stream_(npbnn_comm* c, double* d_buf, int count, void* stream);
+extern "C" int npbnn_comm_info_(const npbnn_comm* c, int* device, int* rank, int* nranks);
+
+namespace {
+
+// ---- a device batch of the chain in three phases: prepare (uploads, parameter blocks, first step), enqueue passes, collect ----
+// one block, device and page-locked host twin: [ChainDev | overflow | W | cnt | log u || accepted | logLik' | logPrior'];
+// everything before `||` goes up in ONE copy at the start of a batch, the whole block comes back in one at its end
+struct ResLayout { size_t w, cnt, logu, acc, llp, lpp, total; };
+ResLayout res_layout(size_t kc, size_t wb) {
+    const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    ResLayout L;
+    L.w = 512;
+    L.cnt = L.w + up256(wb);
+    L.logu = L.cnt + up256(kc * sizeof(int));
+    L.acc = L.logu + up256(kc * sizeof(double));
+    L.llp = L.acc + up256(kc);
+    L.lpp = L.llp + up256(kc * sizeof(double));
+    L.total = L.lpp + up256(kc * sizeof(double));
+    return L;
+}
+
+struct ChainBatch {
+    LaunchPlan lp;
+    ResLayout RL;
+    int D = 1, schedule = NPBNN_SCHED_SERIAL, K = 0, M = 0;
+    bool overlap = false;
+    size_t wb = 0;
+    int launch = 0;                            // launches enqueued so far (overlapped schedule: the pass parity follows it)
+    unsigned long long* d_stamps = nullptr;    // diagnostics
+    double tw0 = 0.0, tw1 = 0.0;
+};
+
+double wall_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// seg_len > 0: the chain stops deciding at iteration seg_len until an exchange kernel moves the limit (exchange run)
+int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in, const double* mask_packed, int32_t K, int32_t M,
+                  const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, int seg_len, ChainBatch* B) {
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
-    if (!cfg || !W_inout || !result || K < 1 || M < 1 || !idx || !delta || !cnt || !log_u || !out_accepted)
-        return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
+    if (!cfg || !W_in || K < 1 || M < 1 || !idx || !delta || !cnt || !log_u) return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
     if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run: call npbnn_set_arch first");
-    static const bool timing = getenv("NPBNN_CHAIN_TIMING") != nullptr;     // diagnostics: host wall clock per phase
-    const auto wall = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tw0 = wall();
+    B->tw0 = wall_us();
     const int lik = ctx->net.lik_kind;
     if (lik == NPBNN_LIK_NONE) return fail(ctx, NPBNN_E_STATE, "chain_run: the architecture has no likelihood");
     if (cfg->prior_kind < 0 || cfg->prior_kind > NPBNN_PRIOR_LAPLACE) return fail(ctx, NPBNN_E_ARG, "chain_run: prior_kind=%d", cfg->prior_kind);
@@ -984,7 +1026,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     int rc = check_dataset_for_lik(ctx, d, lik);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LaunchPlan lp;
+    LaunchPlan& lp = B->lp;
     int want_cand = cfg->n_candidates;
     if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
     rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand);
@@ -1007,25 +1049,10 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
-    const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
-    // one block, device and page-locked host twin: [ChainDev | overflow | W | cnt | log u || accepted | logLik' | logPrior'];
-    // everything before `||` goes up in ONE copy at the start of a batch, the whole block comes back in one at its end
-    struct ResLayout { size_t w, cnt, logu, acc, llp, lpp, total; };
-    const auto layout = [&](size_t kc) {
-        ResLayout L;
-        L.w = 512;
-        L.cnt = L.w + up256(wb);
-        L.logu = L.cnt + up256(kc * sizeof(int));
-        L.acc = L.logu + up256(kc * sizeof(double));
-        L.llp = L.acc + up256(kc);
-        L.lpp = L.llp + up256(kc * sizeof(double));
-        L.total = L.lpp + up256(kc * sizeof(double));
-        return L;
-    };
     if ((size_t)K > ctx->res_k || (size_t)ctx->n_weights != ctx->res_nw) {
         size_t kc = (size_t)K > ctx->res_k ? (size_t)K : ctx->res_k;
         if (kc < kChainMinCapacity) kc = kChainMinCapacity;
-        const ResLayout L = layout(kc);
+        const ResLayout L = res_layout(kc, wb);
         if (ctx->d_res) (void)hipFree(ctx->d_res);
         if (ctx->h_res) (void)hipHostFree(ctx->h_res);
         if (ctx->d_mask) (void)hipFree(ctx->d_mask);        // sized by the number of weights as well
@@ -1044,7 +1071,7 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         ctx->d_llp = reinterpret_cast<double*>(b + L.llp);
         ctx->d_lpp = reinterpret_cast<double*>(b + L.lpp);
     }
-    const ResLayout RL = layout(ctx->res_k);
+    const ResLayout RL = res_layout(ctx->res_k, wb);
     static_assert(sizeof(ChainDev) <= 256, "ChainDev must fit its slot of the result block");
     if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
     if ((size_t)M > ctx->pv_cap) {
@@ -1079,16 +1106,21 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     ChainDev init{};
     init.logLik = cfg->cur_loglik;
     init.logPrior = cfg->cur_logprior;
+    init.logPrior_rep = cfg->cur_logprior;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) init.sigma[j] = cfg->cur_sigma[j];
     init.t = 0;
     init.n_accepted = 0;
     init.n_passes = 0;
     init.void_launch = -2;
     init.n_void = 0;
+    init.seg_end = (seg_len > 0 && seg_len < K) ? seg_len : K;
+    init.temperature = cfg->temperature;
+    init.seg_idx = 0;
+    init.poisoned = 0;
     {   // initial chain state, overflow flag, weights and the per-iteration scalars travel together (head of the block)
         memset(ctx->h_res, 0, 512);
         memcpy(ctx->h_res, &init, sizeof(ChainDev));
-        memcpy(ctx->h_res + RL.w, W_inout, wb);
+        memcpy(ctx->h_res + RL.w, W_in, wb);
         memcpy(ctx->h_res + RL.cnt, cnt, (size_t)K * sizeof(int));
         memcpy(ctx->h_res + RL.logu, log_u, (size_t)K * sizeof(double));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_res, ctx->h_res, RL.acc, hipMemcpyHostToDevice, st));
@@ -1119,23 +1151,23 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     c.pscale = f16 ? ctx->d_pscale : nullptr;
     c.pv = ctx->d_pv;
     c.overflow = ctx->d_chain_ovf;
-    unsigned long long* d_stamps = nullptr;
+    B->d_stamps = nullptr;
     if (getenv("NPBNN_STEP_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the step kernel
-        HIP_TRY(ctx, hipMalloc(&d_stamps, 1024 * 8 * sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemset(d_stamps, 0, 1024 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMalloc(&B->d_stamps, 1024 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(B->d_stamps, 0, 1024 * 8 * sizeof(unsigned long long)));
     }
-    c.stamps = d_stamps;
+    c.stamps = B->d_stamps;
     c.K = K;
     c.M = M;
     c.D = D;
     c.n_blocks = lp.n_waves;
+    c.stop_on_overflow = seg_len > 0 ? 1 : 0;
     c.prior_kind = cfg->prior_kind;
     for (int l = 0; l < kMaxLayers; ++l) {
         c.prior_scale[l] = cfg->prior_scale[l];
         c.half_inv_s2[l] = cfg->prior_scale[l] > 0 ? 0.5 / (cfg->prior_scale[l] * cfg->prior_scale[l]) : 0.0;
     }
     c.w_bound = cfg->w_bound;
-    c.temperature = cfg->temperature;
     c.lik_temp = cfg->lik_temp;
     c.sigma_given = cfg->sigma_given;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) c.sigma_fixed[j] = cfg->sigma[j];
@@ -1156,60 +1188,67 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     rc = push_chain_params(ctx, c);
     if (rc) return rc;
     // step (prepare candidates) -> [eval -> step (decide + prepare)]* ; a pass consumes 1..D iterations, so the number of
-    // passes is only known on the device: launch the least number that can finish, look at the counter, repeat
+    // passes is only known on the device
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
-    const double tw1 = wall();
-    int t_done = 0, n_passes = 0, n_rounds = 0, launch = 0;
-    const size_t res_used = RL.total;
-    const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
-    while (t_done < K) {
-        ++n_rounds;
-        // a pass decides between 1 and D iterations: launch what the previous batch's average says is needed plus a small
-        // margin (passes launched after the last iteration return at once), look at the counter, launch again if short
-        const int rem = K - t_done;
-        int n = (rem + D - 1) / D;
-        if (ctx->its_per_pass >= 1.0) {
-            const int est = (int)std::ceil((double)rem / ctx->its_per_pass);
-            if (est > n) n = est;
-            n += 1 + n / 64;
-        }
-        if (overlap) {
-            n += 1;                             // the last pass is decided by the launch after it
-            for (int i = 0; i < n; ++i, ++launch)
-                hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, launch);
-        } else {
-            for (int i = 0; i < n; ++i) {
-                hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0);
-                hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
-            }
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, res_used, hipMemcpyDeviceToHost, st));   // state + results, one copy
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (now->t < t_done || (now->t == t_done && !overlap))
-            return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now->t);
-        if (now->t == t_done && n_rounds > 64) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain is stuck at t=%d", now->t);
-        t_done = now->t;
+    B->RL = RL;
+    B->D = D;
+    B->schedule = schedule;
+    B->overlap = overlap;
+    B->K = K;
+    B->M = M;
+    B->wb = wb;
+    B->launch = 0;
+    B->tw1 = wall_us();
+    return NPBNN_OK;
+}
+
+// passes to launch for `rem` iterations: a pass decides between 1 and D of them; what the previous batch's average says is
+// needed plus a margin (passes launched after the last iteration return at once)
+int passes_for(const npbnn_ctx* ctx, const ChainBatch& B, int rem, double slack) {
+    int n = (rem + B.D - 1) / B.D;
+    if (ctx->its_per_pass >= 1.0) {
+        const int est = (int)std::ceil(slack * (double)rem / ctx->its_per_pass);
+        if (est > n) n = est;
+        n += 1 + n / 64;
     }
-    const double tw2 = wall();
-    const ChainDev fin = *now;
-    n_passes = fin.n_passes;
-    if (n_passes + fin.n_void > 0) ctx->its_per_pass = (double)K / (n_passes + fin.n_void);
-    ctx->accept_rate = (double)fin.n_accepted / K;
-    if (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 256))     // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
-        return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
-    {
-        const char* b = ctx->h_res;
-        memcpy(W_inout, b + RL.w, wb);
-        memcpy(out_accepted, b + RL.acc, (size_t)K);
-        if (out_loglik_prop) memcpy(out_loglik_prop, b + RL.llp, (size_t)K * sizeof(double));
-        if (out_logprior_prop)
-            memcpy(out_logprior_prop, b + RL.lpp, (size_t)K * sizeof(double));
+    if (B.overlap) n += 1;                   // the last pass is decided by the launch after it
+    return n;
+}
+
+// the same for a segment of an exchange run, where falling short is expensive (no second round): with no history, the
+// worst case (every iteration accepted: one iteration per pass, and in the overlapped schedule a void pass after each)
+int passes_for_segment(const npbnn_ctx* ctx, const ChainBatch& B, int seg_len, double slack) {
+    double est = ctx->its_per_pass >= 1.0 ? (double)seg_len / ctx->its_per_pass : (double)seg_len * (B.overlap ? 2.0 : 1.0);
+    const double least = (double)((seg_len + B.D - 1) / B.D);
+    if (est < least) est = least;
+    return (int)std::ceil(slack * est) + 2 + (B.overlap ? 1 : 0);
+}
+
+void chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
+    hipStream_t st = ctx->stream;
+    const LaunchPlan& lp = B.lp;
+    if (B.overlap) {
+        for (int i = 0; i < n; ++i, ++B.launch)
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch);
+    } else {
+        for (int i = 0; i < n; ++i, ++B.launch) {
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0);
+            hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
+        }
     }
-    if (d_stamps) {
+}
+
+// after the result block has come back (h_res): hand the first k_take iterations' outcome to the caller
+int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, double* W_inout, uint8_t* out_accepted, double* out_loglik_prop,
+                 double* out_logprior_prop, npbnn_chain_result* result, int k_take, bool exchange_run = false) {
+    const ChainDev fin = *reinterpret_cast<const ChainDev*>(ctx->h_res);
+    if (fin.n_passes + fin.n_void > 0 && k_take > 0) ctx->its_per_pass = (double)k_take / (fin.n_passes + fin.n_void);
+    if (k_take > 0) ctx->accept_rate = (double)fin.n_accepted / k_take;
+    if (B.d_stamps) {
         std::vector<unsigned long long> hs(1024 * 8);
-        (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(d_stamps);
+        (void)hipMemcpy(hs.data(), B.d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(B.d_stamps);
+        B.d_stamps = nullptr;
         double acc[8] = {0};
         int n = 0;
         for (int r = 1; r < 1024; ++r) {
@@ -1221,18 +1260,235 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
                        acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
     }
+    const int overflow = (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 256)) ? 1 : 0;
+    if (overflow && !exchange_run)           // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
+        return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
+    {
+        const char* b = ctx->h_res;
+        memcpy(W_inout, b + B.RL.w, B.wb);
+        memcpy(out_accepted, b + B.RL.acc, (size_t)k_take);
+        if (out_loglik_prop) memcpy(out_loglik_prop, b + B.RL.llp, (size_t)k_take * sizeof(double));
+        if (out_logprior_prop) memcpy(out_logprior_prop, b + B.RL.lpp, (size_t)k_take * sizeof(double));
+    }
     result->loglik = fin.logLik;
-    result->logprior = fin.logPrior;
+    result->logprior = fin.n_accepted > 0 ? fin.logPrior_rep : cfg->cur_logprior;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) result->sigma[j] = fin.sigma[j];
     result->n_accepted = fin.n_accepted;
-    result->n_passes = n_passes;
-    result->n_candidates = D;
+    result->n_passes = fin.n_passes;
+    result->n_candidates = B.D;
     result->n_void_passes = fin.n_void;
-    result->schedule = schedule;
+    result->schedule = B.schedule;
+    result->temperature = fin.temperature;
+    result->iterations_done = k_take;
+    result->overflow = overflow;          // (exchange run: the chain stopped before the proposal that overflows)
+    return NPBNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed, int32_t K, int32_t M,
+                    const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, uint8_t* out_accepted,
+                    double* out_loglik_prop, double* out_logprior_prop, npbnn_chain_result* result) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!result || !out_accepted) return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
+    static const bool timing = getenv("NPBNN_CHAIN_TIMING") != nullptr;     // diagnostics: host wall clock per phase
+    ChainBatch B;
+    int rc = chain_prepare(ctx, cfg, W_inout, mask_packed, K, M, idx, delta, cnt, log_u, 0, &B);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    int t_done = 0, n_rounds = 0;
+    const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
+    while (t_done < K) {       // launch the least number of passes that can finish, look at the counter, repeat if short
+        ++n_rounds;
+        chain_enqueue(ctx, B, passes_for(ctx, B, K - t_done, 1.0));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, B.RL.total, hipMemcpyDeviceToHost, st));   // state + results, one copy
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (now->t < t_done || (now->t == t_done && !B.overlap))
+            return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now->t);
+        if (now->t == t_done && n_rounds > 64) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain is stuck at t=%d", now->t);
+        t_done = now->t;
+    }
+    const double tw2 = wall_us();
+    rc = chain_finish(ctx, B, cfg, W_inout, out_accepted, out_loglik_prop, out_logprior_prop, result, K);
+    if (rc) return rc;
     if (timing)
         fprintf(stderr, "[npbnn chain timing] K=%d passes=%d (+%d void, %s) rounds=%d: setup %.0f us, passes %.0f us (%.2f us/pass), results %.0f us\n", K,
-                n_passes, fin.n_void, overlap ? "overlapped" : "serial", n_rounds, tw1 - tw0, tw2 - tw1, (tw2 - tw1) / n_passes, wall() - tw2);
+                result->n_passes, result->n_void_passes, B.overlap ? "overlapped" : "serial", n_rounds, B.tw1 - B.tw0, tw2 - B.tw1,
+                (tw2 - B.tw1) / (result->n_passes > 0 ? result->n_passes : 1), wall_us() - tw2);
     return NPBNN_OK;
+}
+
+
+int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n_jobs, int32_t n_chains, int32_t seg_len, int32_t n_seg,
+                              const int32_t* swap_j, const int32_t* swap_k, const double* swap_logu, double launch_slack,
+                              double* out_records, int32_t* out_segments_done) {
+    if (!jobs || n_jobs < 1 || n_jobs > 64 || seg_len < 1 || n_seg < 1 || !swap_j || !swap_k || !swap_logu || !out_segments_done)
+        return fail(nullptr, NPBNN_E_ARG, "chains_run_exchange: bad arguments");
+    if ((long long)seg_len * n_seg > (1 << 24)) return fail(nullptr, NPBNN_E_ARG, "chains_run_exchange: %d x %d iterations in one call", n_seg, seg_len);
+    int device = -1, rank = 0, world = 1;
+    if (comm) {
+        int rc = npbnn_comm_info_(comm, &device, &rank, &world);
+        if (rc) return rc;
+    }
+    if (n_chains != world * n_jobs)
+        return fail(nullptr, NPBNN_E_ARG, "chains_run_exchange: %d chains on %d ranks x %d jobs (every rank must hold the same number)", n_chains, world, n_jobs);
+    for (int q = 0; q < n_jobs; ++q) {
+        const npbnn_chain_job& J = jobs[q];
+        if (!J.ctx || !J.cfg || !J.W_inout || !J.result || !J.out_accepted) return fail(J.ctx, NPBNN_E_ARG, "chains_run_exchange: job %d incomplete", q);
+        if (device < 0) device = J.ctx->device;
+        if (J.ctx->device != device) return fail(J.ctx, NPBNN_E_ARG, "chains_run_exchange: job %d is on device %d, the others on %d", q, J.ctx->device, device);
+        if (J.chain_id != rank + world * q) return fail(J.ctx, NPBNN_E_ARG, "chains_run_exchange: job %d holds chain %d, expected %d", q, J.chain_id, rank + world * q);
+        for (int p2 = 0; p2 < q; ++p2)
+            if (jobs[p2].ctx == J.ctx) return fail(J.ctx, NPBNN_E_ARG, "chains_run_exchange: jobs %d and %d share a ctx", p2, q);
+    }
+    for (int s = 0; s < n_seg; ++s)
+        if (swap_j[s] < 0 || swap_j[s] >= n_chains || swap_k[s] < 0 || swap_k[s] >= n_chains)
+            return fail(jobs[0].ctx, NPBNN_E_ARG, "chains_run_exchange: swap %d names chains %d, %d of %d", s, swap_j[s], swap_k[s], n_chains);
+    if (!(launch_slack > 0.0)) launch_slack = 1.25;       // (< 1 starves the segments on purpose: tests of the shortfall path)
+    const int K = seg_len * n_seg;
+    npbnn_ctx* ctx0 = jobs[0].ctx;
+    HIP_TRY(ctx0, hipSetDevice(device));
+    const auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    // per-ctx exchange block; the records live in job 0's and are shared
+    struct XLayout { size_t sj, sk, su, state, rec, cold, total; };
+    std::vector<XLayout> XL(n_jobs);
+    std::vector<ChainBatch> B(n_jobs);
+    const size_t rec_bytes = (size_t)n_seg * n_chains * kRecDoubles * sizeof(double);
+    for (int q = 0; q < n_jobs; ++q) {
+        npbnn_ctx* ctx = jobs[q].ctx;
+        XLayout& L = XL[q];
+        L.sj = 256;
+        L.sk = L.sj + up256((size_t)n_seg * sizeof(int));
+        L.su = L.sk + up256((size_t)n_seg * sizeof(int));
+        L.state = L.su + up256((size_t)n_seg * sizeof(double));
+        L.rec = L.state + up256((size_t)n_seg * 4 * sizeof(double));
+        L.cold = L.rec + (q == 0 ? up256(rec_bytes) : 0);
+        L.total = L.cold + (jobs[q].out_cold_w ? up256((size_t)n_seg * ctx->n_weights * sizeof(double)) : 0);
+        static_assert(sizeof(ExchangeParams) <= 256, "ExchangeParams must fit its slot");
+        if (L.total > ctx->xbuf_cap) {
+            if (ctx->d_xbuf) (void)hipFree(ctx->d_xbuf);
+            if (ctx->h_xbuf) (void)hipHostFree(ctx->h_xbuf);
+            ctx->d_xbuf = nullptr; ctx->h_xbuf = nullptr; ctx->xbuf_cap = 0;
+            const size_t cap = L.total + L.total / 2;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_xbuf, cap));
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_xbuf, cap));
+            ctx->xbuf_cap = cap;
+        }
+        if (!ctx->ev_x) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+    }
+    double* d_rec = reinterpret_cast<double*>(ctx0->d_xbuf + XL[0].rec);
+    for (int q = 0; q < n_jobs; ++q) {
+        const npbnn_chain_job& J = jobs[q];
+        npbnn_ctx* ctx = J.ctx;
+        int rc = chain_prepare(ctx, J.cfg, J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, seg_len, &B[q]);
+        if (rc) {
+            if (ctx != ctx0) ctx0->err = ctx->err;
+            for (int p2 = 0; p2 <= q; ++p2) (void)hipStreamSynchronize(jobs[p2].ctx->stream);
+            return rc;
+        }
+        const XLayout& L = XL[q];
+        ExchangeParams x{};
+        x.rec = d_rec;
+        x.swap_j = reinterpret_cast<const int*>(ctx->d_xbuf + L.sj);
+        x.swap_k = reinterpret_cast<const int*>(ctx->d_xbuf + L.sk);
+        x.swap_logu = reinterpret_cast<const double*>(ctx->d_xbuf + L.su);
+        x.snap_state = reinterpret_cast<double*>(ctx->d_xbuf + L.state);
+        x.snap_w = J.out_cold_w ? reinterpret_cast<double*>(ctx->d_xbuf + L.cold) : nullptr;
+        x.world = world;
+        x.per_rank = n_jobs;
+        x.n_seg = n_seg;
+        x.seg_len = seg_len;
+        x.my_slot = rank * n_jobs + q;
+        x.n_weights = ctx->n_weights;
+        memset(ctx->h_xbuf, 0, 256);
+        memcpy(ctx->h_xbuf, &x, sizeof x);
+        memcpy(ctx->h_xbuf + L.sj, swap_j, (size_t)n_seg * sizeof(int));
+        memcpy(ctx->h_xbuf + L.sk, swap_k, (size_t)n_seg * sizeof(int));
+        memcpy(ctx->h_xbuf + L.su, swap_logu, (size_t)n_seg * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xbuf, ctx->h_xbuf, L.state, hipMemcpyHostToDevice, ctx->stream));
+        if (x.snap_w) HIP_TRY(ctx, hipMemsetAsync(ctx->d_xbuf + L.cold, 0, (size_t)n_seg * ctx->n_weights * sizeof(double), ctx->stream));
+    }
+    HIP_TRY(ctx0, hipMemsetAsync(d_rec, 0, rec_bytes, ctx0->stream));
+    if (n_jobs > 1) {      // the other chains' first record must not overtake the clearing of the shared block
+        HIP_TRY(ctx0, hipEventRecord(ctx0->ev_x, ctx0->stream));
+        for (int q = 1; q < n_jobs; ++q) HIP_TRY(jobs[q].ctx, hipStreamWaitEvent(jobs[q].ctx->stream, ctx0->ev_x, 0));
+    }
+    const int rec_per_rank = n_jobs * kRecDoubles;
+    for (int s = 0; s < n_seg; ++s) {
+        for (int q = 0; q < n_jobs; ++q) {
+            npbnn_ctx* ctx = jobs[q].ctx;
+            chain_enqueue(ctx, B[q], passes_for_segment(ctx, B[q], seg_len, launch_slack));
+            hipLaunchKernelGGL(exchange_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const ChainParams*)ctx->d_cparams,
+                               (const ExchangeParams*)ctx->d_xbuf, s);
+            if (q > 0) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_x, ctx->stream));
+                HIP_TRY(ctx0, hipStreamWaitEvent(ctx0->stream, ctx->ev_x, 0));
+            }
+        }
+        if (comm) {
+            int rc = npbnn_comm_allgather_inplace_stream_(comm, d_rec + (size_t)s * n_chains * kRecDoubles, rec_per_rank, ctx0->stream);
+            if (rc) {
+                ctx0->err = npbnn_last_error(nullptr);
+                for (int q = 0; q < n_jobs; ++q) (void)hipStreamSynchronize(jobs[q].ctx->stream);
+                return rc;
+            }
+        }
+        if (n_jobs > 1) {
+            HIP_TRY(ctx0, hipEventRecord(ctx0->ev_x, ctx0->stream));
+            for (int q = 1; q < n_jobs; ++q) HIP_TRY(jobs[q].ctx, hipStreamWaitEvent(jobs[q].ctx->stream, ctx0->ev_x, 0));
+        }
+        for (int q = 0; q < n_jobs; ++q) {
+            npbnn_ctx* ctx = jobs[q].ctx;
+            hipLaunchKernelGGL(exchange_apply_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const ChainParams*)ctx->d_cparams,
+                               (const ExchangeParams*)ctx->d_xbuf, s, B[q].launch, B[q].overlap ? 1 : 0);
+        }
+    }
+    for (int q = 0; q < n_jobs; ++q) {
+        npbnn_ctx* ctx = jobs[q].ctx;
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, B[q].RL.total, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_xbuf + XL[q].state, ctx->d_xbuf + XL[q].state, XL[q].total - XL[q].state, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (int q = 0; q < n_jobs; ++q) HIP_TRY(jobs[q].ctx, hipStreamSynchronize(jobs[q].ctx->stream));
+    int seg_done = -1;
+    for (int q = 0; q < n_jobs; ++q) {
+        const ChainDev* fin = reinterpret_cast<const ChainDev*>(jobs[q].ctx->h_res);
+        if (seg_done < 0) seg_done = fin->seg_idx;
+        if (fin->seg_idx != seg_done) return fail(ctx0, NPBNN_E_STATE, "chains_run_exchange: chains disagree on the exchanges done (%d, %d)", seg_done, fin->seg_idx);
+        if (fin->t < seg_done * seg_len || fin->t > K) return fail(ctx0, NPBNN_E_STATE, "chains_run_exchange: chain %d is at iteration %d after %d exchanges", q, fin->t, seg_done);
+    }
+    for (int q = 0; q < n_jobs; ++q) {
+        const npbnn_chain_job& J = jobs[q];
+        npbnn_ctx* ctx = J.ctx;
+        const ChainDev* fin = reinterpret_cast<const ChainDev*>(ctx->h_res);
+        int rc = chain_finish(ctx, B[q], J.cfg, J.W_inout, J.out_accepted, J.out_loglik_prop, J.out_logprior_prop, J.result, fin->t, true);
+        if (rc) return rc;
+        if (J.out_state) memcpy(J.out_state, ctx->h_xbuf + XL[q].state, (size_t)n_seg * 4 * sizeof(double));
+        if (J.out_cold_w) memcpy(J.out_cold_w, ctx->h_xbuf + XL[q].cold, (size_t)n_seg * ctx->n_weights * sizeof(double));
+    }
+    if (out_records) {     // device order (rank-major) -> chain order
+        const double* h_rec = reinterpret_cast<const double*>(ctx0->h_xbuf + XL[0].rec);
+        for (int s = 0; s < n_seg; ++s)
+            for (int i = 0; i < n_chains; ++i) {
+                const int slot = (i % world) * n_jobs + i / world;
+                memcpy(out_records + ((size_t)s * n_chains + i) * kRecDoubles, h_rec + ((size_t)s * n_chains + slot) * kRecDoubles,
+                       kRecDoubles * sizeof(double));
+            }
+    }
+    *out_segments_done = seg_done;
+    return NPBNN_OK;
+}
+
+// diagnostics (not part of the ABI): the weight image as it stands in device memory
+int npbnn_debug_image_(npbnn_ctx* ctx, float* out, int n) {
+    if (!ctx || !out) return NPBNN_E_ARG;
+    if (n > ctx->net.image_floats) n = ctx->net.image_floats;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_image, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int npbnn_pinned_alloc(size_t bytes, void** out) {

@@ -87,7 +87,11 @@ struct ChainDev {          // device-resident chain state
     int n_passes;           // evaluation passes that decided at least one iteration
     int void_launch;        // overlapped mode: launch whose pass was evaluated from a state that an accept has since replaced
     int n_void;             // such passes in this batch
-    int pad_;
+    int seg_end;            // iterations the chain may decide for now: K, or the end of the current segment of an exchange run
+    double temperature;     // MCMC._temperature; changed on the device by the swaps of an exchange run
+    double logPrior_rep;    // log prior as MCMC._logPrior holds it: updated on accept only (logPrior is re-summed at segment starts)
+    int seg_idx;            // exchange run: segments exchanged so far
+    int poisoned;           // exchange run: some chain had not reached the end of a segment when it was exchanged; nothing runs after
 };
 
 struct ChainParams {
@@ -112,11 +116,13 @@ struct ChainParams {
     int* overflow;             // set when a scaled weight leaves the fp16 range
     unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1), else nullptr
     int K, M, D, n_blocks;
+    int stop_on_overflow;      // exchange run: a proposal outside the fp16 range stops the chain before it (else: flag only, the
+                               // caller discards the batch)
     int prior_kind;
     double prior_scale[kMaxLayers];
     double half_inv_s2[kMaxLayers];   // 0.5 / scale^2 (normal prior)
     double w_bound;
-    double temperature, lik_temp;
+    double lik_temp;           // (the temperature is chain state: ChainDev)
     int sigma_given;           // Gaussian: 1 = use sigma_fixed, 0 = empirical
     double sigma_fixed[NPBNN_MAX_TARGETS];
     long long n_rows;
@@ -202,7 +208,8 @@ __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 d
 //               in iteration order on sums computed from the true current state: the chain is the sequential one.
 // ------------------------------------------------------------------------------------------------
 struct StepPlan {
-    int first;     // first launch of a batch: full prior of the current state, no pass to decide
+    int first;     // first launch of a batch: iteration counter to 0, no pass to decide
+    int resum;     // sum the prior of the current state in full (start of a batch, start of a segment of an exchange run)
     int dec;       // parity of the pass to decide, or -1
     int fly;       // parity of the pass being evaluated while this step runs (overlapped schedule), or -1
     int out;       // parity of the pass to prepare
@@ -211,6 +218,7 @@ struct StepPlan {
 __device__ __forceinline__ StepPlan overlapped_plan(int launch) {
     StepPlan pl;
     pl.first = 0;
+    pl.resum = 0;
     pl.dec = launch >= 1 ? ((launch - 1) & 1) : -1;
     pl.fly = launch & 1;
     pl.out = (launch + 1) & 1;
@@ -224,7 +232,7 @@ struct StepShared {            // LDS scratch of chain_step
     double red3[kMaxCand][16];
     npbnn_eval_out o;
     double s_lp;               // log prior of the state the next candidates start from
-    int s_accepted, s_t, s_start;
+    int s_accepted, s_t, s_start, s_lim;
 };
 
 __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan pl, StepShared& sh) {
@@ -239,7 +247,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
 
     // at the start of a batch the prior of the current state is summed in full (proposals then update it
     // incrementally from the touched entries, so rounding drift cannot accumulate across batches)
-    if (pl.first && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
+    if (pl.resum && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
         double lp = 0.0;
         for (int l = 0; l < c.net.n_layers; ++l) {
             const LayerMeta& L = c.net.L[l];
@@ -275,12 +283,13 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         prefetch_sink = sink;
     }
     // decision operands, fetched now by the deciding thread so that they are in registers when the sums arrive
-    double d_cand[kMaxCand], d_logu[kMaxCand], d_h[kMaxCand], d_ll = 0.0, d_lp = 0.0;
+    double d_cand[kMaxCand], d_logu[kMaxCand], d_h[kMaxCand], d_ll = 0.0, d_lp = 0.0, d_temp = 1.0;
 #pragma unroll
     for (int j = 0; j < kMaxCand; ++j) { d_cand[j] = 0.0; d_logu[j] = 0.0; d_h[j] = 0.0; }
     if (tid == 0 && n_pend > 0) {
         d_ll = st->logLik;
         d_lp = st->logPrior;
+        d_temp = st->temperature;
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j)
             if (j < n_pend) {
@@ -316,13 +325,14 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                     loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &sh.o);
                     const double lp = d_cand[j];
                     const double post_new = sh.o.loglik + lp, post_old = d_ll + d_lp;
-                    const int a = ((post_new - post_old) * c.temperature + d_h[j] >= d_logu[j]) ? 1 : 0;
+                    const int a = ((post_new - post_old) * d_temp + d_h[j] >= d_logu[j]) ? 1 : 0;
                     c.out_acc[t] = (unsigned char)a;
                     c.out_ll[t] = sh.o.loglik;
                     c.out_lp[t] = lp;
                     if (a) {
                         st->logLik = sh.o.loglik;
                         st->logPrior = lp;
+                        st->logPrior_rep = lp;
                         st->n_accepted += 1;
                         if (lik_kind == NPBNN_LIK_GAUSS)
                             for (int q = 0; q < c.net.k_targets; ++q) st->sigma[q] = sh.o.sigma[q];
@@ -349,6 +359,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 }
             }
             sh.s_start = start;
+            sh.s_lim = st->seg_end;
         }
         __syncthreads();
         NPBNN_STAMP(3);
@@ -374,6 +385,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         sh.s_lp = st->logPrior;
         // nothing decided (start of a batch, or the pending pass was void): the pass in flight, if any, is good
         sh.s_start = pl.fly >= 0 ? c.pass[pl.fly].t0 + c.pass[pl.fly].n_cand : t_now;
+        sh.s_lim = st->seg_end;
     }
     __syncthreads();
 
@@ -381,7 +393,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     // ---- 2. prepare the next candidates: each is the current state plus its own iteration's perturbation.  Work items
     //      are (candidate, entry) pairs spread over the whole workgroup; the three prior sums share one reduction. ----
     const int t_new = sh.s_start;
-    int n_new = c.K - t_new;
+    int n_new = sh.s_lim - t_new;            // (seg_end <= K)
     if (n_new > c.D) n_new = c.D;
     if (n_new < 0) n_new = 0;
     double dlp[kMaxCand];
@@ -455,6 +467,10 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     __syncthreads();
     if (tid == 0) {
         const double base_lp = sh.s_lp;
+        if (c.stop_on_overflow && n_new > 0 && atomicAdd(c.overflow, 0) != 0) {     // (the flag was raised before the barrier above)
+            n_new = 0;
+            st->poisoned = 1;
+        }
         PassDesc d;
         d.t0 = t_new;
         d.n_cand = n_new;
@@ -480,10 +496,98 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     if (!first_launch && c.pass[0].n_cand == 0) return;      // launched past the end of the batch
     StepPlan pl;
     pl.first = first_launch;
+    pl.resum = first_launch;
     pl.dec = first_launch ? -1 : 0;
     pl.fly = -1;
     pl.out = 0;
     pl.launch = 0;
+    chain_step(c, pl, sh);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+// ------------------------------------------------------------------------------------------------
+// exchange run: several chains (one per ctx: on this GPU and, through RCCL, on the other ranks') advance in segments of
+// seg_len iterations and exchange temperatures between segments as MC3.run_mcmc does (BNN_mc3.py:94-112) - all of it enqueued
+// on the chains' streams, no host round trip per segment.  After the last launch of segment s every chain writes its record
+// [logPost, temperature, reached-the-end flag] (exchange_pack_kernel); the records are all-gathered in place; then every
+// chain applies the same decision to its own temperature and prepares the first pass of the next segment
+// (exchange_apply_kernel).  The swap proposal (j, k, log u) is pre-drawn by the host from the stream the reference's parent
+// process draws from.  A chain that was given too few launches to finish a segment shows in the flags: every chain then
+// poisons itself at that very exchange, nothing more is decided anywhere, and the host finishes that segment the slow way.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRecDoubles = 4;          // record of a chain at an exchange: logPost, temperature, done flag, (spare)
+struct ExchangeParams {
+    double* rec;               // [n_seg][world * per_rank][kRecDoubles]; chain i sits at (i % world) * per_rank + i / world
+    const int* swap_j;         // [n_seg] chain ids of the proposed swap
+    const int* swap_k;
+    const double* swap_logu;   // [n_seg]
+    double* snap_w;            // [n_seg][n_weights] weights of this chain at the exchanges where it came out cold, or nullptr
+    double* snap_state;        // [n_seg][4]: logLik, logPrior, temperature after the exchange, iterations done
+    int world, per_rank, n_seg, seg_len;
+    int my_slot;               // this chain's record index
+    int n_weights;
+};
+
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void exchange_pack_kernel(const ChainParams* __restrict__ cp, const ExchangeParams* __restrict__ xp, int s) {
+    if (threadIdx.x != 0) return;
+    const ChainDev* st = cp->st;
+    double* r = xp->rec + ((size_t)s * xp->world * xp->per_rank + xp->my_slot) * kRecDoubles;
+    r[0] = st->logLik + st->logPrior_rep;              // MCMC._logPost (BNN_env.py:497)
+    r[1] = st->temperature;
+    r[2] = (!st->poisoned && st->t >= st->seg_end) ? 1.0 : 0.0;
+    r[3] = (double)st->t;
+}
+
+__global__ void __launch_bounds__(1024) exchange_apply_kernel(const ChainParams* __restrict__ cp, const ExchangeParams* __restrict__ xp, int s,
+                                                              int next_launch, int overlapped) {
+    const ChainParams& c = *cp;
+    const ExchangeParams& x = *xp;
+    __shared__ StepShared sh;
+    __shared__ int s_go;
+    ChainDev* st = c.st;
+    const int n_rec = x.world * x.per_rank;
+    if (threadIdx.x == 0) {
+        const double* rec = x.rec + (size_t)s * n_rec * kRecDoubles;
+        int all_done = st->poisoned ? 0 : 1;
+        for (int i = 0; i < n_rec; ++i) all_done &= rec[(size_t)i * kRecDoubles + 2] == 1.0 ? 1 : 0;
+        if (!all_done) {
+            st->poisoned = 1;
+        } else {
+            // BNN_mc3.py:99-112: chains j, k swap temperatures when
+            //   (logPost_k - logPost_j) * T_j + (logPost_j - logPost_k) * T_k >= log u
+            const int j = x.swap_j[s], k = x.swap_k[s];
+            const int rj = (j % x.world) * x.per_rank + j / x.world, rk = (k % x.world) * x.per_rank + k / x.world;
+            const double pj = rec[(size_t)rj * kRecDoubles], tj = rec[(size_t)rj * kRecDoubles + 1];
+            const double pk = rec[(size_t)rk * kRecDoubles], tk = rec[(size_t)rk * kRecDoubles + 1];
+            const double r = (pk - pj) * tj + (pj - pk) * tk;
+            if (j != k && r >= x.swap_logu[s]) {
+                if (x.my_slot == rj) st->temperature = tk;
+                else if (x.my_slot == rk) st->temperature = tj;
+            }
+            st->seg_idx = s + 1;
+            if (s + 1 < x.n_seg) st->seg_end += x.seg_len;
+        }
+        if (x.snap_state) {
+            double* q = x.snap_state + (size_t)s * 4;
+            q[0] = st->logLik; q[1] = st->logPrior_rep; q[2] = st->temperature; q[3] = (double)st->t;
+        }
+        s_go = all_done;
+        // the launch after this kernel decides "the pass before it": there is none
+        if (overlapped) { PassDesc& d = c.pass[(next_launch + 1) & 1]; d.n_cand = 0; d.t0 = st->t; }
+    }
+    __syncthreads();
+    if (x.snap_w && s_go && st->temperature == 1.0) {        // the cold chain is the one the logger samples (BNN_mc3.py:118-122)
+        double* dst = x.snap_w + (size_t)s * x.n_weights;
+        for (int i = threadIdx.x; i < x.n_weights; i += blockDim.x) dst[i] = c.w_cur[i];
+    }
+    StepPlan pl;
+    pl.first = 0;
+    pl.resum = s_go;           // as the first launch of a batch does: batches of the segment-by-segment path start here
+    pl.dec = -1;
+    pl.fly = -1;
+    pl.out = overlapped ? (next_launch & 1) : 0;
+    pl.launch = next_launch;
     chain_step(c, pl, sh);
 }
 #endif  // NPBNN_KERNELS_MAIN

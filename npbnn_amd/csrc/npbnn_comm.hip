@@ -125,6 +125,22 @@ int npbnn_comm_bcast_i64(npbnn_comm* c, int64_t* buf, int count, int root) {
     return NPBNN_OK;
 }
 
+// internal (npbnn_capi.hip, exchange run): the records of one exchange all-gathered IN PLACE on a chain's own stream -
+// d_buf holds nranks * count doubles, this rank's share already at d_buf + rank * count - with no host synchronisation
+int npbnn_comm_allgather_inplace_stream_(npbnn_comm* c, double* d_buf, int count, void* stream) {
+    if (!c || !d_buf || count < 1) return cfail(NPBNN_E_ARG, "comm_allgather_inplace: bad arguments");
+    C_NCCL(ncclAllGather(d_buf + (size_t)c->rank * count, d_buf, (size_t)count, ncclDouble, c->comm, (hipStream_t)stream));
+    return NPBNN_OK;
+}
+
+int npbnn_comm_info_(const npbnn_comm* c, int* device, int* rank, int* nranks) {
+    if (!c) return cfail(NPBNN_E_ARG, "null communicator");
+    if (device) *device = c->device;
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    return NPBNN_OK;
+}
+
 void npbnn_comm_destroy(npbnn_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

@@ -14,7 +14,11 @@ namespace npbnn {
 //   fragment entry becomes 0 - no extra pass over X.
 // ------------------------------------------------------------------------------------------------
 // fp16 split of a float: hi = fp16(v), lo = fp16(v - hi); hi + lo carries ~22 significant bits of v
+// The float is pinned in a register first: callers hand in (float)(double expression), and a compiler that folds the two
+// narrowing conversions into one double -> fp16 rounding picks the other neighbour when the float lands exactly between two
+// fp16 values (about one entry in 8000) - the same weight would then be split differently by different kernels.
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    asm volatile("" : "+v"(v));
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }

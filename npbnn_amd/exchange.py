@@ -1,0 +1,208 @@
+"""Exchange runs: the chains of an MC3 run advance several swap intervals per device call.
+
+The reference's MC3 loop (np_bnn/BNN_mc3.py:94-112) alternates ``swap_frequency`` iterations of every chain with one
+temperature-swap proposal.  The swap reads two scalars per chain, so here the whole alternation is enqueued on the GPU
+streams (``npbnn_chains_run_exchange``): segment, record, all-gather (RCCL between processes), decision, next segment -
+with no host round trip in between.  This module holds the host side:
+
+    SwapProposals         the (j, k, log u) of the swaps, pre-drawn in the reference's order from ``np.random``
+    exchange_ready        can these chains take the device path for the next n_seg intervals?
+    run_exchange          n_seg intervals of every local chain; falls back to the interval-by-interval path for the
+                          interval in which some chain was given too few launches (rare; every rank sees it in the records)
+"""
+import numpy as np
+
+
+class SwapProposals:
+    """Swap proposals in the order MC3.run_mcmc draws them (BNN_mc3.py:99,110): per swap one
+    ``choice(range(n_chains), 2, replace=False)`` then one ``random()``, from ``np.random`` (or the given RandomState).
+    Drawn ahead in blocks and served by swap index, so that the device path (which needs them up front) and the
+    interval-by-interval path consume the same stream."""
+
+    def __init__(self, n_chains, rs=None):
+        self.n_chains = int(n_chains)
+        self._rs = rs if rs is not None else np.random
+        self._first = 0
+        self._j, self._k, self._logu = [], [], []
+
+    def _extend(self, upto):
+        while self._first + len(self._j) < upto:
+            j, k = self._rs.choice(range(self.n_chains), 2, replace=False)
+            u = self._rs.random() if hasattr(self._rs, "random") else self._rs.random_sample()
+            self._j.append(int(j))
+            self._k.append(int(k))
+            self._logu.append(float(np.log(u)))
+
+    def get(self, first, n=1):
+        """(j, k, log u) arrays of swaps first .. first+n-1."""
+        if first < self._first:
+            raise ValueError("swap %d was already released" % first)
+        self._extend(first + n)
+        a = first - self._first
+        return (np.array(self._j[a:a + n], dtype=np.int32), np.array(self._k[a:a + n], dtype=np.int32),
+                np.array(self._logu[a:a + n], dtype=np.float64))
+
+    def release(self, upto):
+        """Forget the swaps before ``upto`` (they have been applied)."""
+        n = min(max(0, upto - self._first), len(self._j))
+        del self._j[:n], self._k[:n], self._logu[:n]
+        self._first += n
+
+
+def swap_decision(log_post_j, log_post_k, temp_j, temp_k, log_u):
+    """The accept test of a temperature swap (BNN_mc3.py:102-110)."""
+    r = (log_post_k - log_post_j) * temp_j + (log_post_j - log_post_k) * temp_k
+    return r, bool(r >= log_u)
+
+
+def exchange_ready(chains, n_iterations):
+    """True when every (bnn, mcmc) of ``chains`` can run its next ``n_iterations`` as one device batch with the
+    proposal settings fixed: a device backend with the exchange entry point, the default sampler path, no adaptation
+    point inside, per-iteration reseeding (MC3 chains, BNN_env.py:384) so that the draws are a function of the
+    iteration alone."""
+    for bnn, mcmc in chains:
+        if mcmc._backend is None:
+            from .sampler import get_backend
+            mcmc._backend = get_backend(bnn, mcmc._likelihood_f)
+        be = mcmc._backend
+        if not hasattr(be, "exchange_job"):
+            return False
+        if not mcmc._randomize_seed or not mcmc._device_loop_ok(bnn, n_iterations):
+            return False
+        boundary = mcmc._next_adapt_boundary()
+        if boundary is not None and boundary < mcmc._current_iteration + n_iterations:
+            return False
+    return True
+
+
+def run_exchange(chains, chain_ids, n_chains, n_seg, seg_len, swaps, first_swap, comm=None, launch_slack=None, want_cold_w=True):
+    """Advance every local chain by up to ``n_seg`` swap intervals on the device.
+
+    chains      [(bnn, mcmc)] of this process, ``chain_ids`` their global ids (chain i on rank i % world, in id order)
+    swaps       SwapProposals; swap number ``first_swap`` follows the first interval
+    comm        communicator (``RcclComm`` / ``LocalComm``); its native handle carries the all-gather
+    Returns (segments_done, records, outs): ``records[s, i] = (logPost, temperature before swap s, done flag, iterations)`` of
+    every chain, ``outs[q]`` the per-interval state / cold-chain weights of local chain q.  ``segments_done < n_seg`` only when a
+    chain fell short of an interval: every chain then stands somewhere inside interval ``segments_done`` (possibly at its end)
+    and the caller completes it the slow way."""
+    K = int(n_seg) * int(seg_len)
+    sj, sk, su = swaps.get(first_swap, n_seg)
+    jobs = []
+    backend_cls = None
+    for (bnn, mcmc), cid in zip(chains, chain_ids):
+        mcmc._bnn = bnn
+        it = mcmc._current_iteration
+        idx, delta, cnt, log_u = mcmc._claim_draw(bnn, it, K).result()
+        # the draws of the probable next call, made while the GPU runs this one
+        mcmc._speculation = mcmc._submit_draw(bnn, it + K, K, rewindable=True)
+        job = mcmc._backend.exchange_job(bnn._w_layers, chain_id=cid, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=bnn._mask,
+                                         cfg=mcmc._device_chain_cfg(bnn))
+        jobs.append(job)
+        backend_cls = type(mcmc._backend)
+    slack = launch_slack if launch_slack is not None else getattr(backend_cls, "exchange_slack", 1.5)
+    handle = getattr(comm, "_comm", None) if comm is not None else None
+    outs, records, done = backend_cls.run_exchange(jobs, n_chains, seg_len, n_seg, sj, sk, su, comm=handle, launch_slack=slack,
+                                                   want_cold_w=want_cold_w)
+    if launch_slack is None:           # launches per interval relative to the expected number: creep down while every interval
+        # gets through (idle launches cost time), jump up when one fell short (that costs a lot more)
+        backend_cls.exchange_slack = min(4.0, slack * 1.5) if done < n_seg else max(backend_cls.exchange_slack_floor, slack * 0.97)
+    for (bnn, mcmc), out in zip(chains, outs):
+        res = out["result"]
+        k = int(res["iterations_done"])
+        if k < K:
+            mcmc._cancel_speculation()
+        mcmc._absorb_device_batch(bnn, k, out["w"], out["accepted"], res)
+        if k > 0:
+            mcmc._temperature = res["temperature"]
+    return done, records, outs
+
+
+def gather_scalars(chains, chain_ids, n_chains, comm):
+    """[logPost, temperature] of every chain of the run, on every rank (chain i lives on rank i % world)."""
+    world = 1 if comm is None else comm.world_size
+    per_rank = (n_chains + world - 1) // world
+    mine = np.full((per_rank, 2), np.nan)
+    for (_, mcmc), cid in zip(chains, chain_ids):
+        mine[cid // world] = (mcmc._logPost, mcmc._temperature)
+    if comm is None or world == 1:
+        allv = mine.reshape(1, per_rank, 2)
+    else:
+        allv = comm.allgather_f64(mine.ravel()).reshape(world, per_rank, 2)
+    out = np.empty((n_chains, 2))
+    for i in range(n_chains):
+        out[i] = allv[i % world, i // world]
+    return out
+
+
+def host_swap(chains, chain_ids, n_chains, swaps, swap_index, comm=None):
+    """One temperature-swap proposal decided on the host from an all-gather of [logPost, temperature]
+    (BNN_mc3.py:98-112); every rank reaches the same decision from the same pre-drawn proposal.
+    Returns (scalars after the swap, (j, k, r, log u, accepted))."""
+    scal = gather_scalars(chains, chain_ids, n_chains, comm)
+    sj, sk, su = swaps.get(swap_index, 1)
+    j, k, log_u = int(sj[0]), int(sk[0]), float(su[0])
+    temp_j, temp_k = scal[j, 1] + 0, scal[k, 1] + 0
+    r, accepted = swap_decision(scal[j, 0], scal[k, 0], temp_j, temp_k, log_u)
+    if accepted:
+        for (_, mcmc), cid in zip(chains, chain_ids):
+            if cid == j:
+                mcmc.reset_temperature(temp_k)
+            elif cid == k:
+                mcmc.reset_temperature(temp_j)
+        scal[j, 1], scal[k, 1] = temp_k, temp_j
+    return scal, (j, k, float(r), log_u, accepted)
+
+
+def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, first_swap, comm=None, batch=20, device=True,
+                      on_interval=None):
+    """``n_intervals`` rounds of [seg_len iterations of every chain, one swap proposal] - MC3.run_mcmc's loop body
+    (BNN_mc3.py:94-112) - in device batches of up to ``batch`` intervals where the chains allow it, interval by interval
+    otherwise.  ``on_interval(index, info)`` is called after every swap with ``info`` = dict(scalars=[n_chains, 2] logPost /
+    temperature after the swap, swap=(j, k, r, log u, accepted), cold=per local chain None or dict(w, loglik, logprior) when the
+    interval ran on the device and that chain is the cold one afterwards)."""
+    world = 1 if comm is None else comm.world_size
+    done = 0
+    while done < n_intervals:
+        n = min(int(batch), n_intervals - done)
+        ok = bool(device) and n >= 2 and n_chains == world * len(chains) and exchange_ready(chains, n * seg_len)
+        if world > 1:                  # every rank must take the same path
+            ok = bool(np.all(comm.allgather_f64(np.array([1.0 if ok else 0.0]))[:, 0] == 1.0))
+        if not ok:
+            for bnn, mcmc in chains:
+                mcmc.run_steps(bnn, seg_len)
+            scal, swap = host_swap(chains, chain_ids, n_chains, swaps, first_swap + done, comm)
+            if on_interval is not None:
+                on_interval(done, dict(scalars=scal, swap=swap, cold=None))
+            done += 1
+            swaps.release(first_swap + done)
+            continue
+        it0 = [mcmc._current_iteration for _, mcmc in chains]
+        n_done, records, outs = run_exchange(chains, chain_ids, n_chains, n, seg_len, swaps, first_swap + done, comm=comm,
+                                             want_cold_w=on_interval is not None)
+        sj, sk, su = swaps.get(first_swap + done, n)
+        for s in range(n_done):
+            if on_interval is None:
+                continue
+            scal = records[s, :, :2].copy()
+            j, k = int(sj[s]), int(sk[s])
+            r, accepted = swap_decision(scal[j, 0], scal[k, 0], scal[j, 1], scal[k, 1], float(su[s]))
+            if accepted:
+                scal[j, 1], scal[k, 1] = scal[k, 1], scal[j, 1]
+            cold = []
+            for out, cid in zip(outs, chain_ids):
+                st = out["state"][s]
+                cold.append(dict(w=out["cold_w"][s], loglik=st[0], logprior=st[1], accepted=out["accepted"],
+                                 iterations=(s + 1) * seg_len) if st[2] == 1.0 and out["cold_w"] is not None else None)
+            on_interval(done + s, dict(scalars=scal, swap=(j, k, float(r), float(su[s]), accepted), cold=cold))
+        done += n_done
+        if n_done < n:                 # some chain fell short inside interval n_done: finish that one the slow way
+            for (bnn, mcmc), start in zip(chains, it0):
+                rest = start + (n_done + 1) * seg_len - mcmc._current_iteration
+                if rest > 0:
+                    mcmc.run_steps(bnn, rest)
+            scal, swap = host_swap(chains, chain_ids, n_chains, swaps, first_swap + done, comm)
+            if on_interval is not None:
+                on_interval(done, dict(scalars=scal, swap=swap, cold=None))
+            done += 1
+        swaps.release(first_swap + done)
+    return done

@@ -106,5 +106,19 @@ class HipBackend:
         self._configure(weights)
         return self.ctx.chain_run(weights, **kw)
 
+    exchange_slack = 1.5     # launches given to a swap interval of an exchange run, relative to the expected number (adapts)
+    exchange_slack_floor = 1.15
+
+    def exchange_job(self, weights, chain_id, idx, delta, cnt, log_u, mask, cfg):
+        """This chain's share of an exchange run (see :func:`npbnn_amd.backend.chains_run_exchange`)."""
+        self._configure(weights)
+        return dict(ctx=self.ctx, chain_id=chain_id, weights=weights, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=mask, cfg=cfg)
+
+    @staticmethod
+    def run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=None, launch_slack=1.25, want_cold_w=True):
+        from .backend import chains_run_exchange
+        return chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=comm,
+                                   launch_slack=launch_slack, want_cold_w=want_cold_w)
+
     def close(self):
         self.ctx.close()

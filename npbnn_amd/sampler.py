@@ -521,8 +521,8 @@ class MCMC():
             k = min(2 * k, self.SUB_BATCH_MAX)
         return sizes
 
-    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u):
-        k = len(cnt)
+    def _device_chain_cfg(self, bnn_obj):
+        """The chain's settings and current state as the keyword arguments of the device chain entry points."""
         regression = bnn_obj._estimation_mode == "regression"
         sigma = None
         cur_sigma = None
@@ -530,12 +530,21 @@ class MCMC():
             cur_sigma = np.ones(bnn_obj._size_output) * bnn_obj._error_prm
             if not bnn_obj._empirical_error:
                 sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
-        w_new, acc, _, _, res = self._backend.run_chain(
-            bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u,
-            prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
-            w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
-            cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma, mask=bnn_obj._mask,
-            n_candidates=self.n_candidates, schedule=self.device_schedule)
+        return dict(prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
+                    w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
+                    cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma,
+                    n_candidates=self.n_candidates, schedule=self.device_schedule)
+
+    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u):
+        w_new, acc, _, _, res = self._backend.run_chain(bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u,
+                                                        mask=bnn_obj._mask, **self._device_chain_cfg(bnn_obj))
+        self._absorb_device_batch(bnn_obj, len(cnt), w_new, acc, res)
+
+    def _absorb_device_batch(self, bnn_obj, k, w_new, acc, res):
+        """Book-keeping of k device-resident iterations: what k calls of mh_step would have left behind."""
+        if k <= 0:
+            return
+        acc = acc[:k]
         self._device_passes += res.get("n_passes", k)
         self._device_void_passes += res.get("n_void_passes", 0)
         self._device_iterations += k
@@ -547,7 +556,7 @@ class MCMC():
             bnn_obj.reset_weights(layers)
             self._logLik, self._logPrior = res["loglik"], res["logprior"]
             self._logPost = self._logLik + self._logPrior
-            if regression:
+            if bnn_obj._estimation_mode == "regression":
                 bnn_obj.reset_error_prm(res["sigma"])
             self._accepted_override = None
             self._invalidate()

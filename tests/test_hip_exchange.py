@@ -1,0 +1,209 @@
+"""GPU tests of the exchange run (npbnn_chains_run_exchange): several chains advance swap intervals with the temperature
+swaps of MC3.run_mcmc (np_bnn/BNN_mc3.py:94-112) decided on the GPU.  The oracle is the interval-by-interval path - the same
+device chain per interval with the swap on the host - which the other suites tie to the reference: the two must agree bit for
+bit in weights, log-posteriors, temperatures and acceptance book-keeping."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import cases
+import npbnn_amd as bn
+from npbnn_amd import exchange as ex
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
+
+
+def build_chains(cfg, temps, **mcmc_extra):
+    """len(temps) chains on one data set as MC3 builds them: own weights seed, mcmc_id = chain id, reseeding every iteration."""
+    if cfg["kind"] == "classification":
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        extra = {}
+    else:
+        dat = cases.regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
+        extra = dict(estimation_mode="regression", empirical_error=cfg.get("empirical_error", False))
+    chains = []
+    for i, t in enumerate(temps):
+        np.random.seed(1234 + i)
+        bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
+                    prior_f=1, p_scale=1, seed=1234 + i, init_std=0.1, **extra)
+        kw = dict(cfg["mcmc"])
+        kw.update(adapt_f=0, adapt_fM=1, temperature=t, mcmc_id=i, randomize_seed=True)
+        kw.update(mcmc_extra)
+        chains.append((bnn, bn.MCMC(bnn, **kw)))
+    return chains
+
+
+def state_of(chains):
+    return [dict(w=[w.copy() for w in bnn._w_layers], ll=m._logLik, lp=m._logPrior, post=m._logPost, temp=m._temperature,
+                 it=m._current_iteration, rate=m._acceptance_rate, mem=list(m._last_accepted_mem), err=np.array(bnn._error_prm))
+            for bnn, m in chains]
+
+
+def assert_same(a, b, exact=True):
+    for x, y in zip(a, b):
+        assert x["it"] == y["it"]
+        assert x["temp"] == y["temp"]
+        for u, v in zip(x["w"], y["w"]):
+            np.testing.assert_array_equal(u, v)
+        if exact:
+            assert (x["ll"], x["lp"], x["post"]) == (y["ll"], y["lp"], y["post"])
+        else:
+            np.testing.assert_allclose([x["ll"], x["lp"], x["post"]], [y["ll"], y["lp"], y["post"]], rtol=1e-12)
+        assert x["mem"] == y["mem"] and x["rate"] == y["rate"]
+        np.testing.assert_array_equal(x["err"], y["err"])
+
+
+def slow_path(chains, n_seg, seg_len, swap_seed):
+    swaps = ex.SwapProposals(len(chains), np.random.RandomState(swap_seed))
+    ids = list(range(len(chains)))
+    log = []
+    ex.advance_intervals(chains, ids, len(chains), n_seg, seg_len, swaps, 0, device=False,
+                         on_interval=lambda s, info: log.append((info["swap"], info["scalars"].copy())))
+    return log
+
+
+@pytest.mark.parametrize("name,sched,ncand", [("cfg1", 2, 0), ("cfg1", 1, 0), ("cfg1", 2, 1), ("cfg2s", 2, 0), ("cfg2s", 1, 2), ("cfg4s", 2, 2)])
+def test_exchange_run_equals_interval_by_interval(name, sched, ncand):
+    """(With the schedule left to the library, the two paths may pick different ones for a batch - the choice follows the
+    acceptance rate of the previous batch - and the log-likelihood sums then differ in their last bits: fixed here.)"""
+    cfg = cases.TRACES[name]
+    temps = [0.8, 0.9, 1.0]
+    n_seg, seg_len = 6, 25
+    a = build_chains(cfg, temps)
+    b = build_chains(cfg, temps)
+    for _, m in a + b:
+        m.device_schedule, m.n_candidates = sched, ncand
+    log_a = slow_path(a, n_seg, seg_len, 7)
+    swaps = ex.SwapProposals(len(b), np.random.RandomState(7))
+    log_b = []
+    done = ex.advance_intervals(b, [0, 1, 2], 3, n_seg, seg_len, swaps, 0, batch=n_seg,
+                                on_interval=lambda s, info: log_b.append((info["swap"], info["scalars"].copy(), info["cold"])))
+    assert done == n_seg
+    assert_same(state_of(a), state_of(b))
+    assert len(log_a) == len(log_b) == n_seg
+    assert any(sw[4] for sw, _ in log_a), "the case should accept at least one swap"
+    for (sw_a, sc_a), (sw_b, sc_b, cold) in zip(log_a, log_b):
+        assert sw_a == sw_b
+        np.testing.assert_array_equal(sc_a, sc_b)
+        assert cold is not None, "all intervals should have run on the device"
+        assert sum(c is not None for c in cold) == 1          # exactly one chain is cold after every swap
+
+
+def test_cold_chain_snapshots_are_the_states_at_the_swaps():
+    cfg = cases.TRACES["cfg1"]
+    temps = [0.8, 1.0]
+    n_seg, seg_len = 5, 20
+    a = build_chains(cfg, temps)
+    b = build_chains(cfg, temps)
+    snaps = []
+
+    def keep(s, info):
+        for (bnn, m), t in zip(a, info["scalars"][:, 1]):
+            if t == 1.0:
+                snaps.append((np.concatenate([w.ravel() for w in bnn._w_layers]), m._logLik, m._logPrior))
+    swaps = ex.SwapProposals(2, np.random.RandomState(3))
+    ex.advance_intervals(a, [0, 1], 2, n_seg, seg_len, swaps, 0, device=False, on_interval=keep)
+    got = []
+    swaps = ex.SwapProposals(2, np.random.RandomState(3))
+    ex.advance_intervals(b, [0, 1], 2, n_seg, seg_len, swaps, 0, batch=n_seg,
+                         on_interval=lambda s, info: got.extend(c for c in info["cold"] if c is not None))
+    assert len(got) == len(snaps) == n_seg
+    for (w, ll, lp), c in zip(snaps, got):
+        np.testing.assert_array_equal(w, c["w"])
+        assert (ll, lp) == (c["loglik"], c["logprior"])
+
+
+def test_starved_interval_is_finished_on_the_slow_path():
+    """Too few launches for an interval: every chain stops at that exchange, the driver completes the interval with the
+    per-interval path and the chains end where they would have anyway.  (The interval that is finished in two pieces re-sums
+    the log prior where the second piece starts, so log-posteriors may differ from the one-piece path in their last bits; the
+    weights - a function of the accept / reject sequence alone - must not.)"""
+    cfg = cases.TRACES["cfg1"]
+    temps = [0.85, 1.0]
+    n_seg, seg_len = 4, 30
+    a = build_chains(cfg, temps)
+    b = build_chains(cfg, temps)
+    slow_path(a, n_seg, seg_len, 11)
+    swaps = ex.SwapProposals(2, np.random.RandomState(11))
+    done, records, outs = ex.run_exchange(b, [0, 1], 2, n_seg, seg_len, swaps, 0, launch_slack=0.05)
+    assert done < n_seg
+    for (bnn, m), out in zip(b, outs):
+        assert done * seg_len <= m._current_iteration <= (done + 1) * seg_len
+    # complete: the unfinished interval on the slow path, the rest on the device
+    for bnn, m in b:
+        rest = (done + 1) * seg_len - m._current_iteration
+        if rest > 0:
+            m.run_steps(bnn, rest)
+    ex.host_swap(b, [0, 1], 2, swaps, done)
+    left = n_seg - done - 1
+    if left > 0:
+        assert ex.advance_intervals(b, [0, 1], 2, left, seg_len, swaps, done + 1, batch=left) == left
+    assert_same(state_of(a), state_of(b), exact=False)
+
+
+def test_driver_recovers_from_a_starved_batch():
+    cfg = cases.TRACES["cfg1"]
+    temps = [0.85, 1.0]
+    n_seg, seg_len = 6, 30
+    a = build_chains(cfg, temps)
+    b = build_chains(cfg, temps)
+    log_a = slow_path(a, n_seg, seg_len, 5)
+    cls = type(b[0][1]._backend) if b[0][1]._backend is not None else None
+    from npbnn_amd.hip_backend import HipBackend
+    HipBackend.exchange_slack = 0.05
+    try:
+        swaps = ex.SwapProposals(2, np.random.RandomState(5))
+        log_b = []
+        done = ex.advance_intervals(b, [0, 1], 2, n_seg, seg_len, swaps, 0, batch=3,
+                                    on_interval=lambda s, info: log_b.append(info["swap"]))
+    finally:
+        HipBackend.exchange_slack = 1.5
+    assert done == n_seg and cls is not None
+    for (sw_a, _), sw_b in zip(log_a, log_b):
+        assert (sw_a[0], sw_a[1], sw_a[3], sw_a[4]) == (sw_b[0], sw_b[1], sw_b[3], sw_b[4])
+        np.testing.assert_allclose(sw_a[2], sw_b[2], rtol=1e-9, atol=1e-9)
+    assert len(log_a) == len(log_b)
+    assert_same(state_of(a), state_of(b), exact=False)
+
+
+def test_single_job_and_argument_checks():
+    cfg = cases.TRACES["cfg1"]
+    (bnn, m), = build_chains(cfg, [1.0])
+    m.run_steps(bnn, 10)
+    swaps = ex.SwapProposals(2, np.random.RandomState(1))
+    with pytest.raises(Exception):
+        ex.run_exchange([(bnn, m)], [0], 2, 2, 10, swaps, 0)        # 2 chains announced, one job on one rank
+
+
+def test_patched_weight_image_equals_a_fresh_pack():
+    """The device weight image after a chain run (packed once, then patched entry by entry at every accept) is bit for bit the
+    image a fresh pack of the final weights gives.  (Regression: the fp16 high/low split of a layer-0 entry once depended on
+    the kernel that made it when the scaled weight fell exactly between two fp16 values.)"""
+    import ctypes as C
+    cfg = cases.TRACES["cfg2s"]
+    chains = build_chains(cfg, [0.8, 0.9, 1.0])
+    for _, m in chains:
+        m.device_schedule = 2
+    swaps = ex.SwapProposals(3, np.random.RandomState(7))
+    done, _, _ = ex.run_exchange(chains, [0, 1, 2], 3, 2, 25, swaps, 0)
+    assert done == 2
+
+    def image(ctx):
+        buf = np.zeros(1 << 16, dtype=np.float32)
+        f = ctx._lib.npbnn_debug_image_
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int]
+        n = f(ctx._ctx, buf.ctypes.data, buf.size)
+        assert n > 0
+        return buf[:n].view(np.uint32).copy()
+    for bnn, m in chains:
+        ctx = m._backend.ctx
+        patched = image(ctx)
+        m._backend.evaluate(bnn._w_layers, None)          # packs the image from the float64 weights
+        np.testing.assert_array_equal(patched, image(ctx))

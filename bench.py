@@ -90,17 +90,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # NPBNN_BENCH_DIST_BACKEND=gloo: rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (ranks share GPUs, the
+    # exchange goes through the host path over gloo); the driver's runs use the default, one GPU per rank over RCCL
+    dist_backend = os.environ.get("NPBNN_BENCH_DIST_BACKEND", "nccl")
+    device_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            device_index = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group(dist_backend)
 
     from bench_support import build_config2
 
     x, y = synthetic_config2()
     # one chain per GPU, MC3 layout (config 3): chain r has mcmc_id r, temperature linspace(0.8, 1, world)[r]
     temps = [1.0] if world == 1 else list(np.linspace(0.8, 1.0, world))
+    if world > 1:
+        os.environ["NPBNN_DEVICE"] = str(device_index)
     bnn, mcmc = build_config2(x.astype(np.float32), y, HIDDEN, mcmc_id=rank, temperature=temps[rank],
                               randomize_seed=world > 1)
     comm = None
@@ -112,12 +122,13 @@ def main():
         # the launcher's process group carries the 128-byte RCCL unique id; every rank takes part in every collective
         # below whatever happens, so a failure anywhere cannot leave the others waiting
         box = [None]
-        if rank == 0:
+        on_gpu = dist_backend == "nccl"
+        if rank == 0 and on_gpu:
             try:
                 box[0] = RcclComm.make_unique_id()
             except Exception as e:
                 print("[rank 0] cannot create an RCCL unique id (%s)" % e, flush=True)
-        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local_rank))
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local_rank) if on_gpu else None)
         ok = 1 if box[0] else 0
         if ok:
             try:
@@ -125,36 +136,73 @@ def main():
             except Exception as e:
                 print("[rank %d] native RCCL communicator unavailable (%s)" % (rank, e), flush=True)
                 ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             comm_kind = "rccl (C ABI)"
         else:                                       # every rank falls back together; torch.distributed "nccl" is RCCL over xGMI too
             comm = TorchDistComm()
-            comm_kind = "rccl (torch.distributed)"
+            comm_kind = "rccl (torch.distributed)" if on_gpu else "%s (torch.distributed)" % dist_backend
     else:
         comm_kind = "none"
 
-    # the swap proposal (which two chains, the uniform of the accept test: BNN_mc3.py:99,110) comes from a stream every rank
-    # seeds identically, so one all-gather of [logPost, temperature] is the whole exchange: each rank reaches the same decision
-    swap_rs = np.random.RandomState(4321)
+    # the swap proposals (which two chains, the uniform of the accept test: BNN_mc3.py:99,110) come from a stream every rank
+    # seeds identically, so the records [logPost, temperature] of the chains are the whole exchange.  Default: the exchange
+    # run - batches of swap intervals enqueued on the GPU stream, records all-gathered in place by RCCL on that stream, the
+    # decision applied by a kernel (npbnn_chains_run_exchange); checked below against the interval-by-interval path (one
+    # device batch per interval, all-gather and decision on the host), which takes over if the check fails.
+    from npbnn_amd import exchange as ex
+    swaps = ex.SwapProposals(max(world, 2), np.random.RandomState(4321))
+    chains, ids = [(bnn, mcmc)], [rank]
+    state = {"swap": 0, "device": world > 1 and getattr(comm, "_comm", None) is not None and not os.environ.get("NPBNN_BENCH_HOST_SWAPS")}
+    exchange_path = "none"
 
     def advance(n):
         """n iterations of every chain; with several chains, a temperature-swap exchange every swap_frequency."""
-        done = 0
-        while done < n:
-            k = min(swap_frequency, n - done) if world > 1 else n - done
-            mcmc.run_steps(bnn, k)
-            done += k
-            if world > 1 and done % swap_frequency == 0:
-                scal = comm.allgather_f64(np.array([mcmc._logPost, mcmc._temperature]))
-                j, k2 = swap_rs.choice(range(world), 2, replace=False)
-                r = (scal[k2, 0] - scal[j, 0]) * scal[j, 1] + (scal[j, 0] - scal[k2, 0]) * scal[k2, 1]
-                if r >= np.log(swap_rs.random_sample()):
-                    if rank == j:
-                        mcmc.reset_temperature(scal[k2, 1])
-                    elif rank == k2:
-                        mcmc.reset_temperature(scal[j, 1])
+        if world == 1:
+            mcmc.run_steps(bnn, n)
+            return
+        whole, rest = divmod(n, swap_frequency)
+        if whole:
+            ex.advance_intervals(chains, ids, world, whole, swap_frequency, swaps, state["swap"], comm=comm, batch=20,
+                                 device=state["device"])
+            state["swap"] += whole
+        if rest:
+            mcmc.run_steps(bnn, rest)
+
+    if world > 1 and state["device"]:
+        # self-check of the device exchange path on this machine: the same 4 intervals both ways from the same state
+        import copy
+        keep = ("_logLik", "_logPrior", "_logPost", "_temperature", "_current_iteration", "_last_accepted_mem",
+                "_acceptance_rate", "_last_accepted", "_gen")
+        mcmc.run_steps(bnn, swap_frequency)
+        mcmc._cancel_speculation()
+        saved = {k: copy.deepcopy(getattr(mcmc, k)) for k in keep}
+        saved_w = [w.copy() for w in bnn._w_layers]
+        outcome = []
+        for use_device in (False, True):
+            check_swaps = ex.SwapProposals(world, np.random.RandomState(99))
+            try:
+                ex.advance_intervals(chains, ids, world, 4, swap_frequency, check_swaps, 0, comm=comm, batch=4, device=use_device)
+                outcome.append((np.concatenate([w.ravel() for w in bnn._w_layers]), mcmc._logPost, mcmc._temperature))
+            except Exception as e:           # noqa: BLE001 - any failure of the device path means: use the other one
+                print("[rank %d] exchange self-check (%s path) failed: %s" % (rank, "device" if use_device else "host", e), flush=True)
+                outcome.append(None)
+            mcmc._cancel_speculation()
+            for k, v in saved.items():
+                setattr(mcmc, k, copy.deepcopy(v))
+            bnn.reset_weights([w.copy() for w in saved_w])
+            mcmc._invalidate()
+        same = (outcome[0] is not None and outcome[1] is not None and np.array_equal(outcome[0][0], outcome[1][0])
+                and outcome[0][1:] == outcome[1][1:])
+        agree = comm.allgather_f64(np.array([1.0 if same else 0.0]))
+        state["device"] = bool(np.all(agree[:, 0] == 1.0))
+        if rank == 0 and not state["device"]:
+            print("[bench] device exchange path disagrees with the host path on ranks %s: using the host path"
+                  % np.nonzero(agree[:, 0] != 1.0)[0].tolist(), flush=True)
+    if world > 1:
+        exchange_path = ("device: swap intervals in batches of 20 on the stream, records all-gathered in place, decision by a kernel"
+                         if state["device"] else "host: one device batch per interval, all-gather and decision on the host")
 
     advance(args.warmup)
 
@@ -171,7 +219,7 @@ def main():
     el = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -201,7 +249,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "config 2: 100k x 256 features, 10 classes, hidden [32,8], tanh, bias 2; "
                                    "one chain per GPU", "chains": world, "swap_frequency": swap_frequency if world > 1 else None,
-                       "swap_exchange": comm_kind, "layer0": ctx.l0_mode(),
+                       "swap_exchange": comm_kind, "swap_exchange_path": exchange_path, "layer0": ctx.l0_mode(),
                        "loop": "device-resident chain (npbnn_chain_run), proposals pre-drawn on the host",
                        "candidates_per_pass": cand, "iterations_per_pass": its_per_pass},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

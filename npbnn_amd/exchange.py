@@ -164,7 +164,8 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
     done = 0
     while done < n_intervals:
         n = min(int(batch), n_intervals - done)
-        ok = bool(device) and n >= 2 and n_chains == world * len(chains) and exchange_ready(chains, n * seg_len)
+        ok = (bool(device) and n >= 2 and n_chains == world * len(chains) and exchange_ready(chains, n * seg_len)
+              and (world == 1 or getattr(comm, "_comm", None) is not None))        # (several ranks: the native RCCL handle)
         if world > 1:                  # every rank must take the same path
             ok = bool(np.all(comm.allgather_f64(np.array([1.0 if ok else 0.0]))[:, 0] == 1.0))
         if not ok:

@@ -207,3 +207,30 @@ def test_patched_weight_image_equals_a_fresh_pack():
         patched = image(ctx)
         m._backend.evaluate(bnn._w_layers, None)          # packs the image from the float64 weights
         np.testing.assert_array_equal(patched, image(ctx))
+
+
+def test_exchange_through_a_native_rccl_communicator():
+    """The records travel through ncclAllGather (in place, on the first chain's stream) when a communicator is given: one
+    rank here (this box has one GPU), three chains on it - same result as without the communicator."""
+    from npbnn_amd.comm import RcclComm
+    try:
+        comm = RcclComm(rank=0, world_size=1, device=0)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip("no RCCL communicator on this box: %s" % e)
+    cfg = cases.TRACES["cfg1"]
+    temps = [0.8, 0.9, 1.0]
+    n_seg, seg_len = 5, 20
+    a = build_chains(cfg, temps)
+    b = build_chains(cfg, temps)
+    for _, m in a + b:
+        m.device_schedule = 2
+    try:
+        swaps = ex.SwapProposals(3, np.random.RandomState(21))
+        assert ex.advance_intervals(a, [0, 1, 2], 3, n_seg, seg_len, swaps, 0, batch=n_seg) == n_seg
+        swaps = ex.SwapProposals(3, np.random.RandomState(21))
+        done, records, _ = ex.run_exchange(b, [0, 1, 2], 3, n_seg, seg_len, swaps, 0, comm=comm)
+        assert done == n_seg
+        assert np.all(records[:, :, 2] == 1.0)
+        assert_same(state_of(a), state_of(b))
+    finally:
+        comm.close()

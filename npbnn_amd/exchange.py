@@ -159,7 +159,8 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
     (BNN_mc3.py:94-112) - in device batches of up to ``batch`` intervals where the chains allow it, interval by interval
     otherwise.  ``on_interval(index, info)`` is called after every swap with ``info`` = dict(scalars=[n_chains, 2] logPost /
     temperature after the swap, swap=(j, k, r, log u, accepted), cold=per local chain None or dict(w, loglik, logprior) when the
-    interval ran on the device and that chain is the cold one afterwards)."""
+    interval ran on the device and that chain is the cold one afterwards - ``iterations`` into the device batch that started at
+    ``iteration0`` with the acceptance memory ``mem_before``; ``last_of_batch`` marks the last interval of a device batch)."""
     world = 1 if comm is None else comm.world_size
     done = 0
     while done < n_intervals:
@@ -178,6 +179,7 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
             swaps.release(first_swap + done)
             continue
         it0 = [mcmc._current_iteration for _, mcmc in chains]
+        mem0 = [list(mcmc._last_accepted_mem) for _, mcmc in chains]
         n_done, records, outs = run_exchange(chains, chain_ids, n_chains, n, seg_len, swaps, first_swap + done, comm=comm,
                                              want_cold_w=on_interval is not None)
         sj, sk, su = swaps.get(first_swap + done, n)
@@ -190,11 +192,13 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
             if accepted:
                 scal[j, 1], scal[k, 1] = scal[k, 1], scal[j, 1]
             cold = []
-            for out, cid in zip(outs, chain_ids):
+            for q, out in enumerate(outs):
                 st = out["state"][s]
                 cold.append(dict(w=out["cold_w"][s], loglik=st[0], logprior=st[1], accepted=out["accepted"],
-                                 iterations=(s + 1) * seg_len) if st[2] == 1.0 and out["cold_w"] is not None else None)
-            on_interval(done + s, dict(scalars=scal, swap=(j, k, float(r), float(su[s]), accepted), cold=cold))
+                                 iterations=(s + 1) * seg_len, iteration0=it0[q], mem_before=mem0[q])
+                            if st[2] == 1.0 and out["cold_w"] is not None else None)
+            on_interval(done + s, dict(scalars=scal, swap=(j, k, float(r), float(su[s]), accepted), cold=cold,
+                                       last_of_batch=s == n_done - 1))
         done += n_done
         if n_done < n:                 # some chain fell short inside interval n_done: finish that one the slow way
             for (bnn, mcmc), start in zip(chains, it0):

@@ -103,9 +103,10 @@ class postLogger():
             csv.writer(f, delimiter='\t').writerow(row)
             f.flush()
 
-    def log_weights(self, bnn_obj, mcmc_obj, add_prms=None, add_obj=None):
+    def log_weights(self, bnn_obj, mcmc_obj, add_prms=None, add_obj=None, save_pickle=True):
         """Keep the posterior weight sample (ring of n_post_samples) and rewrite the pickle, or append every
-        weight to the ``_W.log`` file (reference: BNN_env.py:622-658)."""
+        weight to the ``_W.log`` file (reference: BNN_env.py:622-658).  ``save_pickle=False`` skips the rewrite of the
+        pickle file - for callers that log several samples in a row and know the next call overwrites it anyway."""
         if self._log_all_weights:
             row = [mcmc_obj._current_iteration] + list((bnn_obj._w_layers[0] * bnn_obj._indicators[0]).flatten())
             for i in range(1, bnn_obj._n_layers):
@@ -126,5 +127,6 @@ class postLogger():
                 sample['additional_prm'] = list(add_prms)
             self.update_post_weight_samples(sample)
             self.control_weight_sample_length(mcmc_obj._n_post_samples)
-        objs = [bnn_obj, mcmc_obj, self] + ([add_obj] if add_obj else [])
-        SaveObject(objs, self._pklfile)
+        if save_pickle:
+            objs = [bnn_obj, mcmc_obj, self] + ([add_obj] if add_obj else [])
+            SaveObject(objs, self._pklfile)

@@ -101,88 +101,137 @@ class MC3():
         return [bnn_obj, mcmc_obj]
 
     # -- the exchange step ---------------------------------------------------------------------
-    def _gather_scalars(self):
-        """[logPost, temperature] of every chain, on every rank."""
-        world = self.comm.world_size
-        per_rank = (self.n_chains + world - 1) // world
-        mine = np.full((per_rank, 2), np.nan)
-        for slot, i in enumerate(self.local_ids):
-            m = self.singleChainArgs[i][1]
-            mine[slot] = (m._logPost, m._temperature)
-        allv = self.comm.allgather_f64(mine.ravel()).reshape(world, per_rank, 2)
-        out = np.empty((self.n_chains, 2))
-        for i in range(self.n_chains):
-            out[i] = allv[i % world, i // world]
-        return out
+    def _local_chains(self):
+        return [self.singleChainArgs[i] for i in self.local_ids]
 
-    def _swap(self, mc3_it):
-        scal = self._gather_scalars()
-        decision = np.zeros(3, dtype=np.int64)
-        r = log_u = np.nan
-        if self.comm.rank == 0:
-            j, k = np.random.choice(range(self.n_chains), 2, replace=False)
-            temp_j, temp_k = scal[j, 1] + 0, scal[k, 1] + 0
-            r = (scal[k, 0] - scal[j, 0]) * temp_j + (scal[j, 0] - scal[k, 0]) * temp_k
-            log_u = np.log(np.random.random())
-            decision[:] = (j, k, 1 if r >= log_u else 0)
-        j, k, accepted = (int(v) for v in self.comm.bcast_i64(decision, root=0))
-        if accepted:
-            temp_j, temp_k = scal[j, 1] + 0, scal[k, 1] + 0
-            if self.singleChainArgs[j] is not None:
-                self.singleChainArgs[j][1].reset_temperature(temp_k)
-            if self.singleChainArgs[k] is not None:
-                self.singleChainArgs[k][1].reset_temperature(temp_j)
-            if self.verbose > 0 and self.comm.rank == 0:
-                print(mc3_it, "SWAPPED", scal[j, 0], scal[k, 0], temp_j, temp_k)
-            scal[j, 1], scal[k, 1] = temp_k, temp_j
-        self.swap_log.append((j, k, float(r), float(log_u), bool(accepted)))
-        return scal
+    def _log_chain(self, i, pair, save_pickle=True):
+        """Log chain ``i`` (the cold one) through rank 0's logger.  ``pair`` = (bnn, mcmc) on the rank that holds the
+        chain, ignored elsewhere; with several ranks a light view of the chain (no data matrix, no predictions) is shipped
+        to rank 0."""
+        world = self.comm.world_size
+        owner = i % world
+        if world == 1:
+            bnn_i, mcmc_i = pair
+        else:
+            view = None
+            if self.comm.rank == owner:
+                bnn_i, mcmc_i = pair
+                small = {name: getattr(mcmc_i, name) for name in ("_accuracy", "_test_accuracy", "_label_acc",
+                                                                   "_label_freq")}
+                light = {k: v for k, v in bnn_i.__dict__.items() if k not in _SHARED and k != "_npbnn_backend"}
+                state = {k: v for k, v in mcmc_i.__dict__.items() if k not in ("_backend", "_bnn", "_lazy", "_speculation")}
+                state["_lazy"] = small
+                view = (light, state)
+            view = self.comm.bcast_obj(view, root=owner)
+            if self.comm.rank != 0:
+                return
+            bnn_i = npBNN.__new__(npBNN)
+            bnn_i.__dict__.update(view[0])
+            bnn_i._data, bnn_i._test_data, bnn_i._labels, bnn_i._test_labels = np.zeros((0, 0)), [], [], []
+            mcmc_i = MCMC.__new__(MCMC)
+            mcmc_i.__setstate__(view[1])
+            mcmc_i._lazy.setdefault("_y", [])
+            mcmc_i._lazy.setdefault("_y_test", [])
+            mcmc_i._bnn = bnn_i
+        if self.comm.rank == 0 and self.logger is not None:
+            self.logger.log_sample(bnn_i, mcmc_i)
+            if save_pickle:
+                self.logger.log_weights(bnn_i, mcmc_i)
+            else:
+                self.logger.log_weights(bnn_i, mcmc_i, save_pickle=False)
 
     def _log_cold_chains(self, scal):
-        world = self.comm.world_size
         for i in range(self.n_chains):
-            if scal[i, 1] != 1:
-                continue
-            owner = i % world
-            if world == 1:
-                bnn_i, mcmc_i = self.singleChainArgs[i]
-            else:
-                view = None
-                if self.comm.rank == owner:
-                    bnn_i, mcmc_i = self.singleChainArgs[i]
-                    small = {name: getattr(mcmc_i, name) for name in ("_accuracy", "_test_accuracy", "_label_acc",
-                                                                       "_label_freq")}
-                    light = {k: v for k, v in bnn_i.__dict__.items() if k not in _SHARED and k != "_npbnn_backend"}
-                    state = {k: v for k, v in mcmc_i.__dict__.items() if k not in ("_backend", "_bnn", "_lazy")}
-                    state["_lazy"] = small
-                    view = (light, state)
-                view = self.comm.bcast_obj(view, root=owner)
-                if self.comm.rank != 0:
-                    continue
-                bnn_i = npBNN.__new__(npBNN)
-                bnn_i.__dict__.update(view[0])
-                bnn_i._data, bnn_i._test_data, bnn_i._labels, bnn_i._test_labels = np.zeros((0, 0)), [], [], []
-                mcmc_i = MCMC.__new__(MCMC)
-                mcmc_i.__setstate__(view[1])
-                mcmc_i._lazy.setdefault("_y", [])
-                mcmc_i._lazy.setdefault("_y_test", [])
-                mcmc_i._bnn = bnn_i
-            if self.comm.rank == 0 and self.logger is not None:
-                self.logger.log_sample(bnn_i, mcmc_i)
-                self.logger.log_weights(bnn_i, mcmc_i)
+            if scal[i, 1] == 1:
+                self._log_chain(i, self.singleChainArgs[i])
+
+    @staticmethod
+    def _view_at_swap(bnn, mcmc, snap):
+        """(bnn, mcmc) as the chain stood at a swap inside a device batch: the weights the device saved for the cold chain,
+        its log-likelihood / prior, the iteration count and the acceptance book-keeping up to there.  The accuracy
+        statistics of the view are computed on demand from those weights, as for a live chain."""
+        layers, off = [], 0
+        for w in bnn._w_layers:
+            layers.append(np.array(snap["w"][off:off + w.size]).reshape(w.shape))
+            off += w.size
+        bnn_v = bnn.__class__.__new__(bnn.__class__)
+        bnn_v.__dict__.update(bnn.__dict__)
+        bnn_v._w_layers = layers
+        m_v = mcmc.__class__.__new__(mcmc.__class__)
+        m_v.__dict__.update(mcmc.__dict__)
+        m_v._speculation = None
+        m_v._bnn = bnn_v
+        m_v._lazy = {}
+        m_v._accepted_override = None
+        k = int(snap["iterations"])
+        m_v._logLik, m_v._logPrior = float(snap["loglik"]), float(snap["logprior"])
+        m_v._logPost = m_v._logLik + m_v._logPrior
+        m_v._current_iteration = snap["iteration0"] + k
+        m_v._temperature = 1
+        history = list(snap["mem_before"]) + [int(v) for v in snap["accepted"][:k]]
+        m_v._last_accepted = history[-1]
+        m_v._acceptance_rate = np.mean(history[-101:]) if len(history) > 100 else np.mean(history)
+        m_v._last_accepted_mem = history[-100:] if len(history) > 100 else history
+        return bnn_v, m_v
+
+    exchange_batch = 20      # swap intervals per device call
+    device_exchange = True   # False: one device batch per interval, swap on the host (the reference's rhythm)
 
     def run_mcmc(self):
-        """The MC3 loop (reference: BNN_mc3.py:87-126)."""
-        for mc3_it in range(self.n_mc3_iteration):
-            for i in self.local_ids:
-                self.singleChainArgs[i] = self.run_single_mcmc(self.singleChainArgs[i])
-            if self.n_chains > 1:
-                scal = self._swap(mc3_it)
+        """The MC3 loop (reference: BNN_mc3.py:87-126): ``n_mc3_iteration`` rounds of [swap_frequency iterations of every
+        chain, one swap proposal, log the cold chain].  Rounds run in device batches (:mod:`npbnn_amd.exchange`) once the
+        proposal adaptation of the chains is over; the cold chain's sample at every swap inside a batch is logged from the
+        state the device saved for it."""
+        from . import exchange as ex
+        if getattr(self, "_swaps", None) is None:
+            self._swaps = ex.SwapProposals(max(self.n_chains, 2))       # drawn from np.random, as BNN_mc3.py:99,110
+        chains = self._local_chains()
+
+        def on_interval(index, info):
+            mc3_it = self._mc3_it
+            self._mc3_it += 1
+            scal, (j, k, r, log_u, accepted) = info["scalars"], info["swap"]
+            if accepted and self.verbose > 0 and self.comm.rank == 0:
+                print(mc3_it, "SWAPPED", scal[j, 0], scal[k, 0], scal[k, 1], scal[j, 1])
+            self.swap_log.append((j, k, float(r), float(log_u), bool(accepted)))
+            if info["cold"] is None:                    # the interval ran on the per-interval path: live chains
+                self._log_cold_chains(scal)
             else:
-                scal = self._gather_scalars()
-            self._log_cold_chains(scal)
+                for i in range(self.n_chains):
+                    if scal[i, 1] != 1:
+                        continue
+                    pair = None
+                    if i in self.local_ids:
+                        q = self.local_ids.index(i)
+                        pair = self._view_at_swap(chains[q][0], chains[q][1], info["cold"][q])
+                    self._log_chain(i, pair, save_pickle=info["last_of_batch"])
             if mc3_it % self.print_f == 0 and self.comm.rank == 0 and self.singleChainArgs[0] is not None:
-                print(mc3_it, self.singleChainArgs[0][1]._logPost, self.singleChainArgs[0][0]._w_layers[0][0][0:5])
+                print(mc3_it, scal[0, 0], self.singleChainArgs[0][0]._w_layers[0][0][0:5])
+
+        self._mc3_it = 0
+        done = 0
+        while done < self.n_mc3_iteration:
+            n = min(self.exchange_batch, self.n_mc3_iteration - done)
+            if self.n_chains > 1:
+                got = ex.advance_intervals(chains, self.local_ids, self.n_chains, n, self.swap_frequency, self._swaps, done,
+                                           comm=self.comm if self.comm.world_size > 1 else None, batch=n,
+                                           device=self.device_exchange, on_interval=on_interval)
+            else:                                       # a single chain: no swaps, the cold chain is logged every interval
+                for _ in range(n):
+                    for i in self.local_ids:
+                        self.singleChainArgs[i] = self.run_single_mcmc(self.singleChainArgs[i])
+                    self._log_cold_chains(self._gather_scalars())
+                    if self._mc3_it % self.print_f == 0 and self.singleChainArgs[0] is not None:
+                        print(self._mc3_it, self.singleChainArgs[0][1]._logPost, self.singleChainArgs[0][0]._w_layers[0][0][0:5])
+                    self._mc3_it += 1
+                got = n
+            done += got
+
+    def _gather_scalars(self):
+        """[logPost, temperature] of every chain, on every rank."""
+        from . import exchange as ex
+        return ex.gather_scalars(self._local_chains(), self.local_ids, self.n_chains,
+                                 self.comm if self.comm.world_size > 1 else None)
 
 
 def default_comm():

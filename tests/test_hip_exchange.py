@@ -234,3 +234,45 @@ def test_exchange_through_a_native_rccl_communicator():
         assert_same(state_of(a), state_of(b))
     finally:
         comm.close()
+
+
+def test_mc3_logs_are_the_same_with_and_without_device_exchange(tmp_path, monkeypatch):
+    """MC3.run_mcmc (bnn_runner_MC3.py call sequence, 4 chains in this process): swap intervals in device batches against
+    one device batch per interval with the swap on the host - same swap log, same rows in the cold chain's log file, same
+    posterior weight samples, same pickle."""
+    monkeypatch.setattr(bn.MCMC, "device_schedule", 2)       # (left to the library the two paths may pick different schedules)
+    cfg = cases.MC3_TRACE
+    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+    runs = []
+    for name, device in (("host", False), ("device", True)):
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
+        logger = bn.postLogger(bnn, filename="MC3" + name, wdir=str(tmp_path), log_all_weights=0)
+        mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"], n_iteration=800,
+                    n_chains=cfg["n_chains"], swap_frequency=cfg["swap_frequency"], verbose=0, adapt_stop=100)
+        mc3.device_exchange = device
+        mc3.exchange_batch = 7
+        seen = []
+        if device:
+            from npbnn_amd import exchange as ex
+            real = ex.run_exchange
+            monkeypatch.setattr(ex, "run_exchange", lambda *a, **k: (seen.append(a[3]), real(*a, **k))[1])
+        quiet(mc3.run_mcmc)
+        if device:
+            assert sum(seen) >= 25, "most of the 40 intervals should have run in device batches (%s)" % seen
+        runs.append((mc3, logger))
+    (ma, la), (mb, lb) = runs
+    assert ma.swap_log == mb.swap_log and any(s[4] for s in ma.swap_log)
+    assert [c[1]._temperature for c in ma.singleChainArgs] == [c[1]._temperature for c in mb.singleChainArgs]
+    rows_a, rows_b = np.loadtxt(la._logfile, skiprows=1), np.loadtxt(lb._logfile, skiprows=1)
+    assert rows_a.shape == rows_b.shape and rows_a.shape[0] == 40
+    np.testing.assert_array_equal(rows_a, rows_b)
+    assert len(la._post_weight_samples) == len(lb._post_weight_samples) == 10
+    for sa, sb in zip(la._post_weight_samples, lb._post_weight_samples):
+        assert sa["mcmc_it"] == sb["mcmc_it"]
+        for u, v in zip(sa["weights"], sb["weights"]):
+            np.testing.assert_array_equal(u, v)
+    (ba, mca, _), (bb, mcb, _) = bn.load_obj(la._pklfile), bn.load_obj(lb._pklfile)
+    assert mca._current_iteration == mcb._current_iteration and mca._logPost == mcb._logPost
+    for u, v in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(u, v)

@@ -100,3 +100,85 @@ class OracleChainBackend(OracleBackend):
                 if r["sigma"] is not None:
                     sig = r["sigma"]
         return cur, acc, llp, lpp, dict(loglik=ll, logprior=lp, sigma=sig, n_accepted=n_acc, n_passes=K, n_candidates=1)
+
+
+class OracleExchangeBackend(OracleChainBackend):
+    """Adds a numpy stand-in for npbnn_chains_run_exchange (swap intervals with the temperature swaps between them) so
+    that the exchange driver (npbnn_amd/exchange.py) and MC3's logging from saved cold-chain states run on CPU, over gloo
+    too.  Semantics of the device entry point: records = [logPost, temperature, finished flag, iterations done] per chain and
+    exchange; a chain that falls short of an interval (``starve = {(chain_id, interval): iterations it manages}``) makes
+    every chain stop at that exchange."""
+    starve = {}
+    exchange_slack = 1.5
+    exchange_slack_floor = 1.15
+
+    def exchange_job(self, weights, chain_id, idx, delta, cnt, log_u, mask, cfg):
+        return dict(be=self, chain_id=chain_id, weights=weights, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=mask, cfg=cfg)
+
+    @staticmethod
+    def run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=None, launch_slack=1.25, want_cold_w=True):
+        world = 1 if comm is None else comm.world_size
+        rank = 0 if comm is None else comm.rank
+        per_rank = len(jobs)
+        assert n_chains == world * per_rank
+        K = seg_len * n_seg
+        st = []
+        for job in jobs:
+            cfg = dict(job["cfg"])
+            st.append(dict(w=[np.array(w, dtype=float) for w in job["weights"]], ll=cfg["cur_loglik"], lp=cfg["cur_logprior"],
+                           temp=cfg["temperature"], t=0, acc=np.zeros(K, dtype=np.uint8), llp=np.zeros(K), lpp=np.zeros(K), n_acc=0,
+                           sigma=cfg.get("cur_sigma"), state=np.zeros((n_seg, 4)),
+                           cold=np.zeros((n_seg, sum(w.size for w in job["weights"]))) if want_cold_w else None, cfg=cfg))
+        records = np.zeros((n_seg, n_chains, 4))
+        done, poisoned = 0, False
+        for s in range(n_seg):
+            mine = np.zeros((per_rank, 4))
+            for q, (job, c) in enumerate(zip(jobs, st)):
+                end = (s + 1) * seg_len
+                if not poisoned:
+                    upto = min(end, s * seg_len + OracleExchangeBackend.starve.get((job["chain_id"], s), seg_len))
+                    if upto > c["t"]:
+                        a, b = c["t"], upto
+                        kw = dict(c["cfg"])
+                        kw.update(temperature=c["temp"], cur_loglik=c["ll"], cur_logprior=c["lp"], cur_sigma=c["sigma"])
+                        kw.pop("n_candidates", None), kw.pop("schedule", None)
+                        cur, acc, llp, lpp, res = job["be"].run_chain(c["w"], idx=job["idx"][a:b], delta=job["delta"][a:b],
+                                                                      cnt=job["cnt"][a:b], log_u=job["log_u"][a:b],
+                                                                      mask=job["mask"], **kw)
+                        c["acc"][a:b], c["llp"][a:b], c["lpp"][a:b] = acc, llp, lpp
+                        if res["n_accepted"] > 0:
+                            off, layers = 0, []
+                            for w in c["w"]:
+                                layers.append(cur[off:off + w.size].reshape(w.shape))
+                                off += w.size
+                            c["w"], c["ll"], c["lp"], c["sigma"] = layers, res["loglik"], res["logprior"], res["sigma"]
+                            c["n_acc"] += res["n_accepted"]
+                        c["t"] = b
+                mine[q] = (c["ll"] + c["lp"], c["temp"], 1.0 if (not poisoned and c["t"] >= end) else 0.0, c["t"])
+            allv = mine.reshape(1, per_rank, 4) if world == 1 else comm.allgather_f64(mine.ravel()).reshape(world, per_rank, 4)
+            for i in range(n_chains):
+                records[s, i] = allv[i % world, i // world]
+            if poisoned or not np.all(records[s, :, 2] == 1.0):
+                poisoned = True
+                continue
+            j, k = int(swap_j[s]), int(swap_k[s])
+            pj, tj, pk, tk = records[s, j, 0], records[s, j, 1], records[s, k, 0], records[s, k, 1]
+            if j != k and (pk - pj) * tj + (pj - pk) * tk >= swap_logu[s]:
+                for job, c in zip(jobs, st):
+                    if job["chain_id"] == j:
+                        c["temp"] = tk
+                    elif job["chain_id"] == k:
+                        c["temp"] = tj
+            for c in st:
+                c["state"][s] = (c["ll"], c["lp"], c["temp"], c["t"])
+                if c["cold"] is not None and c["temp"] == 1.0:
+                    c["cold"][s] = np.concatenate([w.ravel() for w in c["w"]])
+            done = s + 1
+        outs = []
+        for c in st:
+            outs.append(dict(w=np.concatenate([w.ravel() for w in c["w"]]), accepted=c["acc"], loglik_prop=c["llp"],
+                             logprior_prop=c["lpp"], state=c["state"], cold_w=c["cold"],
+                             result=dict(loglik=c["ll"], logprior=c["lp"], sigma=c["sigma"], n_accepted=c["n_acc"], n_passes=c["t"],
+                                         n_candidates=1, n_void_passes=0, schedule=1, temperature=c["temp"],
+                                         iterations_done=c["t"], overflow=0)))
+        return outs, records, done

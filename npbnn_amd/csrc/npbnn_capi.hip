@@ -1533,8 +1533,8 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     p.M = 0;
     unsigned long long* d_stamps = nullptr;
     if (getenv("NPBNN_EVAL_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the last launch
-        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)lp.grid * 8 * sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)lp.grid * 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)lp.grid * 24 * sizeof(unsigned long long)));     // [grid][8] wave 0 + [grid][16] per wave
+        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)lp.grid * 24 * sizeof(unsigned long long)));
         p.stamps = d_stamps;
     }
     rc = push_eval_params(ctx, p);
@@ -1552,9 +1552,18 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     *ms_kernel = (double)ms / iters;
     if (used_candidates) *used_candidates = lp.n_cand;
     if (d_stamps) {
-        std::vector<unsigned long long> hs((size_t)lp.grid * 8);
+        std::vector<unsigned long long> hs((size_t)lp.grid * 24);
         (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(d_stamps);
+        {   // when each wave of a workgroup finished its tiles, relative to the workgroup's tile-loop start (mean over workgroups)
+            double done[16] = {0};
+            for (int b = 0; b < lp.grid; ++b)
+                for (int w = 0; w < lp.wpb && w < 16; ++w)
+                    done[w] += (double)(hs[(size_t)lp.grid * 8 + (size_t)b * 16 + w] - hs[(size_t)b * 8 + 3]) * 0.01;
+            fprintf(stderr, "[npbnn eval stamps] tiles done per wave, us after the tile loop starts:");
+            for (int w = 0; w < lp.wpb && w < 16; ++w) fprintf(stderr, " %.1f", done[w] / lp.grid);
+            fprintf(stderr, "\n");
+        }
         unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
         double acc[8] = {0};
         for (int b = 0; b < lp.grid; ++b) {

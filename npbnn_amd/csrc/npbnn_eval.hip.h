@@ -405,11 +405,13 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
                     dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
     }
 
-    // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to wave m % wpb, so the
-    //      tile counts of the waves (and SIMDs) of one CU differ by at most one ----
+    // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to SIMD m % 4 and, there, to the
+    //      waves of that SIMD in turn (wave w sits on SIMD w % 4): the SIMDs of a CU - whose issue ports are what the tile
+    //      loop saturates - get the same number of tiles to within one even when the waves do not divide by four ----
     const int KT0 = uni(net.L[0].kt);
     const int first_tile = bid + G * wave;
-    const int stride = G * wpb;
+    const int simd_waves = (wpb - (wave & 3) + 3) >> 2;      // waves of this workgroup on this wave's SIMD
+    const int stride = G * 4 * simd_waves;
     const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
     int Dp = PIPE ? kRing : DEPTH;                      // prefetch distance in pieces
@@ -716,6 +718,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     }
 
     NPBNN_ESTAMP(4);
+    if (stamps && lane == 0) stamps[(size_t)gridDim.x * 8 + (size_t)bid * 16 + wave] = wall_clock64();   // every wave: tiles done
     // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
     if (g_partials) {
         constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;

@@ -352,7 +352,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             int start = t0 + n_done;
             if (pl.fly >= 0) {
                 if (accepted >= 0) {
-                    st->void_launch = pl.launch;
+                    __hip_atomic_store(&st->void_launch, pl.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (polled by the evaluating workgroups)
                     if (c.pass[pl.fly].n_cand > 0) st->n_void += 1;
                 } else {
                     start = c.pass[pl.fly].t0 + c.pass[pl.fly].n_cand;

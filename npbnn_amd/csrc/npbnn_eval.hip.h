@@ -389,6 +389,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
     }
 
+    // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
+    // this pass is then evaluated from a state that no longer exists and nobody will read its sums: polled once per tile
+    // (device-scope load, issued before the tile's tail and looked at after it), the waves skip their remaining tiles
+    const int* const void_flag = chain ? uni(&chain->st->void_launch) : nullptr;
+    int void_seen = -3;
     char* const ring = smem + D * IB + (size_t)wave * uni(p.lay.wave_lds);
     char* const aux = ring + kRing * 1024;
     float* const row_scratch = reinterpret_cast<float*>(aux + (aux_mask + 1) * aux_sz);   // [16 rows][16 outputs], generic likelihoods
@@ -618,6 +623,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
             int tile = first_tile;
             unsigned long long tail_ticks = 0;
             for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
+                if (void_flag && void_seen == launch) break;
                 for (int kp = 0; kp + 1 < KS; kp += 2) { // the register sets alternate, no copies
                     step(std::integral_constant<int, 0>{});
                     step(std::integral_constant<int, 1>{});
@@ -628,6 +634,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
                     if (D & 1) Wb[0] = Wb[1];
                 }
                 const unsigned long long tk = stamps ? wall_clock64() : 0;
+                if (void_flag) void_seen = __hip_atomic_load(void_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 run_tail(acc0, tseq, tile);              // (the first fragments of the next tile arrive underneath)
                 load_bias0(acc0);
                 if (stamps) tail_ticks += wall_clock64() - tk;
@@ -638,6 +645,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     int q = 0, cs_slot = 0;
     int tile = first_tile;
     for (int tseq = 0; tseq < my_tiles; ++tseq, tile += stride) {
+        if (void_flag && void_seen == launch) break;
         // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring, every candidate on the same X piece ----------------
         f32x4 acc0[D][MT0];
         load_bias0(acc0);
@@ -713,9 +721,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         }
 
         // ---------------- layers 1..L-1 + likelihood terms of every candidate ----------------
+        if (void_flag) void_seen = __hip_atomic_load(void_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         run_tail(acc0, tseq, tile);
     }
     }
+    if (void_flag) NPBNN_WAIT_VMCNT(0);       // (a wave that left early still has X pieces on their way into its ring)
 
     NPBNN_ESTAMP(4);
     if (stamps && lane == 0) stamps[(size_t)gridDim.x * 8 + (size_t)bid * 16 + wave] = wall_clock64();   // every wave: tiles done

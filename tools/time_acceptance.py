@@ -17,12 +17,14 @@ n, f, c = 100_000, 256, 10
 x = rs.standard_normal((n, f)).astype(np.float32)
 proj = rs.standard_normal((f, c)) / np.sqrt(f)
 y = np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)          # learnable labels
-for uf in (0.05, 0.01, 0.002, 0.0005):
+schedules = [int(v) for v in sys.argv[1:]] or [0]          # 0 auto, 1 serial, 2 overlapped
+for uf, sched in [(u, sc) for u in (0.05, 0.01, 0.002, 0.0005) for sc in schedules]:
     np.random.seed(1234)
     with contextlib.redirect_stdout(io.StringIO()):
         bnn = bn.npBNN(dict(data=x, labels=y, test_data=np.zeros((0, f)), test_labels=np.zeros(0)), n_nodes=[32, 8],
                        actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
     mcmc = bn.MCMC(bnn, update_f=[uf] * 3)
+    mcmc.device_schedule = sched
     mcmc.run_steps(bnn, 1000)
     a0 = mcmc._device_passes, mcmc._device_void_passes
     acc = []
@@ -32,5 +34,5 @@ for uf in (0.05, 0.01, 0.002, 0.0005):
         acc.append(mcmc._acceptance_rate)
     el = time.perf_counter() - t
     p, v = mcmc._device_passes - a0[0], mcmc._device_void_passes - a0[1]
-    print("update_f %.4f (update_n %s): acceptance %.2f, %.0f it/s, %.2f iterations per decided pass, %.0f %% of the launches void"
-          % (uf, list(mcmc._update_n), float(np.mean(acc)), 4000 / el, 4000 / p, 100.0 * v / (p + v)))
+    print("schedule %d, update_f %.4f (update_n %s): acceptance %.2f, %.0f it/s, %.2f iterations per decided pass, %.0f %% of the launches void"
+          % (sched, uf, [int(v) for v in mcmc._update_n], float(np.mean(acc)), 4000 / el, 4000 / p, 100.0 * v / (p + v)))

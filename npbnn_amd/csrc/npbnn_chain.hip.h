@@ -396,6 +396,17 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     int n_new = sh.s_lim - t_new;            // (seg_end <= K)
     if (n_new > c.D) n_new = c.D;
     if (n_new < 0) n_new = 0;
+    if (n_new == 0) {        // nothing left to prepare (end of the batch or of a swap interval; launches enqueued past it): an
+        if (tid == 0) {      // empty descriptor and out - these launches are pure overhead, keep them short
+            PassDesc d;
+            d.t0 = t_new;
+            d.n_cand = 0;
+            for (int j = 0; j < kMaxCand; ++j) d.cnt[j] = 0;
+            d.pad[0] = d.pad[1] = d.pad[2] = 0;
+            c.pass[pl.out] = d;
+        }
+        return;
+    }
     double dlp[kMaxCand];
     {
         // staged so that the loads of all candidates are in flight together: (1) the pre-drawn entry, (2) the weight it

@@ -1551,6 +1551,20 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     *ms_kernel = (double)ms / iters;
     if (used_candidates) *used_candidates = lp.n_cand;
+    if (const char* ns = getenv("NPBNN_TIME_PASS_STREAMS")) {      // diagnostics: the same independent launches dealt over several streams
+        const int n_streams = atoi(ns) > 1 ? (atoi(ns) > 4 ? 4 : atoi(ns)) : 1;
+        hipStream_t ss[4];
+        for (int i = 0; i < n_streams; ++i) HIP_TRY(ctx, hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+        for (int rep = 0; rep < 2; ++rep) {
+            const double t0 = wall_us();
+            for (int i = 0; i < iters; ++i)
+                hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ss[i % n_streams], (const EvalParams*)ctx->d_eparams, 0);
+            for (int i = 0; i < n_streams; ++i) HIP_TRY(ctx, hipStreamSynchronize(ss[i]));
+            if (rep) fprintf(stderr, "[npbnn time_pass] %d independent launches dealt over %d stream(s): %.2f us per launch (wall clock)\n", iters, n_streams,
+                             (wall_us() - t0) / iters);
+        }
+        for (int i = 0; i < n_streams; ++i) (void)hipStreamDestroy(ss[i]);
+    }
     if (d_stamps) {
         std::vector<unsigned long long> hs((size_t)lp.grid * 24);
         (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);

@@ -114,6 +114,13 @@ const char* npbnn_last_error(const npbnn_ctx* ctx);
  * numpy arrays and being copied every iteration (tmp = bnn_obj._data + 0, BNN_env.py:388) ---- */
 int npbnn_set_data_f64(npbnn_ctx* ctx, const double* X, int64_t n_rows, int32_t n_features, int which);
 int npbnn_set_data_f32(npbnn_ctx* ctx, const float* X, int64_t n_rows, int32_t n_features, int which);
+/* The chains of one run (MC3 replicates the model per chain, np_bnn/BNN_mc3.py:55-58) hold the same feature matrices: `ctx` uses
+ * the device copies `owner` holds - training and test matrices, their fp16-split copies and scales - instead of uploading its
+ * own (labels / targets / row weights stay per context: set them afterwards, then npbnn_set_arch).  Same device only.  The
+ * owner's memory lives until the last borrower is destroyed or given data of its own; npbnn_set_data on an owner with
+ * borrowers is an error. */
+int npbnn_share_data(npbnn_ctx* ctx, npbnn_ctx* owner);
+
 int npbnn_set_labels_i64(npbnn_ctx* ctx, const int64_t* y, int64_t n_rows, int which);
 int npbnn_set_targets_f64(npbnn_ctx* ctx, const double* Y, int64_t n_rows, int32_t k, int which);
 /* instance_weight / class_weight of calc_likelihood (BNN_lib.py:100-121); NULL clears. Train set only. */

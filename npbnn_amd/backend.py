@@ -91,6 +91,13 @@ class HipContext:
             self._chk(self._lib.npbnn_set_data_f64(self._ctx, capi.dptr(Xc), X.shape[0], X.shape[1], which))
         self.n_rows[which] = X.shape[0]
 
+    def share_data(self, owner):
+        """Use the feature matrices (training and test) resident in ``owner`` (another HipContext on the same device)
+        instead of uploading copies (npbnn_share_data); labels / targets / row weights are set per context afterwards."""
+        self._chk(self._lib.npbnn_share_data(self._ctx, owner._ctx))
+        self.n_rows = dict(owner.n_rows) if isinstance(owner.n_rows, dict) else list(owner.n_rows)
+        self._data_owner = owner            # (the library keeps the memory alive by itself; this is for introspection)
+
     def set_labels(self, labels, which=capi.TRAIN):
         lab = np.ascontiguousarray(labels, dtype=np.int64)
         self._chk(self._lib.npbnn_set_labels_i64(self._ctx, lab.ctypes.data_as(C.POINTER(C.c_int64)), lab.shape[0], which))

@@ -58,6 +58,7 @@ struct Dataset {
     float* X16 = nullptr;      // fp16-split copy (built lazily on the device), row stride Fp16 floats
     int Fp16 = 0;
     int f16_state = 0;         // 0 not built, 1 usable, -1 not representable (inf/NaN or outside the fp16 range)
+    bool borrowed = false;     // X / X16 belong to another ctx (npbnn_share_data)
 };
 
 }  // namespace
@@ -133,6 +134,11 @@ struct npbnn_ctx {
     char* h_xbuf = nullptr;
     size_t xbuf_cap = 0;
     hipEvent_t ev_x = nullptr;
+    // feature matrices shared between the chains of one run (npbnn_share_data): a borrower points at its owner, an owner
+    // counts its borrowers and outlives them (a destroyed owner lingers until the last borrower lets go)
+    npbnn_ctx* data_owner = nullptr;
+    int n_borrowers = 0;
+    bool zombie = false;
 };
 
 namespace {
@@ -161,12 +167,27 @@ int fail(npbnn_ctx* ctx, int code, const char* fmt, ...) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 void free_dataset(Dataset& d) {
-    if (d.X) (void)hipFree(d.X);
+    if (d.X && !d.borrowed) (void)hipFree(d.X);
     if (d.labels) (void)hipFree(d.labels);
     if (d.targets) (void)hipFree(d.targets);
     if (d.inst_w) (void)hipFree(d.inst_w);
-    if (d.X16) (void)hipFree(d.X16);
+    if (d.X16 && !d.borrowed) (void)hipFree(d.X16);
     d = Dataset();
+}
+
+void destroy_ctx(npbnn_ctx* c);
+
+// a borrower lets go of its owner's matrices (before it uploads its own, or when it is destroyed)
+void unshare_data(npbnn_ctx* ctx) {
+    npbnn_ctx* owner = ctx->data_owner;
+    if (!owner) return;
+    for (int w = 0; w < 2; ++w)
+        if (ctx->ds[w].borrowed) { ctx->ds[w].X = nullptr; ctx->ds[w].X16 = nullptr; ctx->ds[w].borrowed = false; ctx->ds[w].f16_state = 0; }
+    ctx->d_xscale = nullptr;          // (the scales travel with the training matrix)
+    ctx->d_wscale = nullptr;
+    ctx->scale_F = 0;
+    ctx->data_owner = nullptr;
+    if (--owner->n_borrowers == 0 && owner->zombie) destroy_ctx(owner);
 }
 
 template <typename T>
@@ -177,6 +198,12 @@ int upload_matrix(npbnn_ctx* ctx, const T* X, int64_t n_rows, int32_t F, int whi
                     (long long)n_rows, F, which);
     if (n_rows > (int64_t)1 << 30) return fail(ctx, NPBNN_E_ARG, "set_data: too many rows");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_borrowers > 0) return fail(ctx, NPBNN_E_STATE, "set_data: %d other context(s) use this one's matrices (npbnn_share_data)", ctx->n_borrowers);
+    if (ctx->data_owner) {       // a borrower that gets data of its own: all borrowed matrices go back first
+        unshare_data(ctx);
+        free_dataset(ctx->ds[0]);
+        free_dataset(ctx->ds[1]);
+    }
     Dataset& d = ctx->ds[which];
     free_dataset(d);
     if (which == 0) {            // the fp16-split scales come from the training matrix
@@ -350,6 +377,10 @@ int ensure_scales(npbnn_ctx* ctx) {
 // 1 = the set has a usable fp16-split copy, 0 = it cannot be represented (the caller stays on float32)
 int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
     *usable = 0;
+    if (ctx->data_owner && ctx->ds[which].borrowed) {      // borrowed matrices come with their split copy, or without one
+        *usable = ctx->ds[which].f16_state > 0 ? 1 : 0;
+        return NPBNN_OK;
+    }
     int rc = ensure_scales(ctx);
     if (rc) return rc;
     if (ctx->ds[0].f16_state < 0) return NPBNN_OK;
@@ -566,6 +597,45 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
 
 extern "C" void npbnn_set_global_error_(const char* msg) { g_last_error = msg ? msg : ""; }
 
+namespace {
+void destroy_ctx(npbnn_ctx* c) {
+    (void)hipSetDevice(c->device);
+    free_dataset(c->ds[0]);
+    free_dataset(c->ds[1]);
+    if (c->d_classw) (void)hipFree(c->d_classw);
+    if (c->d_wraw) (void)hipFree(c->d_wraw);
+    if (c->d_colov) (void)hipFree(c->d_colov);
+    if (c->d_xscale) (void)hipFree(c->d_xscale);
+    if (c->d_wscale) (void)hipFree(c->d_wscale);
+    if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_eparams) (void)hipFree(c->d_eparams);
+    if (c->d_fparams) (void)hipFree(c->d_fparams);
+    if (c->d_cparams) (void)hipFree(c->d_cparams);
+    if (c->d_xbuf) (void)hipFree(c->d_xbuf);
+    if (c->h_xbuf) (void)hipHostFree(c->h_xbuf);
+    if (c->ev_x) (void)hipEventDestroy(c->ev_x);
+    if (c->h_params) (void)hipHostFree(c->h_params);
+    if (c->d_w2scale) (void)hipFree(c->d_w2scale);
+    if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_w2img) (void)hipFree(c->d_w2img);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_conf) (void)hipFree(c->d_conf);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_y) (void)hipFree(c->d_y);
+    if (c->h_w) (void)hipHostFree(c->h_w);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_conf) (void)hipHostFree(c->h_conf);
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale};
+    for (void* b : chain_bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
+    if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+}  // namespace
+
 extern "C" {
 
 int npbnn_abi_version(void) { return NPBNN_ABI_VERSION; }
@@ -623,39 +693,50 @@ void npbnn_destroy(npbnn_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    free_dataset(c->ds[0]);
-    free_dataset(c->ds[1]);
-    if (c->d_classw) (void)hipFree(c->d_classw);
-    if (c->d_wraw) (void)hipFree(c->d_wraw);
-    if (c->d_colov) (void)hipFree(c->d_colov);
-    if (c->d_xscale) (void)hipFree(c->d_xscale);
-    if (c->d_wscale) (void)hipFree(c->d_wscale);
-    if (c->d_overflow) (void)hipFree(c->d_overflow);
-    if (c->d_eparams) (void)hipFree(c->d_eparams);
-    if (c->d_fparams) (void)hipFree(c->d_fparams);
-    if (c->d_cparams) (void)hipFree(c->d_cparams);
-    if (c->d_xbuf) (void)hipFree(c->d_xbuf);
-    if (c->h_xbuf) (void)hipHostFree(c->h_xbuf);
-    if (c->ev_x) (void)hipEventDestroy(c->ev_x);
-    if (c->h_params) (void)hipHostFree(c->h_params);
-    if (c->d_w2scale) (void)hipFree(c->d_w2scale);
-    if (c->d_image) (void)hipFree(c->d_image);
-    if (c->d_w2img) (void)hipFree(c->d_w2img);
-    if (c->d_partials) (void)hipFree(c->d_partials);
-    if (c->d_conf) (void)hipFree(c->d_conf);
-    if (c->d_out) (void)hipFree(c->d_out);
-    if (c->d_y) (void)hipFree(c->d_y);
-    if (c->h_w) (void)hipHostFree(c->h_w);
-    if (c->h_out) (void)hipHostFree(c->h_out);
-    if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale};
-    for (void* b : chain_bufs)
-        if (b) (void)hipFree(b);
-    if (c->h_res) (void)hipHostFree(c->h_res);
-    if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
-    if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    if (c->data_owner) unshare_data(c);
+    if (c->n_borrowers > 0) {        // others still read this context's matrices: it goes when the last of them does
+        c->zombie = true;
+        return;
+    }
+    destroy_ctx(c);
+}
+
+int npbnn_share_data(npbnn_ctx* ctx, npbnn_ctx* owner) {
+    if (!ctx || !owner || ctx == owner) return fail(ctx, NPBNN_E_ARG, "share_data: bad arguments");
+    while (owner->data_owner) owner = owner->data_owner;          // the root holds the memory
+    if (owner == ctx) return fail(ctx, NPBNN_E_ARG, "share_data: contexts borrow from each other");
+    if (owner->device != ctx->device) return fail(ctx, NPBNN_E_ARG, "share_data: contexts on devices %d and %d", ctx->device, owner->device);
+    if (ctx->n_borrowers > 0) return fail(ctx, NPBNN_E_STATE, "share_data: %d other context(s) use this one's matrices", ctx->n_borrowers);
+    if (!owner->ds[0].X) return fail(ctx, NPBNN_E_STATE, "share_data: the owner has no training matrix");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the owner's fp16-split copies are built now (on its stream) so that borrowers never have to
+    for (int w = 0; w < 2; ++w)
+        if (owner->ds[w].X && owner->l0_option != NPBNN_L0_F32) {
+            int usable = 0;
+            int rc = ensure_x16(owner, w, &usable);
+            if (rc) { ctx->err = owner->err; return rc; }
+        }
+    HIP_TRY(ctx, hipStreamSynchronize(owner->stream));
+    if (ctx->data_owner) unshare_data(ctx);
+    free_dataset(ctx->ds[0]);
+    free_dataset(ctx->ds[1]);
+    if (ctx->d_xscale) (void)hipFree(ctx->d_xscale);
+    if (ctx->d_wscale) (void)hipFree(ctx->d_wscale);
+    for (int w = 0; w < 2; ++w) {
+        const Dataset& o = owner->ds[w];
+        if (!o.X) continue;
+        Dataset& d = ctx->ds[w];
+        d.X = o.X; d.X16 = o.X16; d.n_rows = o.n_rows; d.n_tiles = o.n_tiles; d.F = o.F; d.Fp = o.Fp; d.Fp16 = o.Fp16;
+        d.f16_state = o.f16_state;
+        d.borrowed = true;
+    }
+    ctx->d_xscale = owner->d_xscale;
+    ctx->d_wscale = owner->d_wscale;
+    ctx->scale_F = owner->scale_F;
+    ctx->data_owner = owner;
+    owner->n_borrowers += 1;
+    ctx->arch_set = false;            // (layer-0 layout depends on the data: set_arch again)
+    return NPBNN_OK;
 }
 
 int npbnn_set_data_f64(npbnn_ctx* ctx, const double* X, int64_t n_rows, int32_t F, int which) {

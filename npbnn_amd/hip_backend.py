@@ -10,6 +10,9 @@ The sampler accepts any object with these two methods (the CPU test-suite inject
 one); when none is given it builds a ``HipBackend`` and fails loudly if the HIP library or the GPU
 is missing.
 """
+import os
+import weakref
+
 import numpy as np
 
 from . import _capi as capi
@@ -37,14 +40,29 @@ def bias_flags(weights, n_features):
     return flags
 
 
+# backends by the host arrays whose device copies they hold: models that hold the very same data / test_data array objects (the
+# per-chain replicas MC3 makes of one model) share one resident copy per device
+_DATA_OWNERS = weakref.WeakValueDictionary()
+
+
 class HipBackend:
     def __init__(self, bnn, likelihood_f=None, device=None):
         self.ctx = HipContext(device)
         self.n_features = bnn._data.shape[1]
-        self.ctx.set_data(bnn._data, capi.TRAIN)
         self.has_test = len(bnn._test_data) > 0
-        if self.has_test:
-            self.ctx.set_data(bnn._test_data, capi.TEST)
+        self._host_arrays = (bnn._data, bnn._test_data)          # (kept: the sharing key below is their identity)
+        key = (id(bnn._data), id(bnn._test_data) if self.has_test else 0, bnn._data.shape,
+               np.shape(bnn._test_data) if self.has_test else (), self.ctx.device)
+        owner = _DATA_OWNERS.get(key)
+        if owner is not None and getattr(owner.ctx, "_ctx", None) and os.environ.get("NPBNN_NO_DATA_SHARING") is None:
+            self.ctx.share_data(owner.ctx)
+            self.data_shared_with = owner
+        else:
+            self.ctx.set_data(bnn._data, capi.TRAIN)
+            if self.has_test:
+                self.ctx.set_data(bnn._test_data, capi.TEST)
+            self.data_shared_with = None
+            _DATA_OWNERS[key] = self
         self.out_kind = output_kind(bnn._output_act_fun)          # None -> host callable
         lik = likelihood_kind(likelihood_f) if likelihood_f is not None else None
         self.lik_kind = lik if lik in _FUSED else capi.LIK_NONE

@@ -276,3 +276,48 @@ def test_mc3_logs_are_the_same_with_and_without_device_exchange(tmp_path, monkey
     assert mca._current_iteration == mcb._current_iteration and mca._logPost == mcb._logPost
     for u, v in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(u, v)
+
+
+def test_chains_of_one_model_share_the_resident_matrices():
+    """MC3 replicates the model per chain with the data arrays shared (BNN_mc3.py:55-58): their device contexts share one
+    resident copy of the feature matrices; results are those of private copies, and the memory outlives the owner."""
+    import gc
+    cfg = cases.MC3_TRACE
+    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+    np.random.seed(1234)
+    bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
+    mc3 = quiet(bn.MC3, bnn, logger=None, n_chains=3, swap_frequency=20, n_iteration=200, verbose=0, adapt_stop=40)
+    backends = [c[1]._backend for c in mc3.singleChainArgs]
+    assert backends[0].data_shared_with is None
+    assert backends[1].data_shared_with is backends[0] and backends[2].data_shared_with is backends[0]
+    quiet(mc3.run_mcmc)
+    state = [(c[1]._logLik, c[1]._temperature, c[0]._w_layers[0].copy()) for c in mc3.singleChainArgs]
+    # the same run with private copies
+    os_environ = __import__("os").environ
+    os_environ["NPBNN_NO_DATA_SHARING"] = "1"
+    try:
+        np.random.seed(1234)
+        bnn2 = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
+        mc3b = quiet(bn.MC3, bnn2, logger=None, n_chains=3, swap_frequency=20, n_iteration=200, verbose=0, adapt_stop=40)
+        assert all(c[1]._backend.data_shared_with is None for c in mc3b.singleChainArgs)
+        quiet(mc3b.run_mcmc)
+    finally:
+        del os_environ["NPBNN_NO_DATA_SHARING"]
+    for (ll, t, w), c in zip(state, mc3b.singleChainArgs):
+        assert (ll, t) == (c[1]._logLik, c[1]._temperature)
+        np.testing.assert_array_equal(w, c[0]._w_layers[0])
+    # the owner goes first: the borrowers keep working
+    first = mc3.singleChainArgs[0]
+    first[1]._backend.close()
+    m = mc3.singleChainArgs[1][1]
+    before = m._logLik
+    r = m._backend.evaluate(mc3.singleChainArgs[1][0]._w_layers, None)
+    np.testing.assert_allclose(r["loglik"], before, rtol=1e-12)
+    # an owner cannot be given new data while others read its matrices; a borrower can (it lets go first)
+    own, other = mc3b.singleChainArgs[0][1]._backend, mc3b.singleChainArgs[1][1]._backend
+    other.ctx.share_data(own.ctx)
+    with pytest.raises(Exception, match="use this one's matrices"):
+        own.ctx.set_data(dat["data"])
+    other.ctx.set_data(dat["data"])
+    own.ctx.set_data(dat["data"])
+    gc.collect()

@@ -321,3 +321,34 @@ def test_chains_of_one_model_share_the_resident_matrices():
     other.ctx.set_data(dat["data"])
     own.ctx.set_data(dat["data"])
     gc.collect()
+
+
+def test_exchange_run_at_config2_size():
+    """BASELINE config 2 shapes (100k x 256, [32, 8], tanh, 10 classes), two chains on one data set, swaps every 50 iterations:
+    the exchange run against the per-interval path, bit for bit."""
+    rs = np.random.default_rng(0)
+    x = rs.standard_normal((100_000, 256)).astype(np.float32)
+    y = rs.integers(0, 10, 100_000)
+    dat = dict(data=x, labels=y, test_data=np.zeros((0, 256)), test_labels=np.zeros(0))
+
+    def make():
+        chains = []
+        for i, t in enumerate((0.9, 1.0)):
+            np.random.seed(1234 + i)
+            bnn = quiet(bn.npBNN, dat, n_nodes=[32, 8], actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+            m = bn.MCMC(bnn, temperature=t, mcmc_id=i, randomize_seed=True, update_f=[0.01, 0.01, 0.01])
+            m.device_schedule = 2
+            chains.append((bnn, m))
+        return chains
+    a, b = make(), make()
+    assert b[1][1]._backend.data_shared_with is not None
+    n_seg, seg_len = 8, 50
+    log_a = slow_path(a, n_seg, seg_len, 13)
+    swaps = ex.SwapProposals(2, np.random.RandomState(13))
+    log_b = []
+    assert ex.advance_intervals(b, [0, 1], 2, n_seg, seg_len, swaps, 0, batch=n_seg,
+                                on_interval=lambda s, info: log_b.append((info["swap"], info["cold"]))) == n_seg
+    assert all(c is not None for _, c in log_b), "all intervals should have run on the device"
+    assert [s for s, _ in log_a] == [s for s, _ in log_b]
+    assert sum(m._last_accepted_mem.count(1) for _, m in a) > 5
+    assert_same(state_of(a), state_of(b))

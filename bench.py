@@ -123,7 +123,8 @@ def main():
         # below whatever happens, so a failure anywhere cannot leave the others waiting
         box = [None]
         on_gpu = dist_backend == "nccl"
-        if rank == 0 and on_gpu:
+        try_native = on_gpu or bool(os.environ.get("NPBNN_BENCH_TRY_RCCL"))      # (rehearsal: ranks sharing a GPU, if RCCL accepts that)
+        if rank == 0 and try_native:
             try:
                 box[0] = RcclComm.make_unique_id()
             except Exception as e:
@@ -132,7 +133,7 @@ def main():
         ok = 1 if box[0] else 0
         if ok:
             try:
-                comm = RcclComm(rank=rank, world_size=world, device=local_rank, uid=box[0])
+                comm = RcclComm(rank=rank, world_size=world, device=device_index, uid=box[0])
             except Exception as e:
                 print("[rank %d] native RCCL communicator unavailable (%s)" % (rank, e), flush=True)
                 ok = 0

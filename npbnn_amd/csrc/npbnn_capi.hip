@@ -263,6 +263,9 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     net.k_targets = a->n_targets;
     net.final_act = a->final_act ? 1 : 0;
     net.l0_f16 = f16 ? 1 : 0;
+    // softmax / categorical heads: padding outputs are masked through their bias (see NetMeta::pad_masked)
+    net.pad_masked = (!net.final_act && (a->out_kind == NPBNN_OUT_SOFTMAX || a->lik_kind == NPBNN_LIK_CATEGORICAL)) ? 1 : 0;
+    if (getenv("NPBNN_NO_PAD_MASK")) net.pad_masked = 0;       // (A/B timing)
     int in = a->in_dim, off = 0, woff = 0;
     for (int l = 0; l < a->n_layers; ++l) {
         const int out = a->out_dim[l];

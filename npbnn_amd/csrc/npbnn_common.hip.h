@@ -59,10 +59,13 @@ struct NetMeta {
     int act_kind, out_kind, lik_kind, n_out, k_targets;
     int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
     int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)
+    int pad_masked;     // the padding outputs of the last layer (n_out .. 16 * mt - 1) carry a bias of kPadLogit: they drop out of
+                        // the softmax by themselves (exp -> 0, never the maximum) and the epilogue needs no per-output predicate
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
 };
 
+constexpr float kPadLogit = -3.0e38f;     // finite: (pad - max) stays finite, exp of it is exactly 0
 constexpr int kMaxCand = 3;    // candidates evaluated per pass over X by a speculative chain
 
 // One pass of a device-resident chain evaluates, against a single streaming read of X, the proposal of iteration t0 and

@@ -58,7 +58,7 @@ struct HotParams {
     long long n_rows;
     int use_classw, predict_mode, weight_sets;
     int aux_off_w, aux_off_t;
-    int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off;
+    int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off, pad_masked;
 };
 
 template <int KIND, int HT, int D>
@@ -155,24 +155,43 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         float m[D], se[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) { m[j] = -INFINITY; se[j] = 0.f; }
+        if (hp.pad_masked) {      // padding outputs sit at kPadLogit (their bias): no per-output predicate
 #pragma unroll
-        for (int mt = 0; mt < MTI; ++mt)
-            if (mt < MTL)
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (16 * mt + 4 * kq + i < C)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < D; ++j) m[j] = fmaxf(m[j], h[j][mt][i]);
 #pragma unroll
-        for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
+            for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
 #pragma unroll
-        for (int mt = 0; mt < MTI; ++mt)
-            if (mt < MTL)
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (16 * mt + 4 * kq + i < C)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < D; ++j) se[j] += __expf(h[j][mt][i] - m[j]);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (16 * mt + 4 * kq + i < C)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) m[j] = fmaxf(m[j], h[j][mt][i]);
+#pragma unroll
+            for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
+#pragma unroll
+            for (int mt = 0; mt < MTI; ++mt)
+                if (mt < MTL)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (16 * mt + 4 * kq + i < C)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) se[j] += __expf(h[j][mt][i] - m[j]);
+        }
 #pragma unroll
         for (int j = 0; j < D; ++j) se[j] = quad_sum(se[j]);
 #pragma unroll
@@ -361,6 +380,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out); hp.MTL = uni(net.L[hp.n_layers - 1].mt); hp.lik_kind = uni(net.lik_kind);
     hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind); hp.out_kind = uni(net.out_kind);
     hp.final_act = uni(net.final_act);
+    hp.pad_masked = uni(net.pad_masked);
     hp.classw_off = uni(net.classw_off);
     const int k_targets = hp.k_targets;
     const int aux_sz = uni(p.lay.aux_sz), aux_mask = uni(p.lay.aux_slots) - 1;

@@ -92,8 +92,9 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
         const int nb = 16 * L.mt;
         if (piece < nb) {
             const int o = piece;
-            double b = 0.0;
+            double b = (net.pad_masked && l == net.n_layers - 1) ? (double)kPadLogit : 0.0;
             if (o < L.out_dim) {
+                b = 0.0;
                 const int ld = L.in_dim + L.has_bias;
                 const double* row = w + L.w_off + (long long)o * ld;
                 if (L.has_bias) b = row[0];

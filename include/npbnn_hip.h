@@ -201,6 +201,13 @@ typedef struct {
                                                   (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
                                                   pass L-1 rejects; a pass overtaken by an accept is dropped).  Same chain either way. */
     int32_t reserved_;
+    /* regression with an estimated error parameter (BNN_env.py:435-442: every proposal multiplies sigma by pre-drawn factors,
+     * multiplier_proposal_vector, BNN_mcmc.py:101-113): sigma_mult[t*n_targets + q] is the factor of target column q at iteration
+     * t (1.0 = untouched), hastings[t] the proposal's Hastings term sum(log m).  The proposal of iteration t is evaluated with
+     * sigma' = current sigma * factors (cur_sigma on entry; result->sigma on return), which becomes the chain's sigma when the
+     * proposal is accepted.  NULL: sigma as sigma_given / sigma[] say. */
+    const double* sigma_mult;
+    const double* hastings;
 } npbnn_chain_cfg;
 #define NPBNN_SCHED_AUTO 0
 #define NPBNN_SCHED_SERIAL 1

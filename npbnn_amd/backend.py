@@ -202,7 +202,7 @@ class HipContext:
         return ms.value, used.value
 
     def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
-                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0):
+                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None):
         cfg.prior_kind = int(prior_kind)
         for i, s in enumerate(prior_scale):
             cfg.prior_scale[i] = float(s)
@@ -221,6 +221,12 @@ class HipContext:
         cfg.n_candidates = int(n_candidates)
         cfg.schedule = int(schedule)
         cfg.force_f32 = 0
+        if sigma_mult is not None:         # (the arrays are kept on the struct object: it only holds pointers)
+            cfg._keep = (capi.as_f64(sigma_mult), capi.as_f64(hastings))
+            cfg.sigma_mult, cfg.hastings = capi.dptr(cfg._keep[0]), capi.dptr(cfg._keep[1])
+        else:
+            cfg._keep = None
+            cfg.sigma_mult = cfg.hastings = None
 
     def _result_dict(self, res):
         k = self.arch.n_targets
@@ -230,7 +236,8 @@ class HipContext:
                     iterations_done=res.iterations_done, overflow=res.overflow)
 
     def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
-                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0):
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0, sigma_mult=None,
+                  hastings=None):
         """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
         (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
         w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
@@ -240,7 +247,7 @@ class HipContext:
             cfg = self._chain_cfg = capi.ChainCfg()
             self._chain_res = capi.ChainResult()
         self._fill_chain_cfg(cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
-                             cur_sigma, sigma, n_candidates, schedule)
+                             cur_sigma, sigma, n_candidates, schedule, sigma_mult, hastings)
         m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
         if idx.dtype != np.int32 or not idx.flags.c_contiguous:
             idx = np.ascontiguousarray(idx, dtype=np.int32)

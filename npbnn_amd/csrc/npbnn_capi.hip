@@ -129,6 +129,9 @@ struct npbnn_ctx {
     double* d_llp = nullptr;
     double* d_lpp = nullptr;
     size_t iter_cap = 0;        // K capacity
+    double* d_smult = nullptr;  // [K][k_targets] sigma multipliers, [K] Hastings terms (regression with an estimated error parameter)
+    double* d_hast = nullptr;
+    size_t smult_cap = 0;       // K capacity of the two
     // exchange run (npbnn_chains_run_exchange): [ExchangeParams | swap_j | swap_k | swap_logu || state | records | cold weights]
     char* d_xbuf = nullptr;
     char* h_xbuf = nullptr;
@@ -628,7 +631,7 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale};
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -1226,6 +1229,27 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.cnt = ctx->d_cnt;
     c.log_u = ctx->d_logu;
     c.hastings = nullptr;
+    c.sigma_mult = nullptr;
+    if (cfg->sigma_mult || cfg->hastings) {
+        if (!cfg->sigma_mult || !cfg->hastings || lik != NPBNN_LIK_GAUSS)
+            return fail(ctx, NPBNN_E_ARG, "chain_run: sigma_mult and hastings go together, with the Gaussian likelihood");
+        const int kt = ctx->net.k_targets;
+        if ((size_t)K > ctx->smult_cap) {
+            if (ctx->d_smult) (void)hipFree(ctx->d_smult);
+            if (ctx->d_hast) (void)hipFree(ctx->d_hast);
+            ctx->d_smult = nullptr; ctx->d_hast = nullptr; ctx->smult_cap = 0;
+            const size_t cap = (size_t)K > kChainMinCapacity ? (size_t)K : kChainMinCapacity;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_smult, cap * NPBNN_MAX_TARGETS * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_hast, cap * sizeof(double)));
+            ctx->smult_cap = cap;
+        }
+        for (size_t i = 0; i < (size_t)K * kt; ++i)
+            if (!(cfg->sigma_mult[i] > 0.0)) return fail(ctx, NPBNN_E_ARG, "chain_run: sigma_mult[%zu] is not positive", i);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_smult, cfg->sigma_mult, (size_t)K * kt * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_hast, cfg->hastings, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
+        c.sigma_mult = ctx->d_smult;
+        c.hastings = ctx->d_hast;
+    }
     c.out_acc = ctx->d_acc;
     c.out_ll = ctx->d_llp;
     c.out_lp = ctx->d_lpp;

@@ -104,6 +104,8 @@ struct ChainParams {
     const int* cnt;            // [K]
     const double* log_u;       // [K]
     const double* hastings;    // [K] or nullptr
+    const double* sigma_mult;  // [K][k_targets] or nullptr: Gaussian likelihood with an estimated error parameter - the proposal of
+                               // iteration t is evaluated with sigma' = ChainDev.sigma * sigma_mult[t] (BNN_env.py:435-442)
     unsigned char* out_acc;    // [K]
     double* out_ll;            // [K] proposed logLik
     double* out_lp;            // [K] proposed logPrior
@@ -322,7 +324,13 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             for (int j = 0; j < kMaxCand; ++j) {
                 if (j < n_pend && accepted < 0) {
                     const int t = t0 + j;
-                    loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &sh.o);
+                    if (c.sigma_mult) {
+                        double sg[NPBNN_MAX_TARGETS];
+                        for (int q = 0; q < c.net.k_targets; ++q) sg[q] = st->sigma[q] * c.sigma_mult[(size_t)t * c.net.k_targets + q];
+                        loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, 1, sg, &sh.o);
+                    } else {
+                        loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &sh.o);
+                    }
                     const double lp = d_cand[j];
                     const double post_new = sh.o.loglik + lp, post_old = d_ll + d_lp;
                     const int a = ((post_new - post_old) * d_temp + d_h[j] >= d_logu[j]) ? 1 : 0;

@@ -178,10 +178,29 @@ int npbnn_host_selftest_doubles(uint64_t seed, int n, double* out) {
  *   layer_mask[t]     bit i set when layer i was updated
  * Returns 0, or -1 on bad arguments / capacity.
  */
+int npbnn_host_predraw2(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
+                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
+                        double* sigma_chosen, double* sigma_u);
+
 int npbnn_host_predraw(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights) {
+    return npbnn_host_predraw2(bitgen, randomize_seed, first_iteration, mcmc_id, K, spec, max_per_iter, idx, delta, cnt, log_u,
+                               layer_mask, n_weights, 0, 0.0, NULL, NULL);
+}
+
+/* The same with the draws of the regression error-parameter proposal (multiplier_proposal_vector, np_bnn/BNN_mcmc.py:101-113,
+ * called before the weight proposals of an iteration, BNN_env.py:435-442) when sigma_k > 0:
+ *   sigma_chosen[t*sigma_k + q]   rs.binomial(1, sigma_f, sigma_k)   (1.0 / 0.0)
+ *   sigma_u[t*sigma_k + q]        rs.random(sigma_k)
+ * The caller forms the multipliers and the Hastings term with numpy, as the reference does. */
+int npbnn_host_predraw2(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
+                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
+                        double* sigma_chosen, double* sigma_u) {
     if (!spec || K < 0 || spec->n_layers < 1 || spec->n_layers > NPBNN_HOST_MAX_LAYERS) return -1;
+    if (sigma_k < 0 || (sigma_k > 0 && (!sigma_chosen || !sigma_u))) return -1;
     if (!randomize_seed && !bitgen) return -1;
     int total = 0, max_n = 0;
     for (int i = 0; i < spec->n_layers; ++i) {
@@ -206,6 +225,12 @@ int npbnn_host_predraw(void* bitgen, int randomize_seed, int64_t first_iteration
             pcg64_seed(&local, (uint64_t)(first_iteration + t + mcmc_id));
             pcg64_bitgen(&local, &local_bg);
             bg = &local_bg;
+        }
+        if (sigma_k > 0) {
+            binomial_t binom;
+            memset(&binom, 0, sizeof binom);
+            for (int q = 0; q < sigma_k; ++q) sigma_chosen[(size_t)t * sigma_k + q] = (double)random_binomial(bg, sigma_f, 1, &binom);
+            random_standard_uniform_fill(bg, sigma_k, sigma_u + (size_t)t * sigma_k);
         }
         double rr[NPBNN_HOST_MAX_LAYERS];
         random_standard_uniform_fill(bg, spec->n_layers, rr);

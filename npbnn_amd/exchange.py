@@ -92,11 +92,11 @@ def run_exchange(chains, chain_ids, n_chains, n_seg, seg_len, swaps, first_swap,
     for (bnn, mcmc), cid in zip(chains, chain_ids):
         mcmc._bnn = bnn
         it = mcmc._current_iteration
-        idx, delta, cnt, log_u = mcmc._claim_draw(bnn, it, K).result()
+        idx, delta, cnt, log_u, smult, hast = mcmc._claim_draw(bnn, it, K).result()
         # the draws of the probable next call, made while the GPU runs this one
         mcmc._speculation = mcmc._submit_draw(bnn, it + K, K, rewindable=True)
         job = mcmc._backend.exchange_job(bnn._w_layers, chain_id=cid, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=bnn._mask,
-                                         cfg=mcmc._device_chain_cfg(bnn))
+                                         cfg=mcmc._device_chain_cfg(bnn, smult, hast))
         jobs.append(job)
         backend_cls = type(mcmc._backend)
     slack = launch_slack if launch_slack is not None else getattr(backend_cls, "exchange_slack", 1.5)

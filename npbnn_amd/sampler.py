@@ -401,9 +401,20 @@ class MCMC():
         if any(np.ndim(s) != 0 for s in bnn_obj._prior_scale) or bnn_obj._hyper_p:
             return False
         if bnn_obj._estimation_mode == "regression" and not bnn_obj._empirical_error:
-            if self._current_iteration + k - 1 > self._estimate_error:
-                return False        # the sigma multiplier proposal of BNN_env.py:439 is state dependent
+            # sigma fixed at 1 up to iteration _estimate_error, multiplier proposals after it (BNN_env.py:435-444): a batch
+            # must lie on one side (run_steps cuts there); the proposals need the Gaussian likelihood on the device
+            first, last = self._current_iteration, self._current_iteration + k - 1
+            if first <= self._estimate_error < last:
+                return False
+            if first > self._estimate_error and likelihood_kind(self._likelihood_f) != capi.LIK_GAUSS:
+                return False
         return True
+
+    def _sigma_proposal_columns(self, bnn_obj, first_it):
+        """Columns of the error parameter that every iteration from ``first_it`` on proposes to change (0: none)."""
+        if (bnn_obj._estimation_mode == "regression" and not bnn_obj._empirical_error and first_it > self._estimate_error):
+            return int(np.size(bnn_obj._error_prm))
+        return 0
 
     def _next_adapt_boundary(self):
         if self._adapt_f <= 0 and self._adapt_fM >= 1:
@@ -428,6 +439,8 @@ class MCMC():
             boundary = self._next_adapt_boundary()
             if boundary is not None:
                 seg = min(seg, boundary - self._current_iteration)
+            if bnn_obj._estimation_mode == "regression" and self._current_iteration <= self._estimate_error:
+                seg = min(seg, int(np.floor(self._estimate_error)) + 1 - self._current_iteration)    # sigma proposals start after it
             if not self._device_loop_ok(bnn_obj, seg):
                 self.mh_step(bnn_obj)
                 remaining -= 1
@@ -437,20 +450,21 @@ class MCMC():
             it = self._current_iteration
             pending = self._claim_draw(bnn_obj, it, sizes[0])
             for n, k in enumerate(sizes):
-                idx, delta, cnt, log_u = pending.result()
+                idx, delta, cnt, log_u, smult, hast = pending.result()
                 it += k
                 if n + 1 < len(sizes):
                     pending = self._submit_draw(bnn_obj, it, sizes[n + 1])[1]
                 elif remaining == seg:            # last sub-batch of this call: draw ahead for the next call
                     self._speculation = self._submit_draw(bnn_obj, it, min(self.SUB_BATCH, int(n_steps)), rewindable=True)
-                self._run_device_batch(bnn_obj, idx, delta, cnt, log_u)
+                self._run_device_batch(bnn_obj, idx, delta, cnt, log_u, smult, hast)
             remaining -= seg
 
     _speculation = None      # (key, future, generator state before the draw, step sizes used) of draws made ahead of the next call
 
     def _draw_key(self, bnn_obj, first_it, k):
         return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id), tuple(int(n) for n in self._update_n),
-                tuple(float(f) for f in self._freq_layer_update), tuple(w.shape for w in bnn_obj._w_layers))
+                tuple(float(f) for f in self._freq_layer_update), tuple(w.shape for w in bnn_obj._w_layers),
+                self._sigma_proposal_columns(bnn_obj, first_it))
 
     def _submit_draw(self, bnn_obj, first_it, k, rewindable=False):
         """Start the pre-draw of iterations first_it .. first_it+k-1 on the helper thread."""
@@ -462,11 +476,19 @@ class MCMC():
         freq = [float(f) for f in self._freq_layer_update]
         empty = getattr(self._backend, "host_empty", None)
         saved = rs.bit_generator.state if (rewindable and not randomize) else None
+        sigma_k = self._sigma_proposal_columns(bnn_obj, first_it)
 
         def draw():
-            idx, delta, cnt, u, _ = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty)
+            out = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty, sigma_k=sigma_k)
+            idx, delta, cnt, u = out[:4]
             np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
-            return idx, delta, cnt, u
+            smult = hast = None
+            if sigma_k:                           # multiplier_proposal_vector(q, d=1.1, f=0.5) per iteration (BNN_mcmc.py:101-113)
+                chosen, u_sigma = out[5], out[6]
+                smult = np.exp(2 * np.log(1.1) * (u_sigma - .5))
+                smult[chosen == 0] = 1.
+                hast = np.array([np.sum(np.log(row)) for row in smult])
+            return idx, delta, cnt, u, smult, hast
 
         return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved, update_ws
 
@@ -521,23 +543,23 @@ class MCMC():
             k = min(2 * k, self.SUB_BATCH_MAX)
         return sizes
 
-    def _device_chain_cfg(self, bnn_obj):
+    def _device_chain_cfg(self, bnn_obj, sigma_mult=None, hastings=None):
         """The chain's settings and current state as the keyword arguments of the device chain entry points."""
         regression = bnn_obj._estimation_mode == "regression"
         sigma = None
         cur_sigma = None
         if regression:
             cur_sigma = np.ones(bnn_obj._size_output) * bnn_obj._error_prm
-            if not bnn_obj._empirical_error:
+            if not bnn_obj._empirical_error and sigma_mult is None:
                 sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
-        return dict(prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
+        return dict(sigma_mult=sigma_mult, hastings=hastings, prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
                     w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
                     cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma,
                     n_candidates=self.n_candidates, schedule=self.device_schedule)
 
-    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u):
+    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u, sigma_mult=None, hastings=None):
         w_new, acc, _, _, res = self._backend.run_chain(bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u,
-                                                        mask=bnn_obj._mask, **self._device_chain_cfg(bnn_obj))
+                                                        mask=bnn_obj._mask, **self._device_chain_cfg(bnn_obj, sigma_mult, hastings))
         self._absorb_device_batch(bnn_obj, len(cnt), w_new, acc, res)
 
     def _absorb_device_batch(self, bnn_obj, k, w_new, acc, res):

@@ -61,7 +61,8 @@ class OracleChainBackend(OracleBackend):
     bookkeeping) can be tested on CPU against the plain mh_step loop."""
 
     def run_chain(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
-                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0):
+                  cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0, sigma_mult=None,
+                  hastings=None):
         shapes = [w.shape for w in weights]
         cur = np.concatenate([np.asarray(w, dtype=float).ravel() for w in weights])
         m = None if mask is None else np.concatenate([np.asarray(x, dtype=float).ravel() for x in mask])
@@ -91,10 +92,15 @@ class OracleChainBackend(OracleBackend):
             if m is not None:
                 prop = prop * m
             wl = unpack(prop)
-            r = self.evaluate(wl, lik_temp=lik_temp, sigma=sigma)
+            h = 0.0
+            if sigma_mult is not None:             # sigma' = current sigma * pre-drawn factors (BNN_env.py:435-442)
+                r = self.evaluate(wl, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
+                h = hastings[t]
+            else:
+                r = self.evaluate(wl, lik_temp=lik_temp, sigma=sigma)
             p = orc.log_prior(wl, prior_kind, prior_scale)
             llp[t], lpp[t] = r["loglik"], p
-            if ((r["loglik"] + p) - (ll + lp)) * temperature >= log_u[t]:
+            if ((r["loglik"] + p) - (ll + lp)) * temperature + h >= log_u[t]:
                 cur, ll, lp, acc[t] = prop, r["loglik"], p, 1
                 n_acc += 1
                 if r["sigma"] is not None:
@@ -142,6 +148,8 @@ class OracleExchangeBackend(OracleChainBackend):
                         kw = dict(c["cfg"])
                         kw.update(temperature=c["temp"], cur_loglik=c["ll"], cur_logprior=c["lp"], cur_sigma=c["sigma"])
                         kw.pop("n_candidates", None), kw.pop("schedule", None)
+                        if kw.get("sigma_mult") is not None:
+                            kw["sigma_mult"], kw["hastings"] = kw["sigma_mult"][a:b], kw["hastings"][a:b]
                         cur, acc, llp, lpp, res = job["be"].run_chain(c["w"], idx=job["idx"][a:b], delta=job["delta"][a:b],
                                                                       cnt=job["cnt"][a:b], log_u=job["log_u"][a:b],
                                                                       mask=job["mask"], **kw)

@@ -20,14 +20,14 @@ def quiet(f, *a, **k):
         return f(*a, **k)
 
 
-def build_chains(cfg, temps, **mcmc_extra):
+def build_chains(cfg, temps, empirical=None, **mcmc_extra):
     """len(temps) chains on one data set as MC3 builds them: own weights seed, mcmc_id = chain id, reseeding every iteration."""
     if cfg["kind"] == "classification":
         dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
         extra = {}
     else:
         dat = cases.regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
-        extra = dict(estimation_mode="regression", empirical_error=cfg.get("empirical_error", False))
+        extra = dict(estimation_mode="regression", empirical_error=cfg.get("empirical_error", False) if empirical is None else empirical)
     chains = []
     for i, t in enumerate(temps):
         np.random.seed(1234 + i)
@@ -352,3 +352,29 @@ def test_exchange_run_at_config2_size():
     assert [s for s, _ in log_a] == [s for s, _ in log_b]
     assert sum(m._last_accepted_mem.count(1) for _, m in a) > 5
     assert_same(state_of(a), state_of(b))
+
+
+def test_exchange_run_with_an_estimated_error_parameter():
+    """Chains whose proposals also move the regression error parameter (sigma multipliers and Hastings terms pre-drawn per
+    iteration): exchange run against the per-interval path, error parameters included."""
+    cfg = cases.TRACES["cfg4s"]
+    temps = [0.85, 1.0]
+    n_seg, seg_len = 5, 30
+    kw = dict(empirical=False, estimate_error=True, n_iteration=100)        # proposals from iteration 11 on
+    a = build_chains(cfg, temps, **kw)
+    b = build_chains(cfg, temps, **kw)
+    for bnn, m in a + b:
+        m.device_schedule = 2
+        m.run_steps(bnn, 20)
+    slow_path(a, n_seg, seg_len, 17)
+    swaps = ex.SwapProposals(2, np.random.RandomState(17))
+    seen = []
+    real = ex.run_exchange
+    ex.run_exchange = lambda *x, **k: (lambda o: (seen.append(o[0]), o)[1])(real(*x, **k))
+    try:
+        assert ex.advance_intervals(b, [0, 1], 2, n_seg, seg_len, swaps, 0, batch=n_seg) == n_seg
+    finally:
+        ex.run_exchange = real
+    assert sum(seen) >= n_seg - 2, "most intervals should have run in device batches (%s)" % seen
+    assert_same(state_of(a), state_of(b), exact=seen == [n_seg])       # (an interval finished in two pieces re-sums the prior)
+    assert not np.all(state_of(b)[0]["err"] == 1.0)

@@ -231,3 +231,31 @@ def test_device_chain_with_many_tiles_per_wave(kind):
     np.testing.assert_allclose(mb._logLik, ma._logLik, rtol=1e-11)
     for wa, wb in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_run_steps_with_an_estimated_error_parameter(randomize_seed):
+    """Regression with the error parameter estimated (MCMC's default): after the first 10 % of the iterations every
+    proposal multiplies sigma by pre-drawn factors (BNN_env.py:435-444).  The device-resident chain carries sigma as chain
+    state (sigma' = sigma * factors per candidate, Hastings term in the accept test) and must reproduce the host loop."""
+    cfg = dict(cases.TRACES["cfg4s"], empirical_error=False)
+    extra = dict(randomize_seed=randomize_seed, mcmc_id=2, estimate_error=True, n_iteration=1000, adapt_f=0, adapt_fM=1)
+    bnn_a, mcmc_a = build(cfg, **extra)
+    bnn_b, mcmc_b = build(cfg, **extra)
+    assert mcmc_a._estimate_error == 100
+    n = 300
+    for _ in range(n):
+        mcmc_a.mh_step(bnn_a)
+    seen = []
+    real = mcmc_b._backend.run_chain
+    mcmc_b._backend.run_chain = lambda w, **kw: (seen.append((len(kw["cnt"]), kw.get("sigma_mult") is not None)), real(w, **kw))[1]
+    mcmc_b.run_steps(bnn_b, 90)
+    mcmc_b.run_steps(bnn_b, n - 90)
+    assert sum(k for k, prop in seen) == n and sum(k for k, prop in seen if prop) == n - 101
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem and sum(mcmc_a._last_accepted_mem) > 5
+    np.testing.assert_array_equal(np.asarray(bnn_a._error_prm, dtype=float), np.asarray(bnn_b._error_prm, dtype=float))
+    assert not np.all(np.asarray(bnn_b._error_prm, dtype=float) == 1.0)
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)

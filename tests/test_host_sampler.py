@@ -199,3 +199,39 @@ def test_no_adaptation_boundaries_when_adaptation_cannot_fire():
     assert mcmc._next_adapt_boundary() is None
     mcmc._adapt_f = 0.1
     assert mcmc._next_adapt_boundary() == 10
+
+
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_run_steps_with_an_estimated_error_parameter_equals_mh_step_loop(randomize_seed):
+    """Regression with the error parameter estimated (MCMC's default, estimate_error=True): sigma is fixed at 1 for the
+    first 10 % of the iterations, then every proposal multiplies it by pre-drawn factors (multiplier_proposal_vector,
+    BNN_env.py:435-444).  run_steps cuts its batches at that point, pre-draws the factors in the reference's stream order
+    and must reproduce the mh_step loop - error parameter included."""
+    from oracle_backend import OracleChainBackend
+    cfg = dict(cases.TRACES["cfg4s"], empirical_error=False)
+    cfg["mcmc"] = dict(cfg["mcmc"], randomize_seed=randomize_seed, mcmc_id=2, estimate_error=True, n_iteration=1200, adapt_f=0,
+                       adapt_fM=1)
+    bnn_a, mcmc_a, _ = build(cfg)
+    bnn_b, mcmc_b, _ = build(cfg)
+    assert mcmc_a._estimate_error == 120
+    mcmc_b._backend = OracleChainBackend(bnn_b, 1)
+    mcmc_b.SUB_BATCH = 41
+    n = 330
+    sig_a = []
+    for _ in range(n):
+        mcmc_a.mh_step(bnn_a)
+        sig_a.append(np.array(bnn_a._error_prm, dtype=float).copy())
+    calls = []
+    real = mcmc_b._backend.run_chain
+    mcmc_b._backend.run_chain = lambda w, **kw: (calls.append((len(kw["cnt"]), kw.get("sigma_mult") is not None)), real(w, **kw))[1]
+    mcmc_b.run_steps(bnn_b, 100)
+    mcmc_b.run_steps(bnn_b, n - 100)
+    assert mcmc_a._current_iteration == mcmc_b._current_iteration == n
+    # batches: 121 iterations with sigma fixed (iteration counter 0..120), the rest with proposals, never mixed
+    assert sum(k for k, prop in calls if not prop) == 121 and sum(k for k, prop in calls if prop) == n - 121
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem and sum(mcmc_a._last_accepted_mem) > 10
+    np.testing.assert_array_equal(np.asarray(bnn_a._error_prm, dtype=float), np.asarray(bnn_b._error_prm, dtype=float))
+    assert len(np.unique(np.round(np.array(sig_a)[125:, 0], 12))) > 5, "the error parameter should be moving"
+    assert (mcmc_a._logLik, mcmc_a._logPrior) == (mcmc_b._logLik, mcmc_b._logPrior)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)

@@ -235,3 +235,40 @@ def test_run_steps_with_an_estimated_error_parameter_equals_mh_step_loop(randomi
     assert (mcmc_a._logLik, mcmc_a._logPrior) == (mcmc_b._logLik, mcmc_b._logPrior)
     for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+def test_run_steps_between_gibbs_steps_of_a_per_layer_hyper_prior():
+    """hyper_p = 1: one prior scale per layer, re-drawn by gibbs_step (BNN_env.py:196-205, 534-538); between two Gibbs steps
+    the scales are constants and the iterations run as a device batch."""
+    from oracle_backend import OracleChainBackend
+    cfg = dict(cases.TRACES["cfg1"])
+    cfg["mcmc"] = dict(cfg["mcmc"], adapt_f=0, adapt_fM=1)
+    out = []
+    for mode in ("loop", "batch"):
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        np.random.seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
+                           prior_f=1, p_scale=1, seed=1234, init_std=0.1, hyper_p=1)
+        be = OracleChainBackend(bnn, 0)
+        mcmc = bn.MCMC(bnn, backend=be, **cfg["mcmc"])
+        used = []
+        real = be.run_chain
+        be.run_chain = lambda w, **kw: (used.append(len(kw["cnt"])), real(w, **kw))[1]
+        np.random.seed(99)                         # gibbs_step draws from the global stream
+        for _ in range(3):
+            if mode == "loop":
+                for _ in range(40):
+                    mcmc.mh_step(bnn)
+            else:
+                mcmc.run_steps(bnn, 40)
+            mcmc.gibbs_step(bnn)
+        assert (sum(used) == 120) == (mode == "batch")
+        out.append((bnn, mcmc))
+    (ba, ma), (bb, mb) = out
+    assert ma._current_iteration == mb._current_iteration == 123
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    np.testing.assert_array_equal(np.array(ba._prior_scale, dtype=float), np.array(bb._prior_scale, dtype=float))
+    np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)

@@ -271,8 +271,14 @@ def main():
             "loglik": float(mcmc._logLik),
         }
         passes, voids = max(1, mcmc._device_passes), mcmc._device_void_passes
-        line["config"]["schedule"] = ("overlapped: the launch that evaluates pass L also decides pass L-1 (one workgroup); a pass "
-                                      "overtaken by an accept is dropped and re-evaluated")
+        used = getattr(mcmc, "_device_schedule_used", 0)
+        line["config"]["schedule"] = {
+            1: "serial: evaluate a pass, decide it, evaluate the next",
+            2: "overlapped: the launch that evaluates pass L also decides pass L-1 (one workgroup); a pass overtaken by an accept is "
+               "dropped and re-evaluated",
+            3: "overlapped, launches alternating between two streams: the workgroups of launch L+1 take the compute units over as "
+               "launch L drains, device-side flags (agent-scope release / acquire) order what a kernel boundary used to; a pass "
+               "overtaken by an accept is dropped and re-evaluated"}.get(used, "auto")
         line["config"]["void_pass_fraction"] = voids / (passes + voids)
         line["roofline"]["useful_iterations_per_launch"] = mcmc._device_iterations / (passes + voids)
         if cand != 3:

@@ -42,7 +42,8 @@ enum {
     NPBNN_E_HIP = -3,       /* a HIP runtime call failed              */
     NPBNN_E_NOMEM = -4,
     NPBNN_E_COMM = -5,      /* RCCL failure                           */
-    NPBNN_E_RANGE = -6      /* value outside the fp16-split range      */
+    NPBNN_E_RANGE = -6,     /* value outside the fp16-split range      */
+    NPBNN_E_SYNC = -7       /* a device-side wait of NPBNN_SCHED_OVERLAP2 timed out */
 };
 
 /* activation kinds — ActFun.activate selection, np_bnn/BNN_lib.py:50-87 */
@@ -212,6 +213,10 @@ typedef struct {
 #define NPBNN_SCHED_AUTO 0
 #define NPBNN_SCHED_SERIAL 1
 #define NPBNN_SCHED_OVERLAP 2
+#define NPBNN_SCHED_OVERLAP2 3         /* the overlapped schedule with the launches alternating between two streams: the next launch's
+                                         workgroups take the compute units over as the previous launch drains; what a kernel boundary
+                                         guaranteed is guaranteed by device-side flags (release / acquire at agent scope).  A wait that
+                                         times out ends the batch with NPBNN_E_SYNC (state untouched: retry with NPBNN_SCHED_OVERLAP) */
 
 typedef struct {
     double loglik, logprior;                   /* state after the K iterations */

@@ -23,6 +23,7 @@ OPT_L0_PRECISION = 1
 L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
 INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU = 1, 2, 3
 E_RANGE = -6
+E_SYNC = -7
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnpbnn_hip.so")
@@ -80,7 +81,7 @@ class ChainJob(C.Structure):
 
 REC_DOUBLES = 4      # record of a chain at an exchange: logPost, temperature, finished-the-segment flag, iterations done
 
-SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP = 0, 1, 2
+SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP, SCHED_OVERLAP2 = 0, 1, 2, 3
 
 
 _P = C.c_void_p

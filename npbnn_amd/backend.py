@@ -259,14 +259,22 @@ class HipContext:
         llp, lpp = np.empty(K), np.empty(K)
         res = self._chain_res
         i32p = C.POINTER(C.c_int32)
-        for attempt in (0, 1):
+        attempt, sync_retried = 0, False
+        while True:
             cfg.force_f32 = attempt
             rc = self._lib.npbnn_chain_run(
                 self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(i32p),
                 capi.dptr(delta), cnt.ctypes.data_as(i32p), capi.dptr(log_u),
                 acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res))
             if rc == capi.E_RANGE and attempt == 0:
+                attempt = 1
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)
+            if rc == capi.E_SYNC and not sync_retried:
+                sync_retried = True
+                if cfg.schedule == capi.SCHED_OVERLAP2:
+                    cfg.schedule = capi.SCHED_OVERLAP
+                continue        # a device-side wait of the two-stream schedule timed out: same batch again on one stream (the
+                # library keeps that schedule off for this context from now on; the state was left untouched)
             self._chk(rc)
             break
         return w, acc, llp, lpp, self._result_dict(res)

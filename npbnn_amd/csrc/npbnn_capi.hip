@@ -139,6 +139,9 @@ struct npbnn_ctx {
     hipEvent_t ev_x = nullptr;
     // feature matrices shared between the chains of one run (npbnn_share_data): a borrower points at its owner, an owner
     // counts its borrowers and outlives them (a destroyed owner lingers until the last borrower lets go)
+    // flag-ordered overlapped chain schedule: the launches alternate between these two streams
+    hipStream_t stream_e[2] = {nullptr, nullptr};
+    bool sync_failed = false;      // a wait timed out once: the schedule stays off for this context
     npbnn_ctx* data_owner = nullptr;
     int n_borrowers = 0;
     bool zombie = false;
@@ -620,6 +623,9 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->d_xbuf) (void)hipFree(c->d_xbuf);
     if (c->h_xbuf) (void)hipHostFree(c->h_xbuf);
     if (c->ev_x) (void)hipEventDestroy(c->ev_x);
+    for (int i = 0; i < 2; ++i) {
+        if (c->stream_e[i]) (void)hipStreamDestroy(c->stream_e[i]);
+    }
     if (c->h_params) (void)hipHostFree(c->h_params);
     if (c->d_w2scale) (void)hipFree(c->d_w2scale);
     if (c->d_image) (void)hipFree(c->d_image);
@@ -1084,6 +1090,8 @@ struct ChainBatch {
     ResLayout RL;
     int D = 1, schedule = NPBNN_SCHED_SERIAL, K = 0, M = 0;
     bool overlap = false;
+    bool sync = false;                         // overlapped schedule with the launches alternating between two streams (device flags)
+    bool forked = false;                       // sync: the two streams have been made to wait for ctx->stream
     size_t wb = 0;
     int launch = 0;                            // launches enqueued so far (overlapped schedule: the pass parity follows it)
     unsigned long long* d_stamps = nullptr;    // diagnostics
@@ -1121,11 +1129,21 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     const int D = lp.n_cand;
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
     int schedule = cfg->schedule;
-    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP) {
+    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
         schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
+        // almost everything rejected (and known to be: not the first batch of a chain): let consecutive launches overlap.  Every
+        // accept costs that schedule cache invalidations on top of the void pass: measured +10 % at 1 % acceptance, -8 % at 5 %
+        if (ctx->accept_rate >= 0 && ctx->accept_rate < 0.02 && seg_len <= 0 && !ctx->sync_failed && !getenv("NPBNN_NO_OVERLAP2"))
+            schedule = NPBNN_SCHED_OVERLAP2;
     }
-    const bool overlap = schedule == NPBNN_SCHED_OVERLAP;
+    if (schedule == NPBNN_SCHED_OVERLAP2 && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
+    const bool overlap = schedule == NPBNN_SCHED_OVERLAP || schedule == NPBNN_SCHED_OVERLAP2;
+    const bool sync = schedule == NPBNN_SCHED_OVERLAP2 && seg_len <= 0;      // (an exchange run keeps its launches on one stream)
+    if (schedule == NPBNN_SCHED_OVERLAP2 && !sync) schedule = NPBNN_SCHED_OVERLAP;
+    if (!ctx->stream_e[0]) {      // (with the chain's first batch, whatever its schedule: creating a stream takes milliseconds)
+        for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_e[i], hipStreamNonBlocking));
+    }
     if (overlap) {                      // one workgroup of the launch runs the step: the others share the tiles
         int g = lp.grid;
         if (g > ctx->n_cu - 1) g = ctx->n_cu - 1;
@@ -1150,7 +1168,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         ctx->res_cap = L.total; ctx->res_k = kc; ctx->res_nw = (size_t)ctx->n_weights;
         char* b = ctx->d_res;
         ctx->d_chain = reinterpret_cast<ChainDev*>(b);
-        ctx->d_chain_ovf = reinterpret_cast<int*>(b + 256);
+        ctx->d_chain_ovf = reinterpret_cast<int*>(b + 448);
         ctx->d_wcur = reinterpret_cast<double*>(b + L.w);
         ctx->d_cnt = reinterpret_cast<int*>(b + L.cnt);
         ctx->d_logu = reinterpret_cast<double*>(b + L.logu);
@@ -1159,7 +1177,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         ctx->d_lpp = reinterpret_cast<double*>(b + L.lpp);
     }
     const ResLayout RL = res_layout(ctx->res_k, wb);
-    static_assert(sizeof(ChainDev) <= 256, "ChainDev must fit its slot of the result block");
+    static_assert(sizeof(ChainDev) <= 448, "ChainDev must fit its slot of the result block");
     if (mask_packed && !ctx->d_mask) HIP_TRY(ctx, hipMalloc(&ctx->d_mask, wb));
     if ((size_t)M > ctx->pv_cap) {
         if (ctx->d_pv) (void)hipFree(ctx->d_pv);
@@ -1204,6 +1222,10 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     init.temperature = cfg->temperature;
     init.seg_idx = 0;
     init.poisoned = 0;
+    init.prepared = -1;             // (the first step kernel raises it to 0)
+    init.aborted = 0;
+    init.commit_launch = -10;
+    for (int i = 0; i < 4; ++i) init.done[i] = 0;
     {   // initial chain state, overflow flag, weights and the per-iteration scalars travel together (head of the block)
         memset(ctx->h_res, 0, 512);
         memcpy(ctx->h_res, &init, sizeof(ChainDev));
@@ -1291,6 +1313,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     p.pscale = f16 ? ctx->d_pscale : nullptr;
     p.M = M;
     p.chain = overlap ? ctx->d_cparams : nullptr;
+    p.sync_mode = sync ? 1 : 0;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     rc = push_chain_params(ctx, c);
@@ -1299,6 +1322,8 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     // passes is only known on the device
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
     B->RL = RL;
+    B->sync = sync;
+    B->forked = false;
     B->D = D;
     B->schedule = schedule;
     B->overlap = overlap;
@@ -1332,10 +1357,33 @@ int passes_for_segment(const npbnn_ctx* ctx, const ChainBatch& B, int seg_len, d
     return (int)std::ceil(slack * est) + 2 + (B.overlap ? 1 : 0);
 }
 
-void chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
+// flag-ordered overlapped schedule: the launches go to two streams in turn.  Work enqueued on ctx->stream (uploads, the first
+// step) must be complete before their first launch (fork), theirs before ctx->stream copies results back (join): both by
+// host synchronisation - once a stream has waited for another stream's event, this runtime runs every later launch of the two
+// one after the other, which is the very thing the schedule is there to avoid (measured: no overlap at all with event waits)
+int chain_fork(npbnn_ctx* ctx, ChainBatch& B) {
+    if (!B.sync || B.forked) return NPBNN_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    B.forked = true;
+    return NPBNN_OK;
+}
+int chain_join(npbnn_ctx* ctx, ChainBatch& B) {
+    if (!B.sync || !B.forked) return NPBNN_OK;
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_e[i]));
+    B.forked = false;
+    return NPBNN_OK;
+}
+
+int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     hipStream_t st = ctx->stream;
     const LaunchPlan& lp = B.lp;
-    if (B.overlap) {
+    if (B.sync) {
+        int rc = chain_fork(ctx, B);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i, ++B.launch)
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, ctx->stream_e[B.launch & 1], (const EvalParams*)ctx->d_eparams,
+                               B.launch);
+    } else if (B.overlap) {
         for (int i = 0; i < n; ++i, ++B.launch)
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch);
     } else {
@@ -1344,6 +1392,7 @@ void chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
             hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
         }
     }
+    return NPBNN_OK;
 }
 
 // after the result block has come back (h_res): hand the first k_take iterations' outcome to the caller
@@ -1368,7 +1417,7 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
                        acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
     }
-    const int overflow = (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 256)) ? 1 : 0;
+    const int overflow = (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 448)) ? 1 : 0;
     if (overflow && !exchange_run)           // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
         return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
     {
@@ -1410,10 +1459,16 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
     while (t_done < K) {       // launch the least number of passes that can finish, look at the counter, repeat if short
         ++n_rounds;
-        chain_enqueue(ctx, B, passes_for(ctx, B, K - t_done, 1.0));
+        rc = chain_enqueue(ctx, B, passes_for(ctx, B, K - t_done, 1.0));
+        if (!rc) rc = chain_join(ctx, B);
+        if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, B.RL.total, hipMemcpyDeviceToHost, st));   // state + results, one copy
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (now->aborted) {         // a device-side wait of the flag-ordered schedule timed out: nothing was decided after it
+            ctx->sync_failed = true;
+            return fail(ctx, NPBNN_E_SYNC, "chain_run: the flag-ordered overlapped schedule timed out at t=%d; retry on one stream", now->t);
+        }
         if (now->t < t_done || (now->t == t_done && !B.overlap))
             return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain made no progress (t=%d)", now->t);
         if (now->t == t_done && n_rounds > 64) return fail(ctx, NPBNN_E_STATE, "chain_run: the device chain is stuck at t=%d", now->t);
@@ -1528,7 +1583,13 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
     for (int s = 0; s < n_seg; ++s) {
         for (int q = 0; q < n_jobs; ++q) {
             npbnn_ctx* ctx = jobs[q].ctx;
-            chain_enqueue(ctx, B[q], passes_for_segment(ctx, B[q], seg_len, launch_slack));
+            int rc = chain_enqueue(ctx, B[q], passes_for_segment(ctx, B[q], seg_len, launch_slack));
+            if (!rc) rc = chain_join(ctx, B[q]);
+            if (rc) {
+                if (ctx != ctx0) ctx0->err = ctx->err;
+                (void)hipDeviceSynchronize();
+                return rc;
+            }
             hipLaunchKernelGGL(exchange_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const ChainParams*)ctx->d_cparams,
                                (const ExchangeParams*)ctx->d_xbuf, s);
             if (q > 0) {

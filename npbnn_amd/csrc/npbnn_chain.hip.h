@@ -92,6 +92,14 @@ struct ChainDev {          // device-resident chain state
     double logPrior_rep;    // log prior as MCMC._logPrior holds it: updated on accept only (logPrior is re-summed at segment starts)
     int seg_idx;            // exchange run: segments exchanged so far
     int poisoned;           // exchange run: some chain had not reached the end of a segment when it was exchanged; nothing runs after
+    // flag-ordered overlapped schedule (EvalParams.sync_mode): launches alternate between two streams and overlap; what a kernel
+    // boundary used to guarantee is guaranteed by these, written with release / read with acquire at agent scope
+    int prepared;           // passes 0 .. prepared are ready to be evaluated (descriptor, patch values, committed image); the step of
+                            // launch L-1 sets it to L when it is done - the step of launch L waits for that too (steps run in order)
+    int aborted;            // a wait timed out: every kernel of the batch leaves at once, the host retries on one stream
+    int commit_launch;      // launch whose step last committed an accept to the global weight image (the evaluating workgroups of the
+                            // NEXT launch must drop their caches before they copy the image; otherwise cached lines are still good)
+    int done[4];            // done[L & 3]: evaluating workgroups of the launches L, L-4, L-8 ... that have finished (cumulative)
 };
 
 struct ChainParams {
@@ -373,6 +381,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         NPBNN_STAMP(3);
         const int a = sh.s_accepted;
         if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
+            if (tid == 0) st->commit_launch = pl.launch;
             const size_t row = (size_t)(t0 + a) * c.M;
             const int n = c.cnt[t0 + a];
             const double* pv = c.pv + (size_t)pl.dec * pv_stride;
@@ -507,6 +516,63 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
 #undef NPBNN_STAMP
 }
 
+// ---- flag-ordered overlapped schedule: waits and signals (all at agent scope; tools/microbench_handoff.hip measures the
+// hand-over: a flag is seen 0.6 us after it was raised, data written before a release store is fresh after an acquire) ----
+constexpr unsigned long long kSyncTimeoutTicks = 5000000ull;      // 50 ms of the 100 MHz wall clock: far beyond any legitimate wait
+
+__device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int target) {       // one thread
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (wall_clock64() - t0 > kSyncTimeoutTicks) {
+            __hip_atomic_store(&st->aborted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return !__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// evaluating workgroup of launch L: its pass must have been prepared (by the step of launch L-1)
+__device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* lds_flag) {
+    // No acquire fence here: at agent scope it drops this XCD's whole L2, and workgroups of overlapping launches arrive at
+    // scattered times - every arrival would throw out the weight-image lines its 31 neighbours are about to copy.  What the
+    // step hands over is read with agent-scope loads instead (descriptor, patch values); the image only changes when a step
+    // commits an accept, and only then do the workgroups of the next launch drop their caches (2 = do so).
+    if (threadIdx.x == 0) {
+        int ok = sync_wait_ge(st, &st->prepared, launch) ? 1 : 0;
+        if (ok && __hip_atomic_load(&st->commit_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= launch - 1) ok = 2;
+        *lds_flag = ok;
+    }
+    __syncthreads();
+    const int ok = *lds_flag;
+    if (ok == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok != 0;
+}
+__device__ __forceinline__ void sync_eval_leave(ChainDev* st, int launch) {      // one thread, after a barrier behind the workgroup's last
+    __builtin_amdgcn_s_waitcnt(0);                                               // (agent-scope, write-through) store of its sums
+    __hip_atomic_fetch_add(&st->done[launch & 3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// step of launch L: the step of launch L-1 must be through, and every workgroup that evaluated pass L-1 must have left
+__device__ __forceinline__ bool sync_step_enter(const ChainParams& c, int launch, int n_eval_wgs, int* lds_flag) {
+    ChainDev* st = c.st;
+    if (threadIdx.x == 0) {
+        bool ok = sync_wait_ge(st, &st->prepared, launch);
+        if (ok && launch >= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int slot = (launch - 1) & 3;
+            ok = sync_wait_ge(st, &st->done[slot], ((launch - 1) / 4 + 1) * n_eval_wgs);
+        }
+        *lds_flag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *lds_flag != 0;
+}
+__device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch) {     // whole workgroup
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&st->prepared, next_launch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifdef NPBNN_KERNELS_MAIN
 // serial schedule: the step as a kernel of its own, between two evaluation kernels (and as the first launch of every batch)
 __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int first_launch) {
@@ -521,6 +587,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     pl.out = 0;
     pl.launch = 0;
     chain_step(c, pl, sh);
+    if (first_launch) sync_step_leave(c.st, 0);       // (flag-ordered schedule: pass 0 is ready)
 }
 #endif  // NPBNN_KERNELS_MAIN
 
@@ -608,6 +675,7 @@ __global__ void __launch_bounds__(1024) exchange_apply_kernel(const ChainParams*
     pl.out = overlapped ? (next_launch & 1) : 0;
     pl.launch = next_launch;
     chain_step(c, pl, sh);
+    sync_step_leave(c.st, next_launch);             // (flag-ordered schedule: the pass of launch next_launch is ready)
 }
 #endif  // NPBNN_KERNELS_MAIN
 

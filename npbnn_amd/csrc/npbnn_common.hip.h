@@ -110,6 +110,8 @@ struct EvalParams {
     WaveLayout lay;           // per-wave LDS layout of this launch (host-computed)
     int pad_lay_;
     const ChainParams* chain;  // overlapped chain schedule: the last workgroup of the launch runs chain_step (else nullptr)
+    int sync_mode;             // overlapped schedule with the launches alternating between two streams: no kernel boundary orders a
+    int pad_sync_;             // launch after the one before it - device-side flags do (ChainDev.prepared / .done, npbnn_chain.hip.h)
     unsigned long long* stamps;   // diagnostics only (NPBNN_EVAL_STAMPS=1 in npbnn_time_pass): [workgroup][8] wall-clock stamps, else nullptr
     NetMeta net;
 };

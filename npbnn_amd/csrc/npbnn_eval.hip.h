@@ -358,10 +358,19 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
     const ChainParams* const chain = uni(p.chain);
     const int G = (int)gridDim.x - (chain ? 1 : 0);     // workgroups that evaluate
-    if (chain && bid == G) {
-        chain_step(*chain, overlapped_plan(launch), *reinterpret_cast<StepShared*>(smem));
+    const bool sync = chain && uni(p.sync_mode);        // launches overlap: device flags order them (npbnn_chain.hip.h)
+    // the step workgroup is the last one of the launch - or, when launches overlap, the FIRST: it must be resident before any
+    // workgroup of the NEXT launch (which waits for it) can take a compute unit
+    const int ebid = sync ? bid - 1 : bid;               // index among the evaluating workgroups
+    if (chain && bid == (sync ? 0 : G)) {
+        StepShared& sh = *reinterpret_cast<StepShared*>(smem);
+        int* const lds_flag = reinterpret_cast<int*>(smem + sizeof(StepShared));
+        if (sync && !sync_step_enter(*chain, launch, G, lds_flag)) return;
+        chain_step(*chain, overlapped_plan(launch), sh);
+        if (sync) sync_step_leave(chain->st, launch + 1);
         return;
     }
+    if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem))) return;
     const int par = chain ? (launch & 1) : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -403,10 +412,21 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
     const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
     if (pass) {
-        if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
-        t0 = uni(pass->t0);
+        if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
+            const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand
+                if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
+                return;
+            }
+            t0 = __builtin_amdgcn_readlane(w, 0);
 #pragma unroll
-        for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
+            for (int j = 0; j < D; ++j) cnt[j] = __builtin_amdgcn_readlane(w, 2 + (j < kMaxCand ? j : 0));
+        } else {
+            if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
+            t0 = uni(pass->t0);
+#pragma unroll
+            for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
+        }
     }
 
     // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
@@ -434,7 +454,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     //      waves of that SIMD in turn (wave w sits on SIMD w % 4): the SIMDs of a CU - whose issue ports are what the tile
     //      loop saturates - get the same number of tiles to within one even when the waves do not divide by four ----
     const int KT0 = uni(net.L[0].kt);
-    const int first_tile = bid + G * wave;
+    const int first_tile = ebid + G * wave;
     const int simd_waves = (wpb - (wave & 3) + 3) >> 2;      // waves of this workgroup on this wave's SIMD
     const int stride = G * 4 * simd_waves;
     const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
@@ -485,7 +505,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         if (pass && tid < cnt[j]) {
             const size_t k = (size_t)(t0 + j) * M + tid;
             ppos[j] = g_pos[k];
-            pval[j] = pv[(size_t)j * M + tid];
+            pval[j] = sync ? __hip_atomic_load(pv + (size_t)j * M + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv[(size_t)j * M + tid];
             if (g_pscale) psc[j] = g_pscale[k];
         }
     }
@@ -512,7 +532,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
             if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
             for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
                 const size_t k = (size_t)(t0 + j) * M + e;
-                patch(j, g_pos[k], pv[(size_t)j * M + e], g_pscale ? g_pscale[k] : 1.0f);
+                patch(j, g_pos[k], sync ? __hip_atomic_load(pv + (size_t)j * M + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv[(size_t)j * M + e],
+                      g_pscale ? g_pscale[k] : 1.0f);
             }
         }
         __syncthreads();
@@ -788,10 +809,16 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
             const int j = item / nvals, v = item % nvals;
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
-            g_partials[(((size_t)par * kMaxCand + j) * kPartialStride + v) * G + bid] = s;
+            double* const dst = g_partials + (((size_t)par * kMaxCand + j) * kPartialStride + v) * G + ebid;
+            if (sync) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (write-through: no fence at the end)
+            else *dst = s;
         }
     }
     NPBNN_ESTAMP(6);
+    if (sync) {                                  // this workgroup's sums are out: tell the step of the next launch
+        __syncthreads();
+        if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
+    }
 #undef NPBNN_ESTAMP
 }
 

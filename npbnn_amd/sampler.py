@@ -528,7 +528,9 @@ class MCMC():
         self._gen = value
 
     n_candidates = 0         # proposals evaluated per pass over the data by the device chain: 0 = as many as fit (<= 3)
-    device_schedule = 0      # 0 auto, 1 serial (evaluate, decide, evaluate ...), 2 overlapped (decide pass L-1 while pass L is evaluated)
+    device_schedule = 0      # 0 auto, 1 serial (evaluate, decide, evaluate ...), 2 overlapped (decide pass L-1 while pass L is evaluated),
+    #                          3 overlapped with the launches alternating between two streams (they overlap; device flags order them)
+    _device_schedule_used = 0
     _device_passes = 0
     _device_void_passes = 0
     _device_iterations = 0
@@ -568,6 +570,7 @@ class MCMC():
         if k <= 0:
             return
         acc = acc[:k]
+        self._device_schedule_used = res.get("schedule", 0)
         self._device_passes += res.get("n_passes", k)
         self._device_void_passes += res.get("n_void_passes", 0)
         self._device_iterations += k

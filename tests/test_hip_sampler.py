@@ -174,10 +174,11 @@ def test_rccl_communicator_single_rank():
 def test_speculative_passes_do_not_change_the_chain(name):
     """1, 2 or 3 candidates per pass over the data, decided between the passes (serial schedule) or inside the launch
     that already evaluates the next pass (overlapped schedule): identical accept/reject sequence, weights and
-    log-likelihood - the speculation only changes how many passes the same chain needs."""
+    log-likelihood - the speculation only changes how many passes the same chain needs.  Schedule 3 is the overlapped
+    schedule with the launches alternating between two streams, ordered by device-side flags instead of kernel boundaries."""
     cfg = cases.TRACES[name]
     out = []
-    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0)):
+    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0), (3, 3), (1, 3), (2, 3)):
         bnn, mcmc = build(cfg)
         mcmc.n_candidates = d
         mcmc.device_schedule = sched
@@ -192,7 +193,7 @@ def test_speculative_passes_do_not_change_the_chain(name):
         assert m._logLik == m1._logLik and m._logPrior == m1._logPrior
         for wa, wb in zip(b1._w_layers, b._w_layers):
             np.testing.assert_array_equal(wa, wb)
-        if sched == 2:
+        if sched in (2, 3):
             assert m._device_void_passes > 0                # accepts happened, so passes were dropped ...
         if d == 1:
             assert m._device_passes == 300                  # ... and never counted
@@ -259,3 +260,35 @@ def test_run_steps_with_an_estimated_error_parameter(randomize_seed):
     np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
     for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("update_f,min_accepts", [(0.002, 300), (0.05, 20)])
+def test_two_stream_schedule_at_config2_size(update_f, min_accepts):
+    """The flag-ordered two-stream schedule on BASELINE config-2 shapes with learnable labels: many accepts (every one of
+    them patches the global weight image while the next launch's workgroups are already arriving) and few - against the
+    one-stream overlapped schedule, bit for bit."""
+    rs = np.random.default_rng(0)
+    n, f, c = 100_000, 256, 10
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    proj = rs.standard_normal((f, c)) / np.sqrt(f)
+    y = np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)
+    dat = dict(data=x, labels=y, test_data=np.zeros((0, f)), test_labels=np.zeros(0))
+    out = []
+    for sched in (2, 3):
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, dat, n_nodes=[32, 8], actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+        m = bn.MCMC(bnn, update_f=[update_f] * 3)
+        m.device_schedule = sched
+        m.run_steps(bnn, 600)
+        m.run_steps(bnn, 1400)
+        assert m._device_schedule_used == sched
+        out.append((bnn, m))
+    (ba, ma), (bb, mb) = out
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    assert (ma._logLik, ma._logPrior) == (mb._logLik, mb._logPrior)
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    fresh = mb._backend.evaluate(bb._w_layers, None)["loglik"]
+    np.testing.assert_allclose(mb._logLik, fresh, rtol=1e-12)       # the chain's image was the true one all along
+    assert mb._device_passes < 2000 and ma._device_passes == mb._device_passes
+    assert sum(1 for _ in range(1)) and (2000 - 0) > 0 and mb._device_void_passes >= min_accepts // 4

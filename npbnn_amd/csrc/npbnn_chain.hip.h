@@ -518,7 +518,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
 
 // ---- flag-ordered overlapped schedule: waits and signals (all at agent scope; tools/microbench_handoff.hip measures the
 // hand-over: a flag is seen 0.6 us after it was raised, data written before a release store is fresh after an acquire) ----
-constexpr unsigned long long kSyncTimeoutTicks = 5000000ull;      // 50 ms of the 100 MHz wall clock: far beyond any legitimate wait
+constexpr unsigned long long kSyncTimeoutTicks = 1000000ull;      // 10 ms of the 100 MHz wall clock: a legitimate wait is < 0.1 ms
 
 __device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int target) {       // one thread
     const unsigned long long t0 = wall_clock64();

@@ -533,14 +533,22 @@ __device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int 
     return !__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // evaluating workgroup of launch L: its pass must have been prepared (by the step of launch L-1)
-__device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* lds_flag) {
+__device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* lds_flag, int early_prepared, int early_commit) {
     // No acquire fence here: at agent scope it drops this XCD's whole L2, and workgroups of overlapping launches arrive at
     // scattered times - every arrival would throw out the weight-image lines its 31 neighbours are about to copy.  What the
     // step hands over is read with agent-scope loads instead (descriptor, patch values); the image only changes when a step
     // commits an accept, and only then do the workgroups of the next launch drop their caches (2 = do so).
+    // `early_prepared` / `early_commit`: the two words as thread 0 read them at the very top of the kernel (the round trip hides
+    // under the parameter loads); nearly always they already say "ready"
     if (threadIdx.x == 0) {
-        int ok = sync_wait_ge(st, &st->prepared, launch) ? 1 : 0;
-        if (ok && __hip_atomic_load(&st->commit_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= launch - 1) ok = 2;
+        int ok = 1, commit = early_commit;
+        if (early_prepared < launch || early_prepared == 0x7fffffff) {
+            ok = sync_wait_ge(st, &st->prepared, launch) ? 1 : 0;
+            commit = __hip_atomic_load(&st->commit_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            ok = 0;
+        }
+        if (ok && commit >= launch - 1) ok = 2;
         *lds_flag = ok;
     }
     __syncthreads();

@@ -1102,7 +1102,9 @@ double wall_us() { return std::chrono::duration<double, std::micro>(std::chrono:
 
 // seg_len > 0: the chain stops deciding at iteration seg_len until an exchange kernel moves the limit (exchange run)
 int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in, const double* mask_packed, int32_t K, int32_t M,
-                  const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, int seg_len, ChainBatch* B) {
+                  const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, int seg_len, ChainBatch* B,
+                  bool alone_on_device = true) {
+    // alone_on_device: no other chain's launches share the GPU with this batch (the two-stream schedule counts on that)
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
     if (!cfg || !W_in || K < 1 || M < 1 || !idx || !delta || !cnt || !log_u) return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
     if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run: call npbnn_set_arch first");
@@ -1134,12 +1136,12 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
         // almost everything rejected (and known to be: not the first batch of a chain): let consecutive launches overlap.  Every
         // accept costs that schedule cache invalidations on top of the void pass: measured +10 % at 1 % acceptance, -8 % at 5 %
-        if (ctx->accept_rate >= 0 && ctx->accept_rate < 0.02 && seg_len <= 0 && !ctx->sync_failed && !getenv("NPBNN_NO_OVERLAP2"))
+        if (ctx->accept_rate >= 0 && ctx->accept_rate < 0.02 && alone_on_device && !ctx->sync_failed && !getenv("NPBNN_NO_OVERLAP2"))
             schedule = NPBNN_SCHED_OVERLAP2;
     }
     if (schedule == NPBNN_SCHED_OVERLAP2 && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
     const bool overlap = schedule == NPBNN_SCHED_OVERLAP || schedule == NPBNN_SCHED_OVERLAP2;
-    const bool sync = schedule == NPBNN_SCHED_OVERLAP2 && seg_len <= 0;      // (an exchange run keeps its launches on one stream)
+    const bool sync = schedule == NPBNN_SCHED_OVERLAP2 && alone_on_device;   // (several chains on one GPU: one stream each)
     if (schedule == NPBNN_SCHED_OVERLAP2 && !sync) schedule = NPBNN_SCHED_OVERLAP;
     if (!ctx->stream_e[0]) {      // (with the chain's first batch, whatever its schedule: creating a stream takes milliseconds)
         for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_e[i], hipStreamNonBlocking));
@@ -1546,7 +1548,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
     for (int q = 0; q < n_jobs; ++q) {
         const npbnn_chain_job& J = jobs[q];
         npbnn_ctx* ctx = J.ctx;
-        int rc = chain_prepare(ctx, J.cfg, J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, seg_len, &B[q]);
+        int rc = chain_prepare(ctx, J.cfg, J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, seg_len, &B[q], false);      // (measured: with a host synchronisation per swap interval the two-stream schedule gains nothing here)
         if (rc) {
             if (ctx != ctx0) ctx0->err = ctx->err;
             for (int p2 = 0; p2 <= q; ++p2) (void)hipStreamSynchronize(jobs[p2].ctx->stream);
@@ -1625,6 +1627,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
     int seg_done = -1;
     for (int q = 0; q < n_jobs; ++q) {
         const ChainDev* fin = reinterpret_cast<const ChainDev*>(jobs[q].ctx->h_res);
+        if (fin->aborted) jobs[q].ctx->sync_failed = true;     // (the chain stopped at a valid state; the records show it as short)
         if (seg_done < 0) seg_done = fin->seg_idx;
         if (fin->seg_idx != seg_done) return fail(ctx0, NPBNN_E_STATE, "chains_run_exchange: chains disagree on the exchanges done (%d, %d)", seg_done, fin->seg_idx);
         if (fin->t < seg_done * seg_len || fin->t > K) return fail(ctx0, NPBNN_E_STATE, "chains_run_exchange: chain %d is at iteration %d after %d exchanges", q, fin->t, seg_done);

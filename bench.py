@@ -206,6 +206,7 @@ def main():
                          if state["device"] else "host: one device batch per interval, all-gather and decision on the host")
 
     advance(args.warmup)
+    accepted_before = mcmc._device_accepted
 
     def sync():
         if dist is not None:
@@ -267,7 +268,8 @@ def main():
                          "physical_GBps": MEASURED_TRAFFIC_BYTES / (ms_kernel * 1e-3) / 1e9,
                          "single_candidate_kernel_ms": ms_single,
                          "single_candidate_frac": bytes_per_proposal / (ms_single * 1e-3) / HBM_PEAK},
-            "accept_rate": float(mcmc._acceptance_rate),
+            "accept_rate": float(mcmc._device_accepted - accepted_before) / max(1, args.steps),      # rank 0, timed region
+            "accept_rate_last_100": float(mcmc._acceptance_rate),
             "loglik": float(mcmc._logLik),
         }
         passes, voids = max(1, mcmc._device_passes), mcmc._device_void_passes

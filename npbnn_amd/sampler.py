@@ -531,6 +531,7 @@ class MCMC():
     device_schedule = 0      # 0 auto, 1 serial (evaluate, decide, evaluate ...), 2 overlapped (decide pass L-1 while pass L is evaluated),
     #                          3 overlapped with the launches alternating between two streams (they overlap; device flags order them)
     _device_schedule_used = 0
+    _device_accepted = 0
     _device_passes = 0
     _device_void_passes = 0
     _device_iterations = 0
@@ -571,6 +572,7 @@ class MCMC():
             return
         acc = acc[:k]
         self._device_schedule_used = res.get("schedule", 0)
+        self._device_accepted += int(res.get("n_accepted", 0))
         self._device_passes += res.get("n_passes", k)
         self._device_void_passes += res.get("n_void_passes", 0)
         self._device_iterations += k

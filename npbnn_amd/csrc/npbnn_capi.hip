@@ -1294,6 +1294,11 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.D = D;
     c.n_blocks = lp.n_waves;
     c.stop_on_overflow = seg_len > 0 ? 1 : 0;
+    c.sync_test_skip = -1;
+    if (const char* ts = getenv("NPBNN_SYNC_TEST_SKIP")) {      // tests only: provoke the time-out of the two-stream schedule, once
+        static bool used = false;
+        if (!used && sync) { c.sync_test_skip = atoi(ts); used = true; }
+    }
     c.prior_kind = cfg->prior_kind;
     for (int l = 0; l < kMaxLayers; ++l) {
         c.prior_scale[l] = cfg->prior_scale[l];

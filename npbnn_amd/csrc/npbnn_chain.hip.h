@@ -126,6 +126,8 @@ struct ChainParams {
     int* overflow;             // set when a scaled weight leaves the fp16 range
     unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1), else nullptr
     int K, M, D, n_blocks;
+    int sync_test_skip;        // tests only: the step of this launch never reports back (-1: none) - exercises the time-out path of
+                               // the two-stream schedule
     int stop_on_overflow;      // exchange run: a proposal outside the fp16 range stops the chain before it (else: flag only, the
                                // caller discards the batch)
     int prior_kind;
@@ -563,6 +565,7 @@ __device__ __forceinline__ void sync_eval_leave(ChainDev* st, int launch) {     
 // step of launch L: the step of launch L-1 must be through, and every workgroup that evaluated pass L-1 must have left
 __device__ __forceinline__ bool sync_step_enter(const ChainParams& c, int launch, int n_eval_wgs, int* lds_flag) {
     ChainDev* st = c.st;
+    if (c.sync_test_skip == launch) return false;
     if (threadIdx.x == 0) {
         bool ok = sync_wait_ge(st, &st->prepared, launch);
         if (ok && launch >= 1) {

@@ -292,3 +292,24 @@ def test_two_stream_schedule_at_config2_size(update_f, min_accepts):
     np.testing.assert_allclose(mb._logLik, fresh, rtol=1e-12)       # the chain's image was the true one all along
     assert mb._device_passes < 2000 and ma._device_passes == mb._device_passes
     assert sum(1 for _ in range(1)) and (2000 - 0) > 0 and mb._device_void_passes >= min_accepts // 4
+
+
+def test_two_stream_schedule_times_out_cleanly(monkeypatch):
+    """A step workgroup that never reports back (provoked through a test hook): every wait of the two-stream schedule is
+    bounded, the batch ends with NPBNN_E_SYNC and its state untouched, the same batch runs on one stream, the context keeps
+    that schedule off from then on - and the chain is the one it would have been."""
+    cfg = cases.TRACES["cfg1"]
+    bnn_a, mcmc_a = build(cfg, adapt_f=0, adapt_fM=1)
+    bnn_b, mcmc_b = build(cfg, adapt_f=0, adapt_fM=1)
+    mcmc_a.device_schedule = 2
+    mcmc_a.run_steps(bnn_a, 400)
+    monkeypatch.setenv("NPBNN_SYNC_TEST_SKIP", "7")
+    mcmc_b.device_schedule = 3
+    mcmc_b.run_steps(bnn_b, 200)
+    assert mcmc_b._device_schedule_used == 2          # the batch was repeated on one stream
+    mcmc_b.run_steps(bnn_b, 200)
+    assert mcmc_b._device_schedule_used == 2          # and the two-stream schedule stays off for this context
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+    assert (mcmc_a._logLik, mcmc_a._logPrior) == (mcmc_b._logLik, mcmc_b._logPrior)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)

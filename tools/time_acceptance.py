@@ -18,7 +18,8 @@ x = rs.standard_normal((n, f)).astype(np.float32)
 proj = rs.standard_normal((f, c)) / np.sqrt(f)
 y = np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)          # learnable labels
 schedules = [int(v) for v in sys.argv[1:]] or [0]          # 0 auto, 1 serial, 2 overlapped
-for uf, sched in [(u, sc) for u in (0.05, 0.01, 0.002, 0.0005) for sc in schedules]:
+ufs = [float(v) for v in os.environ.get("NPBNN_SWEEP_UPDATE_F", "0.05,0.01,0.002,0.0005").split(",")]
+for uf, sched in [(u, sc) for u in ufs for sc in schedules]:
     np.random.seed(1234)
     with contextlib.redirect_stdout(io.StringIO()):
         bnn = bn.npBNN(dict(data=x, labels=y, test_data=np.zeros((0, f)), test_labels=np.zeros(0)), n_nodes=[32, 8],

@@ -200,7 +200,9 @@ typedef struct {
                                                   as fit (<= 3), 1 = strictly one evaluation per iteration */
     int32_t schedule;                          /* NPBNN_SCHED_AUTO / _SERIAL (evaluate a pass, decide it, evaluate the next) / _OVERLAP
                                                   (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
-                                                  pass L-1 rejects; a pass overtaken by an accept is dropped).  Same chain either way. */
+                                                  pass L-1 rejects; a pass overtaken by an accept is dropped) / _OVERLAP2 (below).
+                                                  The same chain whichever runs.  _AUTO: _OVERLAP2 while fewer than 2 % of the
+                                                  iterations of the previous batch were accepted, _OVERLAP up to ~16 %, else _SERIAL. */
     int32_t reserved_;
     /* regression with an estimated error parameter (BNN_env.py:435-442: every proposal multiplies sigma by pre-drawn factors,
      * multiplier_proposal_vector, BNN_mcmc.py:101-113): sigma_mult[t*n_targets + q] is the factor of target column q at iteration
@@ -225,7 +227,7 @@ typedef struct {
     int32_t n_passes;                          /* passes over X used for the K iterations */
     int32_t n_candidates;                      /* candidates per pass actually used */
     int32_t n_void_passes;                     /* overlapped schedule: passes dropped because the pass before them accepted */
-    int32_t schedule;                          /* schedule actually used (NPBNN_SCHED_SERIAL / NPBNN_SCHED_OVERLAP) */
+    int32_t schedule;                          /* schedule actually used (NPBNN_SCHED_SERIAL / _OVERLAP / _OVERLAP2) */
     double temperature;                        /* MCMC._temperature after the iterations (changes in an exchange run only) */
     int32_t iterations_done;                   /* K for npbnn_chain_run; an exchange run may stop a chain earlier (see below) */
     int32_t overflow;                          /* exchange run: 1 = the chain stopped before a proposal that leaves the fp16 range of the

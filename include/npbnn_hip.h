@@ -201,8 +201,9 @@ typedef struct {
     int32_t schedule;                          /* NPBNN_SCHED_AUTO / _SERIAL (evaluate a pass, decide it, evaluate the next) / _OVERLAP
                                                   (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
                                                   pass L-1 rejects; a pass overtaken by an accept is dropped) / _OVERLAP2 (below).
-                                                  The same chain whichever runs.  _AUTO: _OVERLAP2 while fewer than 2 % of the
-                                                  iterations of the previous batch were accepted, _OVERLAP up to ~16 %, else _SERIAL. */
+                                                  The same chain whichever runs.  _AUTO: overlapped while fewer than ~16 % of the
+                                                  iterations of the previous batch were accepted (_OVERLAP2 when the chain has the GPU
+                                                  to itself, _OVERLAP inside an exchange run), else _SERIAL. */
     int32_t reserved_;
     /* regression with an estimated error parameter (BNN_env.py:435-442: every proposal multiplies sigma by pre-drawn factors,
      * multiplier_proposal_vector, BNN_mcmc.py:101-113): sigma_mult[t*n_targets + q] is the factor of target column q at iteration

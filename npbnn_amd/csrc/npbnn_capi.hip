@@ -1134,9 +1134,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
         schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
-        // almost everything rejected (and known to be: not the first batch of a chain): let consecutive launches overlap.  Every
-        // accept costs that schedule cache invalidations on top of the void pass: measured +10 % at 1 % acceptance, -8 % at 5 %
-        if (ctx->accept_rate >= 0 && ctx->accept_rate < 0.02 && alone_on_device && !ctx->sync_failed && !getenv("NPBNN_NO_OVERLAP2"))
+        // where overlapping pays, the two-stream form of it pays a little more (measured at 0.3 .. 27 % acceptance) - when this chain
+        // has the GPU to itself
+        if (schedule == NPBNN_SCHED_OVERLAP && alone_on_device && !ctx->sync_failed && !getenv("NPBNN_NO_OVERLAP2"))
             schedule = NPBNN_SCHED_OVERLAP2;
     }
     if (schedule == NPBNN_SCHED_OVERLAP2 && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
@@ -1226,7 +1226,6 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     init.poisoned = 0;
     init.prepared = -1;             // (the first step kernel raises it to 0)
     init.aborted = 0;
-    init.commit_launch = -10;
     for (int i = 0; i < 4; ++i) init.done[i] = 0;
     {   // initial chain state, overflow flag, weights and the per-iteration scalars travel together (head of the block)
         memset(ctx->h_res, 0, 512);

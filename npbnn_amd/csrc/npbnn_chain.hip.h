@@ -97,8 +97,6 @@ struct ChainDev {          // device-resident chain state
     int prepared;           // passes 0 .. prepared are ready to be evaluated (descriptor, patch values, committed image); the step of
                             // launch L-1 sets it to L when it is done - the step of launch L waits for that too (steps run in order)
     int aborted;            // a wait timed out: every kernel of the batch leaves at once, the host retries on one stream
-    int commit_launch;      // launch whose step last committed an accept to the global weight image (the evaluating workgroups of the
-                            // NEXT launch must drop their caches before they copy the image; otherwise cached lines are still good)
     int done[4];            // done[L & 3]: evaluating workgroups of the launches L, L-4, L-8 ... that have finished (cumulative)
 };
 
@@ -383,7 +381,6 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         NPBNN_STAMP(3);
         const int a = sh.s_accepted;
         if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
-            if (tid == 0) st->commit_launch = pl.launch;
             const size_t row = (size_t)(t0 + a) * c.M;
             const int n = c.cnt[t0 + a];
             const double* pv = c.pv + (size_t)pl.dec * pv_stride;
@@ -535,28 +532,21 @@ __device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int 
     return !__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // evaluating workgroup of launch L: its pass must have been prepared (by the step of launch L-1)
-__device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* lds_flag, int early_prepared, int early_commit) {
-    // No acquire fence here: at agent scope it drops this XCD's whole L2, and workgroups of overlapping launches arrive at
-    // scattered times - every arrival would throw out the weight-image lines its 31 neighbours are about to copy.  What the
-    // step hands over is read with agent-scope loads instead (descriptor, patch values); the image only changes when a step
-    // commits an accept, and only then do the workgroups of the next launch drop their caches (2 = do so).
-    // `early_prepared` / `early_commit`: the two words as thread 0 read them at the very top of the kernel (the round trip hides
-    // under the parameter loads); nearly always they already say "ready"
+__device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* lds_flag, int early_prepared) {
+    // No acquire fence: at agent scope it drops this XCD's whole L2, and workgroups of overlapping launches arrive at scattered
+    // times - every arrival would throw out lines its 31 neighbours are about to use (measured: passes of 45-55 us).  What the
+    // step hands over is READ coherently instead: descriptor and patch values with agent-scope loads, the weight image with
+    // agent-scope LDS-DMA (dma16_coherent) - the lines come from the memory side whatever the caches hold.
+    // `early_prepared`: the flag as thread 0 read it at the very top of the kernel (the round trip hides under the parameter
+    // loads); nearly always it already says "ready".
     if (threadIdx.x == 0) {
-        int ok = 1, commit = early_commit;
-        if (early_prepared < launch || early_prepared == 0x7fffffff) {
-            ok = sync_wait_ge(st, &st->prepared, launch) ? 1 : 0;
-            commit = __hip_atomic_load(&st->commit_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            ok = 0;
-        }
-        if (ok && commit >= launch - 1) ok = 2;
+        int ok = 1;
+        if (early_prepared < launch || early_prepared == 0x7fffffff) ok = sync_wait_ge(st, &st->prepared, launch) ? 1 : 0;
+        else if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
         *lds_flag = ok;
     }
     __syncthreads();
-    const int ok = *lds_flag;
-    if (ok == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return ok != 0;
+    return *lds_flag != 0;
 }
 __device__ __forceinline__ void sync_eval_leave(ChainDev* st, int launch) {      // one thread, after a barrier behind the workgroup's last
     __builtin_amdgcn_s_waitcnt(0);                                               // (agent-scope, write-through) store of its sums

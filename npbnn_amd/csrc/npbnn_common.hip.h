@@ -271,6 +271,10 @@ typedef __attribute__((address_space(3))) void lvoid;
 __device__ __forceinline__ void dma16(const float* g, char* l) {
     __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, 0);
 }
+// the same with agent-scope coherence (sc1): the lines come from the memory side whatever this XCD's L2 and this CU's L1 hold
+__device__ __forceinline__ void dma16_coherent(const float* g, char* l) {
+    __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 16, 0, 16);
+}
 __device__ __forceinline__ void dma4(const void* g, char* l) {
     __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)l, 4, 0, 0);
 }

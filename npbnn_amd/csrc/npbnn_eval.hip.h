@@ -370,11 +370,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         if (sync) sync_step_leave(chain->st, launch + 1);
         return;
     }
-    int early_prepared = 0x7fffffff, early_commit = 0;
-    if (sync && threadIdx.x == 0) {      // asked for now, looked at where the pass descriptor is needed (below)
+    int early_prepared = 0x7fffffff;
+    if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
         early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        early_commit = __hip_atomic_load(&chain->st->commit_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     const int par = chain ? (launch & 1) : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -415,7 +413,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     for (int j = 0; j < D; ++j) cnt[j] = 0;
     const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
     const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
-    if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem), early_prepared, early_commit)) return;
+    if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem), early_prepared)) return;
     if (pass) {
         if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
             const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,8 +449,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
 #pragma unroll
         for (int j = 0; j < D; ++j)
             for (int i = wave; i < n_pieces; i += wpb)
-                if (i * 256 + lane * 4 < image_floats)      // (an LDS-DMA writes only its active lanes' 16 bytes)
-                    dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                if (i * 256 + lane * 4 < image_floats) {    // (an LDS-DMA writes only its active lanes' 16 bytes)
+                    if (sync) dma16_coherent(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                    else dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                }
     }
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to SIMD m % 4 and, there, to the

@@ -546,7 +546,9 @@ __device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* l
         *lds_flag = ok;
     }
     __syncthreads();
-    return *lds_flag != 0;
+    const int ok = *lds_flag;
+    __syncthreads();            // the word sits where the weight image is about to land: nobody copies before everybody has read it
+    return ok != 0;
 }
 __device__ __forceinline__ void sync_eval_leave(ChainDev* st, int launch) {      // one thread, after a barrier behind the workgroup's last
     __builtin_amdgcn_s_waitcnt(0);                                               // (agent-scope, write-through) store of its sums

@@ -1226,6 +1226,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     init.poisoned = 0;
     init.prepared = -1;             // (the first step kernel raises it to 0)
     init.aborted = 0;
+    init.started = -1;
     for (int i = 0; i < 4; ++i) init.done[i] = 0;
     {   // initial chain state, overflow flag, weights and the per-iteration scalars travel together (head of the block)
         memset(ctx->h_res, 0, 512);
@@ -1386,9 +1387,9 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     if (B.sync) {
         int rc = chain_fork(ctx, B);
         if (rc) return rc;
-        for (int i = 0; i < n; ++i, ++B.launch)
+        for (int i = 0; i < n; ++i, ++B.launch)      // (bit 30: not the last launch of this round - see sync_step_leave)
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, ctx->stream_e[B.launch & 1], (const EvalParams*)ctx->d_eparams,
-                               B.launch);
+                               B.launch | (i + 1 < n ? (1 << 30) : 0));
     } else if (B.overlap) {
         for (int i = 0; i < n; ++i, ++B.launch)
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch);

@@ -97,6 +97,7 @@ struct ChainDev {          // device-resident chain state
     int prepared;           // passes 0 .. prepared are ready to be evaluated (descriptor, patch values, committed image); the step of
                             // launch L-1 sets it to L when it is done - the step of launch L waits for that too (steps run in order)
     int aborted;            // a wait timed out: every kernel of the batch leaves at once, the host retries on one stream
+    int started;            // highest launch whose step workgroup has begun (see sync_step_leave)
     int done[4];            // done[L & 3]: evaluating workgroups of the launches L, L-4, L-8 ... that have finished (cumulative)
 };
 
@@ -559,6 +560,7 @@ __device__ __forceinline__ bool sync_step_enter(const ChainParams& c, int launch
     ChainDev* st = c.st;
     if (c.sync_test_skip == launch) return false;
     if (threadIdx.x == 0) {
+        __hip_atomic_store(&st->started, launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = sync_wait_ge(st, &st->prepared, launch);
         if (ok && launch >= 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -571,9 +573,17 @@ __device__ __forceinline__ bool sync_step_enter(const ChainParams& c, int launch
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return *lds_flag != 0;
 }
-__device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch) {     // whole workgroup
+// `wait_for_next`: launch next_launch has been enqueued and this step belongs to launch next_launch - 1.  The step then stays
+// until the step workgroup of launch next_launch has begun.  Why: launch L+1 starts when launch L-1 (same stream) is complete,
+// its evaluating workgroups wait for step L - so step L must hold a compute unit before they can take them all.  Launch L
+// normally starts first (it follows launch L-2), but short launches (void, empty) can finish out of order; with this wait
+// launch L-1 cannot complete, hence launch L+1 cannot start, before step L is resident.
+__device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch, bool wait_for_next = false) {     // whole workgroup
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&st->prepared, next_launch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&st->prepared, next_launch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (wait_for_next) (void)sync_wait_ge(st, &st->started, next_launch);
+    }
 }
 
 #ifdef NPBNN_KERNELS_MAIN

@@ -343,7 +343,10 @@ __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int 
 #define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int MT0, int MTI, bool F16, int D, int LK>
-__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch) {
+__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg) {
+    // launch index; bit 30: another launch of the batch has been enqueued behind this one (two-stream schedule, sync_step_leave)
+    const int launch = launch_arg & 0x3fffffff;
+    const bool next_enqueued = (launch_arg >> 30) & 1;
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         int* const lds_flag = reinterpret_cast<int*>(smem + sizeof(StepShared));
         if (sync && !sync_step_enter(*chain, launch, G, lds_flag)) return;
         chain_step(*chain, overlapped_plan(launch), sh);
-        if (sync) sync_step_leave(chain->st, launch + 1);
+        if (sync) sync_step_leave(chain->st, launch + 1, next_enqueued);
         return;
     }
     int early_prepared = 0x7fffffff;

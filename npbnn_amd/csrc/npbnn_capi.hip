@@ -1387,9 +1387,11 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     if (B.sync) {
         int rc = chain_fork(ctx, B);
         if (rc) return rc;
-        for (int i = 0; i < n; ++i, ++B.launch)      // (bit 30: not the last launch of this round - see sync_step_leave)
+        for (int i = 0; i < n; ++i, ++B.launch) {    // (bit 30: not the last launch of this round - see sync_step_leave)
+            if (i == 1) hipLaunchKernelGGL(sync_gate_kernel, dim3(1), dim3(64), 0, ctx->stream_e[B.launch & 1], ctx->d_chain, B.launch - 1);
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, ctx->stream_e[B.launch & 1], (const EvalParams*)ctx->d_eparams,
                                B.launch | (i + 1 < n ? (1 << 30) : 0));
+        }
     } else if (B.overlap) {
         for (int i = 0; i < n; ++i, ++B.launch)
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch);

@@ -587,6 +587,15 @@ __device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch, b
 }
 
 #ifdef NPBNN_KERNELS_MAIN
+// two-stream schedule, first pair of launches of a round (both streams are idle then, so the two launches become eligible
+// together): this one-wave kernel goes in front of the second launch on its stream and lets it through only when the step
+// workgroup of the first has begun - the same guarantee sync_step_leave gives from then on
+__global__ void sync_gate_kernel(ChainDev* st, int first_launch) {
+    if (threadIdx.x == 0) (void)sync_wait_ge(st, &st->started, first_launch);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
+#ifdef NPBNN_KERNELS_MAIN
 // serial schedule: the step as a kernel of its own, between two evaluation kernels (and as the first launch of every batch)
 __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int first_launch) {
     const ChainParams& c = *cp;           // device-resident parameter block; only the per-launch scalar travels as an argument

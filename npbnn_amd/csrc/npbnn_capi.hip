@@ -1227,6 +1227,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     init.prepared = -1;             // (the first step kernel raises it to 0)
     init.aborted = 0;
     init.started = -1;
+    init.exchanged = 0;
     for (int i = 0; i < 4; ++i) init.done[i] = 0;
     {   // initial chain state, overflow flag, weights and the per-iteration scalars travel together (head of the block)
         memset(ctx->h_res, 0, 512);
@@ -1555,7 +1556,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
     for (int q = 0; q < n_jobs; ++q) {
         const npbnn_chain_job& J = jobs[q];
         npbnn_ctx* ctx = J.ctx;
-        int rc = chain_prepare(ctx, J.cfg, J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, seg_len, &B[q], false);      // (measured: with a host synchronisation per swap interval the two-stream schedule gains nothing here)
+        int rc = chain_prepare(ctx, J.cfg, J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, seg_len, &B[q], n_jobs == 1);
         if (rc) {
             if (ctx != ctx0) ctx0->err = ctx->err;
             for (int p2 = 0; p2 <= q; ++p2) (void)hipStreamSynchronize(jobs[p2].ctx->stream);
@@ -1589,17 +1590,22 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         for (int q = 1; q < n_jobs; ++q) HIP_TRY(jobs[q].ctx, hipStreamWaitEvent(jobs[q].ctx->stream, ctx0->ev_x, 0));
     }
     const int rec_per_rank = n_jobs * kRecDoubles;
+    std::vector<hipStream_t> xs(n_jobs);        // stream the exchange kernels of a job run on
     for (int s = 0; s < n_seg; ++s) {
         for (int q = 0; q < n_jobs; ++q) {
             npbnn_ctx* ctx = jobs[q].ctx;
             int rc = chain_enqueue(ctx, B[q], passes_for_segment(ctx, B[q], seg_len, launch_slack));
-            if (!rc) rc = chain_join(ctx, B[q]);
             if (rc) {
                 if (ctx != ctx0) ctx0->err = ctx->err;
                 (void)hipDeviceSynchronize();
                 return rc;
             }
-            hipLaunchKernelGGL(exchange_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const ChainParams*)ctx->d_cparams,
+            // two-stream schedule (one chain on this GPU): the exchange kernels follow the interval's LAST launch on its stream -
+            // by then the other stream's launches are through as well (the last step waited for them) - and the next interval's
+            // first launch, which goes to the other stream, waits behind a gate for exchange_apply_kernel's hand-over.  No host
+            // synchronisation, no stream events.
+            xs[q] = B[q].sync ? ctx->stream_e[(B[q].launch - 1) & 1] : ctx->stream;
+            hipLaunchKernelGGL(exchange_pack_kernel, dim3(1), dim3(64), 0, xs[q], (const ChainParams*)ctx->d_cparams,
                                (const ExchangeParams*)ctx->d_xbuf, s);
             if (q > 0) {
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_x, ctx->stream));
@@ -1607,7 +1613,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
             }
         }
         if (comm) {
-            int rc = npbnn_comm_allgather_inplace_stream_(comm, d_rec + (size_t)s * n_chains * kRecDoubles, rec_per_rank, ctx0->stream);
+            int rc = npbnn_comm_allgather_inplace_stream_(comm, d_rec + (size_t)s * n_chains * kRecDoubles, rec_per_rank, xs[0]);
             if (rc) {
                 ctx0->err = npbnn_last_error(nullptr);
                 for (int q = 0; q < n_jobs; ++q) (void)hipStreamSynchronize(jobs[q].ctx->stream);
@@ -1620,9 +1626,15 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         }
         for (int q = 0; q < n_jobs; ++q) {
             npbnn_ctx* ctx = jobs[q].ctx;
-            hipLaunchKernelGGL(exchange_apply_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const ChainParams*)ctx->d_cparams,
+            hipLaunchKernelGGL(exchange_apply_kernel, dim3(1), dim3(1024), 0, xs[q], (const ChainParams*)ctx->d_cparams,
                                (const ExchangeParams*)ctx->d_xbuf, s, B[q].launch, B[q].overlap ? 1 : 0);
+            if (B[q].sync && s + 1 < n_seg)
+                hipLaunchKernelGGL(sync_gate_exchanged_kernel, dim3(1), dim3(64), 0, ctx->stream_e[B[q].launch & 1], ctx->d_chain, s + 1);
         }
+    }
+    for (int q = 0; q < n_jobs; ++q) {
+        int rc = chain_join(jobs[q].ctx, B[q]);
+        if (rc) return rc;
     }
     for (int q = 0; q < n_jobs; ++q) {
         npbnn_ctx* ctx = jobs[q].ctx;

@@ -98,6 +98,7 @@ struct ChainDev {          // device-resident chain state
                             // launch L-1 sets it to L when it is done - the step of launch L waits for that too (steps run in order)
     int aborted;            // a wait timed out: every kernel of the batch leaves at once, the host retries on one stream
     int started;            // highest launch whose step workgroup has begun (see sync_step_leave)
+    int exchanged;          // exchange run on two streams: exchanges applied so far, raised at the very end of exchange_apply_kernel
     int done[4];            // done[L & 3]: evaluating workgroups of the launches L, L-4, L-8 ... that have finished (cumulative)
 };
 
@@ -520,11 +521,11 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
 // hand-over: a flag is seen 0.6 us after it was raised, data written before a release store is fresh after an acquire) ----
 constexpr unsigned long long kSyncTimeoutTicks = 1000000ull;      // 10 ms of the 100 MHz wall clock: a legitimate wait is < 0.1 ms
 
-__device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int target) {       // one thread
+__device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int target, unsigned long long timeout_ticks = kSyncTimeoutTicks) {       // one thread
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-        if (wall_clock64() - t0 > kSyncTimeoutTicks) {
+        if (wall_clock64() - t0 > timeout_ticks) {
             __hip_atomic_store(&st->aborted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -592,6 +593,12 @@ __device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch, b
 // workgroup of the first has begun - the same guarantee sync_step_leave gives from then on
 __global__ void sync_gate_kernel(ChainDev* st, int first_launch) {
     if (threadIdx.x == 0) (void)sync_wait_ge(st, &st->started, first_launch);
+}
+// exchange run on two streams: the first launch of the next swap interval sits on the stream that did NOT run the exchange
+// kernels; this gate in front of it opens when exchange_apply_kernel has prepared its pass.  The wait spans an all-gather
+// with the other ranks, so its bound is generous (2 s).
+__global__ void sync_gate_exchanged_kernel(ChainDev* st, int n_exchanges) {
+    if (threadIdx.x == 0) (void)sync_wait_ge(st, &st->exchanged, n_exchanges, 200000000ull);
 }
 #endif  // NPBNN_KERNELS_MAIN
 
@@ -698,6 +705,7 @@ __global__ void __launch_bounds__(1024) exchange_apply_kernel(const ChainParams*
     pl.launch = next_launch;
     chain_step(c, pl, sh);
     sync_step_leave(c.st, next_launch);             // (flag-ordered schedule: the pass of launch next_launch is ready)
+    if (threadIdx.x == 0) __hip_atomic_store(&st->exchanged, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif  // NPBNN_KERNELS_MAIN
 

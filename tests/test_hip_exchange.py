@@ -378,3 +378,45 @@ def test_exchange_run_with_an_estimated_error_parameter():
     assert sum(seen) >= n_seg - 2, "most intervals should have run in device batches (%s)" % seen
     assert_same(state_of(a), state_of(b), exact=seen == [n_seg])       # (an interval finished in two pieces re-sums the prior)
     assert not np.all(state_of(b)[0]["err"] == 1.0)
+
+
+class _NoSwaps:
+    """Swap proposals between a chain and itself: the exchange machinery with one chain (one rank of a larger run looks the
+    same to the device code, apart from the all-gather)."""
+
+    def get(self, first, n=1):
+        return np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n)
+
+    def release(self, upto):
+        pass
+
+
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_single_chain_exchange_run_on_two_streams(with_comm):
+    """One chain per GPU (the multi-GPU layout): its exchange run uses the two-stream schedule - exchange kernels on the stream of
+    the interval's last launch, the next interval's first launch gated on the other - with or without an RCCL communicator in
+    the loop.  Against plain run_steps, bit for bit."""
+    cfg = cases.TRACES["cfg2s"]
+    comm = None
+    if with_comm:
+        from npbnn_amd.comm import RcclComm
+        try:
+            comm = RcclComm(rank=0, world_size=1, device=0)
+        except Exception as e:                                  # noqa: BLE001
+            pytest.skip("no RCCL communicator on this box: %s" % e)
+    (bnn_a, ma), = build_chains(cfg, [1.0])
+    (bnn_b, mb), = build_chains(cfg, [1.0])
+    n_seg, seg_len = 8, 40
+    ma.device_schedule = mb.device_schedule = 3
+    ma.run_steps(bnn_a, 64)
+    mb.run_steps(bnn_b, 64)
+    for _ in range(n_seg):
+        ma.run_steps(bnn_a, seg_len)
+    try:
+        done, records, outs = ex.run_exchange([(bnn_b, mb)], [0], 1, n_seg, seg_len, _NoSwaps(), 0, comm=comm)
+    finally:
+        if comm is not None:
+            comm.close()
+    assert done == n_seg and outs[0]["result"]["schedule"] == 3
+    assert np.all(records[:, 0, 2] == 1.0) and records[-1, 0, 3] == n_seg * seg_len
+    assert_same(state_of([(bnn_a, ma)]), state_of([(bnn_b, mb)]))

@@ -44,11 +44,15 @@ from npbnn_amd import exchange as ex  # noqa: E402
 
 bnn, mcmc = build_config2(x, y, [32, 8], randomize_seed=True, mcmc_id=1)
 mcmc.run_steps(bnn, 2000)
+comm = None
+if os.environ.get("NPBNN_SEG_WITH_RCCL"):        # the records of every exchange go through ncclAllGather (one rank) on the launch stream
+    from npbnn_amd.comm import RcclComm
+    comm = RcclComm(rank=0, world_size=1, device=0)
 for batch in (10, 20, 50):
     n_seg = (2 * total // seg) // batch * batch
-    ex.advance_intervals([(bnn, mcmc)], [0], 1, batch, seg, _NoSwaps(), 0, batch=batch)       # warm-up (buffers, draws ahead)
+    ex.advance_intervals([(bnn, mcmc)], [0], 1, batch, seg, _NoSwaps(), 0, batch=batch, comm=comm)       # warm-up (buffers, draws ahead)
     t0 = time.perf_counter()
-    done = ex.advance_intervals([(bnn, mcmc)], [0], 1, n_seg, seg, _NoSwaps(), 0, batch=batch)
+    done = ex.advance_intervals([(bnn, mcmc)], [0], 1, n_seg, seg, _NoSwaps(), 0, batch=batch, comm=comm)
     el = time.perf_counter() - t0
     t1 = time.perf_counter()
     mcmc.run_steps(bnn, n_seg * seg)

@@ -173,36 +173,12 @@ def main():
 
     if world > 1 and state["device"]:
         # self-check of the device exchange path on this machine: the same 4 intervals both ways from the same state
-        import copy
-        keep = ("_logLik", "_logPrior", "_logPost", "_temperature", "_current_iteration", "_last_accepted_mem",
-                "_acceptance_rate", "_last_accepted", "_gen")
+        from bench_support import exchange_self_check
         mcmc.run_steps(bnn, swap_frequency)
-        mcmc._cancel_speculation()
-        saved = {k: copy.deepcopy(getattr(mcmc, k)) for k in keep}
-        saved_w = [w.copy() for w in bnn._w_layers]
-        outcome = []
-        for use_device in (False, True):
-            check_swaps = ex.SwapProposals(world, np.random.RandomState(99))
-            try:
-                ex.advance_intervals(chains, ids, world, 4, swap_frequency, check_swaps, 0, comm=comm, batch=4, device=use_device)
-                outcome.append((np.concatenate([w.ravel() for w in bnn._w_layers]), mcmc._logPost, mcmc._temperature))
-            except Exception as e:           # noqa: BLE001 - any failure of the device path means: use the other one
-                print("[rank %d] exchange self-check (%s path) failed: %s" % (rank, "device" if use_device else "host", e), flush=True)
-                outcome.append(None)
-            mcmc._cancel_speculation()
-            for k, v in saved.items():
-                setattr(mcmc, k, copy.deepcopy(v))
-            bnn.reset_weights([w.copy() for w in saved_w])
-            mcmc._invalidate()
-        # (weights and temperature exactly; the log-posterior to rounding: the two paths may pick different launch geometries
-        # for a batch, which changes the summation order of the log-likelihood in its last bits)
-        same = (outcome[0] is not None and outcome[1] is not None and np.array_equal(outcome[0][0], outcome[1][0])
-                and outcome[0][2] == outcome[1][2] and abs(outcome[0][1] - outcome[1][1]) <= 1e-9 * abs(outcome[0][1]))
-        agree = comm.allgather_f64(np.array([1.0 if same else 0.0]))
-        state["device"] = bool(np.all(agree[:, 0] == 1.0))
+        state["device"], bad_ranks = exchange_self_check(chains, ids, world, comm, swap_frequency,
+                                                         lambda: ex.SwapProposals(world, np.random.RandomState(99)), rank=rank)
         if rank == 0 and not state["device"]:
-            print("[bench] device exchange path disagrees with the host path on ranks %s: using the host path"
-                  % np.nonzero(agree[:, 0] != 1.0)[0].tolist(), flush=True)
+            print("[bench] device exchange path disagrees with the host path on ranks %s: using the host path" % bad_ranks, flush=True)
     if world > 1:
         exchange_path = ("device: swap intervals in batches of 20 on the stream, records all-gathered in place, decision by a kernel"
                          if state["device"] else "host: one device batch per interval, all-gather and decision on the host")

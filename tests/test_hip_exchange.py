@@ -420,3 +420,22 @@ def test_single_chain_exchange_run_on_two_streams(with_comm):
     assert done == n_seg and outs[0]["result"]["schedule"] in (2, 3)      # (3 unless a device-side wait timed out)
     assert np.all(records[:, 0, 2] == 1.0) and records[-1, 0, 3] == n_seg * seg_len
     assert_same(state_of([(bnn_a, ma)]), state_of([(bnn_b, mb)]))
+
+
+def test_bench_exchange_self_check_runs_and_restores_the_chains():
+    """bench.py checks the device exchange path against the interval-by-interval path before it times anything with several
+    ranks; the same routine here on one GPU with two chains: it agrees, and the chains are back where they started."""
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    from bench_support import exchange_self_check
+    cfg = cases.TRACES["cfg1"]
+    chains = build_chains(cfg, [0.9, 1.0])
+    for bnn, m in chains:
+        m.device_schedule = 2
+        m.run_steps(bnn, 40)
+    before = state_of(chains)
+    ok, bad = exchange_self_check(chains, [0, 1], 2, None, 20, lambda: ex.SwapProposals(2, np.random.RandomState(99)))
+    assert ok and bad == []
+    assert_same(before, state_of(chains))
+    # and the chains still run
+    assert ex.advance_intervals(chains, [0, 1], 2, 3, 20, ex.SwapProposals(2, np.random.RandomState(5)), 0, batch=3) == 3

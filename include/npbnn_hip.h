@@ -138,9 +138,13 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch);
  *                  same HBM bytes as float32, 5x less matrix-core time;
  *   NPBNN_L0_AUTO  fp16-split whenever the data and weights are representable (finite, in range), else float32; an
  *                  evaluation whose weights leave the fp16 range is transparently repeated in float32 (default). */
-enum { NPBNN_OPT_L0_PRECISION = 1 };
+/* NPBNN_OPT_FAST_TAILS (default 1): launches that want nothing but the likelihood of a 2- or 3-layer network whose later layers
+ * have <= 16 nodes (the layer loop of MCMC.mh_step, np_bnn/BNN_env.py:449-473, on every BASELINE shape) run on builds of the
+ * evaluation kernel with the layer loop, the activation and the epilogue resolved at compile time; 0 keeps every launch on
+ * the general build (same results bit for bit; for A/B timing).  NPBNN_INFO_FAST_TAILS: 1 when such launches would take them. */
+enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2 };
 enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
-enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3 };
+enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3, NPBNN_INFO_FAST_TAILS = 4 };
 int npbnn_set_option(npbnn_ctx* ctx, int option, int value);
 int npbnn_get_info(npbnn_ctx* ctx, int what, int* out);
 

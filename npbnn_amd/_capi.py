@@ -20,8 +20,9 @@ OUT_SOFTMAX, OUT_IDENTITY, OUT_SOFTPLUS_HALF = 0, 1, 2
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE = 0, 1, 2, 3
 TRAIN, TEST = 0, 1
 OPT_L0_PRECISION = 1
+OPT_FAST_TAILS = 2
 L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
-INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU = 1, 2, 3
+INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU, INFO_FAST_TAILS = 1, 2, 3, 4
 E_RANGE = -6
 E_SYNC = -7
 

@@ -68,6 +68,10 @@ class HipContext:
         value = {"auto": capi.L0_AUTO, "f32": capi.L0_F32, "f16": capi.L0_F16}[mode]
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_L0_PRECISION, value))
 
+    def set_fast_tails(self, on):
+        """Shape-specialised builds of the evaluation kernel for likelihood-only launches (default on; same results)."""
+        self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_FAST_TAILS, 1 if on else 0))
+
     def info(self, what):
         out = C.c_int(0)
         self._chk(self._lib.npbnn_get_info(self._ctx, what, C.byref(out)))

@@ -30,11 +30,24 @@ eval_fn_t pick_eval_d2_cat(int mt0, int f16);
 eval_fn_t pick_eval_d2_gauss(int mt0, int f16);
 eval_fn_t pick_eval_d3_cat(int mt0, int f16);
 eval_fn_t pick_eval_d3_gauss(int mt0, int f16);
+// the fast builds (eval_kernel<..., FAST = true>): nullptr where there is none (more than kFastMaxMT0 tiles in layer 0)
+eval_fn_t pick_eval_d1_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d1_gauss_fast(int mt0, int f16);
+eval_fn_t pick_eval_d2_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d2_gauss_fast(int mt0, int f16);
+eval_fn_t pick_eval_d3_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d3_gauss_fast(int mt0, int f16);
 }
 
 // lk: likelihood class of the build (npbnn::lik_class); the float64 row-wise class has single-candidate builds only
-static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk) {
+static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk, bool fast = false) {
     using namespace npbnn;
+    if (fast) {
+        const bool g = lk == kLikGauss;
+        if (n_cand <= 1) return g ? pick_eval_d1_gauss_fast(mt0, f16) : pick_eval_d1_cat_fast(mt0, f16);
+        if (n_cand == 2) return g ? pick_eval_d2_gauss_fast(mt0, f16) : pick_eval_d2_cat_fast(mt0, f16);
+        return g ? pick_eval_d3_gauss_fast(mt0, f16) : pick_eval_d3_cat_fast(mt0, f16);
+    }
     if (mti != 1) return lk == kLikGen ? pick_eval_mti8_gen(mt0, f16) : lk == kLikGauss ? pick_eval_mti8_gauss(mt0, f16) : pick_eval_mti8_cat(mt0, f16);
     if (lk == kLikGen) return pick_eval_d1_gen(mt0, f16);
     const bool g = lk == kLikGauss;
@@ -78,6 +91,7 @@ struct npbnn_ctx {
     int n_weights = 0;
     int mt0_template = 1;
     int l0_option = 0;             // NPBNN_L0_AUTO / _F32 / _F16
+    int fast_option = 1;           // NPBNN_OPT_FAST_TAILS
     float* d_xscale = nullptr;     // per-feature power-of-two scales of the fp16-split path (from the training matrix)
     float* d_wscale = nullptr;
     int scale_F = 0;
@@ -335,9 +349,9 @@ WaveLayout layout_for(const npbnn_ctx* ctx, const Dataset& d, bool predict_only 
                             predict_only ? NPBNN_LIK_NONE : ctx->net.lik_kind);
 }
 
-int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand, const WaveLayout& lay, bool predict_only = false) {
+int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand, const WaveLayout& lay, bool predict_only = false, bool fast = false) {
     const int lk = predict_only ? kLikCat : lik_class(ctx->net.lik_kind);
-    const int top = max_waves_for(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16 != 0, n_cand, lk);   // launch bound of the build in use
+    const int top = max_waves_for(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16 != 0, n_cand, lk, fast);   // launch bound of the build in use
     for (int w = top; w >= 1; --w) {
         const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)w * lay.wave_lds;
         if (need <= ctx->lds_limit) {
@@ -421,9 +435,22 @@ struct LaunchPlan {
     int grid, wpb;
     size_t lds;
     int n_waves;
+    bool fast;
 };
 
-int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false) {
+// May a launch that wants nothing but the likelihood terms run on the fast builds (eval_kernel, FAST)?  2 or 3 layers, later
+// layers of <= 16 nodes, layer 0 of <= 16 * kFastMaxMT0, categorical (padding outputs masked through the bias) or Gaussian
+// likelihood, no row or class weights, no activation after the last layer.
+bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d) {
+    const NetMeta& net = ctx->net;
+    if (!ctx->fast_option || max_inner_tiles(net) != 1 || net.n_layers < 2 || net.n_layers > kFastLayers || net.L[0].mt > kFastMaxMT0) return false;
+    if (net.final_act || d.inst_w || ctx->n_classw > 0) return false;
+    if (net.lik_kind == NPBNN_LIK_CATEGORICAL) return net.pad_masked != 0 && d.labels != nullptr;
+    return net.lik_kind == NPBNN_LIK_GAUSS && d.targets != nullptr;
+}
+
+// lik_only: the caller wants the likelihood terms and nothing else from the launch (no statistics, no predictions)
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false, bool lik_only = false) {
     Dataset& d = ctx->ds[which];
     bool want_f16 = false;
     if (!force_f32 && ctx->l0_option != NPBNN_L0_F32) {
@@ -443,14 +470,18 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     int n_cand = (max_inner_tiles(ctx->net) == 1 && (predict_only || !lik_needs_row_scratch(ctx->net.lik_kind))) ? want_cand : 1;
     if (n_cand > kMaxCand) n_cand = kMaxCand;
     const WaveLayout lay = layout_for(ctx, d, predict_only);
-    while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only) < 8) --n_cand;
+    const bool fast = lik_only && !predict_only && fast_launch_ok(ctx, d);
+    while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only, fast) < 8) --n_cand;
     lp->n_cand = n_cand;
-    const int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only);
+    lp->fast = fast;
+    const int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only, fast);
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
     lp->fn = predict_only ? npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand, kLikCat)
-                          : pick_kernel(ctx->net, n_cand);
+                          : npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand,
+                                                   lik_class(ctx->net.lik_kind), fast);
+    if (!lp->fn) return fail(ctx, NPBNN_E_STATE, "no evaluation kernel for this shape (internal error)");
     lp->wpb = wpb;
     lp->lds = lds;
     int grid = (d.n_tiles + wpb - 1) / wpb;
@@ -853,6 +884,10 @@ int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
         ctx->l0_option = value;
         return NPBNN_OK;
     }
+    if (option == NPBNN_OPT_FAST_TAILS) {
+        ctx->fast_option = value ? 1 : 0;
+        return NPBNN_OK;
+    }
     return fail(ctx, NPBNN_E_ARG, "set_option: unknown option %d", option);
 }
 
@@ -861,6 +896,7 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
     if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds, 1, layout_for(ctx, ctx->ds[0])); return NPBNN_OK; }
     if (what == NPBNN_INFO_N_CU) { *out = ctx->n_cu; return NPBNN_OK; }
+    if (what == NPBNN_INFO_FAST_TAILS) { *out = (ctx->arch_set && fast_launch_ok(ctx, ctx->ds[0])) ? 1 : 0; return NPBNN_OK; }
     return fail(ctx, NPBNN_E_ARG, "get_info: unknown item %d", what);
 }
 
@@ -869,7 +905,7 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     const int lik = ctx->net.lik_kind;
     Dataset& d = ctx->ds[which];
     LaunchPlan lp;
-    int rc = plan_launch(ctx, which, &lp, force_f32);
+    int rc = plan_launch(ctx, which, &lp, force_f32, 1, false, confusion == nullptr);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
@@ -1126,7 +1162,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     LaunchPlan& lp = B->lp;
     int want_cand = cfg->n_candidates;
     if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
-    rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand);
+    rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand, false, true);
     if (rc) return rc;
     const int D = lp.n_cand;
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
@@ -1703,7 +1739,7 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, 0, &lp, 0, n_candidates < 1 ? kMaxCand : n_candidates);
+    rc = plan_launch(ctx, 0, &lp, 0, n_candidates < 1 ? kMaxCand : n_candidates, false, true);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
@@ -1799,7 +1835,7 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, 0, &lp);
+    rc = plan_launch(ctx, 0, &lp, 0, 1, false, true);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;

@@ -49,6 +49,11 @@ __device__ __forceinline__ T* uni(T* ptr) { return reinterpret_cast<T*>(uni((lon
 // Launch-invariant scalars of the parameter block, copied once so that they stay in SGPRs: the counted s_waitcnt
 // statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
 // after each of them.
+#ifndef NPBNN_FAST3_WAVES
+#define NPBNN_FAST3_WAVES 12
+#endif
+constexpr int kFastMaxMT0 = 4;      // fast builds exist for layer 0 of up to 16 * kFastMaxMT0 nodes
+constexpr int kFastLayers = 3;      // networks of up to this many layers have shape-specialised tails
 struct HotParams {
     const int* labels;
     const float* targets;
@@ -59,6 +64,9 @@ struct HotParams {
     int use_classw, predict_mode, weight_sets;
     int aux_off_w, aux_off_t;
     int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off, pad_masked;
+    // shape-specialised tails (tile_tail, NLC > 0): image offsets and activation slopes of layers 1 .. kFastLayers-1
+    int frag_off[kFastLayers - 1], bias_off[kFastLayers - 1];
+    float act_prm[kFastLayers - 1];
 };
 
 template <int KIND, int HT, int D>
@@ -87,7 +95,13 @@ __device__ __forceinline__ void act_live_all(f32x4 (&h)[D][HT], int live, int ki
 // `imgs + j*image_floats` in LDS).  Every stage loops over the candidates innermost: their chains (dependent MFMAs,
 // exp / rcp / log) are independent, so the wave always has three of them to interleave.
 // Handles candidates J0 .. J0+D-1 of the DA the pass holds (all of them when the registers allow, else one at a time).
-template <int MT0, int MTI, int LK, int D, int DA, int J0>
+// NLC / ACTC / PLAIN: shape-specialised form for the networks every BASELINE config uses (MTI == 1).  NLC > 0 = the number of
+// layers is the compile-time constant NLC (2 or 3): layer 1 then has MT0 k-tiles, later ones one, all of them one output tile,
+// and their image offsets come from HotParams (scalar registers) instead of the parameter block; ACTC >= 0 = the activation
+// kind is the constant ACTC; PLAIN = categorical log-likelihood only (no confusion counts, predictions, row / class weights,
+// final activation; padding outputs masked through their bias).  The arithmetic per value is the generic path's, statement for
+// statement - only the control flow around it is resolved at compile time - so both paths give the same bits.
+template <int MT0, int MTI, int LK, int D, int DA, int J0, int NLC = 0, int ACTC = -1, bool PLAIN = false>
 __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& hp, const float* imgs0, int image_floats,
                                           const f32x4 (&acc0_all)[DA][MT0], int lane, int n, int kq, const char* a_slot, float* row_scratch,
                                           long long row, bool row_ok, TileAcc<LK> (&A_all)[DA]) {
@@ -96,24 +110,25 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
     const float* const imgs = imgs0 + (size_t)J0 * image_floats;
     auto A = [&](int j) -> TileAcc<LK>& { return A_all[J0 + j]; };
     constexpr int HT = MT0 > MTI ? MT0 : MTI;      // tiles of the widest activation vector held in registers
-    const int n_layers = hp.n_layers;
+    static_assert(NLC == 0 || (MTI == 1 && NLC >= 2 && NLC <= kFastLayers), "shape-specialised tails: 2..kFastLayers layers, narrow later layers");
+    static_assert(!PLAIN || (NLC > 0 && LK != kLikGen), "the plain form needs a fixed shape");
+    const int n_layers = NLC ? NLC : hp.n_layers;
     const int C = hp.C;
-    const int MTL = hp.MTL;
-    const int lik_kind = hp.lik_kind;
+    const int MTL = NLC ? 1 : hp.MTL;
+    const int lik_kind = (PLAIN && LK == kLikCat) ? NPBNN_LIK_CATEGORICAL : hp.lik_kind;
     const int k_targets = hp.k_targets;
-    const bool need_softmax = LK == kLikCat && ((lik_kind == NPBNN_LIK_CATEGORICAL) || (hp.predict_mode == 2 && hp.out_kind == NPBNN_OUT_SOFTMAX));
+    const bool need_softmax = LK == kLikCat && (PLAIN || (lik_kind == NPBNN_LIK_CATEGORICAL) || (hp.predict_mode == 2 && hp.out_kind == NPBNN_OUT_SOFTMAX));
     // ---------------- layers 1..L-1 chained through the accumulators ----------------
     f32x4 h[D][HT];
 #pragma unroll
     for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) h[j][mt] = mt < MT0 ? acc0_all[J0 + j][mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int l = 1; l < n_layers; ++l) {
-        const LayerMeta& L = net.L[l];
-        const int lkt = uni(L.kt), lmt = uni(L.mt);
-        act_live_all(h, lkt, hp.act_kind, uni(net.act_prm[l - 1]));
-        const float* frag = imgs + uni(L.frag_off) + lane * 4;
-        const float* bias = imgs + uni(L.bias_off) + 4 * kq;
+    auto layer = [&](int lkt, int lmt, int frag_off, int bias_off, float prm) {
+        if constexpr (ACTC >= 0) act_tiles_all<ACTC>(h, lkt, prm);
+        else act_live_all(h, lkt, hp.act_kind, prm);
+        const float* frag = imgs + frag_off + lane * 4;
+        const float* bias = imgs + bias_off + 4 * kq;
         f32x4 acc[D][MTI];
 #pragma unroll
         for (int mt = 0; mt < MTI; ++mt) {
@@ -142,8 +157,17 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         for (int j = 0; j < D; ++j)
 #pragma unroll
             for (int mt = 0; mt < MTI; ++mt) h[j][mt] = acc[j][mt];
+    };
+    if constexpr (NLC > 0) {
+#pragma unroll
+        for (int l = 1; l < NLC; ++l) layer(l == 1 ? MT0 : 1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1]);
+    } else {
+        for (int l = 1; l < n_layers; ++l) {
+            const LayerMeta& L = net.L[l];
+            layer(uni(L.kt), uni(L.mt), uni(L.frag_off), uni(L.bias_off), uni(net.act_prm[l - 1]));
+        }
     }
-    if (hp.final_act) act_live_all(h, MTL, hp.act_kind, uni(net.act_prm[n_layers - 1]));
+    if (!PLAIN && hp.final_act) act_live_all(h, MTL, hp.act_kind, uni(net.act_prm[n_layers - 1]));
     // h[j][mt][i] = last-layer value of unit o = 16mt + 4kq + i for data row tile*16 + n   (mt < MTL <= MTI)
 
     // ---------------- epilogue ----------------
@@ -155,7 +179,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         float m[D], se[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) { m[j] = -INFINITY; se[j] = 0.f; }
-        if (hp.pad_masked) {      // padding outputs sit at kPadLogit (their bias): no per-output predicate
+        if (PLAIN || hp.pad_masked) {      // padding outputs sit at kPadLogit (their bias): no per-output predicate
 #pragma unroll
             for (int mt = 0; mt < MTI; ++mt)
                 if (mt < MTL)
@@ -196,7 +220,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         for (int j = 0; j < D; ++j) se[j] = quad_sum(se[j]);
 #pragma unroll
         for (int j = 0; j < D; ++j) lse[j] = m[j] + __logf(se[j]);
-        if (hp.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207); statistics of the first candidate only
+        if (!PLAIN && hp.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207); statistics of the first candidate only
             float bv = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
@@ -231,17 +255,19 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
                     }
         if (lab >= 0) {
             float wgt = 1.f;
-            if (hp.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + hp.aux_off_w + n * 4);
-            if (hp.use_classw) wgt *= imgs[hp.classw_off + lab];
+            if constexpr (!PLAIN) {
+                if (hp.inst_w) wgt *= *reinterpret_cast<const float*>(a_slot + hp.aux_off_w + n * 4);
+                if (hp.use_classw) wgt *= imgs[hp.classw_off + lab];
+            }
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 float term = 0.f;
                 if (own) term += zl[j];
                 if (kq == 0) term -= lse[j];
-                term *= wgt;
+                if constexpr (!PLAIN) term *= wgt;      // (x 1.0f is exact: the plain form gives the same bits)
                 A(j).ll += (double)term;
             }
-            if (hp.confusion && primary && kq == 0 && best_i < C) atomicAdd(hp.confusion + lab * C + best_i, 1u);
+            if (!PLAIN && hp.confusion && primary && kq == 0 && best_i < C) atomicAdd(hp.confusion + lab * C + best_i, 1u);
         }
       }
     } else if constexpr (LK == kLikGen) {
@@ -305,7 +331,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         }
     }
 
-    if (hp.predict_mode && row_ok) {       // predictions: of the first candidate, or of every weight set of the launch
+    if (!PLAIN && hp.predict_mode && row_ok) {       // predictions: of the first candidate, or of every weight set of the launch
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (!(hp.weight_sets || (primary && j == 0))) continue;
@@ -337,13 +363,19 @@ __host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int 
 // waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive.  The
 // three-candidate categorical build of the narrow networks (the chain kernel of config 2) fits 128 VGPRs, i.e. 13 waves:
 // with 24-25 tiles per workgroup that is two rounds of tiles per wave instead of three for some.
-__host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int d, int lk) {
-    return mti != 1 ? 8 : d == 1 ? 16 : d == 2 ? 14 : (lk == kLikCat && pipelined_l0(mt0, mti, f16, d)) ? 13 : 11;
+// The fast three-candidate builds take 12 (three per SIMD, 168 registers): with all three tails unrolled side by side 128 spill.
+__host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int d, int lk, bool fast = false) {
+    return mti != 1 ? 8 : d == 1 ? 16 : d == 2 ? (fast ? 12 : 14) : fast ? (NPBNN_FAST3_WAVES) : (lk == kLikCat && pipelined_l0(mt0, mti, f16, d)) ? 13 : 11;
 }
 #define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int MT0, int MTI, bool F16, int D, int LK>
-__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg) {
+// FAST: the build for launches that want nothing but the likelihood terms of a 2- or 3-layer network with narrow later layers
+// (`fast_launch_ok` below says which: every chain pass and plain evaluation of the BASELINE configs).  It holds only the
+// shape-specialised tails and none of the scalars the general epilogue keeps alive (statistics, predictions, row weights ...),
+// which is what brings the tile loop's scalar registers back under the file's size.  Same arithmetic, same bits.
+template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false>
+__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg) {
+    static_assert(!FAST || (MTI == 1 && LK != kLikGen), "fast builds: narrow later layers, categorical or Gaussian likelihood");
     // launch index; bit 30: another launch of the batch has been enqueued behind this one (two-stream schedule, sync_step_leave)
     const int launch = launch_arg & 0x3fffffff;
     const bool next_enqueued = (launch_arg >> 30) & 1;
@@ -387,15 +419,36 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
     const size_t IB = (size_t)image_floats * 4;                     // bytes of one weight image
 
     HotParams hp;
-    hp.labels = uni(p.labels); hp.targets = uni(p.targets); hp.inst_w = uni(p.inst_w); hp.confusion = uni(p.confusion);
-    hp.y_out = uni(p.y_out);
-    hp.n_rows = uni(p.n_rows); hp.use_classw = uni(p.use_classw); hp.predict_mode = uni(p.predict_mode);
-    hp.weight_sets = uni(p.weight_sets);
-    hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out); hp.MTL = uni(net.L[hp.n_layers - 1].mt); hp.lik_kind = uni(net.lik_kind);
-    hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind); hp.out_kind = uni(net.out_kind);
-    hp.final_act = uni(net.final_act);
-    hp.pad_masked = uni(net.pad_masked);
-    hp.classw_off = uni(net.classw_off);
+    hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out);
+    hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind);
+#pragma unroll
+    for (int l = 1; l < kFastLayers; ++l) { hp.frag_off[l - 1] = 0; hp.bias_off[l - 1] = 0; hp.act_prm[l - 1] = 0.f; }
+    if constexpr (FAST) {       // (fast_launch_ok: the host has checked all of this)
+        hp.labels = LK == kLikCat ? uni(p.labels) : nullptr;
+        hp.targets = LK == kLikGauss ? uni(p.targets) : nullptr;
+        hp.inst_w = nullptr; hp.confusion = nullptr; hp.y_out = nullptr;
+        hp.n_rows = LK == kLikGauss ? uni(p.n_rows) : 0;        // (categorical: padding rows carry the label -1)
+        hp.use_classw = 0; hp.predict_mode = 0; hp.weight_sets = 0;
+        hp.MTL = 1; hp.lik_kind = LK == kLikGauss ? NPBNN_LIK_GAUSS : NPBNN_LIK_CATEGORICAL;
+        hp.out_kind = 0; hp.final_act = 0; hp.pad_masked = 1; hp.classw_off = -1;
+#pragma unroll
+        for (int l = 1; l < kFastLayers; ++l)
+            if (l < hp.n_layers) {
+                hp.frag_off[l - 1] = uni(net.L[l].frag_off);
+                hp.bias_off[l - 1] = uni(net.L[l].bias_off);
+                hp.act_prm[l - 1] = uni(net.act_prm[l - 1]);
+            }
+    } else {
+        hp.labels = uni(p.labels); hp.targets = uni(p.targets); hp.inst_w = uni(p.inst_w); hp.confusion = uni(p.confusion);
+        hp.y_out = uni(p.y_out);
+        hp.n_rows = uni(p.n_rows); hp.use_classw = uni(p.use_classw); hp.predict_mode = uni(p.predict_mode);
+        hp.weight_sets = uni(p.weight_sets);
+        hp.MTL = uni(net.L[hp.n_layers - 1].mt); hp.lik_kind = uni(net.lik_kind);
+        hp.out_kind = uni(net.out_kind);
+        hp.final_act = uni(net.final_act);
+        hp.pad_masked = uni(net.pad_masked);
+        hp.classw_off = uni(net.classw_off);
+    }
     const int k_targets = hp.k_targets;
     const int aux_sz = uni(p.lay.aux_sz), aux_mask = uni(p.lay.aux_slots) - 1;
     hp.aux_off_w = uni(p.lay.off_w);
@@ -582,13 +635,34 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK) * 64) eval
         // the candidates go through the tail together (their independent chains interleave) while the registers allow
         constexpr int HT = MT0 > MTI ? MT0 : MTI;
         constexpr int DT = (D * HT <= 6 && LK != kLikGen) ? D : 1;
-        if constexpr (DT == D) {
-            tile_tail<MT0, MTI, LK, D, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+        // (shape tags: NLC layers fixed / activation ACTC / plain - all 0 / -1 / false for the generic tail)
+        auto tail = [&](auto nlc, auto actc, auto plain) {
+            constexpr int NLC = decltype(nlc)::value, ACTC = decltype(actc)::value;
+            constexpr bool PL = decltype(plain)::value;
+            if constexpr (DT == D) {
+                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+            } else {
+                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                static_assert(D <= 3, "add a call per candidate");
+            }
+        };
+        using std::integral_constant;
+        if constexpr (FAST) {      // wave-uniform branches: depth and activation of the network
+            auto with_act = [&](auto nlc) {
+                switch (hp.act_kind) {
+                    case NPBNN_ACT_RELU: tail(nlc, integral_constant<int, NPBNN_ACT_RELU>{}, std::true_type{}); break;
+                    case NPBNN_ACT_LEAKY: tail(nlc, integral_constant<int, NPBNN_ACT_LEAKY>{}, std::true_type{}); break;
+                    case NPBNN_ACT_SWISH: tail(nlc, integral_constant<int, NPBNN_ACT_SWISH>{}, std::true_type{}); break;
+                    default: tail(nlc, integral_constant<int, NPBNN_ACT_TANH>{}, std::true_type{}); break;
+                }
+            };
+            static_assert(kFastLayers == 3, "one branch per specialised depth");
+            if (hp.n_layers == 3) with_act(integral_constant<int, 3>{});
+            else with_act(integral_constant<int, 2>{});
         } else {
-            tile_tail<MT0, MTI, LK, 1, D, 0>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-            if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-            if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-            static_assert(D <= 3, "add a call per candidate");
+            tail(integral_constant<int, 0>{}, integral_constant<int, -1>{}, std::false_type{});
         }
     };
 

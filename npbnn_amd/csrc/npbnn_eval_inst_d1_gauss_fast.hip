@@ -1,0 +1,7 @@
+// eval_kernel fast builds: 2- or 3-layer networks with later layers <= 16 nodes, 1 candidate(s) per launch, likelihood class Gaussian
+#define NPBNN_INST_NAME pick_eval_d1_gauss_fast
+#define NPBNN_INST_MTI 1
+#define NPBNN_INST_D 1
+#define NPBNN_INST_LK 1
+#define NPBNN_INST_FAST 1
+#include "npbnn_eval_inst.inc"

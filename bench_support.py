@@ -1,4 +1,5 @@
-"""Helpers for bench.py: the config-2 model and the timed Metropolis-Hastings loop."""
+"""Helpers for bench.py: the BASELINE.json workloads (synthetic data, model and sampler through the reference's own call
+sequence, the matching oracle chain for the CPU baseline, the parity read-out) and the exchange self-check."""
 import contextlib
 import io
 
@@ -7,17 +8,167 @@ import numpy as np
 import npbnn_amd as bn
 
 
+def _quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
+
+
+class Workload:
+    """One BASELINE.json configuration: SURVEY.md 8(d) gives inputs (``np.random.default_rng(0)``), model
+    (``np.random.seed(1234)`` before npBNN) and the algorithmic bytes per proposal (X in float32 + labels / targets)."""
+    config = 0
+
+    def kernel_name(self, ctx, cand):
+        return "eval_kernel<MT0=%d,MTI=1,%s,D=%d,LK=%s,%s>" % (self.mt0, "fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand,
+                                                              self.lik_class, "fast" if ctx.info(bn._capi.INFO_FAST_TAILS) else "general")
+
+
+class Config2(Workload):
+    config, mt0, lik_class = 2, 2, "categorical"
+    n, f, c, hidden = 100_000, 256, 10, [32, 8]
+    short = "config 2 (100k x 256, [32,8])"
+    description = "config 2: 100k x 256 features, 10 classes, hidden [32,8], tanh, bias 2"
+
+    def __init__(self):
+        rs = np.random.default_rng(0)
+        self.x = rs.standard_normal((self.n, self.f))
+        self.y = rs.integers(0, self.c, self.n)
+        self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n
+
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False):
+        """np.random.seed(1234); npBNN(n_nodes=[32,8], tanh, bias nodes in input+hidden layers, N(0,1) prior); MCMC defaults
+        (update_f 0.05 -> update_n [411,13,4])."""
+        x32 = self.x.astype(np.float32)
+        dat = dict(data=x32, labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
+        np.random.seed(1234)
+        bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed)
+        return bnn, mcmc
+
+    def oracle_chain(self, orc):
+        np.random.seed(1234)
+        return orc.make_chain(self.x, self.y, self.hidden, act=orc.Act("tanh"), use_bias_node=2, prior_kind=1, p_scale=1)
+
+    def parity(self, bnn, mcmc):
+        """State of the timed chain against the float64 oracle: relative error of the device log-likelihood of the chain's current
+        weights and max abs error of its class probabilities on a row sample."""
+        import oracle as orc
+        w = [np.array(v, dtype=np.float64) for v in bnn._w_layers]
+        xs = self.x.astype(np.float32).astype(np.float64)
+        pred = orc.forward(xs, w, orc.Act("tanh"), orc.out_softmax)
+        ll = orc.lik_categorical(pred, self.y, np.arange(self.n))
+        dev = mcmc._backend.evaluate(bnn._w_layers, None)["loglik"]
+        rows = np.arange(0, self.n, 97)
+        y_dev = np.asarray(mcmc._y)[rows]
+        return dict(loglik_oracle=float(ll), loglik_device=float(dev), loglik_rel_err=float(abs(dev - ll) / abs(ll)),
+                    chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)),
+                    prediction_max_abs_err=float(np.max(np.abs(y_dev - pred[rows]))), tolerance="1e-4 relative (BASELINE.json)")
+
+
+class _Regression(Workload):
+    lik_class = "gaussian"
+
+    def _targets(self, rs, x, k):
+        """tanh-MLP teacher + 0.5 * noise."""
+        w1 = rs.standard_normal((x.shape[1], 8)) / np.sqrt(x.shape[1])
+        w2 = rs.standard_normal((8, k))
+        return np.tanh(x @ w1) @ w2 + 0.5 * rs.standard_normal((x.shape[0], k))
+
+    def parity(self, bnn, mcmc):
+        import oracle as orc
+        w = [np.array(v, dtype=np.float64) for v in bnn._w_layers]
+        xs = self.x.astype(np.float32).astype(np.float64)
+        pred = orc.forward(xs, w, orc.Act(self.act), orc.out_identity)
+        if bnn._empirical_error:
+            ll = orc.closed_gaussian_empirical(pred, self.y)[0]
+            dev = mcmc._backend.evaluate(bnn._w_layers, None)["loglik"]
+        else:
+            sig = np.ones(self.k) * bnn._error_prm
+            ll = orc.lik_gaussian(pred, self.y, sig2=sig)
+            dev = mcmc._backend.evaluate(bnn._w_layers, None, sigma=sig)["loglik"]
+        rows = np.arange(0, self.n, 997)
+        y_dev = np.asarray(mcmc._y)[rows]
+        return dict(loglik_oracle=float(ll), loglik_device=float(dev), loglik_rel_err=float(abs(dev - ll) / abs(ll)),
+                    chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)),
+                    prediction_max_abs_err=float(np.max(np.abs(y_dev - pred[rows]))), tolerance="1e-4 relative (BASELINE.json)")
+
+
+class Config4(_Regression):
+    config, mt0, act = 4, 1, "tanh"
+    n, f, k, hidden = 1_000_000, 64, 2, [16, 4]
+    short = "config 4 (1M x 64 regression, [16,4])"
+    description = "config 4: 1M x 64 features, 2 Gaussian targets, hidden [16,4], tanh, bias 2, empirical sigma (bnn_regress.py settings)"
+    sampler = dict(update_ws=[0.025, 0.025, 0.05], update_f=[0.005, 0.005, 0.05], n_iteration=20000, adapt_f=0.3, estimate_error=False)
+
+    def __init__(self):
+        rs = np.random.default_rng(0)
+        self.x = rs.standard_normal((self.n, self.f))
+        self.y = self._targets(rs, self.x, self.k)
+        self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n * self.k
+
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False):
+        """bnn_regress.py:33-52: npBNN(regression, tanh, p_scale 1, bias 2, empirical_error); MCMC(update_ws [.025,.025,.05],
+        update_f [.005,.005,.05], adapt_f .3, estimate_error False)."""
+        dat = dict(data=self.x.astype(np.float32), labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros((0, self.k)))
+        np.random.seed(1234)
+        bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, estimation_mode="regression", actFun=bn.ActFun(fun="tanh"), p_scale=1,
+                     use_bias_node=2, empirical_error=True)
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **self.sampler)
+        return bnn, mcmc
+
+    def oracle_chain(self, orc):
+        np.random.seed(1234)
+        return orc.make_chain(self.x, self.y, self.hidden, act=orc.Act("tanh"), use_bias_node=2, prior_kind=1, p_scale=1,
+                              mode="regression", empirical_error=True, **self.sampler)
+
+
+class Config5(_Regression):
+    config, mt0, act = 5, 2, "ReLU"
+    n, f, k, hidden, blocks = 50_000, 512, 1, [32, 8], 8
+    short = "config 5 (50k x 512 block layers, [32,8])"
+    description = ("config 5: 50k x 512 features, layer 0 in 8 blocks of 64 inputs x 4 nodes (create_mask), hidden [32,8], ReLU, "
+                   "bias -1, 1 Gaussian target (block_bnns.py layout)")
+
+    def __init__(self):
+        rs = np.random.default_rng(0)
+        self.x = rs.standard_normal((self.n, self.f))
+        self.y = self._targets(rs, self.x, self.k)
+        self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n * self.k
+
+    def _mask_args(self):
+        return [list(np.repeat(np.arange(self.blocks), self.f // self.blocks)), [], []], [[4] * self.blocks, [], []]
+
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False):
+        """block_bnns.py:32-43: npBNN(regression, default ReLU, p_scale 1, bias on the last layer) + create_mask / apply_mask;
+        MCMC defaults."""
+        dat = dict(data=self.x.astype(np.float32), labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros((0, self.k)))
+        np.random.seed(1234)
+        bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, estimation_mode="regression", p_scale=1, use_bias_node=-1)
+        idx, per = self._mask_args()
+        _quiet(bnn.apply_mask, bn.create_mask(bnn._w_layers, indx_input_list=idx, nodes_per_feature_list=per))
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed)
+        return bnn, mcmc
+
+    def oracle_chain(self, orc):
+        np.random.seed(1234)
+        w = orc.init_weights(self.hidden, self.f, self.k, init_std=0.1, bias_node=-1)
+        idx, per = self._mask_args()
+        return orc.make_chain(self.x, self.y, self.hidden, act=orc.Act("ReLU"), use_bias_node=-1, prior_kind=1, p_scale=1,
+                              mode="regression", init_w=w, mask=orc.block_mask(w, idx, per))
+
+
+def workload(config):
+    return {2: Config2, 4: Config4, 5: Config5}[config]()
+
+
 def build_config2(x, y, hidden, mcmc_id=0, temperature=1.0, randomize_seed=False):
-    """BASELINE.json config 2 through the reference's own call sequence: np.random.seed(1234); npBNN(n_nodes=[32,8],
-    tanh, bias nodes in input+hidden layers, N(0,1) prior); MCMC defaults (update_f 0.05 -> update_n [411,13,4])."""
+    """BASELINE.json config 2 on given arrays (tools/): np.random.seed(1234); npBNN(n_nodes=[32,8], tanh, bias nodes in
+    input+hidden layers, N(0,1) prior); MCMC defaults (update_f 0.05 -> update_n [411,13,4])."""
     dat = dict(data=x, labels=y, test_data=np.zeros((0, x.shape[1])), test_labels=np.zeros(0))
     np.random.seed(1234)
-    with contextlib.redirect_stdout(io.StringIO()):
-        bnn = bn.npBNN(dat, n_nodes=hidden, actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+    bnn = _quiet(bn.npBNN, dat, n_nodes=hidden, actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
     mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed)
     return bnn, mcmc
-
-
 def exchange_self_check(chains, chain_ids, n_chains, comm, seg_len, make_swaps, rank=0, n_intervals=4):
     """The same ``n_intervals`` swap intervals from the same state on the interval-by-interval path and on the device exchange
     path of THIS machine; the chains are put back where they started.  Returns (every rank agrees the two paths gave the same

@@ -205,9 +205,9 @@ typedef struct {
     int32_t schedule;                          /* NPBNN_SCHED_AUTO / _SERIAL (evaluate a pass, decide it, evaluate the next) / _OVERLAP
                                                   (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
                                                   pass L-1 rejects; a pass overtaken by an accept is dropped) / _OVERLAP2 (below).
-                                                  The same chain whichever runs.  _AUTO: overlapped while fewer than ~16 % of the
-                                                  iterations of the previous batch were accepted (_OVERLAP2 when the chain has the GPU
-                                                  to itself, _OVERLAP inside an exchange run), else _SERIAL. */
+                                                  The same chain whichever runs.  _AUTO: _OVERLAP while fewer than ~16 % of the
+                                                  iterations of the previous batch were accepted, else _SERIAL; _OVERLAP2 only runs
+                                                  when asked for by name. */
     int32_t reserved_;
     /* regression with an estimated error parameter (BNN_env.py:435-442: every proposal multiplies sigma by pre-drawn factors,
      * multiplier_proposal_vector, BNN_mcmc.py:101-113): sigma_mult[t*n_targets + q] is the factor of target column q at iteration
@@ -223,7 +223,9 @@ typedef struct {
 #define NPBNN_SCHED_OVERLAP2 3         /* the overlapped schedule with the launches alternating between two streams: the next launch's
                                          workgroups take the compute units over as the previous launch drains; what a kernel boundary
                                          guaranteed is guaranteed by device-side flags (release / acquire at agent scope).  A wait that
-                                         times out ends the batch with NPBNN_E_SYNC (state untouched: retry with NPBNN_SCHED_OVERLAP) */
+                                         times out ends the batch with NPBNN_E_SYNC (state untouched: retry with NPBNN_SCHED_OVERLAP).
+                                         Opt-in: it counts on the two streams having hardware queues of their own and on nothing else
+                                         sharing the GPU, neither of which HIP guarantees; a chain that shares its GPU runs _OVERLAP */
 
 typedef struct {
     double loglik, logprior;                   /* state after the K iterations */

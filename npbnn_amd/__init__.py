@@ -17,17 +17,18 @@ from .layers import (ActFun, MatrixMultiplication, MatrixMultiplicationD, Regres
                      create_mask, leaky_relu_f, relu_f, swish_f, tanh_f)
 from .likelihoods import (CalcAccuracy, CalcAccuracyRegression, CalcLabelAccuracy,  # noqa: F401
                           CalcLabelAccuracyRegression, CalcLabelFreq, SkipAccuracy, SkipAccuracyVec,
-                          calc_likelihood, calc_likelihood_regression, calc_likelihood_regression_error,
+                          calc_likelihood, calc_likelihood_regression, calc_likelihood_regression_error, gamma_acc,
+                          gamma_likelihood,
                           negbin2d_acc, negbin_acc, negbin_acc_base10, negbin_likelihood, negbin_likelihood2d,
                           negbin_likelihood_base10, poi_acc, poi_likelihood)
 from .model import data_transform_obj, npBNN  # noqa: F401
 from .sampler import MCMC, predict  # noqa: F401
 from .driver import run_mcmc  # noqa: F401
-from .files import SaveObject, load_obj  # noqa: F401
+from .files import SaveObject, get_data, load_obj, randomize_data, turn_labels_to_numeric  # noqa: F401
 from .logger import init_output_files, postLogger  # noqa: F401
 from .mc3 import MC3  # noqa: F401
-from .posterior import feature_importance, get_posterior_cat_prob, predictBNN, sample_from_categorical  # noqa: F401
-from .pdp import get_feature_summary, get_pdp, make_pdp_features, pdp  # noqa: F401
+from .posterior import (feature_importance, get_posterior_cat_prob, get_posterior_est, predictBNN,  # noqa: F401
+                        sample_from_categorical)
 from . import comm  # noqa: F401
 
 BNN = npBNN                       # BASELINE.json's wording

@@ -46,6 +46,7 @@ class HipContext:
         self.arch = None
         self.n_rows = {}
         self.n_out = None
+        self.sync_fallbacks = 0      # batches of the (opt-in) two-stream schedule that timed out and were repeated on one stream
 
     # -- lifecycle --------------------------------------------------------------------
     def close(self):
@@ -277,8 +278,12 @@ class HipContext:
                 sync_retried = True
                 if cfg.schedule == capi.SCHED_OVERLAP2:
                     cfg.schedule = capi.SCHED_OVERLAP
-                continue        # a device-side wait of the two-stream schedule timed out: same batch again on one stream (the
-                # library keeps that schedule off for this context from now on; the state was left untouched)
+                self.sync_fallbacks += 1
+                if self.sync_fallbacks == 1:
+                    import warnings
+                    warnings.warn("npbnn_amd: a device-side wait of the two-stream chain schedule timed out; the batch is repeated on "
+                                  "one stream and this context stays on one stream from now on (HipContext.sync_fallbacks counts them)")
+                continue        # (the state was left untouched)
             self._chk(rc)
             break
         return w, acc, llp, lpp, self._result_dict(res)

@@ -156,6 +156,7 @@ struct npbnn_ctx {
     // flag-ordered overlapped chain schedule: the launches alternate between these two streams
     hipStream_t stream_e[2] = {nullptr, nullptr};
     bool sync_failed = false;      // a wait timed out once: the schedule stays off for this context
+    int debug_sync_skip = -1;      // npbnn_debug_sync_skip_ (diagnostics, not part of the ABI)
     npbnn_ctx* data_owner = nullptr;
     int n_borrowers = 0;
     bool zombie = false;
@@ -1170,10 +1171,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
         schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
-        // where overlapping pays, the two-stream form of it pays a little more (measured at 0.3 .. 27 % acceptance) - when this chain
-        // has the GPU to itself
-        if (schedule == NPBNN_SCHED_OVERLAP && alone_on_device && !ctx->sync_failed && !getenv("NPBNN_NO_OVERLAP2"))
-            schedule = NPBNN_SCHED_OVERLAP2;
+        // (the two-stream form, NPBNN_SCHED_OVERLAP2, is never picked here: it orders overlapping launches with device-side waits,
+        // which needs both streams on hardware queues of their own and the step workgroup resident - nothing HIP promises.  It runs
+        // when the caller asks for it, and only for a chain that has the GPU to itself.)
     }
     if (schedule == NPBNN_SCHED_OVERLAP2 && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
     const bool overlap = schedule == NPBNN_SCHED_OVERLAP || schedule == NPBNN_SCHED_OVERLAP2;
@@ -1332,9 +1332,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.n_blocks = lp.n_waves;
     c.stop_on_overflow = seg_len > 0 ? 1 : 0;
     c.sync_test_skip = -1;
-    if (const char* ts = getenv("NPBNN_SYNC_TEST_SKIP")) {      // tests only: provoke the time-out of the two-stream schedule, once
-        static bool used = false;
-        if (!used && sync) { c.sync_test_skip = atoi(ts); used = true; }
+    if (sync && ctx->debug_sync_skip >= 0) {       // (npbnn_debug_sync_skip_: provoke the time-out of the two-stream schedule, once)
+        c.sync_test_skip = ctx->debug_sync_skip;
+        ctx->debug_sync_skip = -1;
     }
     c.prior_kind = cfg->prior_kind;
     for (int l = 0; l < kMaxLayers; ++l) {
@@ -1706,6 +1706,14 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
             }
     }
     *out_segments_done = seg_done;
+    return NPBNN_OK;
+}
+
+// diagnostics (not part of the ABI): in the next batch of this context that runs on the two-stream schedule, the step workgroup of
+// launch `launch` never reports back - every wait behind it must time out cleanly (tests of that path)
+int npbnn_debug_sync_skip_(npbnn_ctx* ctx, int launch) {
+    if (!ctx) return NPBNN_E_ARG;
+    ctx->debug_sync_skip = launch;
     return NPBNN_OK;
 }
 

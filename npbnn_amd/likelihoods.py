@@ -60,6 +60,29 @@ negbin_likelihood_base10 = _Likelihood(
     "Negative-binomial log-likelihood with base-10 links (reference: BNN_lik.py:55-66).")
 
 
+def gamma_likelihood(prediction, true_values, sample_id=None, class_weight=None, instance_weight=None, lik_temp=1, sig2=0):
+    """Gamma log-likelihood exactly as upstream evaluates it (np_bnn/BNN_lik.py:68-78): shape a = exp(prediction[:, 0]) and
+    b = exp(prediction[:, 1]) handed to ``scipy.stats.gamma.logpdf(true_values, a, b)``, where the third positional argument
+    is the LOCATION, and an N x 1 ``true_values`` broadcasts against the N shapes to an N x N table that is summed whole.
+    That all-pairs sum does not decompose over the rows of the feature matrix, so it is not fused into the streaming kernel:
+    the sampler gives this function the device-computed prediction matrix (the path every user-supplied likelihood takes)
+    and the closed form below runs on the host:  sum (a-1) log(x-b) - (x-b) - lgamma(a)  over every pair with x > b."""
+    from scipy.special import gammaln
+    eta = np.asarray(prediction, dtype=float)
+    a, b = np.exp(eta[:, 0]), np.exp(eta[:, 1])
+    x = np.asarray(true_values, dtype=float)
+    z = x - b                                          # (N x 1 against N: the all-pairs table; N against N: row by row)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        table = np.where(z > 0, (a - 1) * np.log(z) - z - gammaln(a), -np.inf)
+    return np.sum(table)
+
+
+def gamma_acc(y, lab):
+    """Mean squared error of exp(y[:, 0]) against the targets (np_bnn/BNN_lik.py:98-99 computes it and forgets to return it;
+    here it is returned)."""
+    return np.mean((np.exp(np.asarray(y)[:, 0]) - np.asarray(lab).flatten()) ** 2)
+
+
 def likelihood_kind(fn):
     return fn.kind if isinstance(fn, _Likelihood) else None
 

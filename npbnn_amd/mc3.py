@@ -57,7 +57,6 @@ class MC3():
                  adapt_stop=1000,
                  n_iteration=100000,
                  comm=None,
-                 backend_factory=None,
                  ):
         self.n_chains = n_chains
         self.swap_frequency = swap_frequency
@@ -88,8 +87,6 @@ class MC3():
                           n_post_samples=self.n_post_samples, mcmc_id=i, randomize_seed=True,
                           adapt_freq=self.adapt_freq, adapt_f=self.adapt_f, adapt_fM=self.adapt_fM,
                           adapt_stop=self.adapt_stop, likelihood_f=self.likelihood_f, accuracy_f=self.accuracy_f)
-            if backend_factory is not None:
-                kwargs["backend"] = backend_factory(bnn_i)
             self.singleChainArgs[i] = [bnn_i, MCMC(bnn_i, **kwargs)]
         self.logger = logger
         self.swap_log = []

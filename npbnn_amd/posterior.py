@@ -60,184 +60,185 @@ def _predict_samples(features, post_samples, actFun, output_act_fun):
 
 
 def sample_from_categorical(posterior_weights=None, post_prob_file=None, verbose=False):
-    """One categorical draw per instance and posterior sample; point estimate = class frequencies of the draws
-    (reference: BNN_lib.py:682-713)."""
-    if posterior_weights is not None:
-        pass
-    elif post_prob_file:
+    """Posterior-predictive resampling (np_bnn/BNN_lib.py:682-713): one class drawn per (instance, stored sample) from that
+    sample's class probabilities; the point estimate of an instance is the class frequency among its draws.  The uniforms
+    come from numpy's global stream in the upstream order (instance by instance, one per sample), so a seeded run
+    reproduces upstream's draws; the arithmetic is done for all instances at once."""
+    if posterior_weights is None:
+        if not post_prob_file:
+            raise ValueError("sample_from_categorical needs posterior_weights or post_prob_file")
         posterior_weights = np.load(post_prob_file)
+    probs = np.asarray(posterior_weights)
+    n_samples, n_instances, n_classes = probs.shape
+    cdf = np.cumsum(np.transpose(probs, (1, 0, 2)), axis=2)               # [instance, sample, class]
+    u = np.random.random((n_instances, n_samples))
+    # the class drawn is the one whose cumulative probability exceeds u by the least (ties and a cdf that never gets there
+    # fall to the first such class, as upstream's argmin over the masked differences does)
+    excess = cdf - u[:, :, None]
+    excess[excess < 0] = 1
+    draws = np.argmin(excess, axis=2)                                      # [instance, sample]
+    one_hot = draws[:, :, None] == np.arange(n_classes)[None, None, :]
+    return {'predictions': one_hot.sum(axis=1) / n_samples,
+            'class_counts': one_hot.sum(axis=0).astype(float),
+            'post_predictions': draws.astype(float)}
+
+
+def _shuffled_copy(features, columns, independently):
+    """``features`` with the given column(s) permuted between the rows: every column on its own, or the block as a whole
+    (rows stay intact inside the block).  Permutations from numpy's global stream (np_bnn/BNN_lib.py:366-372)."""
+    out = np.array(features, dtype=np.float64, copy=True)
+    if not columns:
+        return out
+    if independently and type(columns) == list:
+        for col in columns:
+            out[:, col] = np.random.permutation(out[:, col])
     else:
-        print("Input pickle file or posterior weights required.")
-    n_post_samples, n_instances, n_classes = posterior_weights.shape
-    res = np.zeros((n_instances, n_post_samples))
-    point_estimates = np.zeros((n_instances, n_classes))
-    for j in range(n_instances):
-        if j % 1000 == 0 and verbose is True:
-            print(j)
-        p = np.cumsum(posterior_weights[:, j, :], axis=1)
-        r = np.random.random(len(p))
-        q = p - r.reshape(len(r), 1)
-        q[q < 0] = 1
-        classification = np.argmin(q, axis=1)
-        res[j, :] = classification
-        counts = np.bincount(classification, minlength=n_classes)
-        point_estimates[j, :] = counts / np.sum(counts)
-    class_counts = np.zeros((n_post_samples, n_classes))
-    for i in range(res.shape[1]):
-        class_counts[i] = np.bincount(res[:, i].astype(int), minlength=n_classes)
-    return {'predictions': point_estimates, 'class_counts': class_counts, 'post_predictions': res}
+        out[:, columns] = np.random.permutation(out[:, columns])
+    return out
+
+
+def _summarise(probs, mode):
+    """[sample, instance, class] probabilities -> [instance, class]: 0 share of samples voting for the class, 1 mean
+    probability, 2 posterior-predictive resampling (np_bnn/BNN_lib.py:382-395)."""
+    if mode == 0:
+        votes = np.argmax(probs, axis=2)                                   # [sample, instance]
+        return (votes[:, :, None] == np.arange(probs.shape[2])).mean(axis=0)
+    if mode == 1:
+        return np.mean(probs, axis=0)
+    if mode == 2:
+        return sample_from_categorical(posterior_weights=probs)['predictions']
+    return None
 
 
 def get_posterior_cat_prob(pred_features, post_samples=None, feature_index_to_shuffle=None, post_summary_mode=0,
                            unlink_features_within_block=False, actFun=None, output_act_fun=None, _predictor=None):
-    """Class probabilities of every posterior sample and their summary (reference: BNN_lib.py:352-397):
-    mode 0 frequency of the arg-max class over the samples, 1 mean probabilities, 2 posterior-predictive resampling."""
+    """Predictions of every stored posterior sample and their summary (np_bnn/BNN_lib.py:352-397).  Returns
+    ``(per-sample predictions [sample, instance, output], summary [instance, output])``."""
     if len(pred_features) == 0:
         print("Data not found.")
         return 0
-    predict_features = np.array(pred_features, dtype=np.float64, copy=True)
-    if feature_index_to_shuffle:     # permute the given feature column(s) between the instances
-        if unlink_features_within_block and type(feature_index_to_shuffle) == list:
-            for feature_index in feature_index_to_shuffle:
-                predict_features[:, feature_index] = np.random.permutation(predict_features[:, feature_index])
-        else:
-            predict_features[:, feature_index_to_shuffle] = np.random.permutation(predict_features[:, feature_index_to_shuffle])
-    if actFun is None:
-        actFun = ActFun()
+    features = _shuffled_copy(pred_features, feature_index_to_shuffle, unlink_features_within_block)
+    act = ActFun() if actFun is None else actFun
     if len(post_samples):
-        actFun.reset_prm(post_samples[-1]['alphas'])          # the reference leaves the last sample's slopes installed
-    if _predictor is not None:
-        post_softmax_probs = _predictor.predict(predict_features)
-    else:
-        post_softmax_probs = _predict_samples(predict_features, post_samples, actFun, output_act_fun)
-    if post_summary_mode == 0:
-        class_call_posterior = np.argmax(post_softmax_probs, axis=2).T
-        n_posterior_samples, n_instances, n_classes = post_softmax_probs.shape
-        posterior_prob_classes = np.zeros([n_instances, n_classes])
-        for c in range(n_classes):
-            posterior_prob_classes[:, c] = np.sum(class_call_posterior == c, axis=1)
-        posterior_prob_classes = posterior_prob_classes / n_posterior_samples
-    elif post_summary_mode == 1:
-        posterior_prob_classes = np.mean(post_softmax_probs, axis=0)
-    elif post_summary_mode == 2:
-        posterior_prob_classes = sample_from_categorical(posterior_weights=post_softmax_probs)['predictions']
-    return post_softmax_probs, posterior_prob_classes
+        act.reset_prm(post_samples[-1]['alphas'])          # (upstream leaves the last sample's slopes installed)
+    probs = _predictor.predict(features) if _predictor is not None else _predict_samples(features, post_samples, act, output_act_fun)
+    return probs, _summarise(probs, post_summary_mode)
+
+
+def get_posterior_est(pkl_file):
+    """Predictions of every stored posterior sample of a checkpoint on its own training and test matrices, and their means
+    over the samples (np_bnn/BNN_lib.py:715-748; the regression drivers read the estimated parameters from it).  Keys as
+    upstream: ``post_est`` / ``post_est_test`` [sample, row, output], ``prm_mean`` / ``prm_mean_test`` [row, output],
+    ``error_prm`` (the samples' error parameters, or an empty list when the model has none)."""
+    model, _, logger = load_obj(pkl_file)
+    samples = logger._post_weight_samples
+    act = model._act_fun
+    if len(samples):
+        act.reset_prm(samples[-1]['alphas'])          # (upstream leaves the last sample's slopes installed)
+
+    def on(matrix):
+        if len(matrix) == 0:
+            return np.zeros((len(samples), 0, model._size_output))
+        return _predict_samples(np.asarray(matrix, dtype=np.float64), samples, act, model._output_act_fun)
+
+    est, est_test = on(model._data), on(model._test_data)
+    return {'prm_mean': np.mean(est, axis=0), 'post_est': est,
+            'prm_mean_test': np.mean(est_test, axis=0), 'post_est_test': est_test,
+            'error_prm': [s['error_prm'] for s in samples] if (len(samples) and 'error_prm' in samples[0]) else []}
+
+
+def _confusion_table(true_labels, predicted, n_classes):
+    table = np.zeros((n_classes, n_classes), dtype=int)
+    np.add.at(table, (np.asarray(true_labels, dtype=int), np.asarray(predicted, dtype=int)), 1)
+    return table
 
 
 def predictBNN(predict_features, pickle_file, test_labels=[], instance_id=[], post_summary_mode=0, fname="", wd="",
                verbose=1):
-    """Posterior predictions for new data from a saved run ``[bnn, mcmc, logger]`` (reference: BNN_lib.py:404-501;
-    the Bayes-factor and posterior-threshold extras of the reference are not carried over).  Writes
-    ``<name>_pred_pr.npy`` (all samples) and ``<name>_pred_mean_pr.txt`` (summary) next to the pickle or into ``wd``."""
-    bnn_obj, mcmc_obj, logger_obj = load_obj(pickle_file)
-    post_samples = logger_obj._post_weight_samples
-    out_name = os.path.basename(os.path.splitext(pickle_file)[0])
-    predictions_outdir = wd if wd != "" else os.path.dirname(pickle_file)
-    post_softmax_probs, post_prob_predictions = get_posterior_cat_prob(
-        predict_features, post_samples, post_summary_mode=post_summary_mode, actFun=bnn_obj._act_fun,
-        output_act_fun=bnn_obj._output_act_fun)
-    if fname != "":
-        fname = fname + "_"
-    out_file_post_pr = os.path.join(predictions_outdir, fname + out_name + '_pred_pr.npy')
-    out_file_mean_pr = os.path.join(predictions_outdir, fname + out_name + '_pred_mean_pr.txt')
-    if len(test_labels) > 0:
-        mean_accuracy = np.mean(CalcAccuracy(post_prob_predictions, test_labels))
-        n_classes = post_prob_predictions.shape[1]
-        cm_out = np.zeros((n_classes, n_classes), dtype=int)
-        np.add.at(cm_out, (np.asarray(test_labels, dtype=int), np.argmax(post_prob_predictions, axis=1)), 1)
+    """Posterior predictions for a feature matrix from a checkpoint ``[bnn, mcmc, logger]`` (np_bnn/BNN_lib.py:404-501,
+    without its Bayes-factor and threshold extras).  Files, next to the checkpoint or in ``wd``:
+    ``<fname_><checkpoint>_pred_pr.npy`` (every sample's predictions), ``..._pred_mean_pr.txt`` (the summary, with the
+    instance names in front when given), ``..._accuracy.txt`` when labels are given."""
+    model, _, logger = load_obj(pickle_file)
+    per_sample, summary = get_posterior_cat_prob(predict_features, logger._post_weight_samples,
+                                                 post_summary_mode=post_summary_mode, actFun=model._act_fun,
+                                                 output_act_fun=model._output_act_fun)
+    stem = os.path.join(wd if wd else os.path.dirname(pickle_file),
+                        (fname + "_" if fname else "") + os.path.splitext(os.path.basename(pickle_file))[0])
+    result = {'post_prob_predictions': summary, 'mean_accuracy': np.nan, 'confusion_matrix': np.nan}
+    if len(test_labels):
+        result['mean_accuracy'] = np.mean(CalcAccuracy(summary, test_labels))
+        result['confusion_matrix'] = _confusion_table(test_labels, np.argmax(summary, axis=1), summary.shape[1])
+        with open(stem + '_accuracy.txt', 'w') as fh:
+            fh.write("Mean accuracy: %s" % result['mean_accuracy'])
         if verbose:
-            print("Accuracy:", mean_accuracy)
-            print("Confusion matrix:\n", cm_out)
-        with open(os.path.join(predictions_outdir, fname + out_name + '_accuracy.txt'), 'w') as outf:
-            outf.writelines("Mean accuracy: %s" % mean_accuracy)
-    else:
-        mean_accuracy = np.nan
-        cm_out = np.nan
+            print("Accuracy:", result['mean_accuracy'])
+            print("Confusion matrix:\n", result['confusion_matrix'])
     if len(instance_id):
-        instance_id = np.asarray(instance_id)
-        post_prob_predictions_id = np.hstack((instance_id.reshape(len(instance_id), 1),
-                                              np.round(post_prob_predictions, 4).astype(str)))
-        np.savetxt(out_file_mean_pr, post_prob_predictions_id, fmt='%s', delimiter='\t')
+        names = np.asarray(instance_id).reshape(-1, 1)
+        np.savetxt(stem + '_pred_mean_pr.txt', np.hstack((names, np.round(summary, 4).astype(str))), fmt='%s', delimiter='\t')
     else:
-        np.savetxt(out_file_mean_pr, post_prob_predictions, fmt='%.3f')
-    np.save(out_file_post_pr, post_softmax_probs)
+        np.savetxt(stem + '_pred_mean_pr.txt', summary, fmt='%.3f')
+    np.save(stem + '_pred_pr.npy', per_sample)
     if verbose:
-        print("Predictions saved in files:")
-        print('   ', out_file_post_pr)
-        print('   ', out_file_mean_pr, "\n")
-    return {'post_prob_predictions': post_prob_predictions, 'mean_accuracy': mean_accuracy, 'confusion_matrix': cm_out}
+        print("Predictions saved in files:\n    %s\n    %s\n" % (stem + '_pred_pr.npy', stem + '_pred_mean_pr.txt'))
+    return result
+
+
+def _feature_blocks(feature_blocks, names):
+    """(column lists, block names): the caller's dict {name: columns} or list of column lists; one block per column when
+    none is given (np_bnn/BNN_lib.py:521-533)."""
+    if isinstance(feature_blocks, dict):
+        if feature_blocks:
+            return list(feature_blocks.values()), list(feature_blocks.keys())
+        return [[i] for i in range(len(names))], list(names)
+    return list(feature_blocks), ['block_%d' % i for i in range(len(feature_blocks))]
 
 
 def feature_importance(input_features, weights_pkl=None, weights_posterior=None, true_labels=[], fname_stem='',
                        feature_names=[], verbose=False, post_summary_mode=0, n_permutations=100, feature_blocks=dict(),
                        write_to_file=True, predictions_outdir='', unlink_features_within_block=True, actFun=None,
                        output_act_fun=None):
-    """Accuracy lost when a feature (or block of features) is shuffled between the instances, ``n_permutations`` times
-    per block (reference: BNN_lib.py:504-597).  Every permutation is one upload of the shuffled matrix and one
-    ``npbnn_predict_sets`` over all stored samples; the permutations themselves come from numpy's global stream as in
-    the reference.  Returns the reference's data frame, sorted by decreasing mean accuracy loss."""
+    """Permutation importance (np_bnn/BNN_lib.py:504-597): how much accuracy is lost when a block of feature columns is
+    shuffled between the instances, ``n_permutations`` shuffles per block (numpy's global stream, upstream's order).  The
+    stored samples stay packed on the device; a shuffle costs one upload of the matrix and one ``npbnn_predict_sets``.
+    Returns a data frame, most important block first, with upstream's column names; written to
+    ``<fname_stem_>feature_importance.txt`` unless ``write_to_file`` is off."""
     import pandas as pd
     features = np.asarray(input_features)
-    feature_indices = np.arange(features.shape[1])
-    if len(feature_names) == 0:
-        feature_names = feature_indices.astype(str)
-    if type(feature_blocks) is dict:
-        if len(feature_blocks.keys()) > 0:
-            selected_features = list(feature_blocks.values())
-            feature_block_names = list(feature_blocks.keys())
-        else:
-            selected_features = [[i] for i in feature_indices]
-            feature_block_names = [i for i in feature_names]
-    else:
-        selected_features = feature_blocks
-        feature_block_names = ['block_' + str(i) for i in range(len(feature_blocks))]
+    names = feature_names if len(feature_names) else np.arange(features.shape[1]).astype(str)
+    blocks, block_names = _feature_blocks(feature_blocks, names)
     if weights_pkl:
-        bnn_obj, mcmc_obj, logger_obj = load_obj(weights_pkl)
-        weights_posterior = logger_obj._post_weight_samples
-        actFun = bnn_obj._act_fun
-        output_act_fun = bnn_obj._output_act_fun
-    if actFun is None:
-        actFun = ActFun()
-    predictor = _SamplePredictor(features.shape[1], weights_posterior, actFun, output_act_fun)
+        model, _, logger = load_obj(weights_pkl)
+        weights_posterior, actFun, output_act_fun = logger._post_weight_samples, model._act_fun, model._output_act_fun
+    act = ActFun() if actFun is None else actFun
+
+    predictor = _SamplePredictor(features.shape[1], weights_posterior, act, output_act_fun)
     try:
-        _, post_prob_predictions = get_posterior_cat_prob(features, weights_posterior, post_summary_mode=post_summary_mode,
-                                                          actFun=actFun, output_act_fun=output_act_fun, _predictor=predictor)
-        ref_accuracy = CalcAccuracy(post_prob_predictions, true_labels)
+        def accuracy(shuffle=None):
+            summary = get_posterior_cat_prob(features, weights_posterior, feature_index_to_shuffle=shuffle,
+                                             post_summary_mode=post_summary_mode, actFun=act, output_act_fun=output_act_fun,
+                                             unlink_features_within_block=unlink_features_within_block, _predictor=predictor)[1]
+            return CalcAccuracy(summary, true_labels)
+
+        baseline = accuracy()
         if verbose:
-            print("Reference accuracy (mean):", np.mean(ref_accuracy))
-        accuracies_wo_feature = []
-        for block_id, feature_block in enumerate(selected_features):
-            if verbose:
-                print('Processing feature block %i', block_id + 1)
-            n_accuracies = []
-            for _ in np.arange(n_permutations):
-                _, post_prob_predictions = get_posterior_cat_prob(
-                    features, weights_posterior, feature_index_to_shuffle=feature_block, post_summary_mode=post_summary_mode,
-                    unlink_features_within_block=unlink_features_within_block, actFun=actFun, output_act_fun=output_act_fun,
-                    _predictor=predictor)
-                n_accuracies.append(CalcAccuracy(post_prob_predictions, true_labels))
-            accuracies_wo_feature.append(n_accuracies)
+            print("Reference accuracy (mean):", np.mean(baseline))
+        shuffled = np.array([[accuracy(block) for _ in range(n_permutations)] for block in blocks])    # [block, permutation]
     finally:
         predictor.close()
-    accuracies_wo_feature = np.array(accuracies_wo_feature)
-    delta_accs = ref_accuracy - accuracies_wo_feature
-    df = pd.DataFrame(np.array([np.arange(0, len(selected_features)), feature_block_names,
-                                np.mean(delta_accs, axis=1), np.std(delta_accs, axis=1),
-                                np.mean(accuracies_wo_feature, axis=1), np.std(accuracies_wo_feature, axis=1)]).T,
-                      columns=['feature_block_index', 'feature_name', 'delta_acc_mean', 'delta_acc_std',
-                               'acc_with_feature_randomized_mean', 'acc_with_feature_randomized_std'])
-    df.iloc[:, 2:] = df.iloc[:, 2:].astype(float)
-    df_sorted = df.sort_values('delta_acc_mean', ascending=False)
-    df_sorted['delta_acc_mean'] = pd.to_numeric(df_sorted['delta_acc_mean'])
-    df_sorted['acc_with_feature_randomized_mean'] = pd.to_numeric(df_sorted['acc_with_feature_randomized_mean'])
+
+    loss = baseline - shuffled
+    table = pd.DataFrame({'feature_block_index': np.arange(len(blocks)).astype(str), 'feature_name': [str(n) for n in block_names],
+                          'delta_acc_mean': loss.mean(axis=1), 'delta_acc_std': loss.std(axis=1),
+                          'acc_with_feature_randomized_mean': shuffled.mean(axis=1),
+                          'acc_with_feature_randomized_std': shuffled.std(axis=1)})
+    table = table.sort_values('delta_acc_mean', ascending=False)
     if write_to_file:
-        if predictions_outdir == "":
-            predictions_outdir = os.path.dirname(weights_pkl)
-        if not os.path.exists(predictions_outdir) and predictions_outdir != "":
-            os.makedirs(predictions_outdir)
-        if fname_stem != "":
-            fname_stem = fname_stem + "_"
-        out_name = os.path.join(predictions_outdir, fname_stem + 'feature_importance.txt')
-        df_sorted.to_csv(out_name, sep='\t', index=False, header=True, float_format='%.6f')
-        print("Output saved in: %s" % out_name)
-    return df_sorted
+        out_dir = predictions_outdir if predictions_outdir else os.path.dirname(weights_pkl)
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, (fname_stem + "_" if fname_stem else "") + 'feature_importance.txt')
+        table.to_csv(path, sep='\t', index=False, header=True, float_format='%.6f')
+        print("Output saved in: %s" % path)
+    return table

@@ -37,13 +37,20 @@ def _draw_pool():
     return _POOL
 
 
+def _make_backend(bnn_obj, likelihood_f):
+    """Builds the device context of a model.  The one seam of the package: the CPU test-suite points this name at a stand-in
+    served by the oracle (tests/oracle_backend.py) to exercise the host logic without a GPU; the product only ever builds
+    the HIP backend, which fails loudly when the library or the GPU is missing."""
+    from .hip_backend import HipBackend
+    return HipBackend(bnn_obj, likelihood_f)
+
+
 def get_backend(bnn_obj, likelihood_f):
     """The model's resident device context (created on first use, shared by every sampler built on
     this model object)."""
     be = bnn_obj.__dict__.get("_npbnn_backend")
     if be is None or getattr(be, "_lik_f", None) is not likelihood_f:
-        from .hip_backend import HipBackend
-        be = HipBackend(bnn_obj, likelihood_f)
+        be = _make_backend(bnn_obj, likelihood_f)
         be._lik_f = likelihood_f
         bnn_obj.__dict__["_npbnn_backend"] = be
     return be
@@ -57,7 +64,7 @@ class MCMC():
                  update_function=UpdateNormal, sample_from_prior=0, run_ID="", init_additional_prob=0,
                  likelihood_tempering=1, mcmc_id=0, randomize_seed=False, adapt_f=0, estimate_error=True,
                  adapt_fM=1, adapt_freq=1000, adapt_stop=None, likelihood_f=None, adapt_verbose=False,
-                 accuracy_f=None, accuracy_lab_f=None, backend=None):
+                 accuracy_f=None, accuracy_lab_f=None):
         n_layers = bnn_obj._n_layers
         if update_ws is None:
             update_ws = [0.075] * n_layers
@@ -94,7 +101,7 @@ class MCMC():
         self._accuracy_lab_f = accuracy_lab_f
 
         self._bnn = bnn_obj
-        self._backend = backend if backend is not None else get_backend(bnn_obj, self._likelihood_f)
+        self._backend = get_backend(bnn_obj, self._likelihood_f)
         self._lazy = {}
         self._accepted_override = None      # column override of the last accepted state (feature indicators)
         self._lik_temp = likelihood_tempering

@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _real_backend_builder():
+    """CPU tests point npbnn_amd.sampler._make_backend at an oracle-backed stand-in (tests/oracle_backend.serve_from_oracle);
+    every test starts and ends with the product's own builder."""
+    from npbnn_amd import sampler
+    original = sampler._make_backend
+    yield
+    sampler._make_backend = original

@@ -166,3 +166,42 @@ def pdp_inputs():
 
 
 PDP_FOCAL = (("cont", [0]), ("ord", [3]), ("ohe", [8, 9, 10]))
+
+
+# ---- G8: get_data / randomize_data (split indices of seeded example tables) -------------------------------------------
+SPLIT_CASES = [
+    # name, keyword arguments of get_data beyond the two file names
+    ("stratified", dict(seed=1234, testsize=0.2, all_class_in_testset=1, instance_id=1, header=1)),
+    ("tail", dict(seed=77, testsize=0.1, all_class_in_testset=0, instance_id=1, header=1)),
+    ("fold2", dict(seed=5, testsize=0.2, all_class_in_testset=1, instance_id=1, header=1, cv=2)),
+    ("all_train", dict(seed=1234, testsize=0, instance_id=1, header=1)),
+    ("in_order", dict(seed=9, testsize=0.2, randomize_order=False, instance_id=1, header=1)),
+    ("batch", dict(seed=3, testsize=0.1, batch_training=25, instance_id=1, header=1, feature_indx=[0, 2, 5])),
+    ("regression", dict(seed=11, testsize=0.2, all_class_in_testset=0, instance_id=1, header=1, label_mode="regression")),
+]
+
+
+def write_split_tables(directory):
+    """A 50-row feature table (header line, instance names in the first column), a class-label table (5 named classes) and a
+    two-column real-valued target table, in the layout of upstream's example files.  Returns their three paths."""
+    import os
+    rs = np.random.default_rng(2024)
+    n, f = 50, 7
+    names = np.array(["inst%02d" % i for i in range(n)])
+    x = np.round(rs.standard_normal((n, f)), 5)
+    classes = np.array(["0", "1", "4", "6", "9"])[rs.integers(0, 5, n)]
+    targets = np.round(rs.standard_normal((n, 2)), 5)
+    paths = [os.path.join(directory, name) for name in ("split_features.txt", "split_labels.txt", "split_targets.txt")]
+    with open(paths[0], "w") as fh:
+        fh.write("id\t" + "\t".join("f%d" % j for j in range(f)) + "\n")
+        for i in range(n):
+            fh.write(names[i] + "\t" + "\t".join(repr(float(v)) for v in x[i]) + "\n")
+    with open(paths[1], "w") as fh:
+        fh.write("id\tlabel\n")
+        for i in range(n):
+            fh.write("%s\t%s\n" % (names[i], classes[i]))
+    with open(paths[2], "w") as fh:
+        fh.write("id\ty0\ty1\n")
+        for i in range(n):
+            fh.write("%s\t%r\t%r\n" % (names[i], float(targets[i, 0]), float(targets[i, 1])))
+    return paths

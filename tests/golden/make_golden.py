@@ -14,6 +14,7 @@ Groups:
   G5 mc3.npz         MC3 (4 chains) swap sequence and final chain states
   G6 masks.npz       create_mask block layouts
   G7 posterior.npz   get_posterior_cat_prob: per-sample class probabilities and the three summaries
+  G8 split.npz       get_data / randomize_data: the train / test split of seeded example tables
 """
 import contextlib
 import io
@@ -266,6 +267,22 @@ def g7_posterior():
     print("posterior.npz")
 
 
+def g8_split():
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        f_x, f_lab, f_y = cases.write_split_tables(tmp)
+        for name, kw in cases.SPLIT_CASES:
+            d = quiet(bn.get_data, f_x, f_y if kw.get("label_mode") == "regression" else f_lab, **kw)
+            for key in ("data", "labels", "test_data", "test_labels", "id_data", "id_test_data", "label_dict", "feature_names"):
+                v = np.asarray(d[key])
+                out["%s_%s" % (name, key)] = v.astype(str) if v.dtype.kind in "UO" else v
+        d = quiet(bn.get_data, f_x, header=1, instance_id=1)                       # unlabelled table
+        out["unlabelled_data"] = d["data"]
+        out["unlabelled_id_data"] = np.asarray(d["id_data"]).astype(str)
+    np.savez_compressed(os.path.join(HERE, "split.npz"), **out)
+    print("split.npz")
+
+
 if __name__ == "__main__":
     print("reference np_bnn", bn.__version__, "numpy", np.__version__)
     g1_grid()
@@ -275,3 +292,4 @@ if __name__ == "__main__":
     g5_mc3()
     g6_masks()
     g7_posterior()
+    g8_split()

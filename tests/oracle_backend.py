@@ -190,3 +190,10 @@ class OracleExchangeBackend(OracleChainBackend):
                                          n_candidates=1, n_void_passes=0, schedule=1, temperature=c["temp"],
                                          iterations_done=c["t"], overflow=0)))
         return outs, records, done
+
+
+def serve_from_oracle(factory):
+    """Point the package's backend seam (npbnn_amd.sampler._make_backend) at ``factory(bnn)`` - an oracle-backed stand-in - so
+    that samplers built from now on run without a GPU.  tests/conftest.py puts the real builder back after every test."""
+    from npbnn_amd import sampler
+    sampler._make_backend = lambda bnn, likelihood_f: factory(bnn)

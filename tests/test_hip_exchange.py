@@ -417,7 +417,7 @@ def test_single_chain_exchange_run_on_two_streams(with_comm):
     finally:
         if comm is not None:
             comm.close()
-    assert done == n_seg and outs[0]["result"]["schedule"] in (2, 3)      # (3 unless a device-side wait timed out)
+    assert done == n_seg and outs[0]["result"]["schedule"] == 3      # (a wait that timed out would have left the run short)
     assert np.all(records[:, 0, 2] == 1.0) and records[-1, 0, 3] == n_seg * seg_len
     assert_same(state_of([(bnn_a, ma)]), state_of([(bnn_b, mb)]))
 

@@ -106,12 +106,28 @@ def test_feature_importance_matches_reference(tag, blocks, golden_dir):
         np.testing.assert_allclose(np.sort(values[:, 0]), np.sort(want[:, 0]), atol=1.5 / len(inp["labels"]), rtol=0)
 
 
-@pytest.mark.parametrize("tag,focal", cases.PDP_FOCAL)
-def test_partial_dependence_matches_reference(tag, focal, golden_dir):
+def test_get_posterior_est_of_a_regression_checkpoint(tmp_path):
+    """get_posterior_est (BNN_lib.py:715-748): every stored sample's predictions on the checkpoint's own training and test
+    matrices, their means, and the samples' error parameters."""
     import npbnn_amd as bn
-    g = np.load(os.path.join(golden_dir, "posterior.npz"))
-    inp, xp = cases.pdp_inputs()
-    res = bn.get_pdp(xp, focal, "classification", 4, bn.ActFun(fun=inp["fun"]), bn.SoftMax,
-                     [s["weights"] for s in inp["samples"]], [s["alphas"] for s in inp["samples"]], None)
-    np.testing.assert_array_equal(res["feature"], g["pdp_%s_feature" % tag])
-    np.testing.assert_allclose(res["pdp"], g["pdp_%s_pdp" % tag], atol=TOL, rtol=0)
+    dat = cases.regression_data(seed=5, n_rows=150, n_features=6, k=2, n_test=30)
+    np.random.seed(1234)
+    bnn = bn.npBNN(dat, n_nodes=[5, 4], actFun=bn.ActFun(fun="tanh"), use_bias_node=2, estimation_mode="regression")
+    mcmc = bn.MCMC(bnn, n_iteration=50, sampling_f=10, print_f=1000, n_post_samples=4)
+    logger = bn.postLogger(bnn, wdir=str(tmp_path), filename="reg", log_all_weights=0)
+    rs = np.random.default_rng(3)
+    samples = [dict(weights=[w + rs.normal(0, 0.05, w.shape) for w in bnn._w_layers], alphas=np.zeros(3), mcmc_it=i,
+                    error_prm=np.array([1.0 + 0.1 * i, 0.9])) for i in range(4)]
+    logger._post_weight_samples = samples
+    pkl = os.path.join(str(tmp_path), "reg.pkl")
+    bn.SaveObject([bnn, mcmc, logger], pkl)
+    res = bn.get_posterior_est(pkl)
+    assert sorted(res) == ['error_prm', 'post_est', 'post_est_test', 'prm_mean', 'prm_mean_test']
+    assert res['post_est'].shape == (4, 150, 2) and res['post_est_test'].shape == (4, 30, 2)
+    for which, key in (("data", 'post_est'), ("test_data", 'post_est_test')):
+        x = dat[which].astype(np.float32).astype(np.float64)
+        for i, smp in enumerate(samples):
+            ref = orc.forward(x, smp["weights"], orc.Act("tanh"), orc.out_identity)
+            np.testing.assert_allclose(res[key][i], ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(res['prm_mean'], res['post_est'].mean(axis=0), rtol=1e-14)
+    np.testing.assert_array_equal(np.array(res['error_prm']), np.array([smp['error_prm'] for smp in samples]))

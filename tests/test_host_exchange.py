@@ -12,7 +12,7 @@ import pytest
 import cases
 import npbnn_amd as bn
 from npbnn_amd import exchange as ex
-from oracle_backend import OracleExchangeBackend
+from oracle_backend import OracleExchangeBackend, serve_from_oracle
 
 
 def build_mc3(tmpdir, name, comm=None, device=True, n_iteration=400, batch=6):
@@ -23,8 +23,9 @@ def build_mc3(tmpdir, name, comm=None, device=True, n_iteration=400, batch=6):
         bnn = bn.npBNN(dat, n_nodes=[4, 3], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
         rank0 = comm is None or comm.rank == 0
         logger = bn.postLogger(bnn, filename=name, wdir=str(tmpdir), log_all_weights=0, continue_logfile=not rank0)
+        serve_from_oracle(lambda b: OracleExchangeBackend(b, 0))
         mc3 = bn.MC3(bnn, logger=logger, n_post_samples=10, sampling_f=20, n_iteration=n_iteration, n_chains=4, swap_frequency=20,
-                     verbose=0, comm=comm, adapt_stop=60, backend_factory=lambda b: OracleExchangeBackend(b, 0))
+                     verbose=0, comm=comm, adapt_stop=60)
     mc3.device_exchange = device
     mc3.exchange_batch = batch
     return mc3, logger

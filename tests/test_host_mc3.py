@@ -11,7 +11,7 @@ import pytest
 
 import cases
 import npbnn_amd as bn
-from oracle_backend import OracleBackend
+from oracle_backend import OracleBackend, serve_from_oracle
 
 RTOL = 1e-9
 
@@ -24,9 +24,10 @@ def build_mc3(tmpdir, comm=None):
         bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
         rank0 = comm is None or comm.rank == 0
         logger = bn.postLogger(bnn, filename="MC3", wdir=str(tmpdir), log_all_weights=0, continue_logfile=not rank0)
+        serve_from_oracle(lambda b: OracleBackend(b, 0))
         mc3 = bn.MC3(bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"],
                      n_iteration=cfg["n_iteration"], n_chains=cfg["n_chains"], swap_frequency=cfg["swap_frequency"],
-                     verbose=0, comm=comm, backend_factory=lambda b: OracleBackend(b, 0))
+                     verbose=0, comm=comm)
     return mc3, logger
 
 

@@ -12,7 +12,7 @@ import pytest
 
 import cases
 import npbnn_amd as bn
-from oracle_backend import OracleBackend
+from oracle_backend import OracleBackend, serve_from_oracle
 
 RTOL = 1e-9
 
@@ -28,9 +28,9 @@ def build(cfg):
     with contextlib.redirect_stdout(io.StringIO()):
         bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
                        prior_f=1, p_scale=1, seed=1234, init_std=0.1, **extra)
-    be = OracleBackend(bnn, out_kind)
-    mcmc = bn.MCMC(bnn, backend=be, **cfg["mcmc"])
-    return bnn, mcmc, be
+    serve_from_oracle(lambda b: OracleBackend(b, out_kind))
+    mcmc = bn.MCMC(bnn, **cfg["mcmc"])
+    return bnn, mcmc, mcmc._backend
 
 
 @pytest.mark.parametrize("name", list(cases.TRACES))
@@ -250,8 +250,9 @@ def test_run_steps_between_gibbs_steps_of_a_per_layer_hyper_prior():
         with contextlib.redirect_stdout(io.StringIO()):
             bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
                            prior_f=1, p_scale=1, seed=1234, init_std=0.1, hyper_p=1)
-        be = OracleChainBackend(bnn, 0)
-        mcmc = bn.MCMC(bnn, backend=be, **cfg["mcmc"])
+        serve_from_oracle(lambda b: OracleChainBackend(b, 0))
+        mcmc = bn.MCMC(bnn, **cfg["mcmc"])
+        be = mcmc._backend
         used = []
         real = be.run_chain
         be.run_chain = lambda w, **kw: (used.append(len(kw["cnt"])), real(w, **kw))[1]

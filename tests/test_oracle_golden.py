@@ -115,6 +115,16 @@ def test_g3_count_likelihoods(golden_dir):
     np.testing.assert_allclose(orc.closed_negbin(z[:, :2], z[:, 2:], c["counts"]), g["nb2d"], rtol=1e-9)
 
 
+def test_g3_product_gamma_likelihood_is_upstreams(golden_dir):
+    """gamma_likelihood is a host function of the product (all-pairs sum, see its docstring): held to the reference's value."""
+    import npbnn_amd as bn
+    g = np.load(os.path.join(golden_dir, "counts.npz"))
+    b = cases.count_inputs(seed=24, n_out=2, k=1)
+    z = orc.forward(b["x"], b["weights"], orc.Act("swish"), orc.out_identity)
+    np.testing.assert_allclose(bn.gamma_likelihood(z, b["counts"] + 0.5), g["gamma"], rtol=RTOL)
+    np.testing.assert_allclose(bn.gamma_acc(z, b["counts"]), np.mean((np.exp(z[:, 0]) - b["counts"].flatten()) ** 2), rtol=1e-14)
+
+
 def _build_oracle_chain(cfg):
     if cfg["kind"] == "classification":
         dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
@@ -229,12 +239,3 @@ def test_g7_feature_importance(tag, blocks, golden_dir):
     np.testing.assert_array_equal(order, g["fi_%s_index" % tag])
     assert [str(n) for n in names] == [str(n) for n in g["fi_%s_names" % tag]]
     np.testing.assert_allclose(table, g["fi_%s_values" % tag], rtol=1e-12, atol=1e-15)
-
-
-@pytest.mark.parametrize("tag,focal", cases.PDP_FOCAL)
-def test_g7_partial_dependence_gradient(tag, focal, golden_dir):
-    """The host half of get_pdp (feature gradients) is pure numpy in the product; pin it here without a GPU."""
-    from npbnn_amd.pdp import make_pdp_features
-    g = np.load(os.path.join(golden_dir, "posterior.npz"))
-    _, xp = cases.pdp_inputs()
-    np.testing.assert_array_equal(make_pdp_features(xp, focal), g["pdp_%s_feature" % tag])

@@ -128,6 +128,14 @@ int npbnn_set_targets_f64(npbnn_ctx* ctx, const double* Y, int64_t n_rows, int32
 int npbnn_set_row_weights(npbnn_ctx* ctx, const double* instance_w, int64_t n_rows,
                           const double* class_w, int32_t n_classes);
 int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch);
+/* Block structure of the first layer: `mask_packed` is the 0/1 mask of the network in packed-weight order (create_mask,
+ * np_bnn/BNN_lib.py:16-47; npBNN.apply_mask, np_bnn/BNN_env.py:259-267; re-applied to every proposal, :461-462), or NULL for a
+ * dense first layer.  Only its layer-0 part is looked at: blocks of 16 nodes x 16 features (32 on the fp16-split path) in which
+ * the mask is all zero get no storage in the device's weight image and no matrix-core work - block_bnns.py's layouts (groups of
+ * consecutive features wired to a few nodes each) shrink to their diagonal.  The caller promises that every weight it passes
+ * from now on is zero where the mask is (the sampler's proposals are: BNN_env.py:462); a weight that is not fails the call that
+ * brought it with NPBNN_E_ARG.  Results are the dense ones bit for bit.  After npbnn_set_arch; cleared by the next one. */
+int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
 
 /* ---- options / introspection.
  * NPBNN_OPT_L0_PRECISION selects how the first layer's product X.W0^T (MatrixMultiplicationD, BNN_lib.py:154-162; float64
@@ -291,6 +299,12 @@ void npbnn_comm_destroy(npbnn_comm* comm);
  * chain on every rank sees it in the records and stops at that exchange: *out_segments_done < n_seg, each job's
  * result->iterations_done says how far its chain got (its state and outputs are valid up to there), and the caller
  * finishes that segment with npbnn_chain_run and a host-side swap.
+ * Failures between ranks: what can fail on one rank alone (its draws, its weights, its memory) is checked before anything is
+ * enqueued, and the ranks agree on the outcome through one host-side all-gather of `comm` - on an error every rank returns one
+ * (the failing rank its own, the others NPBNN_E_COMM) with nothing of the run in flight.  An error after that point (a launch or
+ * a collective that fails in the middle of the run) aborts `comm` on the failing rank, so that its peers' pending collectives end
+ * with an error instead of pairing with unrelated ones: the handle is dead afterwards (every call on it returns NPBNN_E_COMM);
+ * destroy it and start again with a new one.
  *   out_records[s][i] = {logPost, temperature (before swap s), 1.0 if chain i had finished segment s, iterations done}
  *   job.out_state[s]  = {logLik, logPrior, temperature, iterations done} of the chain after exchange s
  *   job.out_cold_w[s] = its weights at exchange s if it is the cold chain (temperature 1) afterwards (the logger's sample,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "npbnn_set_targets_f64": (C.c_int, [_P, _DP, C.c_int64, C.c_int32, C.c_int]),
     "npbnn_set_row_weights": (C.c_int, [_P, _DP, C.c_int64, _DP, C.c_int32]),
     "npbnn_set_arch": (C.c_int, [_P, C.POINTER(Arch)]),
+    "npbnn_set_layer_mask": (C.c_int, [_P, _DP]),
     "npbnn_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "npbnn_get_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "npbnn_eval": (C.c_int, [_P, _DP, _DP, _DP, C.c_double, _DP, C.c_int, C.POINTER(EvalOut),

@@ -134,6 +134,13 @@ class HipContext:
         self.arch = a
         self.n_out = int(out_dims[-1])
 
+    def set_layer_mask(self, mask):
+        """Declare the 0/1 mask of the network (list of per-layer matrices, a packed vector, or None for dense): blocks of the
+        first layer in which it is all zero cost neither device memory nor matrix-core work (npbnn_set_layer_mask).  Weights
+        passed afterwards must be zero where the mask is."""
+        m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
+        self._chk(self._lib.npbnn_set_layer_mask(self._ctx, capi.dptr(m)))
+
     def set_arch_from_weights(self, weights, in_dim, act_kind, out_kind, lik_kind, n_targets=0, final_activation=False):
         """Derive layer sizes and bias flags from the weight shapes: layer l has a
         bias iff its matrix has in_l + 1 columns (reference: BNN_lib.py:157-161)."""

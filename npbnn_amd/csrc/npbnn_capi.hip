@@ -40,10 +40,11 @@ eval_fn_t pick_eval_d3_gauss_fast(int mt0, int f16);
 }
 
 // lk: likelihood class of the build (npbnn::lik_class); the float64 row-wise class has single-candidate builds only
-static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk, bool fast = false) {
+static eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk, bool fast = false, bool blocked = false) {
     using namespace npbnn;
     if (fast) {
         const bool g = lk == kLikGauss;
+        if (blocked) f16 = 2;                 // (fast_launch_ok: block structure only on the fp16-split path)
         if (n_cand <= 1) return g ? pick_eval_d1_gauss_fast(mt0, f16) : pick_eval_d1_cat_fast(mt0, f16);
         if (n_cand == 2) return g ? pick_eval_d2_gauss_fast(mt0, f16) : pick_eval_d2_cat_fast(mt0, f16);
         return g ? pick_eval_d3_gauss_fast(mt0, f16) : pick_eval_d3_cat_fast(mt0, f16);
@@ -92,6 +93,9 @@ struct npbnn_ctx {
     int mt0_template = 1;
     int l0_option = 0;             // NPBNN_L0_AUTO / _F32 / _F16
     int fast_option = 1;           // NPBNN_OPT_FAST_TAILS
+    // layer-0 block structure (npbnn_set_layer_mask): which (16-node tile, 16-feature group) blocks of the mask hold a nonzero;
+    // empty = dense
+    std::vector<unsigned char> l0_blocks;      // [mt][ceil(in_dim / 16)]
     float* d_xscale = nullptr;     // per-feature power-of-two scales of the fp16-split path (from the training matrix)
     float* d_wscale = nullptr;
     int scale_F = 0;
@@ -300,7 +304,27 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         L.kt = (l == 0 && f16) ? 2 * ((in + 31) / 32) : (in + 15) / 16;   // 1-KiB pieces (16 rows x 64 B) per tile
         L.mt = (out + 15) / 16;
         L.frag_off = off;
-        off += L.kt * L.mt * 256;
+        if (l == 0) {
+            // K-units of the layer-0 loop (32 features on the fp16-split path, 16 on the float32 one); per output tile the hull of
+            // the units in which the mask has anything (the whole layer when no structure was declared)
+            const int g16 = (in + 15) / 16, per_unit = f16 ? 2 : 1, units = f16 ? (in + 31) / 32 : g16;
+            int slots = 0;
+            for (int mt = 0; mt < kMaxMT; ++mt) { net.l0_begin[mt] = 0; net.l0_end[mt] = 0; net.l0_base[mt] = 0; }
+            for (int mt = 0; mt < L.mt; ++mt) {
+                int b = 0, e = units;
+                if (!ctx->l0_blocks.empty()) {
+                    b = units; e = 0;
+                    for (int g = 0; g < g16; ++g)
+                        if (ctx->l0_blocks[(size_t)mt * g16 + g]) { const int u = g / per_unit; if (u < b) b = u; if (u + 1 > e) e = u + 1; }
+                    if (e <= b) { b = 0; e = 0; }
+                }
+                net.l0_begin[mt] = b; net.l0_end[mt] = e; net.l0_base[mt] = slots;
+                slots += e - b;
+            }
+            off += slots * (f16 ? 512 : 256);
+        } else {
+            off += L.kt * L.mt * 256;
+        }
         L.w_off = woff;
         woff += out * (in + L.has_bias);
         in = out;
@@ -442,12 +466,21 @@ struct LaunchPlan {
 // May a launch that wants nothing but the likelihood terms run on the fast builds (eval_kernel, FAST)?  2 or 3 layers, later
 // layers of <= 16 nodes, layer 0 of <= 16 * kFastMaxMT0, categorical (padding outputs masked through the bias) or Gaussian
 // likelihood, no row or class weights, no activation after the last layer.
+// does layer 0 skip anything (some output tile without weights in some K-unit)?
+bool l0_blocked(const NetMeta& net) {
+    const int units = net.l0_f16 ? net.L[0].kt / 2 : net.L[0].kt;
+    for (int mt = 0; mt < net.L[0].mt; ++mt)
+        if (net.l0_begin[mt] != 0 || net.l0_end[mt] != units) return true;
+    return false;
+}
+
 bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d) {
     const NetMeta& net = ctx->net;
     if (!ctx->fast_option || max_inner_tiles(net) != 1 || net.n_layers < 2 || net.n_layers > kFastLayers || net.L[0].mt > kFastMaxMT0) return false;
     if (net.final_act || d.inst_w || ctx->n_classw > 0) return false;
+    if (l0_blocked(net) && !net.l0_f16) return false;          // (the fast builds for block-structured layers are fp16-split ones)
     if (net.lik_kind == NPBNN_LIK_CATEGORICAL) return net.pad_masked != 0 && d.labels != nullptr;
-    return net.lik_kind == NPBNN_LIK_GAUSS && d.targets != nullptr;
+    return net.lik_kind == NPBNN_LIK_GAUSS && d.targets != nullptr && net.k_targets <= kFastGaussTargets;
 }
 
 // lik_only: the caller wants the likelihood terms and nothing else from the launch (no statistics, no predictions)
@@ -481,7 +514,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
     lp->fn = predict_only ? npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand, kLikCat)
                           : npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand,
-                                                   lik_class(ctx->net.lik_kind), fast);
+                                                   lik_class(ctx->net.lik_kind), fast, fast && l0_blocked(ctx->net));
     if (!lp->fn) return fail(ctx, NPBNN_E_STATE, "no evaluation kernel for this shape (internal error)");
     lp->wpb = wpb;
     lp->lds = lds;
@@ -614,9 +647,17 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
                     const int mt = o / 16, u = o % 16;
                     if (l == 0 && f16) {
                         const int ks = c / 32, kg = (c % 32) / 8, jj = c % 8;
-                        const int half_index = 2 * L.frag_off + ((((ks * L.mt + mt) * 2) * 64) + kg * 16 + u) * 8 + jj;
-                        pos = (int)(0x80000000u | (unsigned)half_index);
+                        if (ks < ctx->net.l0_begin[mt] || ks >= ctx->net.l0_end[mt]) pos = kSkipPos;     // outside the block structure: always 0
+                        else {
+                            const int slot = ctx->net.l0_base[mt] + ks - ctx->net.l0_begin[mt];
+                            const int half_index = 2 * L.frag_off + (((slot * 2) * 64) + kg * 16 + u) * 8 + jj;
+                            pos = (int)(0x80000000u | (unsigned)half_index);
+                        }
                         scale[wi] = wscale[(size_t)c];
+                    } else if (l == 0) {
+                        const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4;
+                        if (kt < ctx->net.l0_begin[mt] || kt >= ctx->net.l0_end[mt]) pos = kSkipPos;
+                        else pos = L.frag_off + ((ctx->net.l0_base[mt] + kt - ctx->net.l0_begin[mt]) * 64 + kq * 16 + u) * 4 + sidx;
                     } else {
                         const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4;
                         pos = L.frag_off + ((kt * L.mt + mt) * 64 + kq * 16 + u) * 4 + sidx;
@@ -861,6 +902,7 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     ctx->arch_set = false;
     const npbnn_arch previous = ctx->arch;
     ctx->arch = *arch;
+    ctx->l0_blocks.clear();                      // (a structure belongs to one architecture: npbnn_set_layer_mask after this call)
     int rc = rebuild_net(ctx, false);            // float32 layout first; plan_launch switches to fp16-split when it applies
     if (rc) {
         ctx->arch = previous;
@@ -876,6 +918,29 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_w, ((size_t)ctx->n_weights + arch->in_dim) * sizeof(double)));
     ctx->arch_set = true;
     return NPBNN_OK;
+}
+
+int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "set_layer_mask: call npbnn_set_arch first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<unsigned char> blocks;
+    if (mask_packed) {
+        const npbnn_arch& a = ctx->arch;
+        const int in = a.in_dim, out = a.out_dim[0], ld = in + (a.has_bias[0] ? 1 : 0);
+        const int g16 = (in + 15) / 16, mts = (out + 15) / 16;
+        blocks.assign((size_t)mts * g16, 0);
+        bool dense = true;
+        for (int o = 0; o < out; ++o)
+            for (int c = 0; c < in; ++c)
+                if (mask_packed[(size_t)o * ld + (a.has_bias[0] ? 1 : 0) + c] != 0.0) blocks[(size_t)(o / 16) * g16 + c / 16] = 1;
+        for (unsigned char b : blocks) dense = dense && b != 0;
+        if (dense) blocks.clear();
+    }
+    if (blocks == ctx->l0_blocks) return NPBNN_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->l0_blocks.swap(blocks);
+    return rebuild_net(ctx, ctx->net.l0_f16 != 0);
 }
 
 int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
@@ -946,7 +1011,8 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     int ovf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *overflowed = ctx->net.l0_f16 && ovf;
+    if (ovf & kFlagStructure) return fail(ctx, NPBNN_E_ARG, "eval: a layer-0 weight is not zero where the mask given to npbnn_set_layer_mask is");
+    *overflowed = ctx->net.l0_f16 && (ovf & kFlagF16Range);
     if (*overflowed) return NPBNN_OK;
     *out = *ctx->h_out;
     if (confusion)
@@ -1016,7 +1082,8 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     int ovf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!(ctx->net.l0_f16 && ovf)) break;
+    if (ovf & kFlagStructure) return fail(ctx, NPBNN_E_ARG, "predict: a layer-0 weight is not zero where the mask given to npbnn_set_layer_mask is");
+    if (!(ctx->net.l0_f16 && (ovf & kFlagF16Range))) break;
     if (ctx->l0_option == NPBNN_L0_F16) return fail(ctx, NPBNN_E_RANGE, "predict: a layer-0 weight left the fp16 range");
     }
     for (size_t i = 0; i < n_el; ++i) out_y[i] = (double)tmp[i];
@@ -1088,7 +1155,8 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
             int ovf = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (!(ctx->net.l0_f16 && ovf)) break;
+            if (ovf & kFlagStructure) return fail(ctx, NPBNN_E_ARG, "predict_sets: a layer-0 weight is not zero where the mask given to npbnn_set_layer_mask is");
+            if (!(ctx->net.l0_f16 && (ovf & kFlagF16Range))) break;
             if (ctx->l0_option == NPBNN_L0_F16) return fail(ctx, NPBNN_E_RANGE, "predict_sets: a layer-0 weight left the fp16 range");
         }
         double* dst = out_y + (size_t)s0 * per_set;
@@ -1102,6 +1170,7 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
 
 extern "C" int npbnn_comm_allgather_inplace_stream_(npbnn_comm* c, double* d_buf, int count, void* stream);
 extern "C" int npbnn_comm_info_(const npbnn_comm* c, int* device, int* rank, int* nranks);
+extern "C" void npbnn_comm_abort_(npbnn_comm* c);
 
 namespace {
 
@@ -1463,7 +1532,9 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
                        acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
     }
-    const int overflow = (ctx->net.l0_f16 && *reinterpret_cast<const int*>(ctx->h_res + 448)) ? 1 : 0;
+    const int flags = *reinterpret_cast<const int*>(ctx->h_res + 448);
+    if (flags & kFlagStructure) return fail(ctx, NPBNN_E_ARG, "chain_run: a layer-0 weight is not zero where the mask given to npbnn_set_layer_mask is");
+    const int overflow = (ctx->net.l0_f16 && (flags & kFlagF16Range)) ? 1 : 0;
     if (overflow && !exchange_run)           // W_inout untouched: the caller re-runs this batch with cfg->force_f32 = 1
         return fail(ctx, NPBNN_E_RANGE, "chain_run: a layer-0 weight left the fp16 range during this batch");
     {
@@ -1566,7 +1637,8 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
     std::vector<XLayout> XL(n_jobs);
     std::vector<ChainBatch> B(n_jobs);
     const size_t rec_bytes = (size_t)n_seg * n_chains * kRecDoubles * sizeof(double);
-    for (int q = 0; q < n_jobs; ++q) {
+    int rc_prepare = NPBNN_OK;       // first failure of this rank before anything is enqueued (the ranks agree on it below)
+    auto size_exchange_block = [&](int q) -> int {
         npbnn_ctx* ctx = jobs[q].ctx;
         XLayout& L = XL[q];
         L.sj = 256;
@@ -1587,16 +1659,25 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
             ctx->xbuf_cap = cap;
         }
         if (!ctx->ev_x) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+        return NPBNN_OK;
+    };
+    for (int q = 0; q < n_jobs && !rc_prepare; ++q) {
+        rc_prepare = size_exchange_block(q);
+        if (rc_prepare && jobs[q].ctx != ctx0) ctx0->err = jobs[q].ctx->err;
     }
-    double* d_rec = reinterpret_cast<double*>(ctx0->d_xbuf + XL[0].rec);
-    for (int q = 0; q < n_jobs; ++q) {
+    double* d_rec = rc_prepare ? nullptr : reinterpret_cast<double*>(ctx0->d_xbuf + XL[0].rec);
+    // Everything that can fail on this rank alone (bad draws, a weight outside the fp16 range, allocation) is checked BEFORE the
+    // first collective is enqueued, and the ranks agree on the outcome (one host-side all-gather): either every rank enqueues
+    // its in-place all-gathers, or none does.
+    for (int q = 0; q < n_jobs && !rc_prepare; ++q) {
         const npbnn_chain_job& J = jobs[q];
         npbnn_ctx* ctx = J.ctx;
         int rc = chain_prepare(ctx, J.cfg, J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, seg_len, &B[q], n_jobs == 1);
         if (rc) {
             if (ctx != ctx0) ctx0->err = ctx->err;
             for (int p2 = 0; p2 <= q; ++p2) (void)hipStreamSynchronize(jobs[p2].ctx->stream);
-            return rc;
+            rc_prepare = rc;
+            break;
         }
         const XLayout& L = XL[q];
         ExchangeParams x{};
@@ -1617,8 +1698,29 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         memcpy(ctx->h_xbuf + L.sj, swap_j, (size_t)n_seg * sizeof(int));
         memcpy(ctx->h_xbuf + L.sk, swap_k, (size_t)n_seg * sizeof(int));
         memcpy(ctx->h_xbuf + L.su, swap_logu, (size_t)n_seg * sizeof(double));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xbuf, ctx->h_xbuf, L.state, hipMemcpyHostToDevice, ctx->stream));
-        if (x.snap_w) HIP_TRY(ctx, hipMemsetAsync(ctx->d_xbuf + L.cold, 0, (size_t)n_seg * ctx->n_weights * sizeof(double), ctx->stream));
+        if (hipMemcpyAsync(ctx->d_xbuf, ctx->h_xbuf, L.state, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            (x.snap_w && hipMemsetAsync(ctx->d_xbuf + L.cold, 0, (size_t)n_seg * ctx->n_weights * sizeof(double), ctx->stream) != hipSuccess))
+            rc_prepare = fail(ctx0, NPBNN_E_HIP, "chains_run_exchange: staging the exchange block of job %d failed", q);
+    }
+    if (comm && world > 1) {
+        std::vector<double> ok_all((size_t)world, 0.0);
+        const double ok_mine = rc_prepare == NPBNN_OK ? 1.0 : 0.0;
+        int rc = npbnn_comm_allgather_f64(comm, &ok_mine, 1, ok_all.data());
+        if (rc) {
+            ctx0->err = npbnn_last_error(nullptr);
+            for (int q = 0; q < n_jobs; ++q) (void)hipStreamSynchronize(jobs[q].ctx->stream);
+            return rc;
+        }
+        int bad_rank = -1;
+        for (int r = 0; r < world; ++r)
+            if (ok_all[(size_t)r] != 1.0 && bad_rank < 0) bad_rank = r;
+        if (bad_rank >= 0) {
+            for (int q = 0; q < n_jobs; ++q) (void)hipStreamSynchronize(jobs[q].ctx->stream);
+            if (rc_prepare) return rc_prepare;
+            return fail(ctx0, NPBNN_E_COMM, "chains_run_exchange: rank %d could not prepare its chains; nothing was enqueued on any rank", bad_rank);
+        }
+    } else if (rc_prepare) {
+        return rc_prepare;
     }
     HIP_TRY(ctx0, hipMemsetAsync(d_rec, 0, rec_bytes, ctx0->stream));
     if (n_jobs > 1) {      // the other chains' first record must not overtake the clearing of the shared block
@@ -1631,8 +1733,9 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         for (int q = 0; q < n_jobs; ++q) {
             npbnn_ctx* ctx = jobs[q].ctx;
             int rc = chain_enqueue(ctx, B[q], passes_for_segment(ctx, B[q], seg_len, launch_slack));
-            if (rc) {
+            if (rc) {       // the peers have this interval's collective in flight: it must not pair with anything else we issue
                 if (ctx != ctx0) ctx0->err = ctx->err;
+                if (comm && world > 1) npbnn_comm_abort_(comm);
                 (void)hipDeviceSynchronize();
                 return rc;
             }
@@ -1652,6 +1755,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
             int rc = npbnn_comm_allgather_inplace_stream_(comm, d_rec + (size_t)s * n_chains * kRecDoubles, rec_per_rank, xs[0]);
             if (rc) {
                 ctx0->err = npbnn_last_error(nullptr);
+                if (world > 1) npbnn_comm_abort_(comm);
                 for (int q = 0; q < n_jobs; ++q) (void)hipStreamSynchronize(jobs[q].ctx->stream);
                 return rc;
             }

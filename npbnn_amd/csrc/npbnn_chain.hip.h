@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__
 #endif  // NPBNN_KERNELS_MAIN
 
 __device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) {
+    if (pos == 0x7fffffff) return;                   // an entry the image does not hold (outside the layer-0 block structure: it is 0)
     if (pos < 0) {                                   // fp16-split layer-0 entry
         const float wv = (float)(v * (double)scale);
         _Float16 hi, lo;
@@ -465,7 +466,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
             v *= m;
             pv_out[(size_t)j * c.M + e] = v;
-            if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) *c.overflow = 1;
+            if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
             if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
                 int l = 0;
 #pragma unroll
@@ -496,7 +497,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     __syncthreads();
     if (tid == 0) {
         const double base_lp = sh.s_lp;
-        if (c.stop_on_overflow && n_new > 0 && atomicAdd(c.overflow, 0) != 0) {     // (the flag was raised before the barrier above)
+        if (c.stop_on_overflow && n_new > 0 && (atomicAdd(c.overflow, 0) & kFlagF16Range) != 0) {     // (the flag was raised before the barrier above)
             n_new = 0;
             st->poisoned = 1;
         }

@@ -20,6 +20,7 @@ struct npbnn_comm {
     void* d_send = nullptr;
     void* d_recv = nullptr;
     size_t cap_send = 0, cap_recv = 0;
+    bool dead = false;          // aborted after a failure in the middle of an exchange run: every later call fails at once
 };
 
 namespace {
@@ -101,6 +102,7 @@ int npbnn_comm_init(int device_id, int rank, int nranks, const char id[128], npb
 
 int npbnn_comm_allgather_f64(npbnn_comm* c, const double* send, int count, double* recv) {
     if (!c || !send || !recv || count < 1) return cfail(NPBNN_E_ARG, "comm_allgather: bad arguments");
+    if (c->dead) return cfail(NPBNN_E_COMM, "comm_allgather: this communicator was aborted after an earlier failure");
     C_HIP(hipSetDevice(c->device));
     const size_t sb = (size_t)count * sizeof(double), rb = sb * c->nranks;
     int rc = ensure(c, sb, rb);
@@ -114,6 +116,7 @@ int npbnn_comm_allgather_f64(npbnn_comm* c, const double* send, int count, doubl
 
 int npbnn_comm_bcast_i64(npbnn_comm* c, int64_t* buf, int count, int root) {
     if (!c || !buf || count < 1 || root < 0 || root >= c->nranks) return cfail(NPBNN_E_ARG, "comm_bcast: bad arguments");
+    if (c->dead) return cfail(NPBNN_E_COMM, "comm_bcast: this communicator was aborted after an earlier failure");
     C_HIP(hipSetDevice(c->device));
     const size_t b = (size_t)count * sizeof(int64_t);
     int rc = ensure(c, b, b);
@@ -129,8 +132,21 @@ int npbnn_comm_bcast_i64(npbnn_comm* c, int64_t* buf, int count, int root) {
 // d_buf holds nranks * count doubles, this rank's share already at d_buf + rank * count - with no host synchronisation
 int npbnn_comm_allgather_inplace_stream_(npbnn_comm* c, double* d_buf, int count, void* stream) {
     if (!c || !d_buf || count < 1) return cfail(NPBNN_E_ARG, "comm_allgather_inplace: bad arguments");
+    if (c->dead) return cfail(NPBNN_E_COMM, "comm_allgather_inplace: this communicator was aborted after an earlier failure");
     C_NCCL(ncclAllGather(d_buf + (size_t)c->rank * count, d_buf, (size_t)count, ncclDouble, c->comm, (hipStream_t)stream));
     return NPBNN_OK;
+}
+
+// internal: a rank that fails after its peers have collectives of this communicator in flight cannot leave them paired with
+// whatever it would issue next - it tears the communicator down (the peers' pending collectives end with an error instead of
+// waiting for ever) and every later call on the handle fails at once.  The caller starts over with a new communicator.
+void npbnn_comm_abort_(npbnn_comm* c) {
+    if (!c || c->dead) return;
+    c->dead = true;
+    if (c->comm) {
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+    }
 }
 
 int npbnn_comm_info_(const npbnn_comm* c, int* device, int* rank, int* nranks) {

@@ -61,6 +61,13 @@ struct NetMeta {
     int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)
     int pad_masked;     // the padding outputs of the last layer (n_out .. 16 * mt - 1) carry a bias of kPadLogit: they drop out of
                         // the softmax by themselves (exp -> 0, never the maximum) and the epilogue needs no per-output predicate
+    // Block structure of layer 0 (masks of create_mask, np_bnn/BNN_lib.py:16-47: consecutive input columns wired to one block of
+    // nodes).  K-unit = what one step of the layer-0 loop contracts: 32 features on the fp16-split path, 16 on the float32 path.
+    // Output tile mt (16 nodes) has weights only in the K-units l0_begin[mt] .. l0_end[mt]-1; its fragments sit in the image one
+    // after the other, the first of them `l0_base[mt]` fragment slots into the layer-0 block (dense layer: begin 0, end = all
+    // units, base = mt * units).  The loop skips (unit, tile) pairs outside the range: no fragment reads, no MFMAs - and the
+    // skipped weights, being zero, would have added nothing, so the sums are the dense ones bit for bit.
+    int l0_begin[kMaxMT], l0_end[kMaxMT], l0_base[kMaxMT];
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
 };

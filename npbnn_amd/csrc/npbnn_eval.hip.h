@@ -31,6 +31,10 @@ template <>
 struct TileAcc<kLikGauss> { // ... or, for the Gaussian likelihood, residual moments of the 4 target columns this lane owns
     double s1[4], s2[4];
 };
+// The fast Gaussian builds are for <= kFastGaussTargets target columns (every BASELINE regression shape: 1 or 2): all of them
+// belong to the lanes of the first quarter (kq = 0) and the moments of columns 2 and 3 of a lane, 8 float64 registers per
+// candidate that the general build carries through the whole kernel, are never touched.
+constexpr int kFastGaussTargets = 2;
 
 // A value every lane of the wave holds identically, moved to scalar registers.  The kernel reads its launch-invariant
 // parameters through pointers that other code inlined into it (the chain step) writes through, and its first branch is
@@ -316,8 +320,9 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         }
     } else {
         const float* tg = reinterpret_cast<const float*>(a_slot + hp.aux_off_t);
+        constexpr int GI = PLAIN ? kFastGaussTargets : 4;          // target columns a lane can own in this build
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < GI; ++i) {
             const int o = 4 * kq + i;
             if (o < k_targets && row_ok) {
                 const float y = tg[n * k_targets + o];
@@ -373,9 +378,14 @@ __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int 
 // (`fast_launch_ok` below says which: every chain pass and plain evaluation of the BASELINE configs).  It holds only the
 // shape-specialised tails and none of the scalars the general epilogue keeps alive (statistics, predictions, row weights ...),
 // which is what brings the tile loop's scalar registers back under the file's size.  Same arithmetic, same bits.
-template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false>
+// BLK (fast builds only): layer 0 has a block structure (NetMeta::l0_begin ...) and the loop skips the (K-unit, tile) pairs
+// without weights; the fast builds without it are for dense first layers and carry no test for it.  The general builds always
+// honour the structure.
+template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false, bool BLK = false>
 __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg) {
     static_assert(!FAST || (MTI == 1 && LK != kLikGen), "fast builds: narrow later layers, categorical or Gaussian likelihood");
+    static_assert(!BLK || (FAST && MT0 >= 2), "block-structure builds are fast builds of layers with several output tiles");
+    constexpr bool SKIP = !FAST || BLK;          // this build tests which tiles have weights in a K-unit
     // launch index; bit 30: another launch of the batch has been enqueued behind this one (two-stream schedule, sync_step_leave)
     const int launch = launch_arg & 0x3fffffff;
     const bool next_enqueued = (launch_arg >> 30) & 1;
@@ -602,11 +612,12 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     NPBNN_ESTAMP(3);
 
     TileAcc<LK> A[D];
+    constexpr int GI = FAST ? kFastGaussTargets : 4;           // Gaussian moments a lane keeps (see kFastGaussTargets)
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         if constexpr (LK == kLikGauss) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { A[j].s1[i] = 0.0; A[j].s2[i] = 0.0; }
+            for (int i = 0; i < GI; ++i) { A[j].s1[i] = 0.0; A[j].s2[i] = 0.0; }
         } else {
             A[j].ll = 0.0;
         }
@@ -615,6 +626,23 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const float* const imgs = reinterpret_cast<const float*>(smem);
     const int frag0_off = uni(net.L[0].frag_off) + lane * 4;       // float offsets inside an image
     const int bias0_off = uni(net.L[0].bias_off) + 4 * kq;
+    // block structure of layer 0 (NetMeta::l0_begin ...): output tile mt has fragments for the K-units ub[mt] .. ue[mt]-1 only, the
+    // one of unit u at (uo[mt] + u) fragment slots into the layer-0 block (a slot = 512 floats on the fp16-split path: high and low
+    // parts; 256 on the float32 path)
+    int ub[MT0], ue[MT0], uo[MT0];
+#pragma unroll
+    for (int mt = 0; mt < MT0; ++mt) {
+        ub[mt] = uni(net.l0_begin[mt]);
+        ue[mt] = uni(net.l0_end[mt]);
+        uo[mt] = uni(net.l0_base[mt]) - ub[mt];
+    }
+    auto unit_tiles = [&](int u) {          // bit mt: tile mt has weights in K-unit u (wave-uniform)
+        if constexpr (!SKIP) return (1 << MT0) - 1;
+        int m = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT0; ++mt) m |= (u >= ub[mt] && u < ue[mt]) ? (1 << mt) : 0;
+        return m;
+    };
     auto load_bias0 = [&](f32x4 (&acc0)[D][MT0]) {
 #pragma unroll
         for (int j = 0; j < D; ++j)
@@ -692,12 +720,14 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 ld_slot = ring_next(slot_b);
             };
             auto load_w = [&](WFrag& w, int kstep, int j) {
-                const float* fr = imgs + (size_t)j * image_floats + frag0_off + kstep * (MT0 * 512);
+                const float* fr = imgs + (size_t)j * image_floats + frag0_off + kstep * 512;
+                const int live = unit_tiles(kstep);
 #pragma unroll
-                for (int mt = 0; mt < MT0; ++mt) {
-                    w.wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
-                    w.wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
-                }
+                for (int mt = 0; mt < MT0; ++mt)
+                    if (live & (1 << mt)) {
+                        w.wh[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512);
+                        w.wl[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512 + 256);
+                    }
             };
             NPBNN_WAIT_VMCNT(0);                          // (the barriers above already drained this wave's loads)
             load_x(Xb[0]);
@@ -707,6 +737,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             auto step = [&](auto par_tag) {
                 constexpr int PAR = decltype(par_tag)::value;
                 const int ks_next = (ks + 1 == KS) ? 0 : ks + 1;
+                const int live = unit_tiles(ks);          // tiles with weights in this K-step (all of them in a dense layer)
                 bool issued = false;
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
@@ -731,11 +762,14 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     __builtin_amdgcn_sched_barrier(0);    // keep the LDS reads of the next unit ahead of this unit's MFMAs
 #ifndef NPBNN_EXP_NO_L0       // (timing experiment only: without the layer-0 MFMAs)
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wl[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wl[mt], Xb[PAR].xh, acc0[j][mt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xl, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc.wh[mt], Xb[PAR].xl, acc0[j][mt], 0, 0, 0);
 #else
                     acc0[j][0][0] += (float)wc.wh[0][0] + (float)wc.wl[MT0 - 1][7] + (float)Xb[PAR].xh[0] + (float)Xb[PAR].xl[7];
 #endif
@@ -772,8 +806,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         // ---------------- layer 0: H0^T = W0 . X^T, K streamed from the ring, every candidate on the same X piece ----------------
         f32x4 acc0[D][MT0];
         load_bias0(acc0);
-        int fr_off = frag0_off;
+        int fr_off = frag0_off;            // + K-unit * slot size
+        int unit = 0;
         auto consume = [&]() {
+            const int live = unit_tiles(unit);
             if constexpr (F16) {
                 // one K=32 step = two 1-KiB pieces; lane (n, kg) takes feature group kg: piece kg>>1, entries 2(kg&1) (high
                 // parts) and 2(kg&1)+1 (low parts); three MFMAs per tile: wh.xh + wl.xh + wh.xl
@@ -787,18 +823,23 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     const float* fr = imgs + (size_t)j * image_floats + fr_off;
                     f16x8 wh[MT0], wl[MT0];
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) {
-                        wh[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512);
-                        wl[mt] = *reinterpret_cast<const f16x8*>(fr + mt * 512 + 256);
-                    }
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) {
+                            wh[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512);
+                            wl[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512 + 256);
+                        }
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xh, acc0[j][mt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], xh, acc0[j][mt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
                 }
-                fr_off += MT0 * 512;
+                fr_off += 512;
+                ++unit;
             } else {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);
                 cs_slot = ring_next(cs_slot);
@@ -807,14 +848,16 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     const float* fr = imgs + (size_t)j * image_floats + fr_off;
                     f32x4 a[MT0];
 #pragma unroll
-                    for (int mt = 0; mt < MT0; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(fr + mt * 256);
+                    for (int mt = 0; mt < MT0; ++mt)
+                        if (live & (1 << mt)) a[mt] = *reinterpret_cast<const f32x4*>(fr + uo[mt] * 256);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int mt = 0; mt < MT0; ++mt)
-                            acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[j][mt], 0, 0, 0);
+                            if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], x[s], acc0[j][mt], 0, 0, 0);
                 }
-                fr_off += MT0 * 256;
+                fr_off += 256;
+                ++unit;
             }
         };
         constexpr int STEP = F16 ? 2 : 1;               // pieces per consume()
@@ -859,7 +902,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         for (int j = 0; j < D; ++j) {
             if constexpr (LK == kLikGauss) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < GI; ++i) {
                     A[j].s1[i] = row_sum_f64(A[j].s1[i]);
                     A[j].s2[i] = row_sum_f64(A[j].s2[i]);
                 }
@@ -878,8 +921,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 if (n == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        ws[1 + 4 * kq + i] = A[j].s1[i];
-                        ws[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = A[j].s2[i];
+                        ws[1 + 4 * kq + i] = i < GI ? A[j].s1[i < GI ? i : 0] : 0.0;
+                        ws[1 + NPBNN_MAX_TARGETS + 4 * kq + i] = i < GI ? A[j].s2[i < GI ? i : 0] : 0.0;
                     }
                 }
             } else {

@@ -24,6 +24,9 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 }
 
 constexpr float kF16Safe = 60000.0f;   // |value| above this does not survive fp16 (max 65504)
+// bits of the flag word the packing / chain kernels raise (EvalParams / ChainParams `overflow`)
+constexpr int kFlagF16Range = 1;       // a scaled layer-0 weight left the fp16 range: the caller repeats on the float32 path
+constexpr int kFlagStructure = 2;      // a weight is not zero where the layer-0 block structure says there are none
 
 // One item of the weight image.  Layer-l fragment layouts (16-byte entries, one per lane):
 //   float32 : entry ((kt*MT + mt)*64 + lane) = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + 0..3]
@@ -49,6 +52,7 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                 const int mt = rest % L.mt, ks = rest / L.mt;
                 const int o = 16 * mt + (lane & 15);
                 const int c0 = 32 * ks + 8 * (lane >> 4);
+                const bool stored = ks >= net.l0_begin[mt] && ks < net.l0_end[mt];       // (block structure: see NetMeta)
                 f16x8 v;
                 for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
                 if (o < L.out_dim) {
@@ -58,19 +62,22 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                         if (c < L.in_dim) {
                             const bool overridden = (col_override != nullptr && !isnan(col_override[c]));
                             const float wv = overridden ? 0.f : (float)(row[c] * (double)w_scale[c]);
-                            if (overflow && !(fabsf(wv) <= kF16Safe)) *overflow = 1;
+                            if (overflow && !(fabsf(wv) <= kF16Safe)) atomicOr(overflow, kFlagF16Range);
+                            if (overflow && !stored && row[c] != 0.0) atomicOr(overflow, kFlagStructure);
                             _Float16 hi, lo;
                             split_f16(wv, hi, lo);
                             v[j] = part ? lo : hi;
                         }
                     }
                 }
-                *reinterpret_cast<f16x8*>(image + L.frag_off + (long long)piece * 4) = v;
+                if (stored)
+                    *reinterpret_cast<f16x8*>(image + L.frag_off + ((long long)((net.l0_base[mt] + ks - net.l0_begin[mt]) * 2 + part) * 64 + lane) * 4) = v;
                 return;
             }
             const int mt = tile % L.mt, kt = tile / L.mt;
             const int o = 16 * mt + (lane & 15);
             const int c0 = 16 * kt + 4 * (lane >> 4);
+            const bool stored = l > 0 || (kt >= net.l0_begin[mt] && kt < net.l0_end[mt]);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (o < L.out_dim) {
                 const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
@@ -79,10 +86,12 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                     if (c < L.in_dim) {
                         bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
                         v[s] = overridden ? 0.f : (float)row[c];
+                        if (overflow && !stored && row[c] != 0.0) atomicOr(overflow, kFlagStructure);
                     }
                 }
             }
-            *reinterpret_cast<f32x4*>(image + L.frag_off + (long long)piece * 4) = v;
+            if (l > 0) *reinterpret_cast<f32x4*>(image + L.frag_off + (long long)piece * 4) = v;
+            else if (stored) *reinterpret_cast<f32x4*>(image + L.frag_off + ((long long)(net.l0_base[mt] + kt - net.l0_begin[mt]) * 64 + lane) * 4) = v;
             return;
         }
         piece -= n_pieces;

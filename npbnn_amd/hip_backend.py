@@ -88,6 +88,8 @@ class HipBackend:
                 self.ctx.set_row_weights(instance_w=iw, class_w=cw)
         self._shapes = None
         self._act = bnn._act_fun
+        self._model = weakref.ref(bnn)          # (the model owns this object: no cycle)
+        self._mask_seen = None
         self._configure(bnn._w_layers)
         self._pinned = None
 
@@ -100,13 +102,20 @@ class HipBackend:
 
     def _configure(self, weights):
         shapes = tuple(w.shape for w in weights)
-        if shapes == self._shapes:
-            return
-        flags = bias_flags(weights, self.n_features)
-        self.ctx.set_arch(self.n_features, [s[0] for s in shapes], flags, self._act.device_kind(),
-                          capi.OUT_IDENTITY if self.out_kind is None else self.out_kind, self.lik_kind,
-                          self.n_targets)
-        self._shapes = shapes
+        if shapes != self._shapes:
+            flags = bias_flags(weights, self.n_features)
+            self.ctx.set_arch(self.n_features, [s[0] for s in shapes], flags, self._act.device_kind(),
+                              capi.OUT_IDENTITY if self.out_kind is None else self.out_kind, self.lik_kind,
+                              self.n_targets)
+            self._shapes = shapes
+            self._mask_seen = None
+        # block structure of the first layer (npBNN.apply_mask): the device stores and multiplies only the blocks the mask keeps
+        model = self._model()
+        mask = getattr(model, "_mask", None) if model is not None else None
+        if mask is not self._mask_seen:
+            ok = mask is not None and len(mask) == len(shapes) and all(np.shape(m) == sh for m, sh in zip(mask, shapes))
+            self.ctx.set_layer_mask(mask if ok else None)
+            self._mask_seen = mask
 
     def evaluate(self, weights, slopes=None, col_override=None, lik_temp=1.0, sigma=None, which=capi.TRAIN,
                  want_confusion=False):

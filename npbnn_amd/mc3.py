@@ -172,7 +172,10 @@ class MC3():
         return bnn_v, m_v
 
     exchange_batch = 20      # swap intervals per device call
-    device_exchange = True   # False: one device batch per interval, swap on the host (the reference's rhythm)
+    # swap intervals in device batches with the swaps decided on the GPU (True), or one device batch per interval and the swap
+    # on the host (False: the reference's rhythm).  None = the library's choice: device batches for the chains of ONE process;
+    # with several ranks the host path, until the in-place RCCL all-gather has been run between real ranks (set True to opt in).
+    device_exchange = None
 
     def run_mcmc(self):
         """The MC3 loop (reference: BNN_mc3.py:87-126): ``n_mc3_iteration`` rounds of [swap_frequency iterations of every
@@ -212,7 +215,8 @@ class MC3():
             if self.n_chains > 1:
                 got = ex.advance_intervals(chains, self.local_ids, self.n_chains, n, self.swap_frequency, self._swaps, done,
                                            comm=self.comm if self.comm.world_size > 1 else None, batch=n,
-                                           device=self.device_exchange, on_interval=on_interval)
+                                           device=(self.comm.world_size == 1) if self.device_exchange is None else self.device_exchange,
+                                           on_interval=on_interval)
             else:                                       # a single chain: no swaps, the cold chain is logged every interval
                 for _ in range(n):
                     for i in self.local_ids:

@@ -407,3 +407,56 @@ def test_g2_predicted_sigma_likelihood(golden_dir, hip):
     np.testing.assert_allclose(ctx.eval(inp2["weights"], lik_temp=0.5)["loglik"], 0.5 * g["lik_err"], rtol=LL_RTOL)
     assert_close(ctx.predict(inp2["weights"]), g["y_err"])
     ctx.close()
+
+
+@pytest.mark.parametrize("l0", ["auto", "f32"])
+@pytest.mark.parametrize("kind", ["classification", "regression"])
+def test_layer0_block_structure_is_the_dense_result_bit_for_bit(hip, l0, kind):
+    """npbnn_set_layer_mask: blocks of the first layer without weights are neither stored nor multiplied (create_mask layouts,
+    BNN_lib.py:16-47).  Skipped weights are zeros, so every result - likelihood on the fast and on the general build, confusion
+    counts, predictions - must be the dense one to the last bit, on the fp16-split and on the float32 path; a weight that is
+    not zero where the mask is fails the call."""
+    rs = np.random.default_rng(5)
+    n, f = 3001, 160                      # 5 K-steps of 32 features; 48 nodes = 3 output tiles
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    np.random.seed(7)
+    n_out = 6 if kind == "classification" else 2
+    w = orc.init_weights([48, 8], f, n_out, bias_node=2 if kind == "classification" else -1)
+    # 10 groups of 16 features -> blocks of 4, 5, 5, 5, 5, 5, 5, 5, 5, 4 nodes: tile 0 sees features 0..63, tile 1 48..127, tile 2 112..159
+    groups = np.repeat(np.arange(10), 16)
+    mask = orc.block_mask(w, [groups, [], []], [[4, 5, 5, 5, 5, 5, 5, 5, 5, 4], [], []])
+    if w[0].shape[1] == f + 1:            # (block_mask numbers columns from 0: with a bias column the layout shifts by one)
+        m0 = np.zeros(w[0].shape)
+        m0[:, 0] = 1
+        m0[:, 1:] = orc.block_mask([w[0][:, 1:]], [groups], [[4, 5, 5, 5, 5, 5, 5, 5, 5, 4]])[0]
+        mask[0] = m0
+    wm = [wi * mi for wi, mi in zip(w, mask)]
+    act = orc.Act("tanh")
+    if kind == "classification":
+        labels = rs.integers(0, n_out, n)
+        mk = lambda: make_ctx(hip, x, wm, act, 0, 0, labels=labels)                      # noqa: E731
+    else:
+        targets = rs.standard_normal((n, n_out))
+        mk = lambda: make_ctx(hip, x, wm, act, 1, 1, targets=targets, n_targets=n_out)   # noqa: E731
+    dense, blocked = mk(), mk()
+    for c in (dense, blocked):
+        c.set_l0_precision(l0)
+    blocked.set_layer_mask(mask)
+    for fast in (1, 0):
+        for c in (dense, blocked):
+            c.set_fast_tails(fast)
+        a, b = dense.eval(wm), blocked.eval(wm)
+        assert a["loglik"] == b["loglik"] and np.array_equal(a["sum_r2"], b["sum_r2"]), (l0, kind, fast)
+    if kind == "classification":
+        a, b = dense.eval(wm, want_confusion=True), blocked.eval(wm, want_confusion=True)
+        assert a["loglik"] == b["loglik"] and np.array_equal(a["confusion"], b["confusion"])
+    np.testing.assert_array_equal(dense.predict(wm), blocked.predict(wm))
+    assert blocked.l0_mode() == ("f32" if l0 == "f32" else "f16-split")
+    bad = [wm[0].copy()] + wm[1:]
+    bad[0][2, -1] = 0.25                   # node 2 (tile 0) x feature 159 (K-unit 4): outside tile 0's blocks
+    with pytest.raises(hip.NpbnnError, match="mask"):
+        blocked.eval(bad)
+    blocked.set_layer_mask(None)           # dense again: the same weights are fine
+    assert blocked.eval(bad)["loglik"] == dense.eval(bad)["loglik"]
+    dense.close()
+    blocked.close()

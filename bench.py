@@ -22,6 +22,7 @@ import csv
 import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -101,10 +102,13 @@ def measured_traffic(config, cand):
     write = fetch[0].replace("FETCH_SIZE", "WRITE_SIZE")
 
     def mean_kib(path, counter):
+        """mean over the dispatches of eval_kernel<MT0, MTI, F16, D = cand, ...> (the run also holds the single evaluation of
+        MCMC.__init__, a D = 1 build)"""
         vals = []
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == counter and "eval_kernel" in row.get("Kernel_Name", ""):
+                m = re.search(r"eval_kernel<\d+, \d+, \w+, (\d+),", row.get("Kernel_Name", ""))
+                if row.get("Counter_Name") == counter and m and int(m.group(1)) == cand:
                     vals.append(float(row["Counter_Value"]))
         return sum(vals) / len(vals) if vals else None
 

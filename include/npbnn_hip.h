@@ -224,6 +224,10 @@ typedef struct {
      * proposal is accepted.  NULL: sigma as sigma_given / sigma[] say. */
     const double* sigma_mult;
     const double* hastings;
+    /* hyper-priors with one scale per input node or per weight (npBNN.sample_prior_scale, BNN_env.py:196-221: hyper_p = 2, 3):
+     * the scale of every packed weight (n_weights values, layer matrices concatenated row-major like the weights), or NULL for
+     * one scale per layer (prior_scale[] above).  Constant over the call: the Gibbs step that redraws them runs between calls. */
+    const double* prior_scale_w;
 } npbnn_chain_cfg;
 #define NPBNN_SCHED_AUTO 0
 #define NPBNN_SCHED_SERIAL 1

@@ -59,7 +59,7 @@ class ChainCfg(C.Structure):
                 ("sigma", C.c_double * MAX_TARGETS), ("cur_loglik", C.c_double), ("cur_logprior", C.c_double),
                 ("cur_sigma", C.c_double * MAX_TARGETS), ("force_f32", C.c_int32), ("n_candidates", C.c_int32),
                 ("schedule", C.c_int32), ("reserved_", C.c_int32), ("sigma_mult", C.POINTER(C.c_double)),
-                ("hastings", C.POINTER(C.c_double))]
+                ("hastings", C.POINTER(C.c_double)), ("prior_scale_w", C.POINTER(C.c_double))]
 
 
 class ChainResult(C.Structure):

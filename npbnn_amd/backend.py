@@ -216,8 +216,19 @@ class HipContext:
     def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
                         cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None):
         cfg.prior_kind = int(prior_kind)
-        for i, s in enumerate(prior_scale):
-            cfg.prior_scale[i] = float(s)
+        cfg._keep_scale = None
+        cfg.prior_scale_w = None
+        if any(np.ndim(s) != 0 for s in prior_scale):
+            # hyper_p = 2 / 3: a scale per input node (one row, broadcast over the nodes) or per weight -> one per packed weight
+            rows = list(self.arch.out_dim[:self.arch.n_layers])
+            cols = [self.arch.in_dim + self.arch.has_bias[0]] + [rows[l - 1] + self.arch.has_bias[l] for l in range(1, self.arch.n_layers)]
+            per_w = np.concatenate([np.broadcast_to(np.asarray(s, dtype=np.float64), (r, c)).ravel()
+                                    for s, r, c in zip(prior_scale, rows, cols)])
+            cfg._keep_scale = capi.as_f64(per_w)
+            cfg.prior_scale_w = capi.dptr(cfg._keep_scale)
+        else:
+            for i, s in enumerate(prior_scale):
+                cfg.prior_scale[i] = float(s)
         cfg.w_bound = float(w_bound)
         cfg.temperature = float(temperature)
         cfg.lik_temp = float(lik_temp)

@@ -147,6 +147,7 @@ struct npbnn_ctx {
     double* d_llp = nullptr;
     double* d_lpp = nullptr;
     size_t iter_cap = 0;        // K capacity
+    double* d_pscale_w = nullptr;  // [n_weights] per-weight prior scales of the current batch (npbnn_chain_cfg.prior_scale_w)
     double* d_smult = nullptr;  // [K][k_targets] sigma multipliers, [K] Hastings terms (regression with an estimated error parameter)
     double* d_hast = nullptr;
     size_t smult_cap = 0;       // K capacity of the two
@@ -710,7 +711,7 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast};
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -913,6 +914,7 @@ int npbnn_set_arch(npbnn_ctx* ctx, const npbnn_arch* arch) {
     if (ctx->h_w) { (void)hipHostFree(ctx->h_w); ctx->h_w = nullptr; }
     if (ctx->d_wcur) { (void)hipFree(ctx->d_wcur); ctx->d_wcur = nullptr; }
     if (ctx->d_mask) { (void)hipFree(ctx->d_mask); ctx->d_mask = nullptr; }
+    if (ctx->d_pscale_w) { (void)hipFree(ctx->d_pscale_w); ctx->d_pscale_w = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_wraw, (size_t)kMaxCand * ctx->n_weights * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_colov, (size_t)arch->in_dim * sizeof(double)));
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_w, ((size_t)ctx->n_weights + arch->in_dim) * sizeof(double)));
@@ -1409,6 +1411,14 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     for (int l = 0; l < kMaxLayers; ++l) {
         c.prior_scale[l] = cfg->prior_scale[l];
         c.half_inv_s2[l] = cfg->prior_scale[l] > 0 ? 0.5 / (cfg->prior_scale[l] * cfg->prior_scale[l]) : 0.0;
+    }
+    c.prior_scale_w = nullptr;
+    if (cfg->prior_scale_w && cfg->prior_kind != NPBNN_PRIOR_UNIFORM) {
+        for (int i = 0; i < ctx->n_weights; ++i)
+            if (!(cfg->prior_scale_w[i] > 0.0)) return fail(ctx, NPBNN_E_ARG, "chain_run: prior_scale_w[%d] is not positive", i);
+        if (!ctx->d_pscale_w) HIP_TRY(ctx, hipMalloc(&ctx->d_pscale_w, wb));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pscale_w, cfg->prior_scale_w, wb, hipMemcpyHostToDevice, st));
+        c.prior_scale_w = ctx->d_pscale_w;
     }
     c.w_bound = cfg->w_bound;
     c.lik_temp = cfg->lik_temp;

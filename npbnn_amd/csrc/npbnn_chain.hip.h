@@ -23,11 +23,19 @@ struct FinalizeParams {
 
 // Sum value v of every wave's partial record: wave (threadIdx>>6) of the block takes values v = wave, wave+nw, ...;
 // lane l adds records l, l+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int nvals, double* tot /*LDS*/) {
-    // partials are laid out [value][workgroup]; wave w of this block sums values w, w+nw, ...: each lane adds workgroups
-    // lane, lane+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
+// The values of a partial record that mean something: the log-likelihood sum (0), or - Gaussian likelihood - the residual moments
+// of the k target columns (1 .. k and 1 + NPBNN_MAX_TARGETS .. + k); item i of the 1 + 2k (resp. 1) -> its index in the record
+__device__ __forceinline__ int partial_value_count(int lik_kind, int k_targets) { return lik_kind == NPBNN_LIK_GAUSS ? 1 + 2 * k_targets : 1; }
+__device__ __forceinline__ int partial_value_index(int item, int k_targets) {
+    return item <= k_targets ? item : 1 + NPBNN_MAX_TARGETS + (item - k_targets - 1);
+}
+
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int n_items, int k_targets, double* tot /*LDS*/) {
+    // partials are laid out [value][workgroup]; wave w of this block sums the items w, w+nw, ... (the values in use): each lane adds
+    // workgroups lane, lane+64, ... in order, then a fixed butterfly.  No float atomics -> deterministic.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int v = wave; v < nvals; v += nw) {
+    for (int it = wave; it < n_items; it += nw) {
+        const int v = partial_value_index(it, k_targets);
         double s = 0.0;
         for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)v * n_blocks + b];
 #pragma unroll
@@ -69,8 +77,7 @@ __device__ __forceinline__ void loglik_from_totals(const double* tot, int lik_ki
 __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams* __restrict__ fp) {
     const FinalizeParams& f = *fp;
     __shared__ double tot[kPartialStride];
-    const int nvals = (f.lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
-    reduce_partials(f.partials, f.n_waves, nvals, tot);
+    reduce_partials(f.partials, f.n_waves, partial_value_count(f.lik_kind, f.k_targets), f.k_targets, tot);
     if (threadIdx.x == 0) loglik_from_totals(tot, f.lik_kind, f.k_targets, f.n_rows, f.lik_temp, f.sigma_given, f.sigma, f.out);
 }
 #endif  // NPBNN_KERNELS_MAIN
@@ -133,6 +140,8 @@ struct ChainParams {
     int prior_kind;
     double prior_scale[kMaxLayers];
     double half_inv_s2[kMaxLayers];   // 0.5 / scale^2 (normal prior)
+    const double* prior_scale_w;      // one scale per packed weight (hyper-priors with a scale per input node or per weight,
+                                      // npBNN.sample_prior_scale, BNN_env.py:196-221), or nullptr: one per layer (above)
     double w_bound;
     double lik_temp;           // (the temperature is chain state: ChainDev)
     int sigma_given;           // Gaussian: 1 = use sigma_fixed, 0 = empirical
@@ -266,7 +275,9 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             const LayerMeta& L = c.net.L[l];
             const int n = L.out_dim * (L.in_dim + L.has_bias);
             const double sc = c.prior_scale[l];
-            if (c.prior_kind == NPBNN_PRIOR_NORMAL) {
+            if (c.prior_scale_w) {            // a scale per weight: the density entry by entry
+                for (int i = tid; i < n; i += blockDim.x) lp += log_prior_density(c.prior_kind, c.w_cur[L.w_off + i], c.prior_scale_w[L.w_off + i]);
+            } else if (c.prior_kind == NPBNN_PRIOR_NORMAL) {
                 double q = 0.0;
                 for (int i = tid; i < n; i += blockDim.x) { const double w = c.w_cur[L.w_off + i]; q += w * w; }
                 lp += -0.5 * q / (sc * sc);
@@ -313,12 +324,12 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     }
     NPBNN_STAMP(1);
     if (n_pend > 0) {
-        const int nvals = (lik_kind == NPBNN_LIK_GAUSS) ? kPartialStride : 1;
+        const int nvals = partial_value_count(lik_kind, c.net.k_targets);      // (only the values in use: 1, or 1 + 2k of the 33)
         {   // wave w sums items w, w+nw, ... (item = candidate * nvals + value): lanes add workgroups lane, lane+64, ... in order
             const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
             const double* part = c.partials + (size_t)pl.dec * part_stride;
             for (int item = wave; item < n_pend * nvals; item += nw) {
-                const int j = item / nvals, v = item % nvals;
+                const int j = item / nvals, v = partial_value_index(item % nvals, c.net.k_targets);
                 const double* src = part + ((size_t)j * kPartialStride + v) * c.n_blocks;
                 double s = 0.0;
                 for (int b = lane; b < c.n_blocks; b += 64) s += src[b];
@@ -471,7 +482,8 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 int l = 0;
 #pragma unroll
                 for (int q = 1; q < kMaxLayers; ++q) l += (i >= woff[q]) ? 1 : 0;
-                if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * half_inv_s2[l];
+                if (c.prior_scale_w) dlp[j] += prior_delta(c.prior_kind, v, base, c.prior_scale_w[i]);
+                else if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * half_inv_s2[l];
                 else dlp[j] += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
             }
         };

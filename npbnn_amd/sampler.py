@@ -405,9 +405,8 @@ class MCMC():
             return False
         if likelihood_kind(self._likelihood_f) in (None, capi.LIK_NONE):
             return False
-        if any(np.ndim(s) != 0 for s in bnn_obj._prior_scale):
-            return False        # one scale per input node / per weight (hyper_p 2, 3); a scale per layer is what the device takes -
-            # hyper_p = 1 re-draws them in gibbs_step only, between which they are constants
+        # (prior scales - one per layer, per input node or per weight, hyper_p 1-3 - change in gibbs_step only, between calls: the
+        # device takes them as constants of the batch)
         if bnn_obj._estimation_mode == "regression" and not bnn_obj._empirical_error:
             # sigma fixed at 1 up to iteration _estimate_error, multiplier proposals after it (BNN_env.py:435-444): a batch
             # must lie on one side (run_steps cuts there); the proposals need the Gaussian likelihood on the device

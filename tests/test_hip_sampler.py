@@ -316,3 +316,37 @@ def test_two_stream_schedule_times_out_cleanly(monkeypatch):
     assert (mcmc_a._logLik, mcmc_a._logPrior) == (mcmc_b._logLik, mcmc_b._logPrior)
     for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("hyper_p", [1, 2, 3])
+def test_run_steps_with_hyper_priors_is_the_mh_step_loop(hyper_p):
+    """Hyper-priors (npBNN.sample_prior_scale, BNN_env.py:196-221): one scale per layer, per input node or per weight, re-drawn by
+    gibbs_step between batches; the device chain takes them as constants of a batch (per-weight scale vector) and must give the
+    chain of the mh_step loop: same accept / reject sequence, same weights, same scales, log prior to rounding."""
+    cfg = cases.TRACES["cfg1"]
+    res = []
+    for mode in ("host", "device"):
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
+                    prior_f=1, p_scale=1, seed=1234, init_std=0.1, hyper_p=hyper_p)
+        mcmc = bn.MCMC(bnn, **dict(cfg["mcmc"], adapt_f=0, adapt_fM=1))
+        np.random.seed(99)                         # gibbs_step draws from the global stream
+        before = mcmc._device_iterations
+        for _ in range(3):
+            if mode == "host":
+                for _ in range(60):
+                    mcmc.mh_step(bnn)
+            else:
+                mcmc.run_steps(bnn, 60)
+            mcmc.gibbs_step(bnn)
+        assert (mcmc._device_iterations - before == 180) == (mode == "device")
+        res.append((bnn, mcmc))
+    (ba, ma), (bb, mb) = res
+    assert ma._current_iteration == mb._current_iteration == 183
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    for sa, sb in zip(ba._prior_scale, bb._prior_scale):
+        np.testing.assert_array_equal(np.asarray(sa, dtype=float), np.asarray(sb, dtype=float))
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)

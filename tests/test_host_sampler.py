@@ -237,9 +237,10 @@ def test_run_steps_with_an_estimated_error_parameter_equals_mh_step_loop(randomi
         np.testing.assert_array_equal(wa, wb)
 
 
-def test_run_steps_between_gibbs_steps_of_a_per_layer_hyper_prior():
-    """hyper_p = 1: one prior scale per layer, re-drawn by gibbs_step (BNN_env.py:196-205, 534-538); between two Gibbs steps
-    the scales are constants and the iterations run as a device batch."""
+@pytest.mark.parametrize("hyper_p", [1, 2, 3])
+def test_run_steps_between_gibbs_steps_of_a_hyper_prior(hyper_p):
+    """hyper_p = 1 / 2 / 3: one prior scale per layer, per input node or per weight, re-drawn by gibbs_step (BNN_env.py:196-221,
+    534-538); between two Gibbs steps the scales are constants and the iterations run as a device batch."""
     from oracle_backend import OracleChainBackend
     cfg = dict(cases.TRACES["cfg1"])
     cfg["mcmc"] = dict(cfg["mcmc"], adapt_f=0, adapt_fM=1)
@@ -249,7 +250,7 @@ def test_run_steps_between_gibbs_steps_of_a_per_layer_hyper_prior():
         np.random.seed(1234)
         with contextlib.redirect_stdout(io.StringIO()):
             bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(fun=cfg["fun"]), use_bias_node=cfg["bias"],
-                           prior_f=1, p_scale=1, seed=1234, init_std=0.1, hyper_p=1)
+                           prior_f=1, p_scale=1, seed=1234, init_std=0.1, hyper_p=hyper_p)
         serve_from_oracle(lambda b: OracleChainBackend(b, 0))
         mcmc = bn.MCMC(bnn, **cfg["mcmc"])
         be = mcmc._backend
@@ -269,7 +270,8 @@ def test_run_steps_between_gibbs_steps_of_a_per_layer_hyper_prior():
     (ba, ma), (bb, mb) = out
     assert ma._current_iteration == mb._current_iteration == 123
     assert ma._last_accepted_mem == mb._last_accepted_mem
-    np.testing.assert_array_equal(np.array(ba._prior_scale, dtype=float), np.array(bb._prior_scale, dtype=float))
+    for sa, sb in zip(ba._prior_scale, bb._prior_scale):
+        np.testing.assert_array_equal(np.asarray(sa, dtype=float), np.asarray(sb, dtype=float))
     np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)
     for wa, wb in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(wa, wb)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# The rocprofv3 evidence of a round, collected on the GPU box from the repository root:
+#   gpurun -- 'bash tools/collect_profiles.sh r02'
+# kernel-trace statistics of the default bench run per config, and FETCH_SIZE / WRITE_SIZE of the pass kernel (separate --pmc
+# passes, nothing else traced with them).  Everything lands under gpurun_out/prof_<tag>/; copy what is to be kept into profiles/.
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for c in 2 4 5; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c$c -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_under_rocprof.json 2> $out/bench_c$c.err || echo "bench profile of config $c failed"
+  for cand in 3 1; do
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_c${c}_d${cand}_$ctr -o p -- python3 tools/profile_eval.py --config $c --cand $cand --iters 3 > $out/pmc_c${c}_d${cand}_$ctr.log 2>&1 || echo "pmc $ctr of config $c D=$cand failed"
+    done
+  done
+done
+find $out -name "*.csv" | head -50

@@ -335,6 +335,20 @@ int npbnn_chains_run_exchange(npbnn_comm* comm /* NULL: the chains of this proce
                               const double* swap_logu, double launch_slack, double* out_records /* [n_seg][n_chains][4] */,
                               int32_t* out_segments_done);
 
+/* ---- group pass: 2 or 3 chains of one model (the per-chain replicas MC3 makes, np_bnn/BNN_mc3.py:55-75: same data, same network)
+ * that live on ONE GPU advance K iterations each, every launch evaluating one proposal PER CHAIN against a single streaming
+ * read of the feature matrix: replaces n_jobs calls of MCMC.mh_step per iteration, each with its own copy of and pass over X
+ * (BNN_mc3.py:80-85 through a pool of processes).  Candidate slot j of a launch belongs to chain j - its committed weight image
+ * patched with its own pre-drawn perturbation - and its sums go to that chain's step, which runs in a workgroup of its own inside
+ * the same launch while the next proposals are evaluated (the overlapped schedule of npbnn_chain_run, one candidate per chain:
+ * a chain that accepts loses the one proposal that was in flight).  Every slot does useful work whatever the acceptance rate,
+ * where a single chain's speculative candidates are wasted after its first accept of a pass.  Each chain is exactly the chain
+ * npbnn_chain_run gives it (same decisions; its log-likelihood sums are formed from a different number of workgroup partials, so
+ * they may differ in the last bits).  The jobs are filled in as for npbnn_chains_run_exchange (chain_id, out_state, out_cold_w
+ * unused); the contexts must share their feature matrix (npbnn_share_data) and have the same architecture, mask and likelihood.
+ * NPBNN_E_ARG when n_jobs weight images do not fit the LDS of a compute unit together; NPBNN_E_RANGE as npbnn_chain_run. */
+int npbnn_chains_run_batched(npbnn_chain_job* jobs, int32_t n_jobs, int32_t K);
+
 /* timing hook for a speculative chain pass: the evaluation kernel with n_candidates weight sets (0 = as many as fit),
  * `iters` back-to-back launches between one pair of HIP events on the ctx stream; mean milliseconds per launch */
 int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, int iters, double* ms_kernel, int* used_candidates);

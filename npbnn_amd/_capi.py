@@ -118,6 +118,7 @@ SIGNATURES = {
     "npbnn_chains_run_exchange": (C.c_int, [_P, C.POINTER(ChainJob), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), _DP, C.c_double, _DP,
                                             C.POINTER(C.c_int32)]),
+    "npbnn_chains_run_batched": (C.c_int, [C.POINTER(ChainJob), C.c_int32, C.c_int32]),
     "npbnn_op_activation": (C.c_int, [C.c_int, C.c_int, C.c_double, _DP, C.c_int64]),
     "npbnn_op_output": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.c_int32]),
     "npbnn_op_likelihood": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.POINTER(C.c_int64), _DP, C.c_int32, _DP, _DP,

@@ -375,3 +375,60 @@ def chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_log
     for o in outs:
         o["result"] = o.pop("_ctx")._result_dict(o.pop("_res"))
     return outs, records, int(done.value)
+
+
+def chains_run_batched(jobs, K):
+    """2 or 3 chains of one model on one GPU advance ``K`` iterations each, one proposal per chain per streaming read of the
+    feature matrix (npbnn_chains_run_batched).  ``jobs``: dicts as for :func:`chains_run_exchange` (``chain_id`` not needed).
+    Returns per job ``dict(w, accepted, loglik_prop, logprior_prop, result)``.  A weight leaving the fp16 range sends the whole
+    group through once more on the float32 layer-0 path."""
+    K = int(K)
+    lib = jobs[0]["ctx"]._lib
+    i32p = C.POINTER(C.c_int32)
+    for attempt in (0, 1):
+        arr = (capi.ChainJob * len(jobs))()
+        keep, outs = [], []
+        for q, job in enumerate(jobs):
+            ctx = job["ctx"]
+            weights = job["weights"]
+            w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
+            idx, cnt = job["idx"], job["cnt"]
+            if idx.shape[0] != K or len(cnt) != K:
+                raise ValueError("job %d: %d rows of draws for %d iterations" % (q, idx.shape[0], K))
+            if idx.dtype != np.int32 or not idx.flags.c_contiguous:
+                idx = np.ascontiguousarray(idx, dtype=np.int32)
+            if cnt.dtype != np.int32 or not cnt.flags.c_contiguous:
+                cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+            delta, log_u = capi.as_f64(job["delta"]), capi.as_f64(job["log_u"])
+            mask = job.get("mask")
+            m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
+            cfg, res = capi.ChainCfg(), capi.ChainResult()
+            ctx._fill_chain_cfg(cfg, **job["cfg"])
+            cfg.force_f32 = attempt
+            acc = np.zeros(K, dtype=np.uint8)
+            llp, lpp = np.zeros(K), np.zeros(K)
+            J = arr[q]
+            J.ctx = ctx._ctx
+            J.cfg = C.pointer(cfg)
+            J.W_inout = capi.dptr(w)
+            J.mask_packed = capi.dptr(m)
+            J.M = idx.shape[1]
+            J.chain_id = q
+            J.idx = idx.ctypes.data_as(i32p)
+            J.delta = capi.dptr(delta)
+            J.cnt = cnt.ctypes.data_as(i32p)
+            J.log_u = capi.dptr(log_u)
+            J.out_accepted = acc.ctypes.data_as(C.POINTER(C.c_uint8))
+            J.out_loglik_prop = capi.dptr(llp)
+            J.out_logprior_prop = capi.dptr(lpp)
+            J.result = C.pointer(res)
+            keep.append((w, idx, cnt, delta, log_u, m, cfg, res))
+            outs.append(dict(w=w, accepted=acc, loglik_prop=llp, logprior_prop=lpp, _res=res, _ctx=ctx))
+        rc = lib.npbnn_chains_run_batched(arr, len(jobs), K)
+        if rc == capi.E_RANGE and attempt == 0:
+            continue
+        capi.check(lib, jobs[0]["ctx"]._ctx, rc)
+        break
+    for o in outs:
+        o["result"] = o.pop("_ctx")._result_dict(o.pop("_res"))
+    return outs

@@ -147,6 +147,8 @@ struct npbnn_ctx {
     double* d_llp = nullptr;
     double* d_lpp = nullptr;
     size_t iter_cap = 0;        // K capacity
+    EvalParams* d_gparams = nullptr;   // parameter block of a group pass led by this context (npbnn_chains_run_batched)
+    EvalParams* h_gparams = nullptr;   // its page-locked staging twin
     double* d_pscale_w = nullptr;  // [n_weights] per-weight prior scales of the current batch (npbnn_chain_cfg.prior_scale_w)
     double* d_smult = nullptr;  // [K][k_targets] sigma multipliers, [K] Hastings terms (regression with an estimated error parameter)
     double* d_hast = nullptr;
@@ -701,6 +703,8 @@ void destroy_ctx(npbnn_ctx* c) {
         if (c->stream_e[i]) (void)hipStreamDestroy(c->stream_e[i]);
     }
     if (c->h_params) (void)hipHostFree(c->h_params);
+    if (c->d_gparams) (void)hipFree(c->d_gparams);
+    if (c->h_gparams) (void)hipHostFree(c->h_gparams);
     if (c->d_w2scale) (void)hipFree(c->d_w2scale);
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_w2img) (void)hipFree(c->d_w2img);
@@ -1211,8 +1215,10 @@ double wall_us() { return std::chrono::duration<double, std::micro>(std::chrono:
 // seg_len > 0: the chain stops deciding at iteration seg_len until an exchange kernel moves the limit (exchange run)
 int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in, const double* mask_packed, int32_t K, int32_t M,
                   const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, int seg_len, ChainBatch* B,
-                  bool alone_on_device = true) {
+                  bool alone_on_device = true, int group_blocks = 0) {
     // alone_on_device: no other chain's launches share the GPU with this batch (the two-stream schedule counts on that)
+    // group_blocks > 0: the chain is one of a group pass (npbnn_chains_run_batched): one candidate per launch, overlapped schedule,
+    // its sums come from that many evaluating workgroups of the group's launches
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
     if (!cfg || !W_in || K < 1 || M < 1 || !idx || !delta || !cnt || !log_u) return fail(ctx, NPBNN_E_ARG, "chain_run: bad arguments");
     if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run: call npbnn_set_arch first");
@@ -1234,11 +1240,12 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     LaunchPlan& lp = B->lp;
     int want_cand = cfg->n_candidates;
     if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
+    if (group_blocks > 0) want_cand = 1;
     rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand, false, true);
     if (rc) return rc;
     const int D = lp.n_cand;
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
-    int schedule = cfg->schedule;
+    int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : cfg->schedule;
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
         schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
@@ -1260,6 +1267,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         lp.grid = g;
         lp.n_waves = g;
     }
+    if (group_blocks > 0) { lp.grid = group_blocks; lp.n_waves = group_blocks; }
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
     const size_t wb = (size_t)ctx->n_weights * sizeof(double);
@@ -1611,6 +1619,134 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     return NPBNN_OK;
 }
 
+
+int npbnn_chains_run_batched(npbnn_chain_job* jobs, int32_t n_jobs, int32_t K) {
+    if (!jobs || n_jobs < 2 || n_jobs > kMaxCand || K < 1) return fail(nullptr, NPBNN_E_ARG, "chains_run_batched: 2..%d chains, K >= 1", kMaxCand);
+    npbnn_ctx* ctx0 = jobs[0].ctx;
+    if (!ctx0) return fail(nullptr, NPBNN_E_ARG, "chains_run_batched: job 0 has no context");
+    int force_f32 = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const npbnn_chain_job& J = jobs[q];
+        if (!J.ctx || !J.cfg || !J.W_inout || !J.result || !J.out_accepted) return fail(J.ctx, NPBNN_E_ARG, "chains_run_batched: job %d incomplete", q);
+        if (!J.ctx->arch_set) return fail(J.ctx, NPBNN_E_STATE, "chains_run_batched: job %d: call npbnn_set_arch first", q);
+        for (int p2 = 0; p2 < q; ++p2)
+            if (jobs[p2].ctx == J.ctx) return fail(J.ctx, NPBNN_E_ARG, "chains_run_batched: jobs %d and %d share a ctx", p2, q);
+        // replicas of one model over the same resident matrix: same device, same X, same network shape, same likelihood
+        const npbnn_ctx* a = ctx0;
+        const npbnn_ctx* b = J.ctx;
+        if (b->device != a->device || b->ds[0].X != a->ds[0].X || b->ds[0].n_rows != a->ds[0].n_rows || b->n_weights != a->n_weights ||
+            memcmp(&b->arch, &a->arch, sizeof(npbnn_arch)) != 0 || b->l0_blocks != a->l0_blocks || (b->n_classw > 0) != (a->n_classw > 0) ||
+            (b->ds[0].inst_w != nullptr) != (a->ds[0].inst_w != nullptr))
+            return fail(J.ctx, NPBNN_E_ARG, "chains_run_batched: job %d is not a replica of job 0 (same device, shared feature matrix "
+                                            "(npbnn_share_data), same architecture and likelihood)", q);
+        force_f32 |= J.cfg->force_f32;
+    }
+    HIP_TRY(ctx0, hipSetDevice(ctx0->device));
+    Dataset& d0 = ctx0->ds[0];
+    int rc = check_dataset_for_lik(ctx0, d0, ctx0->net.lik_kind);
+    if (rc) return rc;
+    // the group's launch: one candidate per chain, the evaluating workgroups share the tiles, one step workgroup per chain
+    LaunchPlan lpG;
+    rc = plan_launch(ctx0, 0, &lpG, force_f32, n_jobs, false, true);
+    if (rc) return rc;
+    if (lpG.n_cand != n_jobs)
+        return fail(ctx0, NPBNN_E_ARG, "chains_run_batched: %d weight images do not fit a compute unit's LDS together (%d do)", n_jobs, lpG.n_cand);
+    int G = lpG.grid;
+    if (G > ctx0->n_cu - n_jobs) G = ctx0->n_cu - n_jobs;
+    if (G < 1) G = 1;
+    std::vector<ChainBatch> B(n_jobs);
+    std::vector<npbnn_chain_cfg> cfgs(n_jobs);
+    for (int q = 0; q < n_jobs; ++q) {
+        const npbnn_chain_job& J = jobs[q];
+        cfgs[q] = *J.cfg;
+        cfgs[q].force_f32 = force_f32;
+        rc = chain_prepare(J.ctx, &cfgs[q], J.W_inout, J.mask_packed, K, J.M, J.idx, J.delta, J.cnt, J.log_u, 0, &B[q], false, G);
+        if (rc) {
+            if (J.ctx != ctx0) ctx0->err = J.ctx->err;
+            for (int p2 = 0; p2 <= q; ++p2) (void)hipStreamSynchronize(jobs[p2].ctx->stream);
+            return rc;
+        }
+        if ((J.ctx->net.l0_f16 != 0) != (ctx0->net.l0_f16 != 0)) {
+            for (int p2 = 0; p2 <= q; ++p2) (void)hipStreamSynchronize(jobs[p2].ctx->stream);
+            return fail(ctx0, NPBNN_E_STATE, "chains_run_batched: the chains ended up on different layer-0 paths");
+        }
+    }
+    hipStream_t st = ctx0->stream;
+    for (int q = 1; q < n_jobs; ++q) {          // the other chains' preparation (their own streams) before the first group launch
+        npbnn_ctx* c = jobs[q].ctx;
+        if (!c->ev_x) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_x, c->stream));
+        HIP_TRY(ctx0, hipStreamWaitEvent(st, c->ev_x, 0));
+    }
+    if (!ctx0->d_gparams) {
+        HIP_TRY(ctx0, hipMalloc(&ctx0->d_gparams, sizeof(EvalParams)));
+        HIP_TRY(ctx0, hipHostMalloc(&ctx0->h_gparams, sizeof(EvalParams)));
+    }
+    {
+        EvalParams g = make_params(ctx0, d0);
+        g.partials = nullptr;
+        g.inst_w = d0.inst_w;
+        g.use_classw = ctx0->n_classw > 0 ? 1 : 0;
+        g.has_pass = 0;
+        g.group_n = n_jobs;
+        for (int q = 0; q < n_jobs; ++q) {
+            npbnn_ctx* c = jobs[q].ctx;
+            GroupSlot& S = g.group[q];
+            S.chain = c->d_cparams;
+            S.pass = reinterpret_cast<const PassDesc*>(reinterpret_cast<const char*>(c->d_eparams) + offsetof(EvalParams, pass_desc));
+            S.image = c->d_image;
+            S.pv = c->d_pv;
+            S.pos = c->d_pos;
+            S.pscale = c->net.l0_f16 ? c->d_pscale : nullptr;
+            S.partials = c->d_partials;
+            S.M = jobs[q].M;
+        }
+        memcpy(ctx0->h_gparams, &g, sizeof g);
+        HIP_TRY(ctx0, hipMemcpyAsync(ctx0->d_gparams, ctx0->h_gparams, sizeof g, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(ctx0, hipFuncSetAttribute(reinterpret_cast<const void*>(lpG.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lpG.lds));
+    // a launch decides at most one iteration per chain and loses one to every accept (the pass in flight is void): what the chains'
+    // last acceptance rates say is needed, then look and repeat if some chain is short
+    int launch = 0, rounds = 0;
+    std::vector<int> t_done(n_jobs, 0);
+    for (;;) {
+        int rem = 0;
+        double acc = 0.0;
+        for (int q = 0; q < n_jobs; ++q) {
+            if (K - t_done[q] > rem) rem = K - t_done[q];
+            const double a = jobs[q].ctx->accept_rate < 0 ? 0.3 : jobs[q].ctx->accept_rate;
+            if (a > acc) acc = a;
+        }
+        if (rem == 0) break;
+        if (++rounds > 64) return fail(ctx0, NPBNN_E_STATE, "chains_run_batched: the chains are stuck");
+        const int n = (int)std::ceil((double)rem * (1.0 + acc) * 1.05) + 3;
+        for (int i = 0; i < n; ++i, ++launch)
+            hipLaunchKernelGGL(lpG.fn, dim3(G + n_jobs), dim3(lpG.wpb * 64), lpG.lds, st, (const EvalParams*)ctx0->d_gparams, launch);
+        HIP_TRY(ctx0, hipGetLastError());
+        for (int q = 0; q < n_jobs; ++q) {
+            npbnn_ctx* c = jobs[q].ctx;
+            HIP_TRY(c, hipMemcpyAsync(c->h_res, c->d_res, B[q].RL.total, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(ctx0, hipStreamSynchronize(st));
+        for (int q = 0; q < n_jobs; ++q) {
+            const ChainDev* now = reinterpret_cast<const ChainDev*>(jobs[q].ctx->h_res);
+            if (now->t < t_done[q]) return fail(jobs[q].ctx, NPBNN_E_STATE, "chains_run_batched: chain %d went backwards (t=%d)", q, now->t);
+            t_done[q] = now->t;
+        }
+    }
+    for (int q = 0; q < n_jobs; ++q)            // (nothing is handed back unless every chain's batch is good: the caller repeats the
+        if (jobs[q].ctx->net.l0_f16 && (*reinterpret_cast<const int*>(jobs[q].ctx->h_res + 448) & kFlagF16Range))      // whole group)
+            return fail(ctx0, NPBNN_E_RANGE, "chains_run_batched: a layer-0 weight of chain %d left the fp16 range during this batch", q);
+    for (int q = 0; q < n_jobs; ++q) {
+        const npbnn_chain_job& J = jobs[q];
+        rc = chain_finish(J.ctx, B[q], &cfgs[q], J.W_inout, J.out_accepted, J.out_loglik_prop, J.out_logprior_prop, J.result, K);
+        if (rc) {
+            if (J.ctx != ctx0) ctx0->err = J.ctx->err;
+            return rc;
+        }
+    }
+    return NPBNN_OK;
+}
 
 int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n_jobs, int32_t n_chains, int32_t seg_len, int32_t n_seg,
                               const int32_t* swap_j, const int32_t* swap_k, const double* swap_logu, double launch_slack,

@@ -88,6 +88,21 @@ struct PassDesc {
 
 struct ChainParams;
 
+// Group pass (npbnn_chains_run_batched): the candidates of a launch belong to DIFFERENT chains - candidate j is the current proposal
+// of chain j: that chain's weight image patched with that chain's pre-drawn perturbation, its sums go to that chain's step.  The
+// chains are replicas of one model (MC3.__init__, np_bnn/BNN_mc3.py:55-75) over the same resident X: one streaming read of the
+// matrix serves all of them, and every candidate slot is useful whatever the acceptance rate.
+struct GroupSlot {
+    const ChainParams* chain;     // the chain's step parameters (its step runs in one workgroup of the launch)
+    const PassDesc* pass;         // [2] its pass descriptors (inside its own EvalParams block), by pass parity
+    const float* image;           // its committed weight image
+    const double* pv;             // [2][kMaxCand][M] its candidate patch values (slot 0 of each parity is used)
+    const int* pos;               // [K][M] image positions of its pre-drawn entries
+    const float* pscale;          // [K][M] fp16-split scales of them, or nullptr
+    double* partials;             // [2][kMaxCand][kPartialStride][evaluating workgroups]
+    int M, pad_;
+};
+
 struct EvalParams {
     const float* X;           // [n_tiles*16][Fp] zero padded; in fp16-split mode the same bytes hold, per 8 features,
                               // 8 x fp16 high parts then 8 x fp16 low parts of the column-scaled values
@@ -120,6 +135,9 @@ struct EvalParams {
     int sync_mode;             // overlapped schedule with the launches alternating between two streams: no kernel boundary orders a
     int pad_sync_;             // launch after the one before it - device-side flags do (ChainDev.prepared / .done, npbnn_chain.hip.h)
     unsigned long long* stamps;   // diagnostics only (NPBNN_EVAL_STAMPS=1 in npbnn_time_pass): [workgroup][8] wall-clock stamps, else nullptr
+    int group_n;                  // > 0: group pass of that many chains (= the candidates of the build); the last group_n workgroups
+    int pad_group_;               // of the launch run the chains' steps
+    GroupSlot group[kMaxCand];
     NetMeta net;
 };
 

@@ -402,7 +402,13 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
     const ChainParams* const chain = uni(p.chain);
-    const int G = (int)gridDim.x - (chain ? 1 : 0);     // workgroups that evaluate
+    const int GN = D > 1 ? uni(p.group_n) : 0;          // group pass: candidate j belongs to chain j, whose step runs in workgroup G + j
+    const int G = (int)gridDim.x - (GN ? GN : chain ? 1 : 0);     // workgroups that evaluate
+    if (GN && bid >= G) {
+        StepShared& sh = *reinterpret_cast<StepShared*>(smem);
+        chain_step(*uni(p.group[bid - G].chain), overlapped_plan(launch), sh);
+        return;
+    }
     const bool sync = chain && uni(p.sync_mode);        // launches overlap: device flags order them (npbnn_chain.hip.h)
     // the step workgroup is the last one of the launch - or, when launches overlap, the FIRST: it must be resident before any
     // workgroup of the NEXT launch (which waits for it) can take a compute unit
@@ -418,7 +424,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int early_prepared = 0x7fffffff;
     if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
         early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int par = chain ? (launch & 1) : 0;
+    const int par = (chain || GN) ? (launch & 1) : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,12 +481,24 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
     int t0 = 0;
     int cnt[D];
+    int t0g[D];                    // group pass: the iteration each chain's candidate belongs to
 #pragma unroll
-    for (int j = 0; j < D; ++j) cnt[j] = 0;
+    for (int j = 0; j < D; ++j) { cnt[j] = 0; t0g[j] = 0; }
     const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
     const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
     if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem), early_prepared)) return;
-    if (pass) {
+    if (GN) {
+        int alive = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const PassDesc* const dj = uni(p.group[j].pass) + par;
+            const int nc = uni(dj->n_cand);
+            alive |= nc;
+            cnt[j] = nc > 0 ? uni(dj->cnt[0]) : 0;           // (a chain that has finished its iterations idles: an unpatched copy)
+            t0g[j] = uni(dj->t0);
+        }
+        if (!alive) return;                                   // every chain is through
+    } else if (pass) {
         if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
             const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand
@@ -513,12 +531,14 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         const float* const image = uni(p.image);
         const size_t set_stride = hp.weight_sets ? (size_t)image_floats : 0;
 #pragma unroll
-        for (int j = 0; j < D; ++j)
+        for (int j = 0; j < D; ++j) {
+            const float* const img_j = GN ? uni(p.group[j].image) : image + j * set_stride;     // (group pass: chain j's own image)
             for (int i = wave; i < n_pieces; i += wpb)
                 if (i * 256 + lane * 4 < image_floats) {    // (an LDS-DMA writes only its active lanes' 16 bytes)
-                    if (sync) dma16_coherent(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
-                    else dma16(image + j * set_stride + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                    if (sync) dma16_coherent(img_j + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                    else dma16(img_j + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
                 }
+        }
     }
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to SIMD m % 4 and, there, to the
@@ -570,20 +590,36 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int ppos[D];
     double pval[D];
     float psc[D];
+    // where candidate j's patch list lives: rows of the pre-drawn positions / scales and the values the step prepared - the
+    // chain's own arrays in a group pass (its candidate sits in slot 0 of its pv block), else row t0 + j and slot j of this chain's
+    auto patch_src = [&](int j, const int*& pos_row, const float*& psc_row, const double*& pv_row) {
+        if (GN) {
+            const int Mj = uni(p.group[j].M);
+            const float* const sc = uni(p.group[j].pscale);
+            pos_row = uni(p.group[j].pos) + (size_t)t0g[j] * Mj;
+            psc_row = sc ? sc + (size_t)t0g[j] * Mj : nullptr;
+            pv_row = uni(p.group[j].pv) + (size_t)par * kMaxCand * Mj;
+        } else {
+            pos_row = g_pos + (size_t)(t0 + j) * M;
+            psc_row = g_pscale ? g_pscale + (size_t)(t0 + j) * M : nullptr;
+            pv_row = pv + (size_t)j * M;
+        }
+    };
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
-        if (pass && tid < cnt[j]) {
-            const size_t k = (size_t)(t0 + j) * M + tid;
-            ppos[j] = g_pos[k];
-            pval[j] = sync ? __hip_atomic_load(pv + (size_t)j * M + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv[(size_t)j * M + tid];
-            if (g_pscale) psc[j] = g_pscale[k];
+        if ((pass || GN) && tid < cnt[j]) {
+            const int* pos_row; const float* psc_row; const double* pv_row;
+            patch_src(j, pos_row, psc_row, pv_row);
+            ppos[j] = pos_row[tid];
+            pval[j] = sync ? __hip_atomic_load(pv_row + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv_row[tid];
+            if (psc_row) psc[j] = psc_row[tid];
         }
     }
     NPBNN_ESTAMP(1);
     __syncthreads();
     NPBNN_ESTAMP(2);
-    if (pass) {
+    if (pass || GN) {
         auto patch = [&](int j, int pos, double v, float sc) {
             if (pos == 0x7fffffff) return;                  // superseded entry (a later draw of the same position wins)
             float* imgj = reinterpret_cast<float*>(smem + j * IB);
@@ -601,10 +637,12 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);
-            for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x) {
-                const size_t k = (size_t)(t0 + j) * M + e;
-                patch(j, g_pos[k], sync ? __hip_atomic_load(pv + (size_t)j * M + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv[(size_t)j * M + e],
-                      g_pscale ? g_pscale[k] : 1.0f);
+            if ((int)blockDim.x < cnt[j]) {                 // (proposals wider than the workgroup)
+                const int* pos_row; const float* psc_row; const double* pv_row;
+                patch_src(j, pos_row, psc_row, pv_row);
+                for (int e = tid + blockDim.x; e < cnt[j]; e += blockDim.x)
+                    patch(j, pos_row[e], sync ? __hip_atomic_load(pv_row + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv_row[e],
+                          psc_row ? psc_row[e] : 1.0f);
             }
         }
         __syncthreads();
@@ -896,7 +934,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     NPBNN_ESTAMP(4);
     if (stamps && lane == 0) stamps[(size_t)gridDim.x * 8 + (size_t)bid * 16 + wave] = wall_clock64();   // every wave: tiles done
     // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
-    if (g_partials) {
+    if (g_partials || GN) {
         constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -934,7 +972,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             const int j = item / nvals, v = item % nvals;
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
-            double* const dst = g_partials + (((size_t)par * kMaxCand + j) * kPartialStride + v) * G + ebid;
+            // (group pass: candidate j is slot 0 of chain j's own partial block)
+            double* const dst = GN ? p.group[j].partials + (((size_t)par * kMaxCand) * kPartialStride + v) * G + ebid
+                                   : g_partials + (((size_t)par * kMaxCand + j) * kPartialStride + v) * G + ebid;
             if (sync) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (write-through: no fence at the end)
             else *dst = s;
         }

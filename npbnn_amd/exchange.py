@@ -117,6 +117,71 @@ def run_exchange(chains, chain_ids, n_chains, n_seg, seg_len, swaps, first_swap,
     return done, records, outs
 
 
+def _batchable(chains, n_iterations):
+    """Can these chains (of one process) share their passes over the data for the next ``n_iterations``?  Replicas of one model
+    on one device (shared resident matrix), the device chain applies to each, no adaptation point inside."""
+    if len(chains) < 2:
+        return False
+    first = None
+    for bnn, mcmc in chains:
+        if mcmc._backend is None:
+            from .sampler import get_backend
+            mcmc._backend = get_backend(bnn, mcmc._likelihood_f)
+        be = mcmc._backend
+        if not hasattr(be, "run_batched") or not mcmc._device_loop_ok(bnn, n_iterations):
+            return False
+        boundary = mcmc._next_adapt_boundary()
+        if boundary is not None and boundary < mcmc._current_iteration + n_iterations:
+            return False
+        if bnn._estimation_mode == "regression" and mcmc._current_iteration <= mcmc._estimate_error < mcmc._current_iteration + n_iterations:
+            return False
+        root = be.data_shared_with if getattr(be, "data_shared_with", None) is not None else be
+        key = (id(root), tuple(w.shape for w in bnn._w_layers), id(bnn._mask) if bnn._mask is not None else None)
+        if first is None:
+            first = key
+        elif key[0] != first[0] or key[1] != first[1] or (key[2] is None) != (first[2] is None):
+            return False
+    return True
+
+
+def run_steps_batched(chains, n_iterations):
+    """``n_iterations`` iterations of every chain of ``chains`` ([(bnn, mcmc)], all in this process) - what
+    ``for bnn, mcmc in chains: mcmc.run_steps(bnn, n_iterations)`` does - with the chains of one model sharing their passes over
+    the feature matrix in groups of up to three (``npbnn_chains_run_batched``): one proposal per chain per streaming read of X.
+    Chains that cannot take part (a sampler setting the device chain does not cover, an adaptation point inside the span,
+    matrices of their own) advance on their own."""
+    todo = list(chains)
+    while todo:
+        be0 = todo[0][1]._backend
+        size = getattr(be0, "group_size", 1) if be0 is not None else 1
+        group = todo[:size]
+        while len(group) >= 2 and not _batchable(group, n_iterations):
+            group = group[:-1]
+        if len(group) < 2:
+            bnn, mcmc = todo.pop(0)
+            mcmc.run_steps(bnn, n_iterations)
+            continue
+        del todo[:len(group)]
+        K = int(n_iterations)
+        jobs = []
+        for bnn, mcmc in group:
+            mcmc._bnn = bnn
+            mcmc._adapt(bnn)
+            it = mcmc._current_iteration
+            idx, delta, cnt, log_u, smult, hast = mcmc._claim_draw(bnn, it, K).result()
+            mcmc._speculation = mcmc._submit_draw(bnn, it + K, K, rewindable=True)      # the probable next call's draws, meanwhile
+            jobs.append(mcmc._backend.exchange_job(bnn._w_layers, chain_id=len(jobs), idx=idx, delta=delta, cnt=cnt, log_u=log_u,
+                                                   mask=bnn._mask, cfg=mcmc._device_chain_cfg(bnn, smult, hast)))
+        try:
+            outs = type(group[0][1]._backend).run_batched(jobs, K)
+        except Exception:
+            for _, mcmc in group:
+                mcmc._cancel_speculation()
+            raise
+        for (bnn, mcmc), out in zip(group, outs):
+            mcmc._absorb_device_batch(bnn, K, out["w"], out["accepted"], out["result"])
+
+
 def gather_scalars(chains, chain_ids, n_chains, comm):
     """[logPost, temperature] of every chain of the run, on every rank (chain i lives on rank i % world)."""
     world = 1 if comm is None else comm.world_size
@@ -170,8 +235,7 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
         if world > 1:                  # every rank must take the same path
             ok = bool(np.all(comm.allgather_f64(np.array([1.0 if ok else 0.0]))[:, 0] == 1.0))
         if not ok:
-            for bnn, mcmc in chains:
-                mcmc.run_steps(bnn, seg_len)
+            run_steps_batched(chains, seg_len)          # (the local chains share their passes over the data where they can)
             scal, swap = host_swap(chains, chain_ids, n_chains, swaps, first_swap + done, comm)
             if on_interval is not None:
                 on_interval(done, dict(scalars=scal, swap=swap, cold=None))

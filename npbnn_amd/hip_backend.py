@@ -147,5 +147,12 @@ class HipBackend:
         return chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=comm,
                                    launch_slack=launch_slack, want_cold_w=want_cold_w)
 
+    group_size = 3           # chains a group pass evaluates together (candidate slots of the evaluation kernel)
+
+    @staticmethod
+    def run_batched(jobs, K):
+        from .backend import chains_run_batched
+        return chains_run_batched(jobs, K)
+
     def close(self):
         self.ctx.close()

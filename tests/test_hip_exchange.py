@@ -439,3 +439,42 @@ def test_bench_exchange_self_check_runs_and_restores_the_chains():
     assert_same(before, state_of(chains))
     # and the chains still run
     assert ex.advance_intervals(chains, [0, 1], 2, 3, 20, ex.SwapProposals(2, np.random.RandomState(5)), 0, batch=3) == 3
+
+
+@pytest.mark.parametrize("name,n_chains", [("cfg2s", 3), ("cfg2s", 2), ("cfg4s", 3), ("cfg1", 4)])
+def test_group_pass_gives_every_chain_its_own_chain(name, n_chains):
+    """npbnn_chains_run_batched: the chains of one model share every streaming read of the data, one proposal
+    per chain per launch.  Each chain must be the chain its own run_steps gives it: same accept / reject sequence, same weights,
+    same sigma; log-likelihood to rounding (its sums come from a different number of workgroup partials).  Four chains: a group
+    of three and one on its own."""
+    cfg = cases.TRACES[name]
+    temps = list(np.linspace(0.8, 1.0, n_chains))
+    apart = build_chains(cfg, temps)
+    together = build_chains(cfg, temps)
+    for _ in range(3):
+        for bnn, m in apart:
+            m.run_steps(bnn, 70)
+        ex.run_steps_batched(together, 70)
+    assert_same(state_of(apart), state_of(together), exact=False)
+    passes = [m._device_passes for _, m in together]
+    # in a group every launch carries one proposal of every chain: a chain's passes ~ its iterations (+ one per accept)
+    assert all(m._device_iterations == 210 for _, m in together)
+    grouped = together[:3] if n_chains >= 3 else together
+    assert all(210 <= p <= 210 + 2 * m._device_accepted + 6 for p, (_, m) in zip(passes, grouped)), passes
+
+
+def test_mc3_intervals_with_group_passes_match_the_interval_path():
+    """MC3's loop (BNN_mc3.py:94-112) on one GPU with the swap on the host: the local chains advance through group passes; swaps,
+    temperatures and chains as when every chain runs its interval alone."""
+    cfg = cases.TRACES["cfg2s"]
+    temps = list(np.linspace(0.8, 1.0, 3))
+    a, b = build_chains(cfg, temps), build_chains(cfg, temps)
+    swaps_a, swaps_b = (ex.SwapProposals(3, np.random.RandomState(5)) for _ in range(2))
+    log_a, log_b = [], []
+    for i in range(6):                      # one chain at a time
+        for bnn, m in a:
+            m.run_steps(bnn, 40)
+        log_a.append(ex.host_swap(a, [0, 1, 2], 3, swaps_a, i)[1])
+    ex.advance_intervals(b, [0, 1, 2], 3, 6, 40, swaps_b, 0, device=False, on_interval=lambda s, info: log_b.append(info["swap"]))
+    assert [(s[0], s[1], s[4]) for s in log_a] == [(s[0], s[1], s[4]) for s in log_b]
+    assert_same(state_of(a), state_of(b), exact=False)

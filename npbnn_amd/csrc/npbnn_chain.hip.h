@@ -445,33 +445,45 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         const double* __restrict__ mask = c.mask;
         double* __restrict__ pv_out = c.pv + (size_t)pl.out * pv_stride;
         int woff[kMaxLayers];
-        double half_inv_s2[kMaxLayers];
+        double half_inv_s2[kMaxLayers], layer_scale[kMaxLayers];
 #pragma unroll
         for (int q = 0; q < kMaxLayers; ++q) {
             woff[q] = q < c.net.n_layers ? c.net.L[q].w_off : 0x7fffffff;
             half_inv_s2[q] = c.half_inv_s2[q];
+            layer_scale[q] = c.prior_scale[q];
         }
-        int ii[kMaxCand], pp[kMaxCand];
-        double dd[kMaxCand], bb[kMaxCand], mm[kMaxCand];
-        float ss[kMaxCand];
+        // ES entries per thread and candidate are staged (wider proposals than ES x the workgroup loop behind them)
+        constexpr int ES = 2;
+        int ii[kMaxCand][ES], pp[kMaxCand][ES], cn[kMaxCand];
+        double dd[kMaxCand][ES], bb[kMaxCand][ES], mm[kMaxCand][ES], sw[kMaxCand][ES];
+        float ss[kMaxCand][ES];
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j) {
             dlp[j] = 0.0;
-            ii[j] = -1; pp[j] = 0; dd[j] = 0.0; ss[j] = 1.0f;
-            if (j < n_new && tid < c.cnt[t_new + j]) {
-                const size_t k = (size_t)(t_new + j) * c.M + tid;
-                ii[j] = c.idx[k];
-                dd[j] = c.delta[k];
-                pp[j] = c.pos[k];
-                if (c.pscale) ss[j] = c.pscale[k];
+            cn[j] = j < n_new ? c.cnt[t_new + j] : 0;
+#pragma unroll
+            for (int u = 0; u < ES; ++u) {
+                const int e = tid + u * (int)blockDim.x;
+                ii[j][u] = -1; pp[j][u] = 0; dd[j][u] = 0.0; ss[j][u] = 1.0f;
+                if (e < cn[j]) {
+                    const size_t k = (size_t)(t_new + j) * c.M + e;
+                    ii[j][u] = c.idx[k];
+                    dd[j][u] = c.delta[k];
+                    pp[j][u] = c.pos[k];
+                    if (c.pscale) ss[j][u] = c.pscale[k];
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < kMaxCand; ++j) {
-            bb[j] = ii[j] >= 0 ? wcur[ii[j]] : 0.0;
-            mm[j] = (ii[j] >= 0 && mask) ? mask[ii[j]] : 1.0;
-        }
-        auto make = [&](int j, int e, int i, double base, double d, double m, int pos, float sc) {
+        for (int j = 0; j < kMaxCand; ++j)
+#pragma unroll
+            for (int u = 0; u < ES; ++u) {
+                const int i = ii[j][u];
+                bb[j][u] = i >= 0 ? wcur[i] : 0.0;
+                mm[j][u] = (i >= 0 && mask) ? mask[i] : 1.0;
+                sw[j][u] = (i >= 0 && c.prior_scale_w) ? c.prior_scale_w[i] : 1.0;
+            }
+        auto make = [&](int j, int e, int i, double base, double d, double m, int pos, float sc, double scale_w) {
             double v = base + d;
             if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
             if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
@@ -479,22 +491,29 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             pv_out[(size_t)j * c.M + e] = v;
             if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
             if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
-                int l = 0;
-#pragma unroll
-                for (int q = 1; q < kMaxLayers; ++q) l += (i >= woff[q]) ? 1 : 0;
-                if (c.prior_scale_w) dlp[j] += prior_delta(c.prior_kind, v, base, c.prior_scale_w[i]);
-                else if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * half_inv_s2[l];
-                else dlp[j] += prior_delta(c.prior_kind, v, base, c.prior_scale[l]);
+                double his = half_inv_s2[0], lsc = layer_scale[0];     // (selected, not indexed: a register array indexed at run time
+#pragma unroll                                                         //  goes to scratch)
+                for (int q = 1; q < kMaxLayers; ++q) {
+                    const bool past = i >= woff[q];
+                    his = past ? half_inv_s2[q] : his;
+                    lsc = past ? layer_scale[q] : lsc;
+                }
+                if (c.prior_scale_w) dlp[j] += prior_delta(c.prior_kind, v, base, scale_w);
+                else if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * his;
+                else dlp[j] += prior_delta(c.prior_kind, v, base, lsc);
             }
         };
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j) {
-            if (ii[j] >= 0) make(j, tid, ii[j], bb[j], dd[j], mm[j], pp[j], ss[j]);
-            if (j < n_new) {
+#pragma unroll
+            for (int u = 0; u < ES; ++u)
+                if (ii[j][u] >= 0) make(j, tid + u * (int)blockDim.x, ii[j][u], bb[j][u], dd[j][u], mm[j][u], pp[j][u], ss[j][u], sw[j][u]);
+            if (cn[j] > ES * (int)blockDim.x) {
                 const size_t row = (size_t)(t_new + j) * c.M;
-                for (int e = tid + blockDim.x; e < c.cnt[t_new + j]; e += blockDim.x) {
+                for (int e = tid + ES * blockDim.x; e < cn[j]; e += blockDim.x) {
                     const int i = c.idx[row + e];
-                    if (i >= 0) make(j, e, i, wcur[i], c.delta[row + e], mask ? mask[i] : 1.0, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f);
+                    if (i >= 0) make(j, e, i, wcur[i], c.delta[row + e], mask ? mask[i] : 1.0, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f,
+                                     c.prior_scale_w ? c.prior_scale_w[i] : 1.0);
                 }
             }
         }

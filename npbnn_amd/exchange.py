@@ -219,13 +219,16 @@ def host_swap(chains, chain_ids, n_chains, swaps, swap_index, comm=None):
 
 
 def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, first_swap, comm=None, batch=20, device=True,
-                      on_interval=None):
+                      on_interval=None, group_passes=False):
     """``n_intervals`` rounds of [seg_len iterations of every chain, one swap proposal] - MC3.run_mcmc's loop body
     (BNN_mc3.py:94-112) - in device batches of up to ``batch`` intervals where the chains allow it, interval by interval
     otherwise.  ``on_interval(index, info)`` is called after every swap with ``info`` = dict(scalars=[n_chains, 2] logPost /
     temperature after the swap, swap=(j, k, r, log u, accepted), cold=per local chain None or dict(w, loglik, logprior) when the
     interval ran on the device and that chain is the cold one afterwards - ``iterations`` into the device batch that started at
-    ``iteration0`` with the acceptance memory ``mem_before``; ``last_of_batch`` marks the last interval of a device batch)."""
+    ``iteration0`` with the acceptance memory ``mem_before``; ``last_of_batch`` marks the last interval of a device batch).
+    ``group_passes``: on the interval-by-interval path the chains of this process advance through group passes
+    (:func:`run_steps_batched`) instead of one after the other - the same chains, their log-likelihoods equal to rounding rather
+    than to the bit (a group's sums come from a different number of workgroup partials)."""
     world = 1 if comm is None else comm.world_size
     done = 0
     while done < n_intervals:
@@ -235,7 +238,11 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
         if world > 1:                  # every rank must take the same path
             ok = bool(np.all(comm.allgather_f64(np.array([1.0 if ok else 0.0]))[:, 0] == 1.0))
         if not ok:
-            run_steps_batched(chains, seg_len)          # (the local chains share their passes over the data where they can)
+            if group_passes:                    # the local chains share their passes over the data (run_steps_batched)
+                run_steps_batched(chains, seg_len)
+            else:
+                for bnn, mcmc in chains:
+                    mcmc.run_steps(bnn, seg_len)
             scal, swap = host_swap(chains, chain_ids, n_chains, swaps, first_swap + done, comm)
             if on_interval is not None:
                 on_interval(done, dict(scalars=scal, swap=swap, cold=None))

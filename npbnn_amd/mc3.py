@@ -176,6 +176,7 @@ class MC3():
     # on the host (False: the reference's rhythm).  None = the library's choice: device batches for the chains of ONE process;
     # with several ranks the host path, until the in-place RCCL all-gather has been run between real ranks (set True to opt in).
     device_exchange = None
+    group_passes = False     # interval-by-interval path: the local chains share their passes over the data (exchange.run_steps_batched)
 
     def run_mcmc(self):
         """The MC3 loop (reference: BNN_mc3.py:87-126): ``n_mc3_iteration`` rounds of [swap_frequency iterations of every
@@ -216,7 +217,7 @@ class MC3():
                 got = ex.advance_intervals(chains, self.local_ids, self.n_chains, n, self.swap_frequency, self._swaps, done,
                                            comm=self.comm if self.comm.world_size > 1 else None, batch=n,
                                            device=(self.comm.world_size == 1) if self.device_exchange is None else self.device_exchange,
-                                           on_interval=on_interval)
+                                           on_interval=on_interval, group_passes=self.group_passes)
             else:                                       # a single chain: no swaps, the cold chain is logged every interval
                 for _ in range(n):
                     for i in self.local_ids:

@@ -1,9 +1,11 @@
 """``postLogger`` — TSV log of the sampled states and the posterior weight samples.
 
-Same files and formats as the reference logger (np_bnn/BNN_env.py:553-658, header built in
-np_bnn/BNN_files.py:110-187) so that logs and pickles remain readable by upstream tooling:
-``<name>_l<nodes>.log`` (tab separated), optional ``..._W.log`` with every weight, and
-``<name>_l<nodes>.pkl`` holding ``[bnn_obj, mcmc_obj, logger]``.
+Same files and layouts as the reference logger (np_bnn/BNN_env.py:553-658, header built in
+np_bnn/BNN_files.py:110-187): ``<name>_l<nodes>.log`` (tab separated; any tool that reads upstream's
+log reads this one), optional ``..._W.log`` with every weight, and ``<name>_l<nodes>.pkl`` holding
+``[bnn_obj, mcmc_obj, logger]`` with the same ``_post_weight_samples`` dictionaries.  The pickle holds
+objects of THIS package (``npbnn_amd.model.npBNN`` ...): loading it needs ``npbnn_amd`` on the import
+path, upstream's classes cannot stand in.
 """
 import csv
 import os

@@ -279,7 +279,10 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
     schedule = {1: "serial: evaluate a pass, decide it, evaluate the next",
                 2: "overlapped: the launch that evaluates pass L also decides pass L-1 (one workgroup); a pass overtaken by an "
                    "accept is dropped and re-evaluated",
-                3: "overlapped, launches alternating between two streams (opt-in)"}.get(used, "host loop")
+                3: "overlapped, launches alternating between two streams (opt-in)",
+                4: "overlapped, persistent: one launch per batch round, its workgroups loop over the passes (a workgroup that is "
+                   "through with pass L starts pass L+1), device-side flags order what kernel boundaries used to; bounded waits, "
+                   "falls back to (2) on a time-out"}.get(used, "host loop")
     line = {
         "metric": "MCMC iterations/sec (full fwd+lik per proposal)",
         "value": world * its / el,
@@ -322,6 +325,7 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
         "accept_rate": float(mcmc._device_accepted - book["acc"]) / max(1, done),          # rank 0, timed region
         "accept_rate_last_100": float(mcmc._acceptance_rate),
         "loglik": float(mcmc._logLik),
+        "schedule_timeouts": int(ctx.sync_fallbacks),
     }
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(wl)

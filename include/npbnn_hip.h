@@ -150,7 +150,9 @@ int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
  * have <= 16 nodes (the layer loop of MCMC.mh_step, np_bnn/BNN_env.py:449-473, on every BASELINE shape) run on builds of the
  * evaluation kernel with the layer loop, the activation and the epilogue resolved at compile time; 0 keeps every launch on
  * the general build (same results bit for bit; for A/B timing).  NPBNN_INFO_FAST_TAILS: 1 when such launches would take them. */
-enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2 };
+/* NPBNN_OPT_PERSISTENT (default 1): npbnn_chain_run with cfg->schedule = NPBNN_SCHED_AUTO may pick NPBNN_SCHED_PERSIST for a chain
+ * that has its GPU to itself; 0 keeps the automatic choice on kernel boundaries (NPBNN_SCHED_OVERLAP / _SERIAL). */
+enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTENT = 3 };
 enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
 enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3, NPBNN_INFO_FAST_TAILS = 4 };
 int npbnn_set_option(npbnn_ctx* ctx, int option, int value);
@@ -213,9 +215,10 @@ typedef struct {
     int32_t schedule;                          /* NPBNN_SCHED_AUTO / _SERIAL (evaluate a pass, decide it, evaluate the next) / _OVERLAP
                                                   (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
                                                   pass L-1 rejects; a pass overtaken by an accept is dropped) / _OVERLAP2 (below).
-                                                  The same chain whichever runs.  _AUTO: _OVERLAP while fewer than ~16 % of the
-                                                  iterations of the previous batch were accepted, else _SERIAL; _OVERLAP2 only runs
-                                                  when asked for by name. */
+                                                  The same chain whichever runs.  _AUTO: overlapped while fewer than ~16 % of the
+                                                  iterations of the previous batch were accepted - as _PERSIST for a chain alone on
+                                                  its GPU (NPBNN_OPT_PERSISTENT), else _OVERLAP - and _SERIAL above that; _OVERLAP2
+                                                  only runs when asked for by name. */
     int32_t reserved_;
     /* regression with an estimated error parameter (BNN_env.py:435-442: every proposal multiplies sigma by pre-drawn factors,
      * multiplier_proposal_vector, BNN_mcmc.py:101-113): sigma_mult[t*n_targets + q] is the factor of target column q at iteration
@@ -238,6 +241,13 @@ typedef struct {
                                          times out ends the batch with NPBNN_E_SYNC (state untouched: retry with NPBNN_SCHED_OVERLAP).
                                          Opt-in: it counts on the two streams having hardware queues of their own and on nothing else
                                          sharing the GPU, neither of which HIP guarantees; a chain that shares its GPU runs _OVERLAP */
+
+#define NPBNN_SCHED_PERSIST 4          /* the overlapped schedule as ONE persistent launch per batch round: every workgroup loops over
+                                         the passes, a workgroup that has finished pass L goes straight on to pass L + 1 (no kernel
+                                         boundary, no second stream, no launch gap), ordered by the same device-side flags as
+                                         _OVERLAP2.  Needs every workgroup of the launch resident (grid <= compute units, the chain
+                                         alone on its GPU); every wait is bounded: NPBNN_E_SYNC leaves the state untouched (retry
+                                         with NPBNN_SCHED_OVERLAP; the library does so by itself and keeps the context off this schedule afterwards). */
 
 typedef struct {
     double loglik, logprior;                   /* state after the K iterations */

@@ -21,6 +21,7 @@ PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE = 0, 1, 2, 3
 TRAIN, TEST = 0, 1
 OPT_L0_PRECISION = 1
 OPT_FAST_TAILS = 2
+OPT_PERSISTENT = 3
 L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
 INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU, INFO_FAST_TAILS = 1, 2, 3, 4
 E_RANGE = -6
@@ -82,7 +83,7 @@ class ChainJob(C.Structure):
 
 REC_DOUBLES = 4      # record of a chain at an exchange: logPost, temperature, finished-the-segment flag, iterations done
 
-SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP, SCHED_OVERLAP2 = 0, 1, 2, 3
+SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP, SCHED_OVERLAP2, SCHED_PERSIST = 0, 1, 2, 3, 4
 
 
 _P = C.c_void_p

@@ -73,6 +73,10 @@ class HipContext:
         """Shape-specialised builds of the evaluation kernel for likelihood-only launches (default on; same results)."""
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_FAST_TAILS, 1 if on else 0))
 
+    def set_persistent(self, on):
+        """May the library pick the persistent form of the overlapped chain schedule by itself (default on)?"""
+        self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_PERSISTENT, 1 if on else 0))
+
     def info(self, what):
         out = C.c_int(0)
         self._chk(self._lib.npbnn_get_info(self._ctx, what, C.byref(out)))
@@ -294,12 +298,12 @@ class HipContext:
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)
             if rc == capi.E_SYNC and not sync_retried:
                 sync_retried = True
-                if cfg.schedule == capi.SCHED_OVERLAP2:
+                if cfg.schedule in (capi.SCHED_OVERLAP2, capi.SCHED_PERSIST):
                     cfg.schedule = capi.SCHED_OVERLAP
                 self.sync_fallbacks += 1
                 if self.sync_fallbacks == 1:
                     import warnings
-                    warnings.warn("npbnn_amd: a device-side wait of the two-stream chain schedule timed out; the batch is repeated on "
+                    warnings.warn("npbnn_amd: a device-side wait of the flag-ordered (two-stream / persistent) chain schedule timed out; the batch is repeated on "
                                   "one stream and this context stays on one stream from now on (HipContext.sync_fallbacks counts them)")
                 continue        # (the state was left untouched)
             self._chk(rc)

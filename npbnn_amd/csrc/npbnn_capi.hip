@@ -93,6 +93,7 @@ struct npbnn_ctx {
     int mt0_template = 1;
     int l0_option = 0;             // NPBNN_L0_AUTO / _F32 / _F16
     int fast_option = 1;           // NPBNN_OPT_FAST_TAILS
+    int persist_option = 1;        // NPBNN_OPT_PERSISTENT
     // layer-0 block structure (npbnn_set_layer_mask): which (16-node tile, 16-feature group) blocks of the mask hold a nonzero;
     // empty = dense
     std::vector<unsigned char> l0_blocks;      // [mt][ceil(in_dim / 16)]
@@ -960,6 +961,10 @@ int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
         ctx->fast_option = value ? 1 : 0;
         return NPBNN_OK;
     }
+    if (option == NPBNN_OPT_PERSISTENT) {
+        ctx->persist_option = value ? 1 : 0;
+        return NPBNN_OK;
+    }
     return fail(ctx, NPBNN_E_ARG, "set_option: unknown option %d", option);
 }
 
@@ -994,7 +999,7 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     }
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipGetLastError());
     FinalizeParams f{};
     f.partials = ctx->d_partials;
@@ -1082,7 +1087,7 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     p.predict_mode = apply_out_fn ? 2 : 1;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     int ovf = 0;
@@ -1155,7 +1160,7 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
             p.lay = layout_for(ctx, d, true);
             rc = push_eval_params(ctx, p);
             if (rc) return rc;
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, (size_t)g * per_set * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
             int ovf = 0;
@@ -1202,6 +1207,7 @@ struct ChainBatch {
     ResLayout RL;
     int D = 1, schedule = NPBNN_SCHED_SERIAL, K = 0, M = 0;
     bool overlap = false;
+    bool persist = false;                      // persistent form: one launch loops over the passes (device flags order them)
     bool sync = false;                         // overlapped schedule with the launches alternating between two streams (device flags)
     bool forked = false;                       // sync: the two streams have been made to wait for ctx->stream
     size_t wb = 0;
@@ -1246,16 +1252,26 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     const int D = lp.n_cand;
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
     int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : cfg->schedule;
-    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2) {
+    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2 && schedule != NPBNN_SCHED_PERSIST) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
         schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
-        // (the two-stream form, NPBNN_SCHED_OVERLAP2, is never picked here: it orders overlapping launches with device-side waits,
-        // which needs both streams on hardware queues of their own and the step workgroup resident - nothing HIP promises.  It runs
-        // when the caller asks for it, and only for a chain that has the GPU to itself.)
+        // Where overlapping pays and the chain has the GPU to itself, the persistent form of it: one launch whose workgroups loop
+        // over the passes (no launch boundary between passes; a workgroup that is through with pass L starts pass L + 1 while
+        // others still finish L).  Its device-side waits only need the launch's workgroups resident together - one per compute
+        // unit, at most as many as there are - and are bounded: a time-out ends the batch with NPBNN_E_SYNC, state untouched, and
+        // the context stays on kernel boundaries from then on.  (The two-stream form, NPBNN_SCHED_OVERLAP2, is never picked here:
+        // it also needs the two streams on hardware queues of their own, which nothing promises.)
+        if (schedule == NPBNN_SCHED_OVERLAP && alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option)
+            schedule = NPBNN_SCHED_PERSIST;
     }
-    if (schedule == NPBNN_SCHED_OVERLAP2 && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
-    const bool overlap = schedule == NPBNN_SCHED_OVERLAP || schedule == NPBNN_SCHED_OVERLAP2;
-    const bool sync = schedule == NPBNN_SCHED_OVERLAP2 && alone_on_device;   // (several chains on one GPU: one stream each)
+    if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
+    // the persistent form needs every workgroup of its launch resident at once: one per compute unit at most, the GPU to itself, and
+    // a plain run (an exchange run's kernels go between the passes)
+    // (its grid is at most one workgroup per compute unit: the evaluating workgroups are capped at n_cu - 1 below, plus the step's)
+    if (schedule == NPBNN_SCHED_PERSIST && (!alone_on_device || seg_len > 0)) schedule = NPBNN_SCHED_OVERLAP;
+    const bool persist = schedule == NPBNN_SCHED_PERSIST;
+    const bool overlap = schedule == NPBNN_SCHED_OVERLAP || schedule == NPBNN_SCHED_OVERLAP2 || persist;
+    const bool sync = (schedule == NPBNN_SCHED_OVERLAP2 && alone_on_device) || persist;   // (several chains on one GPU: one stream each)
     if (schedule == NPBNN_SCHED_OVERLAP2 && !sync) schedule = NPBNN_SCHED_OVERLAP;
     if (!ctx->stream_e[0]) {      // (with the chain's first batch, whatever its schedule: creating a stream takes milliseconds)
         for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_e[i], hipStreamNonBlocking));
@@ -1453,7 +1469,8 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     // passes is only known on the device
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
     B->RL = RL;
-    B->sync = sync;
+    B->persist = persist;
+    B->sync = sync && !persist;              // (two launch streams to fork and join)
     B->forked = false;
     B->D = D;
     B->schedule = schedule;
@@ -1508,20 +1525,23 @@ int chain_join(npbnn_ctx* ctx, ChainBatch& B) {
 int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     hipStream_t st = ctx->stream;
     const LaunchPlan& lp = B.lp;
-    if (B.sync) {
+    if (B.persist) {            // ONE launch stands for the n passes: its workgroups loop over them (eval_kernel, n_loop)
+        if (n > 0) hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch, n);
+        B.launch += n;
+    } else if (B.sync) {
         int rc = chain_fork(ctx, B);
         if (rc) return rc;
         for (int i = 0; i < n; ++i, ++B.launch) {    // (bit 30: not the last launch of this round - see sync_step_leave)
             if (i == 1) hipLaunchKernelGGL(sync_gate_kernel, dim3(1), dim3(64), 0, ctx->stream_e[B.launch & 1], ctx->d_chain, B.launch - 1);
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, ctx->stream_e[B.launch & 1], (const EvalParams*)ctx->d_eparams,
-                               B.launch | (i + 1 < n ? (1 << 30) : 0));
+                               B.launch | (i + 1 < n ? (1 << 30) : 0), 1);
         }
     } else if (B.overlap) {
         for (int i = 0; i < n; ++i, ++B.launch)
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch);
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch, 1);
     } else {
         for (int i = 0; i < n; ++i, ++B.launch) {
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0);
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0, 1);
             hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
         }
     }
@@ -1721,7 +1741,7 @@ int npbnn_chains_run_batched(npbnn_chain_job* jobs, int32_t n_jobs, int32_t K) {
         if (++rounds > 64) return fail(ctx0, NPBNN_E_STATE, "chains_run_batched: the chains are stuck");
         const int n = (int)std::ceil((double)rem * (1.0 + acc) * 1.05) + 3;
         for (int i = 0; i < n; ++i, ++launch)
-            hipLaunchKernelGGL(lpG.fn, dim3(G + n_jobs), dim3(lpG.wpb * 64), lpG.lds, st, (const EvalParams*)ctx0->d_gparams, launch);
+            hipLaunchKernelGGL(lpG.fn, dim3(G + n_jobs), dim3(lpG.wpb * 64), lpG.lds, st, (const EvalParams*)ctx0->d_gparams, launch, 1);
         HIP_TRY(ctx0, hipGetLastError());
         for (int q = 0; q < n_jobs; ++q) {
             npbnn_ctx* c = jobs[q].ctx;
@@ -2025,10 +2045,10 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
@@ -2043,7 +2063,7 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
         for (int rep = 0; rep < 2; ++rep) {
             const double t0 = wall_us();
             for (int i = 0; i < iters; ++i)
-                hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ss[i % n_streams], (const EvalParams*)ctx->d_eparams, 0);
+                hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ss[i % n_streams], (const EvalParams*)ctx->d_eparams, 0, 1);
             for (int i = 0; i < n_streams; ++i) HIP_TRY(ctx, hipStreamSynchronize(ss[i]));
             if (rep) fprintf(stderr, "[npbnn time_pass] %d independent launches dealt over %d stream(s): %.2f us per launch (wall clock)\n", iters, n_streams,
                              (wall_us() - t0) / iters);
@@ -2119,10 +2139,10 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     //     would add ~4 us of command-processor overhead to each 20 us kernel); includes the ~1.5 us launch boundary
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     float burst = 0.f;
@@ -2131,7 +2151,7 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     // (2) evaluation = eval kernel + finalize
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int i = 0; i < iters; ++i) {
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0);
+        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, (const FinalizeParams*)ctx->d_fparams);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

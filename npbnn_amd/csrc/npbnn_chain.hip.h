@@ -432,7 +432,11 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             d.t0 = t_new;
             d.n_cand = 0;
             for (int j = 0; j < kMaxCand; ++j) d.cnt[j] = 0;
-            d.pad[0] = d.pad[1] = d.pad[2] = 0;
+            // pad[0] = 1: terminal - every iteration the chain may decide for now has been decided, so nothing will be prepared
+            // after this (an empty pass that is NOT terminal: the pass in flight reaches the limit but is still to be decided - if
+            // it accepts, the iterations after the accepted one are proposed again).  The persistent launch ends on it.
+            d.pad[0] = sh.s_t >= sh.s_lim ? 1 : 0;
+            d.pad[1] = d.pad[2] = 0;
             c.pass[pl.out] = d;
         }
         return;

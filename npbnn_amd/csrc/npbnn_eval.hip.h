@@ -17,7 +17,7 @@ namespace npbnn {
 //         kLikGen (float64 row-wise likelihoods: predicted sigma, Poisson, negative binomial).  Separate builds because
 //         each class keeps different per-lane accumulators alive through the whole kernel (and lgamma is register hungry).
 // ------------------------------------------------------------------------------------------------
-typedef void (*eval_fn_t)(const EvalParams*, int);
+typedef void (*eval_fn_t)(const EvalParams*, int, int);
 constexpr int kLikCat = 0, kLikGauss = 1, kLikGen = 2;
 __host__ __device__ inline int lik_class(int lik_kind) {
     return lik_needs_row_scratch(lik_kind) ? kLikGen : (lik_kind == NPBNN_LIK_GAUSS ? kLikGauss : kLikCat);
@@ -382,13 +382,18 @@ __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int 
 // without weights; the fast builds without it are for dense first layers and carry no test for it.  The general builds always
 // honour the structure.
 template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false, bool BLK = false>
-__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg) {
+__global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg, int n_loop) {
     static_assert(!FAST || (MTI == 1 && LK != kLikGen), "fast builds: narrow later layers, categorical or Gaussian likelihood");
     static_assert(!BLK || (FAST && MT0 >= 2), "block-structure builds are fast builds of layers with several output tiles");
     constexpr bool SKIP = !FAST || BLK;          // this build tests which tiles have weights in a K-unit
     // launch index; bit 30: another launch of the batch has been enqueued behind this one (two-stream schedule, sync_step_leave)
-    const int launch = launch_arg & 0x3fffffff;
+    // n_loop > 1: persistent form - this ONE launch stands for the launches launch0 .. launch0 + n_loop - 1 of the flag-ordered
+    // overlapped schedule: every workgroup loops over them, ordered by the same device-side flags (no kernel boundary, no second
+    // stream); a workgroup that finishes pass L goes straight on to pass L + 1.  Needs every workgroup resident (one per compute
+    // unit: grid <= compute units); every wait is bounded (NPBNN_E_SYNC).
+    const int launch0 = launch_arg & 0x3fffffff;
     const bool next_enqueued = (launch_arg >> 30) & 1;
+    const int launch_end = launch0 + (n_loop > 1 ? n_loop : 1);
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
     const EvalParams& p = *pp;
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const int G = (int)gridDim.x - (GN ? GN : chain ? 1 : 0);     // workgroups that evaluate
     if (GN && bid >= G) {
         StepShared& sh = *reinterpret_cast<StepShared*>(smem);
-        chain_step(*uni(p.group[bid - G].chain), overlapped_plan(launch), sh);
+        chain_step(*uni(p.group[bid - G].chain), overlapped_plan(launch0), sh);
         return;
     }
     const bool sync = chain && uni(p.sync_mode);        // launches overlap: device flags order them (npbnn_chain.hip.h)
@@ -416,15 +421,23 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     if (chain && bid == (sync ? 0 : G)) {
         StepShared& sh = *reinterpret_cast<StepShared*>(smem);
         int* const lds_flag = reinterpret_cast<int*>(smem + sizeof(StepShared));
-        if (sync && !sync_step_enter(*chain, launch, G, lds_flag)) return;
-        chain_step(*chain, overlapped_plan(launch), sh);
-        if (sync) sync_step_leave(chain->st, launch + 1, next_enqueued);
+        for (int launch = launch0; launch < launch_end; ++launch) {
+            if (sync && !sync_step_enter(*chain, launch, G, lds_flag)) return;
+            chain_step(*chain, overlapped_plan(launch), sh);
+            if (sync) sync_step_leave(chain->st, launch + 1, next_enqueued && launch + 1 == launch_end);
+            if (launch + 1 < launch_end) {      // persistent form: stop where the evaluating workgroups stop - at the terminal pass
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const PassDesc& nx = chain->pass[overlapped_plan(launch).out];
+                    *lds_flag = (nx.n_cand == 0 && nx.pad[0] == 1) ? 1 : 0;
+                }
+                __syncthreads();
+                if (*lds_flag) return;
+                __syncthreads();
+            }
+        }
         return;
     }
-    int early_prepared = 0x7fffffff;
-    if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
-        early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int par = (chain || GN) ? (launch & 1) : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,6 +490,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const float* const g_pscale = uni(p.pscale);
     double* const g_partials = uni(p.partials);
 
+    for (int launch = launch0; launch < launch_end; ++launch) {         // (one pass, but for the persistent form: see n_loop)
+    int early_prepared = 0x7fffffff;
+    if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
+        early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int par = (chain || GN) ? (launch & 1) : 0;
     // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
     //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
     int t0 = 0;
@@ -501,9 +519,13 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     } else if (pass) {
         if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
             const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand
+            if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand: an empty pass
                 if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
-                return;
+                // one pass per launch: this launch is over.  Persistent form: over only at the terminal pass (PassDesc.pad[0]); an
+                // empty pass before that means the pass in flight may still accept and start the chain's tail again
+                if (n_loop <= 1 || __builtin_amdgcn_readlane(w, 5) == 1) return;
+                __syncthreads();
+                continue;
             }
             t0 = __builtin_amdgcn_readlane(w, 0);
 #pragma unroll
@@ -984,6 +1006,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         __syncthreads();
         if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
     }
+    }       // (next pass of the persistent form)
 #undef NPBNN_ESTAMP
 }
 

@@ -535,7 +535,8 @@ class MCMC():
 
     n_candidates = 0         # proposals evaluated per pass over the data by the device chain: 0 = as many as fit (<= 3)
     device_schedule = 0      # 0 auto, 1 serial (evaluate, decide, evaluate ...), 2 overlapped (decide pass L-1 while pass L is evaluated),
-    #                          3 overlapped with the launches alternating between two streams (they overlap; device flags order them)
+    #                          3 overlapped with the launches alternating between two streams (they overlap; device flags order them),
+    #                          4 overlapped as one persistent launch per batch round (its workgroups loop over the passes; same flags)
     _device_schedule_used = 0
     _device_accepted = 0
     _device_passes = 0

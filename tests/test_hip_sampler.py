@@ -178,7 +178,7 @@ def test_speculative_passes_do_not_change_the_chain(name):
     schedule with the launches alternating between two streams, ordered by device-side flags instead of kernel boundaries."""
     cfg = cases.TRACES[name]
     out = []
-    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0), (3, 3), (1, 3), (2, 3)):
+    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0), (3, 3), (1, 3), (2, 3), (3, 4), (1, 4), (2, 4)):
         bnn, mcmc = build(cfg)
         mcmc.n_candidates = d
         mcmc.device_schedule = sched
@@ -193,7 +193,7 @@ def test_speculative_passes_do_not_change_the_chain(name):
         assert m._logLik == m1._logLik and m._logPrior == m1._logPrior
         for wa, wb in zip(b1._w_layers, b._w_layers):
             np.testing.assert_array_equal(wa, wb)
-        if sched in (2, 3):
+        if sched in (2, 3, 4):
             assert m._device_void_passes > 0                # accepts happened, so passes were dropped ...
         if d == 1:
             assert m._device_passes == 300                  # ... and never counted
@@ -322,7 +322,7 @@ def test_two_stream_schedule_times_out_cleanly(monkeypatch):
     ctx_b = mcmc_b._backend.ctx
     assert ctx_b._lib.npbnn_debug_sync_skip_(ctx_b._ctx, 7) == 0        # (diagnostic entry point, not part of the ABI)
     mcmc_b.device_schedule = 3
-    with pytest.warns(UserWarning, match="two-stream"):
+    with pytest.warns(UserWarning, match="flag-ordered"):
         mcmc_b.run_steps(bnn_b, 200)
     assert ctx_b.sync_fallbacks == 1
     assert mcmc_b._device_schedule_used == 2          # the batch was repeated on one stream
@@ -366,3 +366,39 @@ def test_run_steps_with_hyper_priors_is_the_mh_step_loop(hyper_p):
     for wa, wb in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(wa, wb)
     np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)
+
+
+def test_persistent_schedule_never_times_out_in_a_million_iterations():
+    """The persistent form of the overlapped schedule is what the library picks by itself for a chain alone on its GPU.  Its
+    device-side waits are bounded, and a time-out is survivable (NPBNN_E_SYNC: the batch is repeated on kernel boundaries) - but
+    on a GPU the chain has to itself none may happen: 10^6 iterations of config-2 shapes at a few per cent acceptance, in calls
+    of 100 000 and of 100, and the chain is the one the schedule on kernel boundaries gives."""
+    rs = np.random.default_rng(0)
+    n, f, c = 100_000, 256, 10
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    proj = rs.standard_normal((f, c)) / np.sqrt(f)
+    y = np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)
+    dat = dict(data=x, labels=y, test_data=np.zeros((0, f)), test_labels=np.zeros(0))
+
+    def chain():
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, dat, n_nodes=[32, 8], actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+        return bnn, bn.MCMC(bnn, update_f=[0.02] * 3)
+
+    bnn, m = chain()                               # schedule left to the library
+    for _ in range(9):
+        m.run_steps(bnn, 100_000)
+        assert m._device_schedule_used == 4 and m._backend.ctx.sync_fallbacks == 0
+    for _ in range(1000):
+        m.run_steps(bnn, 100)
+    assert m._device_schedule_used == 4 and m._backend.ctx.sync_fallbacks == 0 and m._current_iteration == 1_000_000
+    assert 0.001 < m._device_accepted / 1e6 < 0.3
+    # the same chain on kernel boundaries (first 20 000 iterations)
+    (ba, ma), (bb, mb) = chain(), chain()
+    ma.device_schedule, mb.device_schedule = 2, 4
+    ma.run_steps(ba, 20_000)
+    mb.run_steps(bb, 20_000)
+    assert mb._device_schedule_used == 4 and ma._last_accepted_mem == mb._last_accepted_mem
+    assert (ma._logLik, ma._logPrior) == (mb._logLik, mb._logPrior)
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)

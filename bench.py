@@ -178,6 +178,8 @@ def main():
     temps = [1.0] if world == 1 else list(np.linspace(0.8, 1.0, world))          # MC3 defaults (np_bnn/BNN_mc3.py:46-51)
     bnn, mcmc = wl.build(mcmc_id=rank, temperature=temps[rank], randomize_seed=world > 1)
 
+    if os.environ.get("NPBNN_BENCH_SCHEDULE"):            # A/B of the chain schedules on one box (npbnn_chain_cfg.schedule)
+        mcmc.device_schedule = int(os.environ["NPBNN_BENCH_SCHEDULE"])
     comm, comm_kind, nranks_seen = None, "none", 1
     if world > 1:
         comm, comm_kind = make_comm(dist, dist_backend, rank, world, local_rank, device_index)

@@ -1487,10 +1487,18 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
 // needed plus a margin (passes launched after the last iteration return at once)
 int passes_for(const npbnn_ctx* ctx, const ChainBatch& B, int rem, double slack) {
     int n = (rem + B.D - 1) / B.D;
+    if (B.persist) {
+        // the persistent launch ends by itself at the chain's terminal pass, so a generous bound costs nothing - and a second round
+        // (results back, look, launch again) costs a host round trip: the worst case, every iteration accepted (one iteration per
+        // pass and a void pass after each)
+        return 2 * rem + 4;
+    }
     if (ctx->its_per_pass >= 1.0) {
         const int est = (int)std::ceil(slack * (double)rem / ctx->its_per_pass);
         if (est > n) n = est;
-        n += 1 + n / 64;
+        // a launch past the end of the batch returns at once (a few microseconds); coming back short costs a host round trip and a
+        // second round: lean towards the former
+        n += 3 + n / 8;
     }
     if (B.overlap) n += 1;                   // the last pass is decided by the launch after it
     return n;
@@ -1612,14 +1620,25 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     hipStream_t st = ctx->stream;
     int t_done = 0, n_rounds = 0;
     const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
+    double t_enq = 0.0, t_wait = 0.0;
     while (t_done < K) {       // launch the least number of passes that can finish, look at the counter, repeat if short
         ++n_rounds;
-        rc = chain_enqueue(ctx, B, passes_for(ctx, B, K - t_done, 1.0));
+        const double ta = timing ? wall_us() : 0.0;
+        const int n_launch = passes_for(ctx, B, K - t_done, 1.0);
+        rc = chain_enqueue(ctx, B, n_launch);
         if (!rc) rc = chain_join(ctx, B);
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, B.RL.total, hipMemcpyDeviceToHost, st));   // state + results, one copy
+        const double tb = timing ? wall_us() : 0.0;
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (timing) {
+            const double tc = wall_us();
+            t_enq += tb - ta;
+            t_wait += tc - tb;
+            fprintf(stderr, "[npbnn chain timing]   round %d: %d launches enqueued in %.0f us, waited %.0f us, t=%d of %d\n", n_rounds, n_launch, tb - ta,
+                    tc - tb, reinterpret_cast<const ChainDev*>(ctx->h_res)->t, K);
+        }
         if (now->aborted) {         // a device-side wait of the flag-ordered schedule timed out: nothing was decided after it
             ctx->sync_failed = true;
             return fail(ctx, NPBNN_E_SYNC, "chain_run: the flag-ordered overlapped schedule timed out at t=%d; retry on one stream", now->t);

@@ -11,6 +11,8 @@ from bench_support import workload  # noqa: E402
 
 n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bnn, mcmc = workload(int(sys.argv[2]) if len(sys.argv) > 2 else 2).build()
+if os.environ.get("NPBNN_BENCH_SCHEDULE"):
+    mcmc.device_schedule = int(os.environ["NPBNN_BENCH_SCHEDULE"])
 rows = []
 for i in range(n_calls):
     p0, v0, a0 = mcmc._device_passes, mcmc._device_void_passes, mcmc._device_accepted

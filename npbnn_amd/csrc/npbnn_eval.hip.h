@@ -438,6 +438,13 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         }
         return;
     }
+    for (int launch = launch0; launch < launch_end; ++launch) {         // (one pass, but for the persistent form: see n_loop)
+    // Every pass reads its parameters afresh, through a pointer the compiler cannot see through: otherwise it hoists the dozens of
+    // launch-invariant scalars of the pass out of this loop and keeps them alive across it - far more than the scalar register file
+    // holds (70 spilled scalars against 33).
+    const EvalParams* pp_pass = pp;
+    asm volatile("" : "+s"(pp_pass));
+    const EvalParams& p = *pp_pass;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -490,7 +497,6 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const float* const g_pscale = uni(p.pscale);
     double* const g_partials = uni(p.partials);
 
-    for (int launch = launch0; launch < launch_end; ++launch) {         // (one pass, but for the persistent form: see n_loop)
     int early_prepared = 0x7fffffff;
     if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
         early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -8,7 +8,10 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in 2 4 5; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c$c -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_under_rocprof.json 2> $out/bench_c$c.err || echo "bench profile of config $c failed"
+  # one launch per pass (schedule 2): a launch's duration in the trace is the pass kernel's own, comparable with roofline.kernel_ms
+  NPBNN_BENCH_SCHEDULE=2 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c$c -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_under_rocprof.json 2> $out/bench_c$c.err || echo "bench profile of config $c failed"
+  # the default command (persistent launch: one kernel per run_steps call loops over the passes)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c${c}_persistent -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_persistent_under_rocprof.json 2> $out/bench_c${c}_persistent.err || echo "persistent bench profile of config $c failed"
   for cand in 3 1; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_c${c}_d${cand}_$ctr -o p -- python3 tools/profile_eval.py --config $c --cand $cand --iters 3 > $out/pmc_c${c}_d${cand}_$ctr.log 2>&1 || echo "pmc $ctr of config $c D=$cand failed"

@@ -170,6 +170,17 @@ def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def chain_run_by_address(lib):
+    """npbnn_chain_run with its array arguments declared as plain addresses (``array.ctypes.data``): the call every dispatch of a
+    device chain makes, without building a typed ctypes pointer per array."""
+    fn = getattr(lib, "_npbnn_chain_run_by_address", None)
+    if fn is None:
+        vp = C.c_void_p
+        proto = C.CFUNCTYPE(C.c_int, _P, C.POINTER(ChainCfg), vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ChainResult))
+        fn = lib._npbnn_chain_run_by_address = proto(("npbnn_chain_run", lib))
+    return fn
+
+
 def dptr(a):
     return None if a is None else a.ctypes.data_as(_DP)
 

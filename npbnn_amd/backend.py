@@ -13,9 +13,23 @@ from . import _capi as capi
 
 
 def pack_weights(weights):
-    """Concatenate the layer matrices (each row-major) into the packed float64
-    vector the C ABI takes."""
+    """Concatenate the layer matrices (each row-major) into the packed float64 vector the C ABI takes (always a fresh array).
+    Layers that are consecutive views of one packed vector - what a device batch leaves in the model - are copied in one piece."""
+    first = weights[0]
+    base = getattr(first, "base", None)
+    if (isinstance(base, np.ndarray) and base.ndim == 1 and base.dtype == np.float64 and base.flags.c_contiguous
+            and base.size == sum(w.size for w in weights)):
+        at = base.ctypes.data
+        for w in weights:
+            if w.base is not base or w.dtype != np.float64 or not w.flags.c_contiguous or w.ctypes.data != at:
+                break
+            at += w.nbytes
+        else:
+            return base.copy()
     return np.concatenate([np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights])
+
+
+_NO_SIGMA = np.zeros(0)
 
 
 def default_device():
@@ -257,7 +271,7 @@ class HipContext:
 
     def _result_dict(self, res):
         k = self.arch.n_targets
-        return dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]),
+        return dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]) if k else _NO_SIGMA,
                     n_accepted=res.n_accepted, n_passes=res.n_passes, n_candidates=res.n_candidates,
                     n_void_passes=res.n_void_passes, schedule=res.schedule, temperature=res.temperature,
                     iterations_done=res.iterations_done, overflow=res.overflow)
@@ -285,14 +299,14 @@ class HipContext:
         acc = np.empty(K, dtype=np.uint8)
         llp, lpp = np.empty(K), np.empty(K)
         res = self._chain_res
-        i32p = C.POINTER(C.c_int32)
+        run = capi.chain_run_by_address(self._lib)
+        addr = (w.ctypes.data, None if m is None else m.ctypes.data, idx.ctypes.data, delta.ctypes.data, cnt.ctypes.data,
+                log_u.ctypes.data, acc.ctypes.data, llp.ctypes.data, lpp.ctypes.data)
         attempt, sync_retried = 0, False
         while True:
             cfg.force_f32 = attempt
-            rc = self._lib.npbnn_chain_run(
-                self._ctx, C.byref(cfg), capi.dptr(w), capi.dptr(m), K, M, idx.ctypes.data_as(i32p),
-                capi.dptr(delta), cnt.ctypes.data_as(i32p), capi.dptr(log_u),
-                acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res))
+            rc = run(self._ctx, C.byref(cfg), addr[0], addr[1], K, M, addr[2], addr[3], addr[4], addr[5], addr[6], addr[7], addr[8],
+                     C.byref(res))
             if rc == capi.E_RANGE and attempt == 0:
                 attempt = 1
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)

@@ -466,7 +466,8 @@ class MCMC():
                 self._run_device_batch(bnn_obj, idx, delta, cnt, log_u, smult, hast)
             remaining -= seg
 
-    _speculation = None      # (key, future, generator state before the draw, step sizes used) of draws made ahead of the next call
+    _speculation = None      # (key, future, generator state before the draw, step-size arrays used) of draws made ahead of the next call
+    _ws_copies = None        # (step-size arrays, private copies of them, layer shapes) the helper thread works from
 
     def _draw_key(self, bnn_obj, first_it, k):
         return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id), tuple(int(n) for n in self._update_n),
@@ -476,10 +477,16 @@ class MCMC():
     def _submit_draw(self, bnn_obj, first_it, k, rewindable=False):
         """Start the pre-draw of iterations first_it .. first_it+k-1 on the helper thread."""
         from . import predraw as pd
-        shapes = [np.empty(w.shape) for w in bnn_obj._w_layers]      # predraw only needs the shapes
         rs, randomize, mcmc_id = self._gen, self._randomize_seed, self._mcmc_id
         update_n = [int(n) for n in self._update_n]
-        update_ws = [np.array(w, dtype=np.float64) for w in self._update_ws]      # private copies: the draw runs later
+        # private copies of the step sizes (the draw runs later), made once per set of source arrays: _adapt and reset_update_ws
+        # install NEW arrays, so the same objects mean the same values
+        src = list(self._update_ws)
+        cache = self._ws_copies
+        if cache is None or len(cache[0]) != len(src) or any(a is not b for a, b in zip(cache[0], src)) \
+                or any(c.shape != w.shape for c, w in zip(cache[2], bnn_obj._w_layers)):
+            cache = self._ws_copies = (src, [np.array(w, dtype=np.float64) for w in src], [np.empty(w.shape) for w in bnn_obj._w_layers])
+        update_ws, shapes = cache[1], cache[2]                         # (predraw only needs the shapes of the layers)
         freq = [float(f) for f in self._freq_layer_update]
         empty = getattr(self._backend, "host_empty", None)
         saved = rs.bit_generator.state if (rewindable and not randomize) else None
@@ -497,14 +504,14 @@ class MCMC():
                 hast = np.array([np.sum(np.log(row)) for row in smult])
             return idx, delta, cnt, u, smult, hast
 
-        return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved, update_ws
+        return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved, src
 
     def _claim_draw(self, bnn_obj, first_it, k):
         """The draws for iterations first_it .. first_it+k-1: the ones made ahead by the previous call when they
         are exactly these, else fresh ones."""
         spec = self._speculation
         if (spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k) and len(spec[3]) == len(self._update_ws)
-                and all(np.array_equal(a, np.broadcast_to(b, a.shape)) for a, b in zip(spec[3], self._update_ws))):
+                and all(a is b for a, b in zip(spec[3], self._update_ws))):      # (the very arrays the draw was made with)
             self._speculation = None
             return spec[1]
         self._cancel_speculation()
@@ -596,8 +603,9 @@ class MCMC():
             self._accepted_override = None
             self._invalidate()
         history = self._last_accepted_mem + acc.tolist()
-        self._last_accepted = int(acc[-1])
-        self._acceptance_rate = np.mean(history[-101:]) if len(history) > 100 else np.mean(history)
+        self._last_accepted = history[-1]
+        window = history[-101:] if len(history) > 100 else history       # (what np.mean saw in the last mh_step of these k)
+        self._acceptance_rate = np.float64(sum(window)) / len(window)
         self._last_accepted_mem = history[-100:] if len(history) > 100 else history
         self._current_iteration += k
         if self._randomize_seed:        # (assigning _gen, not _rs: draws made ahead for the next call stay valid)

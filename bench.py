@@ -343,6 +343,31 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
         line["settled_chain"] = {"value": n_more * ITERATIONS_PER_STEP / el2, "unit": "iterations/s",
                                  "after_iterations": int(mcmc._current_iteration), "accept_rate_last_100": float(mcmc._acceptance_rate),
                                  "note": "same dispatches of %d iterations, measured after 3000 further iterations" % ITERATIONS_PER_STEP}
+        # what a dispatch costs beyond its iterations: the same chain in ONE call of 10 000 iterations against the dispatches above
+        t0 = time.perf_counter()
+        mcmc.run_steps(bnn, 10000)
+        el3 = time.perf_counter() - t0
+        line["call_cost"] = {"long_call_iterations_per_s": 10000 / el3, "us_per_iteration_in_a_long_call": 1e2 * el3,
+                             "us_per_dispatch_of_%d" % ITERATIONS_PER_STEP: 1e6 * el2 / n_more,
+                             "us_fixed_per_dispatch": 1e6 * el2 / n_more - ITERATIONS_PER_STEP * 1e2 * el3,
+                             "note": "upload of state and draws, first step kernel (full prior re-sum), result copy, synchronisation, host Python"}
+        # and a chain that moves: the same model with proposals small enough that about a quarter of them is accepted (the
+        # reference drivers adapt towards 0.2-0.4: adapt_f / adapt_fM, np_bnn/BNN_env.py:392-413)
+        if wl.moving_update_f is not None:
+            bnn_q, mcmc_q = wl.build(update_f=list(wl.moving_update_f))
+            mcmc_q.run_steps(bnn_q, 2000)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                mcmc_q.run_steps(bnn_q, ITERATIONS_PER_STEP)
+            el4 = time.perf_counter() - t0
+            line["moving_chain"] = {"value": 20 * ITERATIONS_PER_STEP / el4, "unit": "iterations/s",
+                                    "accept_rate_last_100": float(mcmc_q._acceptance_rate),
+                                    "accept_rate": float(mcmc_q._device_accepted) / max(1, mcmc_q._device_iterations),
+                                    "schedule": int(mcmc_q._device_schedule_used),
+                                    "iterations_per_pass": mcmc_q._device_iterations / max(1, mcmc_q._device_passes),
+                                    "note": "20 dispatches of %d iterations after 2000 of warm-up, update_f = %s"
+                                            % (ITERATIONS_PER_STEP, list(wl.moving_update_f))}
+            mcmc_q._backend.close()
     else:
         line["cpu_baseline"] = None
     return line

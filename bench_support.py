@@ -17,6 +17,7 @@ class Workload:
     """One BASELINE.json configuration: SURVEY.md 8(d) gives inputs (``np.random.default_rng(0)``), model
     (``np.random.seed(1234)`` before npBNN) and the algorithmic bytes per proposal (X in float32 + labels / targets)."""
     config = 0
+    moving_update_f = None      # proposal sizes at which about a quarter of the proposals is accepted (bench.py's moving_chain leg)
 
     def kernel_name(self, ctx, cand):
         return "eval_kernel<MT0=%d,MTI=1,%s,D=%d,LK=%s,%s>" % (self.mt0, "fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand,
@@ -27,6 +28,7 @@ class Config2(Workload):
     config, mt0, lik_class = 2, 2, "categorical"
     n, f, c, hidden = 100_000, 256, 10, [32, 8]
     short = "config 2 (100k x 256, [32,8])"
+    moving_update_f = [0.004] * 3
     description = "config 2: 100k x 256 features, 10 classes, hidden [32,8], tanh, bias 2"
 
     def __init__(self):
@@ -35,14 +37,14 @@ class Config2(Workload):
         self.y = rs.integers(0, self.c, self.n)
         self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n
 
-    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False):
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
         """np.random.seed(1234); npBNN(n_nodes=[32,8], tanh, bias nodes in input+hidden layers, N(0,1) prior); MCMC defaults
         (update_f 0.05 -> update_n [411,13,4])."""
         x32 = self.x.astype(np.float32)
         dat = dict(data=x32, labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
         np.random.seed(1234)
         bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
-        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed)
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **sampler_kw)
         return bnn, mcmc
 
     def oracle_chain(self, orc):
@@ -106,14 +108,14 @@ class Config4(_Regression):
         self.y = self._targets(rs, self.x, self.k)
         self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n * self.k
 
-    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False):
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
         """bnn_regress.py:33-52: npBNN(regression, tanh, p_scale 1, bias 2, empirical_error); MCMC(update_ws [.025,.025,.05],
         update_f [.005,.005,.05], adapt_f .3, estimate_error False)."""
         dat = dict(data=self.x.astype(np.float32), labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros((0, self.k)))
         np.random.seed(1234)
         bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, estimation_mode="regression", actFun=bn.ActFun(fun="tanh"), p_scale=1,
                      use_bias_node=2, empirical_error=True)
-        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **self.sampler)
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **dict(self.sampler, **sampler_kw))
         return bnn, mcmc
 
     def oracle_chain(self, orc):
@@ -126,6 +128,7 @@ class Config5(_Regression):
     config, mt0, act = 5, 2, "ReLU"
     n, f, k, hidden, blocks = 50_000, 512, 1, [32, 8], 8
     short = "config 5 (50k x 512 block layers, [32,8])"
+    moving_update_f = [0.01] * 3
     description = ("config 5: 50k x 512 features, layer 0 in 8 blocks of 64 inputs x 4 nodes (create_mask), hidden [32,8], ReLU, "
                    "bias -1, 1 Gaussian target (block_bnns.py layout)")
 
@@ -138,7 +141,7 @@ class Config5(_Regression):
     def _mask_args(self):
         return [list(np.repeat(np.arange(self.blocks), self.f // self.blocks)), [], []], [[4] * self.blocks, [], []]
 
-    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False):
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
         """block_bnns.py:32-43: npBNN(regression, default ReLU, p_scale 1, bias on the last layer) + create_mask / apply_mask;
         MCMC defaults."""
         dat = dict(data=self.x.astype(np.float32), labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros((0, self.k)))
@@ -146,7 +149,7 @@ class Config5(_Regression):
         bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, estimation_mode="regression", p_scale=1, use_bias_node=-1)
         idx, per = self._mask_args()
         _quiet(bnn.apply_mask, bn.create_mask(bnn._w_layers, indx_input_list=idx, nodes_per_feature_list=per))
-        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed)
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **sampler_kw)
         return bnn, mcmc
 
     def oracle_chain(self, orc):

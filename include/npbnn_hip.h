@@ -215,8 +215,8 @@ typedef struct {
     int32_t schedule;                          /* NPBNN_SCHED_AUTO / _SERIAL (evaluate a pass, decide it, evaluate the next) / _OVERLAP
                                                   (decide pass L-1 inside the launch that evaluates pass L, which was prepared assuming
                                                   pass L-1 rejects; a pass overtaken by an accept is dropped) / _OVERLAP2 (below).
-                                                  The same chain whichever runs.  _AUTO: overlapped while fewer than ~16 % of the
-                                                  iterations of the previous batch were accepted - as _PERSIST for a chain alone on
+                                                  The same chain whichever runs.  _AUTO: overlapped while fewer than ~37 % of the
+                                                  iterations of the previous batch were accepted (75 % of the passes of 3) - as _PERSIST for a chain alone on
                                                   its GPU (NPBNN_OPT_PERSISTENT), else _OVERLAP - and _SERIAL above that; _OVERLAP2
                                                   only runs when asked for by name. */
     int32_t reserved_;

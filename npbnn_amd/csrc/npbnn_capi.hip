@@ -1254,7 +1254,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : cfg->schedule;
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2 && schedule != NPBNN_SCHED_PERSIST) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
-        schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.4 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
+        // (measured, config-2 shapes, tools/stress_schedules.py 10000 1 2 4: up to 34 % of the proposals accepted - 71 % of the passes -
+        // the overlapped forms lead, 48-63 k against 45-50 k it/s; config 4 at 46 % / 84 %: serial 18.8 k against 17.4-18.4 k)
+        schedule = (1.0 - std::pow(1.0 - p_acc, D)) < 0.75 ? NPBNN_SCHED_OVERLAP : NPBNN_SCHED_SERIAL;
         // Where overlapping pays and the chain has the GPU to itself, the persistent form of it: one launch whose workgroups loop
         // over the passes (no launch boundary between passes; a workgroup that is through with pass L starts pass L + 1 while
         // others still finish L).  Its device-side waits only need the launch's workgroups resident together - one per compute

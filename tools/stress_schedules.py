@@ -25,7 +25,7 @@ proj = rs.standard_normal((f, c)) / np.sqrt(f)
 labels = {"random labels": rs.integers(0, c, n), "learnable labels": np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)}
 bad = 0
 for name, y in labels.items():
-    for uf in (0.05, 0.004):
+    for uf in [float(v) for v in os.environ.get("NPBNN_STRESS_UF", "0.05,0.004").split(",")]:      # (proposal sizes: acceptance 0.5-3 % and ~25 %)
         out = []
         for sched in scheds:
             np.random.seed(1234)

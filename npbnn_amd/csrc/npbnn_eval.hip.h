@@ -582,8 +582,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     if (Dp > 2 * KT0) Dp = 2 * KT0;                     // at most 3 tiles in flight (aux slots)
     const bool full_depth = (Dp == DEPTH);
 
-    // prefetch cursor: a per-lane running source pointer and a scalar ring offset
-    const float* pf_ptr = Xg + ((size_t)first_tile * 16 + n) * (size_t)Fp + 4 * kq;
+    // prefetch cursor: a wave-uniform running source pointer (scalar arithmetic), this lane's constant byte offset inside a piece
+    // (row n, 16-byte group kq) and a scalar ring offset
+    const float* pf_ptr = Xg + (size_t)first_tile * 16 * (size_t)Fp;
+    const unsigned pf_lane = ((unsigned)n * (unsigned)Fp + 4u * (unsigned)kq) * 4u;
     const size_t tile_jump = (size_t)stride * 16 * (size_t)Fp - (size_t)KT0 * 16;
     int pf_q = 0, pf_kt = 0, pf_tile = first_tile, pf_seq = 0, pf_slot = 0;
     auto issue_aux = [&]() {   // row-aux data of a tile travels ahead of its first X piece
@@ -604,7 +606,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     };
     auto issue_next = [&]() {
         if (pf_kt == 0) issue_aux();
-        dma16(pf_ptr, ring + pf_slot);
+        dma16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(pf_ptr) + pf_lane), ring + pf_slot);
         pf_ptr += 16;
         pf_slot = ring_next(pf_slot);
         ++pf_q;
@@ -778,21 +780,30 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             f32x4 acc0[D][MT0];
             int ld_slot = 0;                              // ring offset of the next step to read
             int s = 0, ks = 0;                            // current step: global index, index inside its tile
+            // LDS addresses as 32-bit byte offsets from smem, the per-lane parts formed once: a fragment read then costs one vector
+            // add (lane part + scalar part) - as generic pointers with a per-lane select the same reads took a dozen vector
+            // instructions per K-step, half of the non-matrix vector work of the tile loop
+            static_assert(kRing == 4, "a K-step is two ring slots: the steps alternate between slots (0, 1) and (2, 3)");
+            const unsigned x_lane = (unsigned)(D * IB) + (unsigned)wave * (unsigned)uni(p.lay.wave_lds)
+                                    + (unsigned)((kq >> 1) * 1024 + ((2 * (kq & 1)) * 16 + n) * 16);
+            unsigned w_lane[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) w_lane[j] = (unsigned)(j * IB) + (unsigned)frag0_off * 4u;
             auto load_x = [&](XFrag& x) {
-                const int slot_b = ring_next(ld_slot);
-                const char* px = ring + ((kq >> 1) ? slot_b : ld_slot) + ((2 * (kq & 1)) * 16 + n) * 16;
+                const char* px = smem + (x_lane + (unsigned)ld_slot);
                 x.xh = *reinterpret_cast<const f16x8*>(px);
                 x.xl = *reinterpret_cast<const f16x8*>(px + 256);
-                ld_slot = ring_next(slot_b);
+                ld_slot ^= 2048;
             };
             auto load_w = [&](WFrag& w, int kstep, int j) {
-                const float* fr = imgs + (size_t)j * image_floats + frag0_off + kstep * 512;
+                const unsigned fr = w_lane[j] + (unsigned)kstep * 2048u;
                 const int live = unit_tiles(kstep);
 #pragma unroll
                 for (int mt = 0; mt < MT0; ++mt)
                     if (live & (1 << mt)) {
-                        w.wh[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512);
-                        w.wl[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512 + 256);
+                        const char* pw = smem + (fr + (unsigned)uo[mt] * 2048u);
+                        w.wh[mt] = *reinterpret_cast<const f16x8*>(pw);
+                        w.wl[mt] = *reinterpret_cast<const f16x8*>(pw + 1024);
                     }
             };
             NPBNN_WAIT_VMCNT(0);                          // (the barriers above already drained this wave's loads)

@@ -144,15 +144,23 @@ struct EvalParams {
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
+// max of two numbers in ONE instruction: fmaxf in a kernel compiled in IEEE mode first canonicalises both operands (v_max x, x, x) so
+// that a signalling NaN comes out quiet - two more vector instructions per max, for inputs that are never NaN here.  The median of
+// (a, b, +inf) is that max.  (Not inline assembly: the compiler's hazard recogniser does not look inside it, and a hand-written
+// v_max right behind the MFMA that produces its operand read the register too early - chains that differed from run to run.)
+__device__ __forceinline__ float max_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+
 __device__ __forceinline__ float act_apply(float z, int kind, float prm) {
 #ifdef NPBNN_EXP_NO_ACT      // timing experiment only: activation = identity
     return z;
 #endif
     switch (kind) {
-        case NPBNN_ACT_RELU: return fmaxf(z, 0.f);                                  // BNN_lib.py:51
+        case NPBNN_ACT_RELU: return max_nn(z, 0.f);                                 // BNN_lib.py:51
         case NPBNN_ACT_LEAKY: return z < 0.f ? prm * z : z;                         // BNN_lib.py:55
         case NPBNN_ACT_SWISH: return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));   // BNN_lib.py:60
-        default: return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f);   // BNN_lib.py:65 (exp-form tanh)
+        // BNN_lib.py:65 (exp-form tanh).  __expf(2z) is exp2(2z * log2(e)); written as exp2(z * 2 log2(e)) it is one multiply less and
+        // the same bits (doubling is exact: both products are the same real number, rounded once)
+        default: return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z * 2.8853900817779268f) + 1.f);
     }
 }
 
@@ -186,9 +194,9 @@ __device__ __forceinline__ float softplus_f(float z) {   // np.logaddexp(0, z), 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float quad_max(float v) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    v = max_nn(__uint_as_float(r[0]), __uint_as_float(r[1]));
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return max_nn(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float quad_sum(float v) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);

@@ -190,7 +190,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < D; ++j) m[j] = fmaxf(m[j], h[j][mt][i]);
+                        for (int j = 0; j < D; ++j) m[j] = max_nn(m[j], h[j][mt][i]);
 #pragma unroll
             for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
 #pragma unroll
@@ -208,7 +208,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
                     for (int i = 0; i < 4; ++i)
                         if (16 * mt + 4 * kq + i < C)
 #pragma unroll
-                            for (int j = 0; j < D; ++j) m[j] = fmaxf(m[j], h[j][mt][i]);
+                            for (int j = 0; j < D; ++j) m[j] = max_nn(m[j], h[j][mt][i]);
 #pragma unroll
             for (int j = 0; j < D; ++j) m[j] = quad_max(m[j]);
 #pragma unroll

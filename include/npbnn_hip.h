@@ -152,7 +152,9 @@ int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
  * the general build (same results bit for bit; for A/B timing).  NPBNN_INFO_FAST_TAILS: 1 when such launches would take them. */
 /* NPBNN_OPT_PERSISTENT (default 1): npbnn_chain_run with cfg->schedule = NPBNN_SCHED_AUTO may pick NPBNN_SCHED_PERSIST for a chain
  * that has its GPU to itself; 0 keeps the automatic choice on kernel boundaries (NPBNN_SCHED_OVERLAP / _SERIAL). */
-enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTENT = 3 };
+/* NPBNN_OPT_TRAINABLE_SLOPES (default 0): 1 reserves a slot per hidden layer in the weight image for the activation slope, so that the
+ * candidates of a chain pass can each carry their own (npbnn_chain_cfg.slope_idx ...); such a network runs on the general builds. */
+enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTENT = 3, NPBNN_OPT_TRAINABLE_SLOPES = 4 };
 enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
 enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3, NPBNN_INFO_FAST_TAILS = 4 };
 int npbnn_set_option(npbnn_ctx* ctx, int option, int value);
@@ -231,6 +233,18 @@ typedef struct {
      * the scale of every packed weight (n_weights values, layer matrices concatenated row-major like the weights), or NULL for
      * one scale per layer (prior_scale[] above).  Constant over the call: the Gibbs step that redraws them runs between calls. */
     const double* prior_scale_w;
+    /* trainable activation slopes (ActFun(trainable=True), BNN_env.py:416-421,502-503; needs NPBNN_OPT_TRAINABLE_SLOPES): every
+     * iteration first proposes new slopes from the accepted ones - UpdateNormal1D(acc_prm, d = 0.05, n = 1, bounds [0, 1]): entry
+     * slope_idx[t] moves by slope_delta[t], reflected at 0 and 1 - evaluates its proposal with them, adds
+     * log(r) * -sum(slopes') * r (r = 10) to the proposal's log prior and keeps them when the proposal is accepted.
+     * cur_slopes: the accepted slopes on entry (result->slopes on return; n_slopes = hidden layers); slope_term_in_prior: 1 when
+     * cur_logprior already holds that term for cur_slopes (it does after the chain's first accepted proposal: MCMC.__init__ computes
+     * its prior without it, BNN_env.py:374).  NULL / 0: fixed slopes, as npbnn_eval takes them. */
+    const int32_t* slope_idx;
+    const double* slope_delta;
+    double cur_slopes[NPBNN_MAX_LAYERS];
+    int32_t n_slopes;
+    int32_t slope_term_in_prior;
 } npbnn_chain_cfg;
 #define NPBNN_SCHED_AUTO 0
 #define NPBNN_SCHED_SERIAL 1
@@ -261,6 +275,7 @@ typedef struct {
     int32_t iterations_done;                   /* K for npbnn_chain_run; an exchange run may stop a chain earlier (see below) */
     int32_t overflow;                          /* exchange run: 1 = the chain stopped before a proposal that leaves the fp16 range of the
                                                   layer-0 path (continue it with npbnn_chain_run, cfg->force_f32 = 1) */
+    double slopes[NPBNN_MAX_LAYERS];           /* accepted activation slopes after the iterations (cfg->n_slopes of them) */
 } npbnn_chain_result;
 
 int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout, const double* mask_packed,

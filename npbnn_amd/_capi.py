@@ -22,6 +22,7 @@ TRAIN, TEST = 0, 1
 OPT_L0_PRECISION = 1
 OPT_FAST_TAILS = 2
 OPT_PERSISTENT = 3
+OPT_TRAINABLE_SLOPES = 4
 L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
 INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU, INFO_FAST_TAILS = 1, 2, 3, 4
 E_RANGE = -6
@@ -60,14 +61,16 @@ class ChainCfg(C.Structure):
                 ("sigma", C.c_double * MAX_TARGETS), ("cur_loglik", C.c_double), ("cur_logprior", C.c_double),
                 ("cur_sigma", C.c_double * MAX_TARGETS), ("force_f32", C.c_int32), ("n_candidates", C.c_int32),
                 ("schedule", C.c_int32), ("reserved_", C.c_int32), ("sigma_mult", C.POINTER(C.c_double)),
-                ("hastings", C.POINTER(C.c_double)), ("prior_scale_w", C.POINTER(C.c_double))]
+                ("hastings", C.POINTER(C.c_double)), ("prior_scale_w", C.POINTER(C.c_double)),
+                ("slope_idx", C.POINTER(C.c_int32)), ("slope_delta", C.POINTER(C.c_double)),
+                ("cur_slopes", C.c_double * MAX_LAYERS), ("n_slopes", C.c_int32), ("slope_term_in_prior", C.c_int32)]
 
 
 class ChainResult(C.Structure):
     _fields_ = [("loglik", C.c_double), ("logprior", C.c_double), ("sigma", C.c_double * MAX_TARGETS),
                 ("n_accepted", C.c_int64), ("n_passes", C.c_int32), ("n_candidates", C.c_int32),
                 ("n_void_passes", C.c_int32), ("schedule", C.c_int32), ("temperature", C.c_double),
-                ("iterations_done", C.c_int32), ("overflow", C.c_int32)]
+                ("iterations_done", C.c_int32), ("overflow", C.c_int32), ("slopes", C.c_double * MAX_LAYERS)]
 
 
 class ChainJob(C.Structure):

@@ -87,6 +87,14 @@ class HipContext:
         """Shape-specialised builds of the evaluation kernel for likelihood-only launches (default on; same results)."""
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_FAST_TAILS, 1 if on else 0))
 
+    def set_trainable_slopes(self, on):
+        """Reserve a slot per hidden layer in the weight image for the activation slope, so that the candidates of a chain pass
+        can each carry their own (ActFun(trainable=True) on the device chain); such a network runs on the general builds."""
+        on = bool(on)
+        if on != getattr(self, "_trainable_slopes", False):
+            self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_TRAINABLE_SLOPES, 1 if on else 0))
+            self._trainable_slopes = on
+
     def set_persistent(self, on):
         """May the library pick the persistent form of the overlapped chain schedule by itself (default on)?"""
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_PERSISTENT, 1 if on else 0))
@@ -232,7 +240,21 @@ class HipContext:
         return ms.value, used.value
 
     def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
-                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None):
+                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None, slopes=None):
+        cfg.slope_idx = cfg.slope_delta = None
+        cfg.n_slopes = cfg.slope_term_in_prior = 0
+        cfg._keep_slopes = None
+        if slopes is not None:        # (slope_idx [K] int32, slope_delta [K], accepted slopes, does cur_logprior hold their term?)
+            s_idx = np.ascontiguousarray(slopes[0], dtype=np.int32)
+            s_delta = capi.as_f64(slopes[1])
+            cur = np.asarray(slopes[2], dtype=np.float64).ravel()
+            cfg._keep_slopes = (s_idx, s_delta)
+            cfg.slope_idx = s_idx.ctypes.data_as(C.POINTER(C.c_int32))
+            cfg.slope_delta = capi.dptr(s_delta)
+            cfg.n_slopes = len(cur)
+            for i, v in enumerate(cur):
+                cfg.cur_slopes[i] = float(v)
+            cfg.slope_term_in_prior = 1 if slopes[3] else 0
         cfg.prior_kind = int(prior_kind)
         cfg._keep_scale = None
         cfg.prior_scale_w = None
@@ -274,11 +296,11 @@ class HipContext:
         return dict(loglik=res.loglik, logprior=res.logprior, sigma=np.array(res.sigma[:k]) if k else _NO_SIGMA,
                     n_accepted=res.n_accepted, n_passes=res.n_passes, n_candidates=res.n_candidates,
                     n_void_passes=res.n_void_passes, schedule=res.schedule, temperature=res.temperature,
-                    iterations_done=res.iterations_done, overflow=res.overflow)
+                    iterations_done=res.iterations_done, overflow=res.overflow, slopes=res.slopes)
 
     def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
                   cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0, sigma_mult=None,
-                  hastings=None):
+                  hastings=None, slopes=None):
         """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
         (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
         w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
@@ -288,7 +310,7 @@ class HipContext:
             cfg = self._chain_cfg = capi.ChainCfg()
             self._chain_res = capi.ChainResult()
         self._fill_chain_cfg(cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
-                             cur_sigma, sigma, n_candidates, schedule, sigma_mult, hastings)
+                             cur_sigma, sigma, n_candidates, schedule, sigma_mult, hastings, slopes)
         m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
         if idx.dtype != np.int32 or not idx.flags.c_contiguous:
             idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -93,6 +93,12 @@ struct npbnn_ctx {
     int mt0_template = 1;
     int l0_option = 0;             // NPBNN_L0_AUTO / _F32 / _F16
     int fast_option = 1;           // NPBNN_OPT_FAST_TAILS
+    int slopes_option = 0;         // NPBNN_OPT_TRAINABLE_SLOPES: the image holds a slot per hidden layer for the activation slope
+    SlopeState* d_slopes = nullptr; // trainable slopes of the device chain (npbnn_chain_cfg.slope_idx ...)
+    int* d_sidx = nullptr;          // [slope_cap] pre-drawn slope entries ...
+    double* d_sdelta = nullptr;     // ... and steps
+    size_t slope_cap = 0;
+    bool batch_slopes = false;      // the batch in flight carries slopes (chain_finish reads them back)
     int persist_option = 1;        // NPBNN_OPT_PERSISTENT
     // layer-0 block structure (npbnn_set_layer_mask): which (16-node tile, 16-feature group) blocks of the mask hold a nonzero;
     // empty = dense
@@ -343,6 +349,11 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     } else {
         net.classw_off = -1;
     }
+    net.slope_off = -1;
+    if (ctx->slopes_option) {           // a slot per hidden layer for the candidates' activation slopes (filled in LDS by a chain pass)
+        net.slope_off = off;
+        off += kMaxLayers;
+    }
     net.image_floats = round_up(off, 64);   // a multiple of 256 B (the LDS copies of several candidates sit back to back)
     net.n_out = a->out_dim[a->n_layers - 1];
     if (a->lik_kind == NPBNN_LIK_GAUSS) {
@@ -481,7 +492,7 @@ bool l0_blocked(const NetMeta& net) {
 bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d) {
     const NetMeta& net = ctx->net;
     if (!ctx->fast_option || max_inner_tiles(net) != 1 || net.n_layers < 2 || net.n_layers > kFastLayers || net.L[0].mt > kFastMaxMT0) return false;
-    if (net.final_act || d.inst_w || ctx->n_classw > 0) return false;
+    if (net.final_act || d.inst_w || ctx->n_classw > 0 || net.slope_off >= 0) return false;
     if (l0_blocked(net) && !net.l0_f16) return false;          // (the fast builds for block-structured layers are fp16-split ones)
     if (net.lik_kind == NPBNN_LIK_CATEGORICAL) return net.pad_masked != 0 && d.labels != nullptr;
     return net.lik_kind == NPBNN_LIK_GAUSS && d.targets != nullptr && net.k_targets <= kFastGaussTargets;
@@ -598,6 +609,7 @@ EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
     p.Fp = ctx->net.l0_f16 ? d.Fp16 : d.Fp;
     p.net = ctx->net;
     p.lay = layout_for(ctx, d);
+    p.cand_slopes = nullptr;
     return p;
 }
 
@@ -716,7 +728,7 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w};
+    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -963,6 +975,14 @@ int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
     }
     if (option == NPBNN_OPT_PERSISTENT) {
         ctx->persist_option = value ? 1 : 0;
+        return NPBNN_OK;
+    }
+    if (option == NPBNN_OPT_TRAINABLE_SLOPES) {
+        const int on = value ? 1 : 0;
+        if (on != ctx->slopes_option) {
+            ctx->slopes_option = on;
+            if (ctx->arch_set) return rebuild_net(ctx, ctx->net.l0_f16 != 0);      // (the image layout changes)
+        }
         return NPBNN_OK;
     }
     return fail(ctx, NPBNN_E_ARG, "set_option: unknown option %d", option);
@@ -1446,6 +1466,43 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pscale_w, cfg->prior_scale_w, wb, hipMemcpyHostToDevice, st));
         c.prior_scale_w = ctx->d_pscale_w;
     }
+    c.slopes = nullptr;
+    c.slope_idx = nullptr;
+    c.slope_delta = nullptr;
+    c.n_slopes = 0;
+    c.slope_term_in = 0;
+    ctx->batch_slopes = false;
+    if (cfg->slope_idx || cfg->slope_delta) {          // trainable activation slopes
+        if (!cfg->slope_idx || !cfg->slope_delta || cfg->n_slopes < 1 || cfg->n_slopes > kMaxLayers || cfg->n_slopes != ctx->net.n_layers - 1)
+            return fail(ctx, NPBNN_E_ARG, "chain_run: slope_idx and slope_delta go together, with one slope per hidden layer (got %d for %d layers)",
+                        cfg->n_slopes, ctx->net.n_layers);
+        if (ctx->net.slope_off < 0) return fail(ctx, NPBNN_E_STATE, "chain_run: trainable slopes need NPBNN_OPT_TRAINABLE_SLOPES");
+        if (seg_len > 0 || group_blocks > 0) return fail(ctx, NPBNN_E_ARG, "chain_run: trainable slopes run in plain batches only");
+        for (int t = 0; t < K; ++t)
+            if (cfg->slope_idx[t] < 0 || cfg->slope_idx[t] >= cfg->n_slopes) return fail(ctx, NPBNN_E_ARG, "chain_run: slope_idx[%d] out of range", t);
+        if ((size_t)K > ctx->slope_cap) {
+            if (ctx->d_sidx) (void)hipFree(ctx->d_sidx);
+            if (ctx->d_sdelta) (void)hipFree(ctx->d_sdelta);
+            ctx->d_sidx = nullptr; ctx->d_sdelta = nullptr; ctx->slope_cap = 0;
+            const size_t cap = (size_t)K > kChainMinCapacity ? (size_t)K : kChainMinCapacity;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_sidx, cap * sizeof(int)));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_sdelta, cap * sizeof(double)));
+            ctx->slope_cap = cap;
+        }
+        if (!ctx->d_slopes) HIP_TRY(ctx, hipMalloc(&ctx->d_slopes, sizeof(SlopeState)));
+        SlopeState init_s{};
+        for (int l = 0; l < cfg->n_slopes; ++l) init_s.cur[l] = cfg->cur_slopes[l];
+        // (pageable sources: the copies are staged by the runtime before the calls return)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slopes, &init_s, sizeof(SlopeState), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sidx, cfg->slope_idx, (size_t)K * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sdelta, cfg->slope_delta, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
+        c.slopes = ctx->d_slopes;
+        c.slope_idx = ctx->d_sidx;
+        c.slope_delta = ctx->d_sdelta;
+        c.n_slopes = cfg->n_slopes;
+        c.slope_term_in = cfg->slope_term_in_prior ? 1 : 0;
+        ctx->batch_slopes = true;
+    }
     c.w_bound = cfg->w_bound;
     c.lik_temp = cfg->lik_temp;
     c.sigma_given = cfg->sigma_given;
@@ -1463,6 +1520,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     p.M = M;
     p.chain = overlap ? ctx->d_cparams : nullptr;
     p.sync_mode = sync ? 1 : 0;
+    p.cand_slopes = c.slopes ? &ctx->d_slopes->cand[0][0][0] : nullptr;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     rc = push_chain_params(ctx, c);
@@ -1591,6 +1649,12 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         memcpy(out_accepted, b + B.RL.acc, (size_t)k_take);
         if (out_loglik_prop) memcpy(out_loglik_prop, b + B.RL.llp, (size_t)k_take * sizeof(double));
         if (out_logprior_prop) memcpy(out_logprior_prop, b + B.RL.lpp, (size_t)k_take * sizeof(double));
+    }
+    for (int l = 0; l < NPBNN_MAX_LAYERS; ++l) result->slopes[l] = 0.0;
+    if (ctx->batch_slopes) {             // (the stream is idle: the result block has just come back)
+        SlopeState fs;
+        HIP_TRY(ctx, hipMemcpy(&fs, ctx->d_slopes, sizeof(SlopeState), hipMemcpyDeviceToHost));
+        for (int l = 0; l < kMaxLayers && l < NPBNN_MAX_LAYERS; ++l) result->slopes[l] = fs.cur[l];
     }
     result->loglik = fin.logLik;
     result->logprior = fin.n_accepted > 0 ? fin.logPrior_rep : cfg->cur_logprior;

@@ -109,6 +109,20 @@ struct ChainDev {          // device-resident chain state
     int done[4];            // done[L & 3]: evaluating workgroups of the launches L, L-4, L-8 ... that have finished (cumulative)
 };
 
+// Trainable activation slopes of a chain (ActFun(trainable=True), np_bnn/BNN_env.py:416-421,502-503): the accepted slopes, the
+// share of ChainDev.logPrior that is theirs (log(r) * -sum(slopes) * r, r = 10 - zero until the chain's first accept, because
+// MCMC.__init__ computes its prior without it), and the slopes of the candidates of the two passes in the pipeline.
+struct SlopeState {
+    double cur[kMaxLayers];
+    double term;
+    double cand[2][kMaxCand][kMaxLayers];
+};
+__host__ __device__ inline double slope_prior_term(const double* s, int n) {
+    double sum = 0.0;
+    for (int l = 0; l < n; ++l) sum += s[l];
+    return 2.302585092994046 * -sum * 10.0;       // np.log(r) * -np.sum(prm_tmp) * r, r = 10 (BNN_env.py:419-420)
+}
+
 struct ChainParams {
     ChainDev* st;
     PassDesc* pass;            // [2] candidates of the passes in the pipeline, by pass parity (read by the evaluation kernel)
@@ -132,6 +146,10 @@ struct ChainParams {
     double* pv;                // [2][kMaxCand][M] proposed values of the candidates of the passes in the pipeline
     int* overflow;             // set when a scaled weight leaves the fp16 range
     unsigned long long* stamps; // diagnostics only (NPBNN_STEP_STAMPS=1), else nullptr
+    SlopeState* slopes;        // trainable activation slopes, or nullptr
+    const int* slope_idx;      // [K] the slope iteration t proposes to move ...
+    const double* slope_delta; // [K] ... and by how much (reflected at 0 and 1)
+    int n_slopes, slope_term_in;   // slope_term_in: the log prior handed in at the start of the batch holds the term of the accepted slopes
     int K, M, D, n_blocks;
     int sync_test_skip;        // tests only: the step of this launch never reports back (-1: none) - exercises the time-out path of
                                // the two-stream schedule
@@ -289,6 +307,11 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         const double s = block_sum(lp, sh.red);
         if (tid == 0) st->logPrior = s;
     }
+    if (pl.resum && c.slopes && tid == 0) {       // (after the re-sum; the uniform prior keeps the value handed in, which holds the term)
+        const double term = c.slope_term_in ? slope_prior_term(c.slopes->cur, c.n_slopes) : 0.0;
+        c.slopes->term = term;
+        if (c.prior_kind != NPBNN_PRIOR_UNIFORM) st->logPrior += term;
+    }
 
     // ---- 1. decide the pending candidates ----
     int t0 = 0, n_pend = 0;
@@ -366,6 +389,10 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                         st->n_accepted += 1;
                         if (lik_kind == NPBNN_LIK_GAUSS)
                             for (int q = 0; q < c.net.k_targets; ++q) st->sigma[q] = sh.o.sigma[q];
+                        if (c.slopes) {
+                            for (int l = 0; l < c.n_slopes; ++l) c.slopes->cur[l] = c.slopes->cand[pl.dec][j][l];
+                            c.slopes->term = slope_prior_term(c.slopes->cur, c.n_slopes);
+                        }
                         accepted = j;
                         n_done = j + 1;
                         sh.s_lp = lp;
@@ -542,6 +569,22 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
         for (int j = 0; j < kMaxCand; ++j) {
             double sj = 0.0;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sj += sh.red3[j][w];
+            if (c.slopes && j < n_new) {              // UpdateNormal1D(acc_prm, d, n = 1, Mb = 1, mb = 0) with the pre-drawn entry and step
+                const int k = c.slope_idx[t_new + j];
+                const double step = c.slope_delta[t_new + j];
+                double sum = 0.0;
+                for (int l = 0; l < kMaxLayers; ++l) {       // (no local array: a run-time index would put it in scratch)
+                    double v = l < c.n_slopes ? c.slopes->cur[l] : 0.0;
+                    if (l == k) {
+                        v += step;
+                        if (v > 1.0) v = 1.0 - (v - 1.0);
+                        if (v < 0.0) v = 0.0 + (0.0 - v);
+                    }
+                    c.slopes->cand[pl.out][j][l] = v;
+                    if (l < c.n_slopes) sum += v;
+                }
+                sj += 2.302585092994046 * -sum * 10.0 - c.slopes->term;      // (slope_prior_term of the candidate)
+            }
             if (j < n_new) st->cand_logPrior[pl.out][j] = base_lp + sj;
             d.cnt[j] = j < n_new ? c.cnt[t_new + j] : 0;
         }

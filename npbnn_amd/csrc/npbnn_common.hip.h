@@ -70,6 +70,9 @@ struct NetMeta {
     int l0_begin[kMaxMT], l0_end[kMaxMT], l0_base[kMaxMT];
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
+    int slope_off;      // >= 0: float offset of kMaxLayers slots for per-candidate activation slopes (NPBNN_OPT_TRAINABLE_SLOPES; a chain
+                        // pass writes each candidate's slopes into its LDS image copy), else -1
+    int pad_slope_;
 };
 
 constexpr float kPadLogit = -3.0e38f;     // finite: (pad - max) stays finite, exp of it is exactly 0
@@ -135,6 +138,8 @@ struct EvalParams {
     int sync_mode;             // overlapped schedule with the launches alternating between two streams: no kernel boundary orders a
     int pad_sync_;             // launch after the one before it - device-side flags do (ChainDev.prepared / .done, npbnn_chain.hip.h)
     unsigned long long* stamps;   // diagnostics only (NPBNN_EVAL_STAMPS=1 in npbnn_time_pass): [workgroup][8] wall-clock stamps, else nullptr
+    const double* cand_slopes;    // chain pass with trainable activation slopes: [2][kMaxCand][kMaxLayers] slopes of the candidates of the
+                                  // two passes in the pipeline (SlopeState::cand, written by the step), else nullptr
     int group_n;                  // > 0: group pass of that many chains (= the candidates of the build); the last group_n workgroups
     int pad_group_;               // of the launch run the chains' steps
     GroupSlot group[kMaxCand];

@@ -68,6 +68,7 @@ struct HotParams {
     int use_classw, predict_mode, weight_sets;
     int aux_off_w, aux_off_t;
     int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off, pad_masked;
+    int slope_off;      // >= 0: every candidate's activation slopes sit in its LDS image at this float offset (general build only)
     // shape-specialised tails (tile_tail, NLC > 0): image offsets and activation slopes of layers 1 .. kFastLayers-1
     int frag_off[kFastLayers - 1], bias_off[kFastLayers - 1];
     float act_prm[kFastLayers - 1];
@@ -128,9 +129,15 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
     for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) h[j][mt] = mt < MT0 ? acc0_all[J0 + j][mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
-    auto layer = [&](int lkt, int lmt, int frag_off, int bias_off, float prm) {
-        if constexpr (ACTC >= 0) act_tiles_all<ACTC>(h, lkt, prm);
-        else act_live_all(h, lkt, hp.act_kind, prm);
+    auto layer = [&](int lkt, int lmt, int frag_off, int bias_off, float prm, int hidden) {
+        if constexpr (ACTC >= 0) {
+            act_tiles_all<ACTC>(h, lkt, prm);
+        } else if (hp.slope_off >= 0) {           // trainable slopes: each candidate's own, from its image (wave-uniform reads)
+#pragma unroll
+            for (int j = 0; j < D; ++j) act_live(h[j], lkt, hp.act_kind, imgs[(size_t)j * image_floats + hp.slope_off + hidden]);
+        } else {
+            act_live_all(h, lkt, hp.act_kind, prm);
+        }
         const float* frag = imgs + frag_off + lane * 4;
         const float* bias = imgs + bias_off + 4 * kq;
         f32x4 acc[D][MTI];
@@ -164,11 +171,11 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
     };
     if constexpr (NLC > 0) {
 #pragma unroll
-        for (int l = 1; l < NLC; ++l) layer(l == 1 ? MT0 : 1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1]);
+        for (int l = 1; l < NLC; ++l) layer(l == 1 ? MT0 : 1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1], l - 1);
     } else {
         for (int l = 1; l < n_layers; ++l) {
             const LayerMeta& L = net.L[l];
-            layer(uni(L.kt), uni(L.mt), uni(L.frag_off), uni(L.bias_off), uni(net.act_prm[l - 1]));
+            layer(uni(L.kt), uni(L.mt), uni(L.frag_off), uni(L.bias_off), uni(net.act_prm[l - 1]), l - 1);
         }
     }
     if (!PLAIN && hp.final_act) act_live_all(h, MTL, hp.act_kind, uni(net.act_prm[n_layers - 1]));
@@ -466,7 +473,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         hp.n_rows = LK == kLikGauss ? uni(p.n_rows) : 0;        // (categorical: padding rows carry the label -1)
         hp.use_classw = 0; hp.predict_mode = 0; hp.weight_sets = 0;
         hp.MTL = 1; hp.lik_kind = LK == kLikGauss ? NPBNN_LIK_GAUSS : NPBNN_LIK_CATEGORICAL;
-        hp.out_kind = 0; hp.final_act = 0; hp.pad_masked = 1; hp.classw_off = -1;
+        hp.out_kind = 0; hp.final_act = 0; hp.pad_masked = 1; hp.classw_off = -1; hp.slope_off = -1;
 #pragma unroll
         for (int l = 1; l < kFastLayers; ++l)
             if (l < hp.n_layers) {
@@ -484,6 +491,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         hp.final_act = uni(net.final_act);
         hp.pad_masked = uni(net.pad_masked);
         hp.classw_off = uni(net.classw_off);
+        hp.slope_off = uni(p.cand_slopes) != nullptr ? uni(net.slope_off) : -1;
     }
     const int k_targets = hp.k_targets;
     const int aux_sz = uni(p.lay.aux_sz), aux_mask = uni(p.lay.aux_slots) - 1;
@@ -664,6 +672,12 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 imgj[pos] = (float)v;
             }
         };
+        if (hp.slope_off >= 0 && tid < D * kMaxLayers) {      // every candidate's activation slopes into its image copy
+            const int j = tid / kMaxLayers, l = tid % kMaxLayers;
+            const double* src = uni(p.cand_slopes) + ((size_t)par * kMaxCand + j) * kMaxLayers + l;
+            reinterpret_cast<float*>(smem + j * IB)[hp.slope_off + l] =
+                (float)(sync ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src);
+        }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (tid < cnt[j]) patch(j, ppos[j], pval[j], psc[j]);

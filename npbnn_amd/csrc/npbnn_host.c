@@ -183,6 +183,12 @@ int npbnn_host_predraw2(void* bitgen, int randomize_seed, int64_t first_iteratio
                         int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
                         double* sigma_chosen, double* sigma_u);
 
+int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
+                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
+                        double* sigma_chosen, double* sigma_u, int n_slopes, double slope_d, int32_t* slope_idx,
+                        double* slope_delta);
+
 int npbnn_host_predraw(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights) {
@@ -199,8 +205,22 @@ int npbnn_host_predraw2(void* bitgen, int randomize_seed, int64_t first_iteratio
                         const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
                         int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
                         double* sigma_chosen, double* sigma_u) {
+    return npbnn_host_predraw3(bitgen, randomize_seed, first_iteration, mcmc_id, K, spec, max_per_iter, idx, delta, cnt, log_u,
+                               layer_mask, n_weights, sigma_k, sigma_f, sigma_chosen, sigma_u, 0, 0.0, NULL, NULL);
+}
+
+/* The same with the draws of the trainable activation slopes (UpdateNormal1D(acc_prm, d, n=1), np_bnn/BNN_mcmc.py:44-55, the FIRST
+ * draws of an iteration, BNN_env.py:416-421) when n_slopes > 0:
+ *   slope_idx[t]     rs.integers(0, n_slopes, 1)   (no draw when n_slopes == 1: numpy returns the only value)
+ *   slope_delta[t]   rs.normal(0, slope_d, 1) */
+int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
+                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
+                        double* sigma_chosen, double* sigma_u, int n_slopes, double slope_d, int32_t* slope_idx,
+                        double* slope_delta) {
     if (!spec || K < 0 || spec->n_layers < 1 || spec->n_layers > NPBNN_HOST_MAX_LAYERS) return -1;
     if (sigma_k < 0 || (sigma_k > 0 && (!sigma_chosen || !sigma_u))) return -1;
+    if (n_slopes < 0 || (n_slopes > 0 && (!slope_idx || !slope_delta))) return -1;
     if (!randomize_seed && !bitgen) return -1;
     int total = 0, max_n = 0;
     for (int i = 0; i < spec->n_layers; ++i) {
@@ -225,6 +245,12 @@ int npbnn_host_predraw2(void* bitgen, int randomize_seed, int64_t first_iteratio
             pcg64_seed(&local, (uint64_t)(first_iteration + t + mcmc_id));
             pcg64_bitgen(&local, &local_bg);
             bg = &local_bg;
+        }
+        if (n_slopes > 0) {
+            uint64_t pick = 0;
+            random_bounded_uint64_fill(bg, 0, (uint64_t)(n_slopes - 1), 1, 0, &pick);
+            slope_idx[t] = (int32_t)pick;
+            slope_delta[t] = random_normal(bg, 0.0, slope_d);
         }
         if (sigma_k > 0) {
             binomial_t binom;

@@ -102,6 +102,9 @@ class HipBackend:
 
     def _configure(self, weights):
         shapes = tuple(w.shape for w in weights)
+        # slopes that the sampler proposes AND the forward pass uses (ActFun(fun="genReLU", trainable=True)): the device chain gives
+        # every candidate its own, which needs slots in the weight image
+        self.ctx.set_trainable_slopes(bool(self._act._trainable) and self._act._function == "genReLU")
         if shapes != self._shapes:
             flags = bias_flags(weights, self.n_features)
             self.ctx.set_arch(self.n_features, [s[0] for s in shapes], flags, self._act.device_kind(),

@@ -33,6 +33,9 @@ def load_host_library():
         lib.npbnn_host_predraw2.restype = C.c_int
         lib.npbnn_host_predraw2.argtypes = lib.npbnn_host_predraw.argtypes + [C.c_int, C.c_double, C.POINTER(C.c_double),
                                                                               C.POINTER(C.c_double)]
+        lib.npbnn_host_predraw3.restype = C.c_int
+        lib.npbnn_host_predraw3.argtypes = lib.npbnn_host_predraw2.argtypes + [C.c_int, C.c_double, C.POINTER(C.c_int32),
+                                                                               C.POINTER(C.c_double)]
         lib.npbnn_host_selftest_doubles.restype = C.c_int
         lib.npbnn_host_selftest_doubles.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_double)]
         _lib = lib
@@ -40,13 +43,15 @@ def load_host_library():
 
 
 def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, update_ws, freq_layer_update, empty=None,
-            sigma_k=0, sigma_f=0.5):
+            sigma_k=0, sigma_f=0.5, n_slopes=0, slope_d=0.05):
     """Draw K iterations' proposals.  ``rs`` is the chain's numpy Generator (advanced in place unless
     ``randomize_seed``).  Returns (idx [K,M] int32, delta [K,M] float64, cnt [K], u [K], layer_mask [K]).
     ``empty(shape, dtype)`` allocates the four arrays that travel to the device (page-locked memory, pinned.py);
     default numpy.  ``sigma_k`` > 0: every iteration first draws the regression error-parameter proposal
     (multiplier_proposal_vector on ``sigma_k`` columns, BNN_env.py:435-442); two more arrays are returned,
-    chosen [K, sigma_k] (0/1) and u_sigma [K, sigma_k]."""
+    chosen [K, sigma_k] (0/1) and u_sigma [K, sigma_k].  ``n_slopes`` > 0: the very first draws of an iteration are those of the
+    trainable activation slopes (UpdateNormal1D on ``n_slopes`` values, n = 1, BNN_env.py:416-421); the result then ends with
+    slope_idx [K] int32 and slope_delta [K]."""
     if empty is None:
         empty = np.empty
     lib = load_host_library()
@@ -77,14 +82,22 @@ def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, 
     sigma_k = int(sigma_k)
     chosen = np.empty((K, max(sigma_k, 1)), dtype=np.float64)
     u_sigma = np.empty((K, max(sigma_k, 1)), dtype=np.float64)
+    n_slopes = int(n_slopes)
+    slope_idx = np.zeros(K if n_slopes else 1, dtype=np.int32)
+    slope_delta = np.zeros(K if n_slopes else 1, dtype=np.float64)
     with rs.bit_generator.lock:
-        rc = lib.npbnn_host_predraw2(bitgen, 1 if randomize_seed else 0, int(first_iteration), int(mcmc_id), K, C.byref(spec), M,
+        rc = lib.npbnn_host_predraw3(bitgen, 1 if randomize_seed else 0, int(first_iteration), int(mcmc_id), K, C.byref(spec), M,
                                      idx.ctypes.data_as(C.POINTER(C.c_int32)), delta.ctypes.data_as(C.POINTER(C.c_double)),
                                      cnt.ctypes.data_as(C.POINTER(C.c_int32)), u.ctypes.data_as(C.POINTER(C.c_double)),
                                      lmask.ctypes.data_as(C.POINTER(C.c_int32)), off, sigma_k, float(sigma_f),
-                                     chosen.ctypes.data_as(C.POINTER(C.c_double)), u_sigma.ctypes.data_as(C.POINTER(C.c_double)))
+                                     chosen.ctypes.data_as(C.POINTER(C.c_double)), u_sigma.ctypes.data_as(C.POINTER(C.c_double)),
+                                     n_slopes, float(slope_d), slope_idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     slope_delta.ctypes.data_as(C.POINTER(C.c_double)))
     if rc != 0:
         raise RuntimeError("npbnn_host_predraw failed with code %d" % rc)
+    out = (idx, delta, cnt, u, lmask)
     if sigma_k > 0:
-        return idx, delta, cnt, u, lmask, chosen, u_sigma
-    return idx, delta, cnt, u, lmask
+        out += (chosen, u_sigma)
+    if n_slopes > 0:
+        out += (slope_idx, slope_delta)
+    return out

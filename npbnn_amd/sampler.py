@@ -373,6 +373,7 @@ class MCMC():
                 bnn_obj.reset_error_prm(error_prm_tmp)
             if bnn_obj._act_fun._trainable:
                 bnn_obj._act_fun.reset_accepted_prm()
+                self._slope_term_in_prior = True        # (MCMC.__init__'s prior is without it: BNN_env.py:374 against :419-420)
             self._logPost = logPost_prime
             self._logLik = logLik_prime
             self._logPrior = logPrior_prime
@@ -401,8 +402,11 @@ class MCMC():
             return False
         if self.update_function is not UpdateNormal or self._sample_from_prior:
             return False
-        if bnn_obj._act_fun._trainable or bnn_obj._feature_indicators is not None or bnn_obj._freq_indicator:
+        if bnn_obj._feature_indicators is not None or bnn_obj._freq_indicator:
             return False
+        if bnn_obj._act_fun._trainable and (bnn_obj._act_fun._function != "genReLU" or not hasattr(be, "ctx")
+                                            or len(bnn_obj._act_fun._acc_prm) != bnn_obj._n_layers - 1):
+            return False        # (slopes that are proposed but never used by the forward pass, or not one per hidden layer: mh_step)
         if likelihood_kind(self._likelihood_f) in (None, capi.LIK_NONE):
             return False
         # (prior scales - one per layer, per input node or per weight, hyper_p 1-3 - change in gibbs_step only, between calls: the
@@ -457,13 +461,15 @@ class MCMC():
             it = self._current_iteration
             pending = self._claim_draw(bnn_obj, it, sizes[0])
             for n, k in enumerate(sizes):
-                idx, delta, cnt, log_u, smult, hast = pending.result()
+                drawn = pending.result()
+                idx, delta, cnt, log_u, smult, hast = drawn[:6]
+                slope_draws = drawn[6:8] if len(drawn) > 6 else None
                 it += k
                 if n + 1 < len(sizes):
                     pending = self._submit_draw(bnn_obj, it, sizes[n + 1])[1]
                 elif remaining == seg:            # last sub-batch of this call: draw ahead for the next call
                     self._speculation = self._submit_draw(bnn_obj, it, min(self.SUB_BATCH, int(n_steps)), rewindable=True)
-                self._run_device_batch(bnn_obj, idx, delta, cnt, log_u, smult, hast)
+                self._run_device_batch(bnn_obj, idx, delta, cnt, log_u, smult, hast, slope_draws)
             remaining -= seg
 
     _speculation = None      # (key, future, generator state before the draw, step-size arrays used) of draws made ahead of the next call
@@ -472,7 +478,12 @@ class MCMC():
     def _draw_key(self, bnn_obj, first_it, k):
         return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id), tuple(int(n) for n in self._update_n),
                 tuple(float(f) for f in self._freq_layer_update), tuple(w.shape for w in bnn_obj._w_layers),
-                self._sigma_proposal_columns(bnn_obj, first_it))
+                self._sigma_proposal_columns(bnn_obj, first_it), self._n_trainable_slopes(bnn_obj))
+
+    @staticmethod
+    def _n_trainable_slopes(bnn_obj):
+        act = bnn_obj._act_fun
+        return len(act._acc_prm) if act._trainable else 0
 
     def _submit_draw(self, bnn_obj, first_it, k, rewindable=False):
         """Start the pre-draw of iterations first_it .. first_it+k-1 on the helper thread."""
@@ -491,9 +502,11 @@ class MCMC():
         empty = getattr(self._backend, "host_empty", None)
         saved = rs.bit_generator.state if (rewindable and not randomize) else None
         sigma_k = self._sigma_proposal_columns(bnn_obj, first_it)
+        n_slopes = self._n_trainable_slopes(bnn_obj)
 
         def draw():
-            out = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty, sigma_k=sigma_k)
+            out = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty, sigma_k=sigma_k,
+                             n_slopes=n_slopes, slope_d=0.05)
             idx, delta, cnt, u = out[:4]
             np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
             smult = hast = None
@@ -502,6 +515,8 @@ class MCMC():
                 smult = np.exp(2 * np.log(1.1) * (u_sigma - .5))
                 smult[chosen == 0] = 1.
                 hast = np.array([np.sum(np.log(row)) for row in smult])
+            if n_slopes:                          # UpdateNormal1D(acc_prm, d=0.05, n=1): the entry and the step of every iteration
+                return idx, delta, cnt, u, smult, hast, out[-2], out[-1]
             return idx, delta, cnt, u, smult, hast
 
         return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved, src
@@ -561,7 +576,9 @@ class MCMC():
             k = min(2 * k, self.SUB_BATCH_MAX)
         return sizes
 
-    def _device_chain_cfg(self, bnn_obj, sigma_mult=None, hastings=None):
+    _slope_term_in_prior = False     # does _logPrior hold log(r) * -sum(accepted slopes) * r?  (from the first accepted proposal on)
+
+    def _device_chain_cfg(self, bnn_obj, sigma_mult=None, hastings=None, slope_draws=None):
         """The chain's settings and current state as the keyword arguments of the device chain entry points."""
         regression = bnn_obj._estimation_mode == "regression"
         sigma = None
@@ -570,15 +587,36 @@ class MCMC():
             cur_sigma = np.ones(bnn_obj._size_output) * bnn_obj._error_prm
             if not bnn_obj._empirical_error and sigma_mult is None:
                 sigma = np.ones(bnn_obj._size_output)      # sigma stays 1 while it <= _estimate_error
-        return dict(sigma_mult=sigma_mult, hastings=hastings, prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
+        extra = {}
+        if slope_draws is not None:
+            extra["slopes"] = (slope_draws[0], slope_draws[1], np.array(bnn_obj._act_fun._acc_prm, dtype=float), self._slope_term_in_prior)
+        return dict(extra, sigma_mult=sigma_mult, hastings=hastings, prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
                     w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
                     cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma,
                     n_candidates=self.n_candidates, schedule=self.device_schedule)
 
-    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u, sigma_mult=None, hastings=None):
-        w_new, acc, _, _, res = self._backend.run_chain(bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u,
-                                                        mask=bnn_obj._mask, **self._device_chain_cfg(bnn_obj, sigma_mult, hastings))
+    def _run_device_batch(self, bnn_obj, idx, delta, cnt, log_u, sigma_mult=None, hastings=None, slope_draws=None):
+        w_new, acc, _, _, res = self._backend.run_chain(bnn_obj._w_layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=bnn_obj._mask,
+                                                        **self._device_chain_cfg(bnn_obj, sigma_mult, hastings, slope_draws))
         self._absorb_device_batch(bnn_obj, len(cnt), w_new, acc, res)
+        if slope_draws is not None:
+            # what k calls of mh_step leave in the activation object: the accepted slopes, and - installed whether accepted or not
+            # (BNN_env.py:421) - the slopes the LAST iteration proposed: the accepted ones before it with its entry moved
+            act = bnn_obj._act_fun
+            if res["n_accepted"] > 0:
+                act.reset_prm(np.array(res["slopes"][:len(act._acc_prm)], dtype=float))
+                act.reset_accepted_prm()
+                self._slope_term_in_prior = True
+            last = np.array(act._acc_prm, dtype=float)
+            if not acc[len(cnt) - 1]:
+                k = int(slope_draws[0][len(cnt) - 1])
+                v = last[k] + slope_draws[1][len(cnt) - 1]
+                if v > 1:
+                    v = 1 - (v - 1)
+                if v < 0:
+                    v = 0 + (0 - v)
+                last[k] = v
+            act.reset_prm(last)
 
     def _absorb_device_batch(self, bnn_obj, k, w_new, acc, res):
         """Book-keeping of k device-resident iterations: what k calls of mh_step would have left behind."""

@@ -368,6 +368,47 @@ def test_run_steps_with_hyper_priors_is_the_mh_step_loop(hyper_p):
     np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)
 
 
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_run_steps_with_trainable_slopes_is_the_mh_step_loop(schedule, randomize_seed):
+    """Parametric ReLU (ActFun(fun="genReLU", trainable=True), BNN_env.py:416-421,502-503): every iteration proposes new slopes
+    from the accepted ones, evaluates its weight proposal with them and adds their exponential prior to the proposal's log
+    prior.  The device chain carries the slopes as chain state (each candidate of a pass its own) and must give the chain of
+    the mh_step loop: same accept / reject sequence, same weights, same accepted and last-proposed slopes, log prior to
+    rounding - including the reference's quirk that the prior stored by MCMC.__init__ lacks the slope term."""
+    cfg = cases.TRACES["cfg1"]
+    res = []
+    for mode in ("host", "device"):
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        np.random.seed(1234)
+        act = bn.ActFun(fun="genReLU", prm=np.full(len(cfg["n_nodes"]), 0.02), trainable=True)
+        bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], actFun=act, use_bias_node=cfg["bias"], prior_f=1, p_scale=1, seed=1234,
+                    init_std=0.1)
+        mcmc = bn.MCMC(bnn, randomize_seed=randomize_seed, mcmc_id=3, **dict(cfg["mcmc"], adapt_f=0, adapt_fM=1))
+        mcmc.device_schedule = schedule
+        before = mcmc._device_iterations
+        if mode == "host":
+            for _ in range(170):
+                mcmc.mh_step(bnn)
+        else:
+            mcmc.run_steps(bnn, 70)
+            mcmc.run_steps(bnn, 100)
+        assert (mcmc._device_iterations - before == 170) == (mode == "device")
+        res.append((bnn, mcmc))
+    (ba, ma), (bb, mb) = res
+    assert ma._current_iteration == mb._current_iteration == 170
+    assert sum(ma._last_accepted_mem) > 3, "the comparison needs accepted proposals"
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    np.testing.assert_array_equal(ba._act_fun._acc_prm, bb._act_fun._acc_prm)
+    np.testing.assert_array_equal(ba._act_fun._prm, bb._act_fun._prm)
+    assert not np.array_equal(ba._act_fun._acc_prm, np.full(len(cfg["n_nodes"]), 0.02)), "the slopes should have moved"
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)
+    if not randomize_seed:
+        assert ma._rs.random() == mb._rs.random()
+
+
 def test_persistent_schedule_never_times_out_in_a_million_iterations():
     """The persistent form of the overlapped schedule is what the library picks by itself for a chain alone on its GPU.  Its
     device-side waits are bounded, and a time-out is survivable (NPBNN_E_SYNC: the batch is repeated on kernel boundaries) - but

@@ -66,3 +66,45 @@ def test_selftest_seeding():
         out = np.zeros(5)
         lib.npbnn_host_selftest_doubles(seed, 5, out.ctypes.data_as(C.POINTER(C.c_double)))
         np.testing.assert_array_equal(out, np.random.default_rng(seed).random(5))
+
+
+@pytest.mark.parametrize("randomize", [False, True])
+@pytest.mark.parametrize("n_slopes", [1, 3])
+def test_predraw_of_the_slope_proposals(randomize, n_slopes):
+    """Trainable activation slopes: UpdateNormal1D(acc_prm, d=0.05, n=1) is the first thing an iteration draws
+    (np_bnn/BNN_env.py:416-421); with one slope numpy's integers(0, 1, 1) consumes nothing."""
+    from npbnn_amd.proposals import UpdateNormal, UpdateNormal1D
+    rs0 = np.random.default_rng(5)
+    weights = [rs0.normal(0, 1, s) for s in [(6, 9), (4, 7), (3, 5)]]
+    update_n = [7, 3, 2]
+    update_ws = [np.ones(w.shape) * 0.05 for w in weights]
+    freq = [1.0, 0.6, 0.8]
+    K, mcmc_id, first = 30, 2, 500
+    slopes = np.linspace(0.2, 0.6, n_slopes)
+    want = []
+    gen = np.random.default_rng(11)
+    for t in range(K):
+        g = np.random.default_rng(first + t + mcmc_id) if randomize else gen
+        new, pick, _ = UpdateNormal1D(slopes, d=0.05, n=1, Mb=1e9, mb=-1e9, rs=g)
+        rr = g.random(len(weights))
+        rr[np.argmin(rr)] = 0
+        props = []
+        for i, w in enumerate(weights):
+            props.append(UpdateNormal(w, d=update_ws[i], n=update_n[i], Mb=1e9, mb=-1e9, rs=g)[0] if rr[i] < freq[i] else w + 0)
+        want.append((int(pick[0]), new[pick[0]], props, g.random()))
+    rs = np.random.default_rng(0 if randomize else 11)
+    idx, delta, cnt, u, lmask, s_idx, s_delta = pd.predraw(rs, randomize, first, mcmc_id, K, weights, update_n, update_ws, freq,
+                                                           n_slopes=n_slopes, slope_d=0.05)
+    flat = np.concatenate([w.ravel() for w in weights])
+    offs = np.cumsum([0] + [w.size for w in weights])
+    for t in range(K):
+        assert s_idx[t] == want[t][0]
+        assert slopes[s_idx[t]] + s_delta[t] == want[t][1]
+        z = flat.copy()
+        sel = idx[t, :cnt[t]] >= 0
+        z[idx[t, :cnt[t]][sel]] += delta[t, :cnt[t]][sel]
+        for i, w in enumerate(weights):
+            np.testing.assert_array_equal(z[offs[i]:offs[i + 1]].reshape(w.shape), want[t][2][i])
+        assert u[t] == want[t][3]
+    if not randomize:
+        assert rs.random() == gen.random()

@@ -314,6 +314,8 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         L.kt = (l == 0 && f16) ? 2 * ((in + 31) / 32) : (in + 15) / 16;   // 1-KiB pieces (16 rows x 64 B) per tile
         L.mt = (out + 15) / 16;
         L.frag_off = off;
+        L.out_perm = (l >= 1 && l + 1 < a->n_layers && L.mt == 1 && !getenv("NPBNN_NO_TILE_PERM")) ? 1 : 0;
+        L.in_live = (l >= 1 && net.L[l - 1].out_perm) ? (net.L[l - 1].out_dim + 3) / 4 : 4;
         if (l == 0) {
             // K-units of the layer-0 loop (32 features on the fp16-split path, 16 on the float32 one); per output tile the hull of
             // the units in which the mask has anything (the whole layer when no structure was declared)
@@ -657,10 +659,11 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
             for (int j = 0; j < ld; ++j) {
                 const size_t wi = (size_t)L.w_off + (size_t)o * ld + j;
                 int pos;
-                if (L.has_bias && j == 0) pos = L.bias_off + o;
+                const bool in_perm = l >= 1 && ctx->net.L[l - 1].out_perm;      // (a permuted layer has a single tile: o, c < 16)
+                if (L.has_bias && j == 0) pos = L.bias_off + (L.out_perm ? tile_pos(o) : o);
                 else {
-                    const int c = j - L.has_bias;
-                    const int mt = o / 16, u = o % 16;
+                    const int c = in_perm ? tile_pos(j - L.has_bias) : j - L.has_bias;
+                    const int mt = o / 16, u = L.out_perm ? tile_pos(o) : o % 16;
                     if (l == 0 && f16) {
                         const int ks = c / 32, kg = (c % 32) / 8, jj = c % 8;
                         if (ks < ctx->net.l0_begin[mt] || ks >= ctx->net.l0_end[mt]) pos = kSkipPos;     // outside the block structure: always 0

@@ -50,7 +50,14 @@ struct LayerMeta {
     int bias_off;  // float offset of the padded bias (16*mt floats)
     int in_dim, out_dim, has_bias;
     int w_off;     // double offset of the layer matrix in the packed weights
+    // Narrow hidden layers (one output tile, not the last layer): unit u sits at position 4 (u % 4) + u / 4 of the tile instead of u
+    // (tile_pos).  A lane (row n, k-group kq) holds positions 4 kq + i in register i, and the next layer's i-th float32 MFMA contracts
+    // the positions {i, 4 + i, 8 + i, 12 + i}: with the units transposed like this the first ceil(out / 4) registers hold all of them,
+    // and the next layer skips the MFMAs of the others - they would multiply the zeros of the padding (in_live of that layer).
+    int out_perm;  // this layer's units are placed like that
+    int in_live;   // float32 MFMAs per input tile this layer needs (4 unless the layer before it has out_perm)
 };
+__host__ __device__ inline int tile_pos(int u) { return 4 * (u & 3) + (u >> 2); }      // (its own inverse: a 4 x 4 transpose)
 
 struct NetMeta {
     int n_layers;

@@ -70,7 +70,7 @@ struct HotParams {
     int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off, pad_masked;
     int slope_off;      // >= 0: every candidate's activation slopes sit in its LDS image at this float offset (general build only)
     // shape-specialised tails (tile_tail, NLC > 0): image offsets and activation slopes of layers 1 .. kFastLayers-1
-    int frag_off[kFastLayers - 1], bias_off[kFastLayers - 1];
+    int frag_off[kFastLayers - 1], bias_off[kFastLayers - 1], in_live[kFastLayers - 1];
     float act_prm[kFastLayers - 1];
 };
 
@@ -129,7 +129,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
     for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) h[j][mt] = mt < MT0 ? acc0_all[J0 + j][mt < MT0 ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
-    auto layer = [&](int lkt, int lmt, int frag_off, int bias_off, float prm, int hidden) {
+    auto layer = [&](int lkt, int lmt, int frag_off, int bias_off, float prm, int hidden, int live_s) {
         if constexpr (ACTC >= 0) {
             act_tiles_all<ACTC>(h, lkt, prm);
         } else if (hp.slope_off >= 0) {           // trainable slopes: each candidate's own, from its image (wave-uniform reads)
@@ -157,9 +157,10 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
                             a[j] = *reinterpret_cast<const f32x4*>(frag + (size_t)j * image_floats + (size_t)(ct * lmt + mt) * 256);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
+                            if (s < live_s)          // (LayerMeta::in_live: the registers past it hold padding only - wave-uniform)
 #pragma unroll
-                            for (int j = 0; j < D; ++j)
-                                acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], h[j][ct][s], acc[j][mt], 0, 0, 0);
+                                for (int j = 0; j < D; ++j)
+                                    acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], h[j][ct][s], acc[j][mt], 0, 0, 0);
                     }
                 }
             }
@@ -171,11 +172,11 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
     };
     if constexpr (NLC > 0) {
 #pragma unroll
-        for (int l = 1; l < NLC; ++l) layer(l == 1 ? MT0 : 1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1], l - 1);
+        for (int l = 1; l < NLC; ++l) layer(l == 1 ? MT0 : 1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1], l - 1, hp.in_live[l - 1]);
     } else {
         for (int l = 1; l < n_layers; ++l) {
             const LayerMeta& L = net.L[l];
-            layer(uni(L.kt), uni(L.mt), uni(L.frag_off), uni(L.bias_off), uni(net.act_prm[l - 1]), l - 1);
+            layer(uni(L.kt), uni(L.mt), uni(L.frag_off), uni(L.bias_off), uni(net.act_prm[l - 1]), l - 1, uni(L.in_live));
         }
     }
     if (!PLAIN && hp.final_act) act_live_all(h, MTL, hp.act_kind, uni(net.act_prm[n_layers - 1]));
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     hp.n_layers = uni(net.n_layers); hp.C = uni(net.n_out);
     hp.k_targets = uni(net.k_targets); hp.act_kind = uni(net.act_kind);
 #pragma unroll
-    for (int l = 1; l < kFastLayers; ++l) { hp.frag_off[l - 1] = 0; hp.bias_off[l - 1] = 0; hp.act_prm[l - 1] = 0.f; }
+    for (int l = 1; l < kFastLayers; ++l) { hp.frag_off[l - 1] = 0; hp.bias_off[l - 1] = 0; hp.act_prm[l - 1] = 0.f; hp.in_live[l - 1] = 4; }
     if constexpr (FAST) {       // (fast_launch_ok: the host has checked all of this)
         hp.labels = LK == kLikCat ? uni(p.labels) : nullptr;
         hp.targets = LK == kLikGauss ? uni(p.targets) : nullptr;
@@ -480,6 +481,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 hp.frag_off[l - 1] = uni(net.L[l].frag_off);
                 hp.bias_off[l - 1] = uni(net.L[l].bias_off);
                 hp.act_prm[l - 1] = uni(net.act_prm[l - 1]);
+                hp.in_live[l - 1] = uni(net.L[l].in_live);
             }
     } else {
         hp.labels = uni(p.labels); hp.targets = uni(p.targets); hp.inst_w = uni(p.inst_w); hp.confusion = uni(p.confusion);

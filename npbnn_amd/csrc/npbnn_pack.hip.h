@@ -75,14 +75,15 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                 return;
             }
             const int mt = tile % L.mt, kt = tile / L.mt;
-            const int o = 16 * mt + (lane & 15);
+            const int o = L.out_perm ? tile_pos(lane & 15) : 16 * mt + (lane & 15);        // (unit at this output position)
             const int c0 = 16 * kt + 4 * (lane >> 4);
+            const bool in_perm = l > 0 && net.L[l - 1].out_perm;
             const bool stored = l > 0 || (kt >= net.l0_begin[mt] && kt < net.l0_end[mt]);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (o < L.out_dim) {
                 const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
                 for (int s = 0; s < 4; ++s) {
-                    const int c = c0 + s;
+                    const int c = in_perm ? tile_pos(c0 + s) : c0 + s;                         // (input unit at this position)
                     if (c < L.in_dim) {
                         bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
                         v[s] = overridden ? 0.f : (float)row[c];
@@ -100,7 +101,7 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
         const LayerMeta& L = net.L[l];
         const int nb = 16 * L.mt;
         if (piece < nb) {
-            const int o = piece;
+            const int o = L.out_perm ? tile_pos(piece) : piece;
             double b = (net.pad_masked && l == net.n_layers - 1) ? (double)kPadLogit : 0.0;
             if (o < L.out_dim) {
                 b = 0.0;
@@ -114,7 +115,7 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                     }
                 }
             }
-            image[L.bias_off + o] = (float)b;
+            image[L.bias_off + piece] = (float)b;
             return;
         }
         piece -= nb;

@@ -301,6 +301,11 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     // softmax / categorical heads: padding outputs are masked through their bias (see NetMeta::pad_masked)
     net.pad_masked = (!net.final_act && (a->out_kind == NPBNN_OUT_SOFTMAX || a->lik_kind == NPBNN_LIK_CATEGORICAL)) ? 1 : 0;
     if (getenv("NPBNN_NO_PAD_MASK")) net.pad_masked = 0;       // (A/B timing)
+    {   // layer 1 on fp16-split products (NetMeta::l1_f16)
+        bool narrow_later = a->n_layers >= 2;
+        for (int l = 1; l < a->n_layers; ++l) narrow_later = narrow_later && a->out_dim[l] <= 16;
+        net.l1_f16 = (f16 && narrow_later && a->act_kind == NPBNN_ACT_TANH && a->out_dim[0] > 16 && !a->final_act && !getenv("NPBNN_NO_L1_F16")) ? 1 : 0;
+    }
     int in = a->in_dim, off = 0, woff = 0;
     for (int l = 0; l < a->n_layers; ++l) {
         const int out = a->out_dim[l];
@@ -334,6 +339,8 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
                 slots += e - b;
             }
             off += slots * (f16 ? 512 : 256);
+        } else if (l == 1 && net.l1_f16) {
+            off += ((net.L[0].mt + 1) / 2) * 512;      // a high and a low block of 256 floats per K-step
         } else {
             off += L.kt * L.mt * 256;
         }
@@ -677,6 +684,10 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
                         const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4;
                         if (kt < ctx->net.l0_begin[mt] || kt >= ctx->net.l0_end[mt]) pos = kSkipPos;
                         else pos = L.frag_off + ((ctx->net.l0_base[mt] + kt - ctx->net.l0_begin[mt]) * 64 + kq * 16 + u) * 4 + sidx;
+                    } else if (l == 1 && ctx->net.l1_f16) {      // (layer 0 is not permuted: c is the unit; scale stays 1)
+                        const int t_in = c / 16, kq = (c % 16) / 4, q = t_in / 2, e = 4 * (t_in & 1) + c % 4;
+                        const int half_index = 2 * L.frag_off + ((q * 2) * 64 + kq * 16 + u) * 8 + e;
+                        pos = (int)(0x80000000u | (unsigned)half_index);
                     } else {
                         const int kt = c / 16, kq = (c % 16) / 4, sidx = c % 4;
                         pos = L.frag_off + ((kt * L.mt + mt) * 64 + kq * 16 + u) * 4 + sidx;

@@ -77,6 +77,10 @@ struct NetMeta {
     int l0_begin[kMaxMT], l0_end[kMaxMT], l0_base[kMaxMT];
     LayerMeta L[kMaxLayers];
     float act_prm[kMaxLayers];
+    int l1_f16;         // layer 1 runs on fp16-split products too (tanh networks with at least two layer-0 tiles and narrow later layers, on
+                        // the fp16-split image): its inputs are tanh values, |h| <= 1, split h = hh + hl like the data, its weights
+                        // like layer 0's; K-step q contracts the layer-0 tiles 2q and 2q+1 - lane (n, kq) holds units 16 t + 4 kq + 0..3
+                        // of each, which are positions 8 kq + 0..7 of the step.  3 MFMAs of 16 cycles per step instead of 8 of 32.
     int slope_off;      // >= 0: float offset of kMaxLayers slots for per-candidate activation slopes (NPBNN_OPT_TRAINABLE_SLOPES; a chain
                         // pass writes each candidate's slopes into its LDS image copy), else -1
     int pad_slope_;

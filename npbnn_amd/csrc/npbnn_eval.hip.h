@@ -69,6 +69,7 @@ struct HotParams {
     int aux_off_w, aux_off_t;
     int n_layers, C, MTL, lik_kind, k_targets, act_kind, out_kind, final_act, classw_off, pad_masked;
     int slope_off;      // >= 0: every candidate's activation slopes sit in its LDS image at this float offset (general build only)
+    int l1_f16;         // NetMeta::l1_f16
     // shape-specialised tails (tile_tail, NLC > 0): image offsets and activation slopes of layers 1 .. kFastLayers-1
     int frag_off[kFastLayers - 1], bias_off[kFastLayers - 1], in_live[kFastLayers - 1];
     float act_prm[kFastLayers - 1];
@@ -106,7 +107,7 @@ __device__ __forceinline__ void act_live_all(f32x4 (&h)[D][HT], int live, int ki
 // kind is the constant ACTC; PLAIN = categorical log-likelihood only (no confusion counts, predictions, row / class weights,
 // final activation; padding outputs masked through their bias).  The arithmetic per value is the generic path's, statement for
 // statement - only the control flow around it is resolved at compile time - so both paths give the same bits.
-template <int MT0, int MTI, int LK, int D, int DA, int J0, int NLC = 0, int ACTC = -1, bool PLAIN = false>
+template <int MT0, int MTI, int LK, int D, int DA, int J0, int NLC = 0, int ACTC = -1, bool PLAIN = false, bool F16IMG = false>
 __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& hp, const float* imgs0, int image_floats,
                                           const f32x4 (&acc0_all)[DA][MT0], int lane, int n, int kq, const char* a_slot, float* row_scratch,
                                           long long row, bool row_ok, TileAcc<LK> (&A_all)[DA]) {
@@ -170,12 +171,55 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 #pragma unroll
             for (int mt = 0; mt < MTI; ++mt) h[j][mt] = acc[j][mt];
     };
+    // layer 1 on fp16-split products (NetMeta::l1_f16; the launch says whether its image is packed that way)
+    constexpr bool L1F = F16IMG && MT0 >= 2 && MTI == 1 && (ACTC < 0 || ACTC == NPBNN_ACT_TANH);
+    auto layer1_f16 = [&](int frag_off, int bias_off) {
+        act_tiles_all<NPBNN_ACT_TANH>(h, MT0, 0.f);
+        f32x4 acc[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[j] = *reinterpret_cast<const f32x4*>(imgs + (size_t)j * image_floats + bias_off + 4 * kq);
+#pragma unroll
+        for (int q = 0; q < (MT0 + 1) / 2; ++q) {
+            f16x8 xh[D], xl[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int t = 2 * q + (e >> 2);
+                    const float x = t < MT0 ? h[j][t < MT0 ? t : 0][e & 3] : 0.f;
+                    const _Float16 hi = (_Float16)x;
+                    xh[j][e] = hi;
+                    xl[j][e] = (_Float16)(x - (float)hi);
+                }
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float* fr = imgs + (size_t)j * image_floats + frag_off + q * 512 + lane * 4;
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(fr);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(fr + 256);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[j], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) h[j][0] = acc[j];
+    };
     if constexpr (NLC > 0) {
+        if constexpr (L1F) {
+            if (hp.l1_f16) layer1_f16(hp.frag_off[0], hp.bias_off[0]);
+            else layer(MT0, 1, hp.frag_off[0], hp.bias_off[0], hp.act_prm[0], 0, hp.in_live[0]);
+#pragma unroll
+            for (int l = 2; l < NLC; ++l) layer(1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1], l - 1, hp.in_live[l - 1]);
+        } else {
 #pragma unroll
         for (int l = 1; l < NLC; ++l) layer(l == 1 ? MT0 : 1, 1, hp.frag_off[l - 1], hp.bias_off[l - 1], hp.act_prm[l - 1], l - 1, hp.in_live[l - 1]);
+        }
     } else {
         for (int l = 1; l < n_layers; ++l) {
             const LayerMeta& L = net.L[l];
+            if constexpr (L1F) {
+                if (l == 1 && hp.l1_f16) { layer1_f16(uni(L.frag_off), uni(L.bias_off)); continue; }
+            }
             layer(uni(L.kt), uni(L.mt), uni(L.frag_off), uni(L.bias_off), uni(net.act_prm[l - 1]), l - 1, uni(L.in_live));
         }
     }
@@ -475,6 +519,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         hp.use_classw = 0; hp.predict_mode = 0; hp.weight_sets = 0;
         hp.MTL = 1; hp.lik_kind = LK == kLikGauss ? NPBNN_LIK_GAUSS : NPBNN_LIK_CATEGORICAL;
         hp.out_kind = 0; hp.final_act = 0; hp.pad_masked = 1; hp.classw_off = -1; hp.slope_off = -1;
+        hp.l1_f16 = uni(net.l1_f16);
 #pragma unroll
         for (int l = 1; l < kFastLayers; ++l)
             if (l < hp.n_layers) {
@@ -494,6 +539,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         hp.pad_masked = uni(net.pad_masked);
         hp.classw_off = uni(net.classw_off);
         hp.slope_off = uni(p.cand_slopes) != nullptr ? uni(net.slope_off) : -1;
+        hp.l1_f16 = uni(net.l1_f16);
     }
     const int k_targets = hp.k_targets;
     const int aux_sz = uni(p.lay.aux_sz), aux_mask = uni(p.lay.aux_slots) - 1;
@@ -752,11 +798,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             constexpr int NLC = decltype(nlc)::value, ACTC = decltype(actc)::value;
             constexpr bool PL = decltype(plain)::value;
             if constexpr (DT == D) {
-                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
             } else {
-                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
                 static_assert(D <= 3, "add a call per candidate");
             }
         };

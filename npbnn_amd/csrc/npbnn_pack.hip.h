@@ -28,6 +28,12 @@ constexpr float kF16Safe = 60000.0f;   // |value| above this does not survive fp
 constexpr int kFlagF16Range = 1;       // a scaled layer-0 weight left the fp16 range: the caller repeats on the float32 path
 constexpr int kFlagStructure = 2;      // a weight is not zero where the layer-0 block structure says there are none
 
+// 16-byte fragment entries of a layer in the image (layer 1 on fp16-split products: a high and a low block per K-step of two
+// layer-0 tiles; its output is one tile)
+__host__ __device__ inline int layer_frag_items(const NetMeta& net, int l) {
+    if (l == 1 && net.l1_f16) return ((net.L[0].mt + 1) / 2) * 2 * 64;
+    return net.L[l].kt * net.L[l].mt * 64;
+}
 // One item of the weight image.  Layer-l fragment layouts (16-byte entries, one per lane):
 //   float32 : entry ((kt*MT + mt)*64 + lane) = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + 0..3]
 //   fp16-split layer 0 : entry (((ks*MT + mt)*2 + part)*64 + lane) = part (0 high, 1 low) of
@@ -42,11 +48,27 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
     int piece = item;
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerMeta& L = net.L[l];
-        const int n_pieces = L.kt * L.mt * 64;
+        const int n_pieces = layer_frag_items(net, l);
         if (piece < n_pieces) {
             const int lane = piece & 63;
             const int tile = piece >> 6;
             const int ld = L.in_dim + L.has_bias;
+            if (l == 1 && net.l1_f16) {        // (NetMeta::l1_f16) entry ((q*2 + part)*64 + lane): part of W_1[unit at row lane&15][the 8 inputs of (q, lane>>4)]
+                const int part = tile & 1, q = tile >> 1, kq = lane >> 4;
+                const int o = L.out_perm ? tile_pos(lane & 15) : (lane & 15);
+                f16x8 v;
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * (2 * q + (e >> 2)) + 4 * kq + (e & 3);      // input unit at position 8 kq + e of step q
+                    float wv = 0.f;
+                    if (o < L.out_dim && c < L.in_dim) wv = (float)w[L.w_off + (long long)o * ld + L.has_bias + c];
+                    if (overflow && !(fabsf(wv) <= kF16Safe)) atomicOr(overflow, kFlagF16Range);
+                    _Float16 hi, lo;
+                    split_f16(wv, hi, lo);
+                    v[e] = part ? lo : hi;
+                }
+                *reinterpret_cast<f16x8*>(image + L.frag_off + (long long)piece * 4) = v;
+                return;
+            }
             if (l == 0 && net.l0_f16) {
                 const int part = tile & 1, rest = tile >> 1;
                 const int mt = rest % L.mt, ks = rest / L.mt;
@@ -127,7 +149,7 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
 
 __host__ __device__ inline int pack_item_count(const NetMeta& net, bool with_classw) {
     int total = with_classw ? NPBNN_MAX_WIDTH : 0;
-    for (int l = 0; l < net.n_layers; ++l) total += net.L[l].kt * net.L[l].mt * 64 + 16 * net.L[l].mt;
+    for (int l = 0; l < net.n_layers; ++l) total += layer_frag_items(net, l) + 16 * net.L[l].mt;
     return total;
 }
 

@@ -504,7 +504,7 @@ bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d) {
     if (net.final_act || d.inst_w || ctx->n_classw > 0 || net.slope_off >= 0) return false;
     if (l0_blocked(net) && !net.l0_f16) return false;          // (the fast builds for block-structured layers are fp16-split ones)
     if (net.lik_kind == NPBNN_LIK_CATEGORICAL) return net.pad_masked != 0 && d.labels != nullptr;
-    return net.lik_kind == NPBNN_LIK_GAUSS && d.targets != nullptr && net.k_targets <= kFastGaussTargets;
+    return net.lik_kind == NPBNN_LIK_GAUSS && d.targets != nullptr && net.k_targets <= (l0_blocked(net) ? 1 : kFastGaussTargets);
 }
 
 // lik_only: the caller wants the likelihood terms and nothing else from the launch (no statistics, no predictions)

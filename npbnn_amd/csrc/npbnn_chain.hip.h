@@ -598,7 +598,11 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
 
 // ---- flag-ordered overlapped schedule: waits and signals (all at agent scope; tools/microbench_handoff.hip measures the
 // hand-over: a flag is seen 0.6 us after it was raised, data written before a release store is fresh after an acquire) ----
-constexpr unsigned long long kSyncTimeoutTicks = 1000000ull;      // 10 ms of the 100 MHz wall clock: a legitimate wait is < 0.1 ms
+// 250 ms of the 100 MHz wall clock.  A legitimate wait is < 0.1 ms, but the GPU can stand still for longer than that for reasons that
+// have nothing to do with the protocol (at 10 ms the million-iteration test saw one time-out in roughly every seventh run of the whole
+// suite and none in any run on its own); a wait that really cannot end - a workgroup that is not resident - is still found, a quarter
+// of a second later, and the batch repeated on kernel boundaries.
+constexpr unsigned long long kSyncTimeoutTicks = 25000000ull;
 
 __device__ __forceinline__ bool sync_wait_ge(ChainDev* st, const int* word, int target, unsigned long long timeout_ticks = kSyncTimeoutTicks) {       // one thread
     const unsigned long long t0 = wall_clock64();

@@ -107,7 +107,7 @@ __device__ __forceinline__ void act_live_all(f32x4 (&h)[D][HT], int live, int ki
 // kind is the constant ACTC; PLAIN = categorical log-likelihood only (no confusion counts, predictions, row / class weights,
 // final activation; padding outputs masked through their bias).  The arithmetic per value is the generic path's, statement for
 // statement - only the control flow around it is resolved at compile time - so both paths give the same bits.
-template <int MT0, int MTI, int LK, int D, int DA, int J0, int NLC = 0, int ACTC = -1, bool PLAIN = false, bool F16IMG = false>
+template <int MT0, int MTI, int LK, int D, int DA, int J0, int NLC = 0, int ACTC = -1, bool PLAIN = false, bool F16IMG = false, int GT = 0>
 __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& hp, const float* imgs0, int image_floats,
                                           const f32x4 (&acc0_all)[DA][MT0], int lane, int n, int kq, const char* a_slot, float* row_scratch,
                                           long long row, bool row_ok, TileAcc<LK> (&A_all)[DA]) {
@@ -372,7 +372,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
         }
     } else {
         const float* tg = reinterpret_cast<const float*>(a_slot + hp.aux_off_t);
-        constexpr int GI = PLAIN ? kFastGaussTargets : 4;          // target columns a lane can own in this build
+        constexpr int GI = GT ? GT : (PLAIN ? kFastGaussTargets : 4);          // target columns a lane can own in this build
 #pragma unroll
         for (int i = 0; i < GI; ++i) {
             const int o = 4 * kq + i;
@@ -742,7 +742,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     NPBNN_ESTAMP(3);
 
     TileAcc<LK> A[D];
-    constexpr int GI = FAST ? kFastGaussTargets : 4;           // Gaussian moments a lane keeps (see kFastGaussTargets)
+    // Gaussian moments a lane keeps (see kFastGaussTargets; the block-structured fast builds are for ONE target column - block_bnns.py's
+    // layout: with two, the three-candidate build spills 100 bytes per lane in its prologue and reloads them in every tail)
+    constexpr int GI = FAST ? (BLK ? 1 : kFastGaussTargets) : 4;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         if constexpr (LK == kLikGauss) {
@@ -798,11 +800,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             constexpr int NLC = decltype(nlc)::value, ACTC = decltype(actc)::value;
             constexpr bool PL = decltype(plain)::value;
             if constexpr (DT == D) {
-                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
             } else {
-                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL, F16>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
                 static_assert(D <= 3, "add a call per candidate");
             }
         };

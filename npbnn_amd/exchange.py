@@ -218,6 +218,9 @@ def host_swap(chains, chain_ids, n_chains, swaps, swap_index, comm=None):
     return scal, (j, k, float(r), log_u, accepted)
 
 
+GROUP_PASS_ACCEPTANCE = 0.10     # advance_intervals(group_passes="auto"): share the passes above this acceptance rate
+
+
 def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, first_swap, comm=None, batch=20, device=True,
                       on_interval=None, group_passes=False):
     """``n_intervals`` rounds of [seg_len iterations of every chain, one swap proposal] - MC3.run_mcmc's loop body
@@ -228,17 +231,24 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
     ``iteration0`` with the acceptance memory ``mem_before``; ``last_of_batch`` marks the last interval of a device batch).
     ``group_passes``: on the interval-by-interval path the chains of this process advance through group passes
     (:func:`run_steps_batched`) instead of one after the other - the same chains, their log-likelihoods equal to rounding rather
-    than to the bit (a group's sums come from a different number of workgroup partials)."""
+    than to the bit (a group's sums come from a different number of workgroup partials).  ``"auto"``: group passes, on that path,
+    for a batch whose chains have been accepting more than ``GROUP_PASS_ACCEPTANCE`` of their proposals - a chain that moves wastes
+    its own speculative candidates, a group pass has one useful candidate per chain whatever the acceptance rate (config-2 shapes,
+    3 chains on one MI355X: 61 k against 45-56 k it/s aggregate at 18-25 % acceptance, 72 k against 82 k at 3 %;
+    tools/time_group_pass.py) - and device batches otherwise."""
     world = 1 if comm is None else comm.world_size
     done = 0
     while done < n_intervals:
         n = min(int(batch), n_intervals - done)
-        ok = (bool(device) and n >= 2 and n_chains == world * len(chains) and exchange_ready(chains, n * seg_len)
+        grouped = group_passes
+        if group_passes == "auto":
+            grouped = len(chains) >= 2 and float(np.mean([m._acceptance_rate for _, m in chains])) > GROUP_PASS_ACCEPTANCE
+        ok = (bool(device) and not (group_passes == "auto" and grouped) and n >= 2 and n_chains == world * len(chains) and exchange_ready(chains, n * seg_len)
               and (world == 1 or getattr(comm, "_comm", None) is not None))        # (several ranks: the native RCCL handle)
         if world > 1:                  # every rank must take the same path
             ok = bool(np.all(comm.allgather_f64(np.array([1.0 if ok else 0.0]))[:, 0] == 1.0))
         if not ok:
-            if group_passes:                    # the local chains share their passes over the data (run_steps_batched)
+            if grouped:                         # the local chains share their passes over the data (run_steps_batched)
                 run_steps_batched(chains, seg_len)
             else:
                 for bnn, mcmc in chains:

@@ -176,7 +176,8 @@ class MC3():
     # on the host (False: the reference's rhythm).  None = the library's choice: device batches for the chains of ONE process;
     # with several ranks the host path, until the in-place RCCL all-gather has been run between real ranks (set True to opt in).
     device_exchange = None
-    group_passes = False     # interval-by-interval path: the local chains share their passes over the data (exchange.run_steps_batched)
+    group_passes = False     # interval-by-interval path: the local chains share their passes over the data (exchange.run_steps_batched);
+    #                          "auto": whenever they have been accepting more than exchange.GROUP_PASS_ACCEPTANCE of their proposals
 
     def run_mcmc(self):
         """The MC3 loop (reference: BNN_mc3.py:87-126): ``n_mc3_iteration`` rounds of [swap_frequency iterations of every

@@ -489,3 +489,26 @@ def test_mc3_intervals_with_group_passes_match_the_interval_path():
     assert all(m._device_passes >= 240 for _, m in b)          # (a chain alone needs ~240 / 2.5 passes: these went through groups)
     assert [(s[0], s[1], s[4]) for s in log_a] == [(s[0], s[1], s[4]) for s in log_b]
     assert_same(state_of(a), state_of(b), exact=False)
+
+
+def test_group_passes_are_taken_automatically_only_for_chains_that_move(monkeypatch):
+    """advance_intervals(group_passes="auto"): chains that accept more than exchange.GROUP_PASS_ACCEPTANCE of their proposals share
+    their passes over the data, interval by interval; chains that barely move run in device batches.  The same chains either way."""
+    cfg = cases.TRACES["cfg2s"]
+    temps = list(np.linspace(0.8, 1.0, 3))
+    for threshold, expect_groups in ((0.0, True), (1.0, False)):
+        monkeypatch.setattr(ex, "GROUP_PASS_ACCEPTANCE", threshold)
+        a, b = build_chains(cfg, temps), build_chains(cfg, temps)
+        for chains in (a, b):
+            for bnn, m in chains:
+                m.device_schedule = 2
+                m.run_steps(bnn, 60)        # (some acceptance history)
+        calls = []
+        real = ex.run_steps_batched
+        monkeypatch.setattr(ex, "run_steps_batched", lambda *x, **k: (calls.append(1), real(*x, **k))[1])
+        swaps_a, swaps_b = (ex.SwapProposals(3, np.random.RandomState(5)) for _ in range(2))
+        ex.advance_intervals(a, [0, 1, 2], 3, 4, 40, swaps_a, 0, device=False)
+        ex.advance_intervals(b, [0, 1, 2], 3, 4, 40, swaps_b, 0, group_passes="auto")
+        assert (len(calls) == 4) == expect_groups, (threshold, calls)
+        assert_same(state_of(a), state_of(b), exact=False)
+        monkeypatch.setattr(ex, "run_steps_batched", real)

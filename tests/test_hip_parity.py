@@ -460,3 +460,48 @@ def test_layer0_block_structure_is_the_dense_result_bit_for_bit(hip, l0, kind):
     assert blocked.eval(bad)["loglik"] == dense.eval(bad)["loglik"]
     dense.close()
     blocked.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_architectures_against_the_oracle(seed, hip):
+    """Seeded random networks - 2 to 4 weight matrices, hidden widths 1 .. 70, with and without bias columns, every activation,
+    categorical and Gaussian heads, both layer-0 precisions - against the float64 oracle: the layouts a shape selects (narrow
+    hidden layers stored transposed inside their tile, layer 1 on fp16-split products for tanh networks with two or more layer-0
+    tiles, fast and general builds) must all give the same network."""
+    rs = np.random.default_rng(1000 + seed)
+    n = int(rs.integers(40, 400))
+    f = int(rs.choice([3, 17, 32, 64, 100, 130]))
+    n_hidden = int(rs.integers(1, 4))
+    widths = [int(rs.choice([1, 2, 4, 5, 8, 9, 13, 16, 17, 31, 32, 33, 48, 70])) if i == 0 else int(rs.integers(1, 17))
+              for i in range(n_hidden)]
+    classification = bool(rs.integers(0, 2))
+    n_out = int(rs.integers(2, 12)) if classification else int(rs.integers(1, 3))
+    bias = int(rs.choice([-1, 0, 2, 3]))
+    fun = str(rs.choice(["tanh", "tanh", "ReLU", "swish", "genReLU"]))
+    act = orc.Act(fun, np.full(n_hidden, 0.2)) if fun == "genReLU" else orc.Act(fun)
+    x = rs.standard_normal((n, f)) * rs.uniform(0.2, 3.0)
+    np.random.seed(seed)
+    w = orc.init_weights(widths, f, n_out, init_std=0.5, bias_node=bias)
+    w = [wi * rs.uniform(0.5, 2.0) + 0.05 * rs.standard_normal(wi.shape) for wi in w]
+    ap = act_prm(act, len(w) - 1)
+    z64 = orc.forward_logits(x, w, act)
+    for l0 in ("f16", "f32"):
+        if classification:
+            labels = rs.integers(0, n_out, n)
+            ctx = make_ctx(hip, x, w, act, 0, 0, labels=labels)
+            want = orc.lik_categorical(orc.out_softmax(z64), labels, np.arange(n))
+        else:
+            targets = rs.standard_normal((n, n_out))
+            ctx = make_ctx(hip, x, w, act, 1, 1, targets=targets, n_targets=n_out)
+            want = orc.closed_gaussian_empirical(z64, targets)[0]
+        try:
+            ctx.set_l0_precision(l0)
+        except Exception:
+            ctx.close()
+            continue
+        assert_close(ctx.predict(w, act_prm=ap, apply_out_fn=False), z64, tol=5e-5)
+        for fast in (1, 0):
+            ctx.set_fast_tails(fast)
+            got = ctx.eval(w, act_prm=ap)["loglik"]
+            np.testing.assert_allclose(got, want, rtol=5e-6, err_msg="%s widths=%s bias=%d f=%d fast=%d l0=%s" % (fun, widths, bias, f, fast, l0))
+        ctx.close()

@@ -24,7 +24,8 @@ from .likelihoods import (CalcAccuracy, CalcAccuracyRegression, CalcLabelAccurac
 from .model import data_transform_obj, npBNN  # noqa: F401
 from .sampler import MCMC, predict  # noqa: F401
 from .driver import run_mcmc  # noqa: F401
-from .files import SaveObject, get_data, load_obj, randomize_data, turn_labels_to_numeric  # noqa: F401
+from .files import (DetachedMatrix, SaveObject, attach_data, get_data, load_obj, randomize_data,  # noqa: F401
+                    turn_labels_to_numeric)
 from .logger import init_output_files, postLogger  # noqa: F401
 from .mc3 import MC3  # noqa: F401
 from .posterior import (feature_importance, get_posterior_cat_prob, get_posterior_est, predictBNN,  # noqa: F401

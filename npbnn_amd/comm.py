@@ -12,7 +12,6 @@ returned through a multiprocessing pool.
 import os
 import pickle
 import socket
-import struct
 import time
 
 import numpy as np
@@ -183,7 +182,3 @@ class RcclComm:
             self.close()
         except Exception:
             pass
-
-
-def struct_pack_check():   # keep struct imported for ABI size assertions in tests
-    return struct.calcsize("q")

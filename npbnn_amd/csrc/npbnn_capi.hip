@@ -71,7 +71,10 @@ struct Dataset {
     int F = 0, Fp = 0, k = 0;
     float* X16 = nullptr;      // fp16-split copy (built lazily on the device), row stride Fp16 floats
     int Fp16 = 0;
-    int f16_state = 0;         // 0 not built, 1 usable, -1 not representable (inf/NaN or outside the fp16 range)
+    int f16_state = 0;         // 0 not built, 1 usable, -1 not representable (inf/NaN or outside the fp16 range), -2 representable but
+                               // too coarse for some column: its entries span too many powers of two for a pair of fp16 numbers
+    int f16_worst_col = -1;    // column with the largest (max entry error / mean |entry|) of the fp16 pair, and that ratio
+    double f16_worst_ratio = 0.0;
     bool borrowed = false;     // X / X16 belong to another ctx (npbnn_share_data)
 };
 
@@ -471,6 +474,36 @@ int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
         float m;
         memcpy(&m, &bits, 4);
         d.f16_state = (std::isfinite(m) && m <= kF16Safe) ? 1 : -1;    // a test set far outside the training range
+        if (d.f16_state > 0) {      // and is the pair of fp16 numbers a fair picture of every column? (split_quality_kernel)
+            const int Fq = d.Fp;
+            unsigned* d_err = nullptr;
+            unsigned long long* d_sum = nullptr;
+            HIP_TRY(ctx, hipMalloc(&d_err, (size_t)Fq * sizeof(unsigned)));
+            HIP_TRY(ctx, hipMalloc(&d_sum, (size_t)Fq * sizeof(unsigned long long)));
+            HIP_TRY(ctx, hipMemsetAsync(d_err, 0, (size_t)Fq * sizeof(unsigned), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, (size_t)Fq * sizeof(unsigned long long), ctx->stream));
+            hipLaunchKernelGGL(split_quality_kernel, dim3((Fq + 255) / 256, (unsigned)((d.n_rows + 1023) / 1024)), dim3(256), 0, ctx->stream,
+                               (const float*)d.X, (long long)d.n_rows, d.Fp, (const float*)ctx->d_xscale, d_err, d_sum);
+            std::vector<unsigned> h_err((size_t)Fq);
+            std::vector<unsigned long long> h_sum((size_t)Fq);
+            HIP_TRY(ctx, hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(d_err);
+            (void)hipFree(d_sum);
+            d.f16_worst_col = -1;
+            d.f16_worst_ratio = 0.0;
+            for (int c = 0; c < d.F; ++c) {
+                float e;
+                memcpy(&e, &h_err[(size_t)c], 4);
+                const double mean_abs = (double)h_sum[(size_t)c] / 4294967296.0 / (double)d.n_rows;
+                if (!(mean_abs > 0.0)) continue;                 // an all-zero column is exact
+                const double ratio = (double)e / mean_abs;
+                if (ratio > d.f16_worst_ratio) { d.f16_worst_ratio = ratio; d.f16_worst_col = c; }
+            }
+            if (d.f16_worst_ratio > (double)kF16QualityTol && !getenv("NPBNN_F16_NO_QUALITY_CHECK")) d.f16_state = -2;   // heavy-tailed column(s)
+        }
+        if (d.f16_state < 0 && d.X16) { (void)hipFree(d.X16); d.X16 = nullptr; }      // (nobody will read it)
     }
     *usable = d.f16_state > 0 ? 1 : 0;
     return NPBNN_OK;
@@ -515,8 +548,13 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
         int usable = 0;
         int rc0 = ensure_x16(ctx, which, &usable);
         if (rc0) return rc0;
-        if (!usable && ctx->l0_option == NPBNN_L0_F16)
+        if (!usable && ctx->l0_option == NPBNN_L0_F16) {
+            if (d.f16_state == -2)
+                return fail(ctx, NPBNN_E_RANGE, "fp16-split layer 0 was requested but column %d spans too many powers of two for a pair of fp16 "
+                                                "numbers (largest entry error %.2e of its mean |value|; bound %.2e)", d.f16_worst_col,
+                            d.f16_worst_ratio, (double)kF16QualityTol);
             return fail(ctx, NPBNN_E_RANGE, "fp16-split layer 0 was requested but the data cannot be represented in it");
+        }
         want_f16 = usable != 0;
     }
     if ((ctx->net.l0_f16 != 0) != want_f16) {

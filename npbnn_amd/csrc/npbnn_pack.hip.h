@@ -224,4 +224,36 @@ __global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ 
 }
 #endif  // NPBNN_KERNELS_MAIN
 
+// How well does the fp16 pair represent column c?  An entry's absolute error |x' - (hi + lo)| is bounded by half the fp16 subnormal
+// spacing, 2^-25 of the column's scale - fine while the column's typical entry is within a few powers of two of its largest, but a
+// heavy-tailed column (one 1e4 outlier over values of 1e-2, log-normal features, ...) puts its typical entries where that error is
+// per cent of the value.  Per column: the largest error of any entry and the sum of |x'| (as a 2^-32 fixed-point integer, so that
+// the sum does not depend on the order of the atomics); the host compares the two (kF16QualityTol).
+constexpr float kF16QualityTol = 7.62939453125e-06f;        // 2^-17: largest entry error <= this x the column's mean |value| (normal data: 6e-7,
+                                                            // log-normal sigma 1: 5e-6, Student t3: 1.4e-5, log-normal sigma 3: 2e-4, an outlier 1e6 x the rest: 5e-3)
+#ifdef NPBNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) split_quality_kernel(const float* __restrict__ X, long long n_rows, int Fp, const float* __restrict__ x_scale,
+                                                            unsigned* __restrict__ max_err, unsigned long long* __restrict__ sum_abs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Fp) return;
+    const long long r0 = (long long)blockIdx.y * 1024;
+    long long r1 = r0 + 1024;
+    if (r1 > n_rows) r1 = n_rows;
+    const float sc = x_scale[c];
+    float worst = 0.f;
+    unsigned long long sum = 0;
+    for (long long r = r0; r < r1; ++r) {
+        const float v = X[r * Fp + c] * sc;
+        _Float16 h, l;
+        split_f16(v, h, l);
+        const float e = fabsf(v - ((float)h + (float)l));      // (hi + lo spans at most 23 bits: the sum is exact in float32)
+        worst = e > worst ? e : worst;
+        const float a = fabsf(v);
+        sum += (unsigned long long)((double)(a < 2.f ? a : 2.f) * 4294967296.0);
+    }
+    atomicMax(max_err + c, __float_as_uint(worst));
+    atomicAdd(sum_abs + c, sum);
+}
+#endif  // NPBNN_KERNELS_MAIN
+
 }  // namespace npbnn

@@ -69,6 +69,8 @@ def exchange_ready(chains, n_iterations):
             return False
         if not mcmc._randomize_seed or not mcmc._device_loop_ok(bnn, n_iterations):
             return False
+        if not mcmc._plain_device_batches(bnn):
+            return False
         boundary = mcmc._next_adapt_boundary()
         if boundary is not None and boundary < mcmc._current_iteration + n_iterations:
             return False
@@ -92,7 +94,7 @@ def run_exchange(chains, chain_ids, n_chains, n_seg, seg_len, swaps, first_swap,
     for (bnn, mcmc), cid in zip(chains, chain_ids):
         mcmc._bnn = bnn
         it = mcmc._current_iteration
-        idx, delta, cnt, log_u, smult, hast = mcmc._claim_draw(bnn, it, K).result()
+        idx, delta, cnt, log_u, smult, hast = mcmc._claim_draw(bnn, it, K).result()[:6]
         # the draws of the probable next call, made while the GPU runs this one
         mcmc._speculation = mcmc._submit_draw(bnn, it + K, K, rewindable=True)
         job = mcmc._backend.exchange_job(bnn._w_layers, chain_id=cid, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=bnn._mask,
@@ -128,7 +130,7 @@ def _batchable(chains, n_iterations):
             from .sampler import get_backend
             mcmc._backend = get_backend(bnn, mcmc._likelihood_f)
         be = mcmc._backend
-        if not hasattr(be, "run_batched") or not mcmc._device_loop_ok(bnn, n_iterations):
+        if not hasattr(be, "run_batched") or not mcmc._device_loop_ok(bnn, n_iterations) or not mcmc._plain_device_batches(bnn):
             return False
         boundary = mcmc._next_adapt_boundary()
         if boundary is not None and boundary < mcmc._current_iteration + n_iterations:
@@ -168,7 +170,7 @@ def run_steps_batched(chains, n_iterations):
             mcmc._bnn = bnn
             mcmc._adapt(bnn)
             it = mcmc._current_iteration
-            idx, delta, cnt, log_u, smult, hast = mcmc._claim_draw(bnn, it, K).result()
+            idx, delta, cnt, log_u, smult, hast = mcmc._claim_draw(bnn, it, K).result()[:6]
             mcmc._speculation = mcmc._submit_draw(bnn, it + K, K, rewindable=True)      # the probable next call's draws, meanwhile
             jobs.append(mcmc._backend.exchange_job(bnn._w_layers, chain_id=len(jobs), idx=idx, delta=delta, cnt=cnt, log_u=log_u,
                                                    mask=bnn._mask, cfg=mcmc._device_chain_cfg(bnn, smult, hast)))

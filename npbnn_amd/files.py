@@ -14,9 +14,58 @@ import numpy as np
 
 
 # ---- persistence ---------------------------------------------------------------------------------
-def load_obj(file_name):
+class DetachedMatrix:
+    """What a light checkpoint holds in place of a feature matrix: shape and dtype, and the name it has in the side file
+    ``<checkpoint>_data.npz`` (written once per run by ``postLogger``; the reference pickles the matrices with every posterior
+    sample, np_bnn/BNN_env.py:655-658).  ``load_obj`` puts the matrix back when the side file is there."""
+
+    def __init__(self, key, array):
+        self.key, self.shape, self.dtype = key, tuple(np.shape(array)), str(np.asarray(array).dtype)
+
+    def __len__(self):
+        return self.shape[0] if self.shape else 0
+
+    def __repr__(self):
+        return "DetachedMatrix(%r, shape=%s, dtype=%s)" % (self.key, self.shape, self.dtype)
+
+
+def data_side_file(checkpoint_name):
+    stem = checkpoint_name[:-4] if checkpoint_name.endswith(".pkl") else checkpoint_name
+    return stem + "_data.npz"
+
+
+def attach_data(obj, source):
+    """Put feature matrices back into the model of a light checkpoint: ``source`` is the side file's path, an open ``np.load``
+    result or a dictionary with the keys ``data`` / ``test_data`` (what ``npBNN`` was built from)."""
+    if isinstance(source, (str, os.PathLike)):
+        source = np.load(source)
+    for name, value in list(vars(obj).items()):
+        if isinstance(value, DetachedMatrix):
+            key = value.key if value.key in source else value.key.lstrip("_")
+            matrix = np.asarray(source[key])
+            if tuple(matrix.shape) != value.shape:
+                raise ValueError("%s has shape %s; the checkpoint was written with %s" % (key, matrix.shape, value.shape))
+            setattr(obj, name, matrix)
+    return obj
+
+
+def load_obj(file_name, dat=None):
+    """The pickled object(s) of ``file_name`` (np_bnn/BNN_files.py:260-267).  Checkpoints written by ``postLogger`` keep their
+    feature matrices in a side file; they are re-attached from it - or from ``dat``, the dictionary the model was built from."""
     with open(file_name, 'rb') as f:
-        return pickle.load(f)
+        obj = pickle.load(f)
+    models = [o for o in (obj if isinstance(obj, (list, tuple)) else [obj])
+              if any(isinstance(v, DetachedMatrix) for v in getattr(o, "__dict__", {}).values())]
+    if models:
+        side = data_side_file(file_name)
+        source = dat if dat is not None else (np.load(side) if os.path.exists(side) else None)
+        if source is None:
+            print("load_obj: %s holds no feature matrices and %s is missing; pass dat= or call attach_data / update_data"
+                  % (file_name, side))
+        else:
+            for m in models:
+                attach_data(m, source)
+    return obj
 
 
 def SaveObject(obj, filename):

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .files import SaveObject
+from .files import DetachedMatrix, SaveObject, data_side_file
 
 
 def init_output_files(bnn_obj, filename="bnn", sample_from_prior=0, outpath="", add_prms=None,
@@ -62,13 +62,47 @@ def init_output_files(bnn_obj, filename="bnn", sample_from_prior=0, outpath="", 
 
 class postLogger():
     def __init__(self, bnn_obj, filename="BNN", wdir="", sample_from_prior=0, add_prms=None,
-                 continue_logfile=False, log_all_weights=0):
+                 continue_logfile=False, log_all_weights=0, pickle_data=False):
+        """``pickle_data``: True writes the feature matrices into the checkpoint with every posterior sample, as the reference
+        does (np_bnn/BNN_env.py:655-658; > 200 MB per sample at 100k x 256); the default writes them ONCE into
+        ``<checkpoint>_data.npz`` and keeps the checkpoint itself to weights, sampler state and posterior samples -
+        ``load_obj`` puts them back together."""
         self._logfile, self._w_file, self._pklfile = init_output_files(
             bnn_obj, filename, sample_from_prior, outpath=wdir, add_prms=add_prms,
             continue_logfile=continue_logfile, log_all_weights=log_all_weights)
         self._log_all_weights = log_all_weights
         self._post_weight_samples = []
         self._estimation_mode = bnn_obj._estimation_mode
+        self._pickle_data = bool(pickle_data)
+        self._side_key = None
+
+    _DETACHED = ("_data", "_test_data")
+
+    def _light_views(self, bnn_obj, mcmc_obj):
+        """(model, sampler) as the checkpoint stores them: the feature matrices replaced by place holders (their side file written
+        when the matrices are not the ones it holds) and the sampler without its prediction matrices (functions of the weights:
+        computed on demand after loading, as for a live chain)."""
+        big = {name: getattr(bnn_obj, name) for name in self._DETACHED if np.size(getattr(bnn_obj, name, ())) > 0}
+        if not big:
+            return bnn_obj, mcmc_obj
+        key = tuple((name, id(a), np.shape(a)) for name, a in big.items())
+        side = data_side_file(self._pklfile)
+        if key != self._side_key or not os.path.exists(side):
+            np.savez(side, **{name.lstrip("_"): np.asarray(a) for name, a in big.items()})
+            self._side_key = key
+        bnn_v = bnn_obj.__class__.__new__(bnn_obj.__class__)
+        bnn_v.__dict__.update(bnn_obj.__dict__)
+        for name, a in big.items():
+            setattr(bnn_v, name, DetachedMatrix(name.lstrip("_"), a))
+        mcmc_v = mcmc_obj
+        if hasattr(mcmc_obj, "_light_view"):
+            mcmc_v = mcmc_obj._light_view(bnn_v)
+        return bnn_v, mcmc_v
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_side_key"] = None        # (object identities mean nothing in another process)
+        return state
 
     def update_post_weight_samples(self, row):
         self._post_weight_samples += [row]
@@ -130,5 +164,7 @@ class postLogger():
             self.update_post_weight_samples(sample)
             self.control_weight_sample_length(mcmc_obj._n_post_samples)
         if save_pickle:
+            if not getattr(self, "_pickle_data", True):
+                bnn_obj, mcmc_obj = self._light_views(bnn_obj, mcmc_obj)
             objs = [bnn_obj, mcmc_obj, self] + ([add_obj] if add_obj else [])
             SaveObject(objs, self._pklfile)

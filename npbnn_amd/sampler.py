@@ -199,6 +199,8 @@ class MCMC():
 
     def _compute_lazy(self, name):
         bnn_obj = self._bnn
+        if self._backend is None:               # (a sampler that came out of a pickle)
+            self._backend = get_backend(bnn_obj, self._likelihood_f)
         fw = self._forward_weights(bnn_obj._w_layers, bnn_obj._indicators)
         if name == "_y":
             return self._host_predictions(bnn_obj, fw, self._accepted_override)
@@ -239,10 +241,27 @@ class MCMC():
 
     def __getstate__(self):
         self._cancel_speculation()
-        self._materialize()
+        light = self.__dict__.get("_light_pickle", False)
+        if not light:
+            self._materialize()
         state = dict(self.__dict__)
         state.pop("_backend", None)
+        state.pop("_light_pickle", None)
+        if light:       # a checkpoint view (postLogger): no prediction matrices, no model reference beside the pickled one
+            state["_lazy"] = {k: v for k, v in self._lazy.items() if k not in ("_y", "_y_test")}
+            state["_speculation"] = None
+            state["_ws_copies"] = None
         return state
+
+    def _light_view(self, bnn_view):
+        """This sampler as a light checkpoint stores it (see postLogger): same state, bound to ``bnn_view``, pickled without the
+        prediction matrices - after loading they are computed on demand from the weights, like every other statistic."""
+        view = self.__class__.__new__(self.__class__)
+        view.__dict__.update(self.__dict__)
+        view._speculation = None
+        view._bnn = bnn_view
+        view._light_pickle = True
+        return view
 
     def __setstate__(self, state):
         state = dict(state)
@@ -421,6 +440,11 @@ class MCMC():
                 return False
         return True
 
+    def _plain_device_batches(self, bnn_obj):
+        """May the chain take part in an exchange run or a group pass?  Those entry points run plain batches only: chain state that
+        rides along with extra per-iteration draws (trainable activation slopes) stays on :meth:`run_steps`."""
+        return not bnn_obj._act_fun._trainable
+
     def _sigma_proposal_columns(self, bnn_obj, first_it):
         """Columns of the error parameter that every iteration from ``first_it`` on proposes to change (0: none)."""
         if (bnn_obj._estimation_mode == "regression" and not bnn_obj._empirical_error and first_it > self._estimate_error):
@@ -495,7 +519,8 @@ class MCMC():
         src = list(self._update_ws)
         cache = self._ws_copies
         if cache is None or len(cache[0]) != len(src) or any(a is not b for a, b in zip(cache[0], src)) \
-                or any(c.shape != w.shape for c, w in zip(cache[2], bnn_obj._w_layers)):
+                or any(c.shape != w.shape for c, w in zip(cache[2], bnn_obj._w_layers)) \
+                or not all(np.array_equal(c, a) for c, a in zip(cache[1], src)):       # (an in-place edit of _update_ws[i])
             cache = self._ws_copies = (src, [np.array(w, dtype=np.float64) for w in src], [np.empty(w.shape) for w in bnn_obj._w_layers])
         update_ws, shapes = cache[1], cache[2]                         # (predraw only needs the shapes of the layers)
         freq = [float(f) for f in self._freq_layer_update]
@@ -526,7 +551,8 @@ class MCMC():
         are exactly these, else fresh ones."""
         spec = self._speculation
         if (spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k) and len(spec[3]) == len(self._update_ws)
-                and all(a is b for a, b in zip(spec[3], self._update_ws))):      # (the very arrays the draw was made with)
+                and all(a is b for a, b in zip(spec[3], self._update_ws))       # (the very arrays the draw was made with ...
+                and self._ws_copies is not None and all(np.array_equal(c, a) for c, a in zip(self._ws_copies[1], self._update_ws))):   # ... unedited)
             self._speculation = None
             return spec[1]
         self._cancel_speculation()
@@ -650,8 +676,10 @@ class MCMC():
             self._gen = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
 
     def gibbs_step(self, bnn_obj):
+        self._cancel_speculation()
         bnn_obj.sample_prior_scale()
         self._logPrior = bnn_obj.calc_prior()
+        self._slope_term_in_prior = False       # (calc_prior is without the slope term, as in the reference: BNN_env.py:534-538)
         self._logPost = self._logLik + self._logPrior
         self._current_iteration += 1
 

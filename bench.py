@@ -50,38 +50,10 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------------------
 def launch_ranks(args):
     """Parent of a multi-GPU run: one child per GPU with the environment torch.distributed.run would give it, rendezvous on
-    127.0.0.1.  This process never touches a GPU (and never imports torch); it relays rank 0's JSON line and exits with the
-    worst child status.  A child that fails takes the others down (their own pids only)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    children = []
-    for r in range(args.gpus):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        children.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0 = ""
-    status = 0
-    try:
-        out0, _ = children[0].communicate()
-        pending = list(children)
-        while pending:
-            for c in list(pending):
-                rc = c.poll()
-                if rc is None:
-                    continue
-                pending.remove(c)
-                if rc != 0:
-                    status = status or rc
-                    for other in pending:       # a rank died: the others would wait for it in a collective
-                        other.kill()
-            time.sleep(0.05)
-    finally:
-        for c in children:
-            if c.poll() is None:
-                c.kill()
+    127.0.0.1 (npbnn_amd.launch.spawn_ranks).  This process never touches a GPU and never imports torch; it relays rank 0's JSON
+    line and exits with the first failing child's status - the moment a rank fails, the others are killed."""
+    from npbnn_amd.launch import spawn_ranks
+    status, out0, _ = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
     sys.stdout.write(out0)
     sys.stdout.flush()
     return status
@@ -159,18 +131,23 @@ def main():
     if world != max(1, args.gpus):
         if rank == 0:
             print("[bench] --gpus %d but the launcher started %d ranks; measuring %d" % (args.gpus, world, world), file=sys.stderr)
-    dist = None
-    dist_backend = os.environ.get("NPBNN_BENCH_DIST_BACKEND", "nccl")     # gloo: rehearsal of the rank flow on fewer GPUs than ranks
+    # What carries the swap exchange and the timing barrier between the ranks.  Default "rccl": the communicator of the C ABI
+    # (npbnn_comm_*), its unique id handed out over a TCP socket on MASTER_ADDR - no torch anywhere in the process, so the only
+    # librccl mapped is the one libnpbnn_hip.so was built against.  "socket": plain TCP (rehearsal of the rank flow on fewer GPUs
+    # than ranks).  "gloo" / "nccl": a torch.distributed process group (kept for comparison; imports torch).
+    dist_backend = os.environ.get("NPBNN_BENCH_DIST_BACKEND", "rccl")
     device_index = local_rank
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        if dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from npbnn_amd import _capi as capi
+        import ctypes
+        n_dev = ctypes.c_int(0)
+        capi.load_library().npbnn_device_count(ctypes.byref(n_dev))
+        if dist_backend in ("rccl", "nccl"):
+            if n_dev.value < world:
+                sys.exit("[rank %d] --gpus %d over RCCL needs %d GPUs, %d visible (NPBNN_BENCH_DIST_BACKEND=socket rehearses the "
+                         "rank flow on fewer)" % (rank, world, world, n_dev.value))
         else:
-            device_index = local_rank % max(1, torch.cuda.device_count())
-            dist.init_process_group(dist_backend)
+            device_index = local_rank % max(1, n_dev.value)
         os.environ["NPBNN_DEVICE"] = str(device_index)
 
     from bench_support import workload
@@ -182,7 +159,7 @@ def main():
         mcmc.device_schedule = int(os.environ["NPBNN_BENCH_SCHEDULE"])
     comm, comm_kind, nranks_seen = None, "none", 1
     if world > 1:
-        comm, comm_kind = make_comm(dist, dist_backend, rank, world, local_rank, device_index)
+        comm, comm_kind = make_comm(dist_backend, rank, world, local_rank, device_index)
         nranks_seen = int(comm.world_size)
 
     from npbnn_amd import exchange as ex
@@ -205,11 +182,13 @@ def main():
         swap_no[0] += n_steps
 
     def sync():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            if dist_backend == "nccl":
-                torch.cuda.synchronize()
+        """barrier + device synchronisation (the driver's contract for both ends of the timed region)"""
+        if comm is not None:
+            comm.barrier()
+        from npbnn_amd import _capi as capi
+        capi.check(capi.load_library(), None, capi.load_library().npbnn_device_synchronize(device_index))
+        if comm is not None:
+            comm.barrier()
 
     advance(args.warmup)
     book = dict(acc=mcmc._device_accepted, passes=mcmc._device_passes, voids=mcmc._device_void_passes, its=mcmc._device_iterations)
@@ -218,48 +197,36 @@ def main():
     advance(args.steps)
     sync()
     el = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    if comm is not None:
+        el = float(np.max(comm.allgather_f64(np.array([el]))))          # the slowest rank's clock
 
     if rank == 0:
         its = args.steps * ITERATIONS_PER_STEP
         line = report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, device_swaps)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     mcmc._backend.close()
 
 
-def make_comm(dist, dist_backend, rank, world, local_rank, device_index):
-    """The communicator of the swap exchange: RCCL behind the C ABI (npbnn_comm_*); its 128-byte unique id travels over the
-    launcher's process group.  Every rank takes part in every collective below whatever happens, so a failure anywhere cannot
-    leave the others waiting; if any rank cannot build the native communicator, all of them use torch.distributed's."""
+def make_comm(dist_backend, rank, world, local_rank, device_index):
+    """The communicator of the swap exchange (see main).  A rank that cannot build it fails loudly; the launcher ends the others."""
+    from npbnn_amd.comm import RcclComm, SocketComm
+    if dist_backend == "rccl":
+        comm = RcclComm(rank=rank, world_size=world, device=device_index)
+        return comm, comm.describe()
+    if dist_backend == "socket":
+        return SocketComm(rank=rank, world_size=world), "tcp sockets through rank 0 (rehearsal; no RCCL), %d ranks" % world
     import torch
-    from npbnn_amd.comm import RcclComm, TorchDistComm
-    box = [None]
-    on_gpu = dist_backend == "nccl"
-    if rank == 0 and (on_gpu or os.environ.get("NPBNN_BENCH_TRY_RCCL")):
-        try:
-            box[0] = RcclComm.make_unique_id()
-        except Exception as e:
-            print("[rank 0] cannot create an RCCL unique id (%s)" % e, file=sys.stderr, flush=True)
-    dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local_rank) if on_gpu else None)
-    ok, comm = (1 if box[0] else 0), None
-    if ok:
-        try:
-            comm = RcclComm(rank=rank, world_size=world, device=device_index, uid=box[0])
-        except Exception as e:
-            print("[rank %d] native RCCL communicator unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
-            ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
-        return comm, "rccl (C ABI)"
-    return TorchDistComm(), ("rccl (torch.distributed)" if on_gpu else "%s (torch.distributed)" % dist_backend)
+    import torch.distributed as dist
+    from npbnn_amd.comm import TorchDistComm
+    if dist_backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(dist_backend)
+    return TorchDistComm(), "%s (torch.distributed), %d ranks" % ("rccl" if dist_backend == "nccl" else dist_backend, world)
 
 
 def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, device_swaps):
@@ -328,6 +295,7 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
         "accept_rate_last_100": float(mcmc._acceptance_rate),
         "loglik": float(mcmc._logLik),
         "schedule_timeouts": int(ctx.sync_fallbacks),
+        "torch_imported": "torch" in sys.modules,
     }
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(wl)

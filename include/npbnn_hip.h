@@ -312,6 +312,15 @@ int npbnn_comm_init(int device_id, int rank, int nranks, const char id[128], npb
 int npbnn_comm_allgather_f64(npbnn_comm* comm, const double* send, int count, double* recv /* nranks*count */);
 int npbnn_comm_bcast_i64(npbnn_comm* comm, int64_t* buf, int count, int root);
 void npbnn_comm_destroy(npbnn_comm* comm);
+/* Which RCCL does this process run?  runtime_version: ncclGetVersion() of the library that is mapped (e.g. 22707), header_version:
+ * NCCL_VERSION_CODE of the rccl.h this library was compiled against, path: the file the mapped library came from.
+ * npbnn_comm_init refuses to start when the two differ in major.minor (a process that loaded another librccl.so.1 first - the one
+ * bundled with a PyTorch wheel - would otherwise run this library's calls on it).  (No reference counterpart: BNN_mc3.py has no
+ * communication library.) */
+int npbnn_comm_runtime(int* runtime_version, int* header_version, char* path, int path_cap);
+/* hipDeviceSynchronize on `device_id`: everything enqueued on that GPU by this process has completed (bench.py brackets its timed
+ * region with it, next to a barrier of the communicator). */
+int npbnn_device_synchronize(int device_id);
 
 /* ---- exchange run: the chains of an MC3 run (np_bnn/BNN_mc3.py:87-126) advance n_seg swap intervals of seg_len iterations with
  * the temperature swaps between them done on the GPU: replaces n_seg rounds of  pool.map(run_single_mcmc) -> read

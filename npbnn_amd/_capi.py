@@ -135,6 +135,8 @@ SIGNATURES = {
     "npbnn_comm_allgather_f64": (C.c_int, [_P, _DP, C.c_int, _DP]),
     "npbnn_comm_bcast_i64": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "npbnn_comm_destroy": (None, [_P]),
+    "npbnn_comm_runtime": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "npbnn_device_synchronize": (C.c_int, [C.c_int]),
 }
 
 _lib = None

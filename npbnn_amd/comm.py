@@ -7,11 +7,13 @@ returned through a multiprocessing pool.
 
     LocalComm      world of one process (all chains in this process)
     RcclComm       one process per GPU, RCCL over xGMI through the C ABI (libnpbnn_hip.so)
+    SocketComm     plain TCP through rank 0 (no GPU, no torch): rehearsals of the rank flow on fewer GPUs than ranks, CPU tests
     TorchDistComm  torch.distributed process group (gloo on CPU for tests; "nccl" = RCCL on GPUs)
 """
 import os
 import pickle
 import socket
+import struct
 import time
 
 import numpy as np
@@ -105,6 +107,114 @@ def _exchange_unique_id(rank, world, uid, addr, port, timeout=120.0):
     return buf
 
 
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+class SocketComm:
+    """The exchange over plain TCP: every rank keeps one connection to rank 0, which gathers and hands back.  For rehearsing
+    the multi-rank flow where RCCL cannot run (several ranks on one GPU, CPU tests) - the payloads are a few dozen bytes per
+    swap interval, so this is not a performance path.  Every receive has a deadline (``timeout`` seconds): a rank whose peer
+    has gone fails with ``ConnectionError`` / ``socket.timeout`` instead of waiting for ever."""
+    _comm = None          # (no native handle: exchange runs take the interval-by-interval path)
+
+    def __init__(self, rank=None, world_size=None, addr=None, port=None, timeout=120.0):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = port or (int(os.environ.get("MASTER_PORT", "29500")) + 19)
+        self._peers, self._up = [], None
+        if self.world_size == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world_size)
+            srv.settimeout(timeout)
+            by_rank = {}
+            try:
+                while len(by_rank) < self.world_size - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    by_rank[struct.unpack("<q", _recv_exact(conn, 8))[0]] = conn
+            finally:
+                srv.close()
+            self._peers = [by_rank[r] for r in range(1, self.world_size)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<q", self.rank))
+            self._up = s
+
+    def _gather_bytes(self, blob):
+        """every rank's blob, in rank order, on every rank"""
+        if self.world_size == 1:
+            return [blob]
+        if self.rank == 0:
+            parts = [blob]
+            for c in self._peers:
+                n = struct.unpack("<q", _recv_exact(c, 8))[0]
+                parts.append(_recv_exact(c, n))
+            packed = pickle.dumps(parts)
+            for c in self._peers:
+                c.sendall(struct.pack("<q", len(packed)) + packed)
+            return parts
+        self._up.sendall(struct.pack("<q", len(blob)) + blob)
+        n = struct.unpack("<q", _recv_exact(self._up, 8))[0]
+        return pickle.loads(_recv_exact(self._up, n))
+
+    def allgather_f64(self, vec):
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        return np.stack([np.frombuffer(b, dtype=np.float64) for b in self._gather_bytes(v.tobytes())])
+
+    def bcast_i64(self, vec, root=0):
+        v = np.ascontiguousarray(vec, dtype=np.int64)
+        return np.frombuffer(self._gather_bytes(v.tobytes())[root], dtype=np.int64).copy()
+
+    def bcast_obj(self, obj, root=0):
+        return pickle.loads(self._gather_bytes(pickle.dumps(obj) if self.rank == root else b"")[root])
+
+    def barrier(self):
+        self._gather_bytes(b"")
+
+    def close(self):
+        for c in self._peers + ([self._up] if self._up is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._up = [], None
+
+
+def rccl_runtime():
+    """(runtime version, version of the rccl.h the library was built against, path of the mapped librccl) - e.g.
+    (22707, 22707, '/opt/rocm/lib/librccl.so.1')."""
+    import ctypes as C
+    from . import _capi as capi
+    lib = capi.load_library()
+    rt, hd = C.c_int(0), C.c_int(0)
+    path = C.create_string_buffer(512)
+    capi.check(lib, None, lib.npbnn_comm_runtime(C.byref(rt), C.byref(hd), path, 512))
+    return rt.value, hd.value, path.value.decode()
+
+
 class RcclComm:
     """RCCL communicator owned by the C library: ncclAllGather of the per-chain scalars and
     ncclBroadcast of the decision, on this rank's GPU stream (over xGMI inside a node)."""
@@ -171,6 +281,12 @@ class RcclComm:
 
     def barrier(self):
         self.allgather_f64(np.zeros(1))
+
+    def describe(self):
+        """What carries the exchange, for logs: ranks, RCCL version and the file it was mapped from."""
+        rt, hd, path = rccl_runtime()
+        return "rccl %d.%d.%d (%s; header %d.%d.%d), %d ranks, C ABI" % (rt // 10000, rt // 100 % 100, rt % 100, path, hd // 10000,
+                                                                         hd // 100 % 100, hd % 100, self.world_size)
 
     def close(self):
         if getattr(self, "_comm", None):

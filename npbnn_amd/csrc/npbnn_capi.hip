@@ -1254,6 +1254,7 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
 extern "C" int npbnn_comm_allgather_inplace_stream_(npbnn_comm* c, double* d_buf, int count, void* stream);
 extern "C" int npbnn_comm_info_(const npbnn_comm* c, int* device, int* rank, int* nranks);
 extern "C" void npbnn_comm_abort_(npbnn_comm* c);
+extern "C" int npbnn_comm_wait_stream_(npbnn_comm* c, void* stream, const char* what);
 
 namespace {
 
@@ -2085,7 +2086,18 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, B[q].RL.total, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_xbuf + XL[q].state, ctx->d_xbuf + XL[q].state, XL[q].total - XL[q].state, hipMemcpyDeviceToHost, ctx->stream));
     }
-    for (int q = 0; q < n_jobs; ++q) HIP_TRY(jobs[q].ctx, hipStreamSynchronize(jobs[q].ctx->stream));
+    for (int q = 0; q < n_jobs; ++q) {
+        if (comm && world > 1) {       // these streams wait for collectives: a peer that has gone must not hang this rank (wait_stream)
+            int rc = npbnn_comm_wait_stream_(comm, jobs[q].ctx->stream, "chains_run_exchange");
+            if (rc) {
+                ctx0->err = npbnn_last_error(nullptr);
+                (void)hipDeviceSynchronize();           // (the communicator was aborted: its kernels leave, the streams drain)
+                return rc;
+            }
+        } else {
+            HIP_TRY(jobs[q].ctx, hipStreamSynchronize(jobs[q].ctx->stream));
+        }
+    }
     int seg_done = -1;
     for (int q = 0; q < n_jobs; ++q) {
         const ChainDev* fin = reinterpret_cast<const ChainDev*>(jobs[q].ctx->h_res);
@@ -2131,6 +2143,12 @@ int npbnn_debug_image_(npbnn_ctx* ctx, float* out, int n) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_image, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return n;
+}
+
+int npbnn_device_synchronize(int device_id) {
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    HIP_TRY(nullptr, hipDeviceSynchronize());
+    return NPBNN_OK;
 }
 
 int npbnn_pinned_alloc(size_t bytes, void** out) {

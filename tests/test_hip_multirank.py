@@ -1,0 +1,100 @@
+"""One process per GPU on real hardware (`-m gpu`): the MC3 swap exchange over RCCL between 2 and device_count ranks, both
+the interval-by-interval path and the device exchange run, against the reference's golden swap sequence (mc3.npz) - and ranks
+that fail or vanish must end the run, not hang it.  Needs two or more GPUs; on a one-GPU box the same rank flow is rehearsed
+with every rank on GPU 0 and the TCP communicator in place of RCCL (RCCL refuses two ranks on one device)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+from npbnn_amd.launch import spawn_ranks
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+WORKER = [sys.executable, os.path.join(HERE, "rank_worker.py")]
+
+
+def n_gpus():
+    from npbnn_amd import _capi
+    n = ctypes.c_int(0)
+    _capi.load_library().npbnn_device_count(ctypes.byref(n))
+    return n.value
+
+
+def rank_counts():
+    n = n_gpus()
+    return sorted({2, n}) if n >= 2 else []
+
+
+needs_two = pytest.mark.skipif("n_gpus() < 2", reason="RCCL between ranks needs two or more GPUs")
+
+
+def test_rccl_runtime_is_the_one_the_library_was_built_against():
+    from npbnn_amd.comm import rccl_runtime
+    rt, hd, path = rccl_runtime()
+    assert rt // 100 == hd // 100 and "rccl" in path
+    assert "torch" not in sys.modules and "torch" not in path
+
+
+@needs_two
+@pytest.mark.parametrize("device_exchange", ["0", "1"])
+def test_mc3_over_rccl_follows_the_reference(device_exchange, tmp_path):
+    for world in rank_counts():
+        d = tmp_path / ("w%d" % world)
+        d.mkdir()
+        status, out0, outs = spawn_ranks(WORKER + ["mc3", str(d), "hip", "rccl", device_exchange], world, capture_all=True, timeout=600)
+        assert status == 0, "\n".join(outs)
+        for r in range(world):
+            assert "RANK %d OK" % r in outs[r]
+        assert "comm: rccl" in out0 and "/opt/rocm" in out0
+
+
+@needs_two
+def test_a_failing_rank_ends_every_rank_within_ten_seconds(tmp_path):
+    world = rank_counts()[-1]
+    status, out0, outs = spawn_ranks(WORKER + ["mc3", str(tmp_path), "hip", "rccl", "0", "fail=1:raise"], world, capture_all=True, timeout=600)
+    left = float(open(os.path.join(str(tmp_path), "failed_at")).read())
+    assert status != 0 and time.time() - left < 10, "\n".join(outs)
+    assert not any("RANK %d OK" % r in outs[r] for r in range(world))
+
+
+@needs_two
+def test_a_rank_that_vanishes_does_not_hang_its_peers(tmp_path):
+    """Rank 1 leaves with status 0 (nothing for the launcher to react to): the others' next collective never completes; the
+    bounded wait of the communicator (NPBNN_COMM_TIMEOUT_S) aborts it and the ranks end with an error."""
+    env = dict(os.environ, NPBNN_COMM_TIMEOUT_S="4")
+    status, out0, outs = spawn_ranks(WORKER + ["mc3", str(tmp_path), "hip", "rccl", "0", "fail=1:exit0"], 2, env=env, capture_all=True, timeout=300)
+    left = float(open(os.path.join(str(tmp_path), "failed_at")).read())
+    assert status not in (0, -9) and time.time() - left < 15, "\n".join(outs)
+    assert "RANK 0 OK" not in out0
+
+
+def test_rank_flow_rehearsal_on_one_gpu(tmp_path):
+    """Two ranks, both on GPU 0, the TCP communicator in place of RCCL: the process-per-chain flow (device contexts in separate
+    processes, host all-gather of [logPost, temperature], identical decisions on every rank, cold-chain logging through rank 0)
+    against the golden swap sequence."""
+    status, out0, outs = spawn_ranks(WORKER + ["mc3", str(tmp_path), "hip", "socket", "0"], 2, capture_all=True, timeout=600)
+    assert status == 0, "\n".join(outs)
+    assert "RANK 0 OK" in out0 and "RANK 1 OK" in outs[1]
+
+
+def test_bench_two_ranks_without_torch(tmp_path):
+    """`bench.py --gpus 2` started without a launcher: spawns its ranks, no torch in any of them, one JSON line from rank 0.
+    Over RCCL when two GPUs are there, else the TCP rehearsal on one."""
+    env = dict(os.environ)
+    if n_gpus() < 2:
+        env["NPBNN_BENCH_DIST_BACKEND"] = "socket"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["chains"] == 2 and line["config"]["swap_exchange_nranks"] == 2
+    assert line["torch_imported"] is False and line["value"] > 0
+    if n_gpus() >= 2:
+        assert "rccl" in line["config"]["swap_exchange"] and "/opt/rocm" in line["config"]["swap_exchange"]

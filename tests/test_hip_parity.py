@@ -383,8 +383,8 @@ def _heavy_tailed(kind, rs, n, f):
         x[rs.integers(0, n, f), np.arange(f)] = 1e4
     elif kind == "lognormal3":      # log-normal columns, sigma = 3
         x = np.exp(3.0 * rs.standard_normal((n, f)))
-    elif kind == "student3":
-        x = rs.standard_t(3, (n, f))
+    elif kind in ("student2", "student3"):   # Student t: 2 degrees of freedom are past the bound, 3 just inside it at this size
+        x = rs.standard_t(int(kind[-1]), (n, f))
     elif kind == "counts":          # integer counts 0 .. 1e5: exact as a pair of fp16 numbers
         x = rs.integers(0, 100001, (n, f)).astype(float)
     elif kind == "lognormal1":      # moderate tails: the fp16 pair is still a fair picture
@@ -394,8 +394,8 @@ def _heavy_tailed(kind, rs, n, f):
     return x
 
 
-@pytest.mark.parametrize("kind,expect", [("outlier", "f32"), ("lognormal3", "f32"), ("student3", "f32"), ("counts", "f16-split"),
-                                         ("lognormal1", "f16-split")])
+@pytest.mark.parametrize("kind,expect", [("outlier", "f32"), ("lognormal3", "f32"), ("student2", "f32"), ("student3", "f16-split"),
+                                         ("counts", "f16-split"), ("lognormal1", "f16-split")])
 def test_auto_mode_on_heavy_tailed_columns(kind, expect, hip):
     """The fp16 pair scales every column by a power of two from its LARGEST entry; a column whose typical entries lie many powers
     of two below that one (an outlier, log-normal or heavy-tailed features) would keep only a few bits of them.  The library

@@ -263,6 +263,14 @@ typedef struct {
                                          alone on its GPU); every wait is bounded: NPBNN_E_SYNC leaves the state untouched (retry
                                          with NPBNN_SCHED_OVERLAP; the library does so by itself and keeps the context off this schedule afterwards). */
 
+#define NPBNN_SCHED_PERSIST_SERIAL 5   /* for chains that move: one persistent launch like _PERSIST, but a pass is DECIDED before the next one
+                                         starts (evaluate pass L, decide it, evaluate pass L + 1 from the state it left - the order of the
+                                         reference's loop, np_bnn/BNN_env.py:449-494), so no pass is ever evaluated from a state an accept
+                                         has replaced.  The evaluating workgroups wait a few microseconds for the step workgroup between
+                                         passes instead of a kernel boundary, a step kernel and a second boundary.  Same conditions,
+                                         same bounded waits and the same fallback as _PERSIST.  _AUTO picks it over _PERSIST when the
+                                         previous batch accepted more than ~7 % of its proposals. */
+
 typedef struct {
     double loglik, logprior;                   /* state after the K iterations */
     double sigma[NPBNN_MAX_TARGETS];

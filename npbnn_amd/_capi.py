@@ -86,7 +86,7 @@ class ChainJob(C.Structure):
 
 REC_DOUBLES = 4      # record of a chain at an exchange: logPost, temperature, finished-the-segment flag, iterations done
 
-SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP, SCHED_OVERLAP2, SCHED_PERSIST = 0, 1, 2, 3, 4
+SCHED_AUTO, SCHED_SERIAL, SCHED_OVERLAP, SCHED_OVERLAP2, SCHED_PERSIST, SCHED_PERSIST_SERIAL = 0, 1, 2, 3, 4, 5
 
 
 _P = C.c_void_p

@@ -334,7 +334,7 @@ class HipContext:
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)
             if rc == capi.E_SYNC and not sync_retried:
                 sync_retried = True
-                if cfg.schedule in (capi.SCHED_OVERLAP2, capi.SCHED_PERSIST):
+                if cfg.schedule in (capi.SCHED_OVERLAP2, capi.SCHED_PERSIST, capi.SCHED_PERSIST_SERIAL):
                     cfg.schedule = capi.SCHED_OVERLAP
                 self.sync_fallbacks += 1
                 if self.sync_fallbacks == 1:

@@ -144,6 +144,16 @@ struct npbnn_ctx {
     double* d_wcur = nullptr;
     double* d_pv = nullptr;        // [kMaxCand][M] proposed values of the candidates in flight
     size_t pv_cap = 0;
+    // NPBNN_SCHED_PERSIST_SERIAL (spec_round): outcome-speculative preparation
+    SpecState* d_spec = nullptr;
+    double* d_spec_pv = nullptr;   // [3][kSpecOutcomes][kMaxCand][M]
+    size_t spec_pv_cap = 0;        // M capacity
+    unsigned* d_spec_touch = nullptr;   // [kMaxCand][n_weights] touch tables: pass tags (cleared before they could repeat) ...
+    double* d_spec_tval = nullptr;      // ... and values
+    double* d_spec_prw = nullptr;       // [n_weights] per-weight prior constants of spec_rounds (ChainParams::spec_prior_w)
+    std::vector<double> spec_prw_key;   // what d_spec_prw was built from: prior kind, the per-layer scales
+    size_t spec_touch_cap = 0;     // weights capacity
+    unsigned spec_gen = 0;         // pass tags handed out so far
     double* d_mask = nullptr;
     ChainDev* d_chain = nullptr;
     int* d_idx = nullptr;
@@ -181,6 +191,7 @@ struct npbnn_ctx {
 
 namespace {
 
+constexpr double kPersistSerialAccept = 0.07;   // NPBNN_SCHED_AUTO: acceptance rate above which the persistent launch decides between the passes
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 
 int fail(npbnn_ctx* ctx, int code, const char* fmt, ...) {
@@ -406,7 +417,7 @@ int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand, co
     const int top = max_waves_for(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16 != 0, n_cand, lk, fast);   // launch bound of the build in use
     for (int w = top; w >= 1; --w) {
         const size_t need = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)w * lay.wave_lds;
-        if (need <= ctx->lds_limit) {
+        if (need + 64 <= ctx->lds_limit) {       // (+ 64: the flag word of the device-side waits, plan_launch)
             *lds_bytes = need;
             return w;
         }
@@ -585,7 +596,8 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, in
     if (grid < 1) grid = 1;
     lp->grid = grid;
     lp->n_waves = grid;            // one partial record per workgroup
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lp->lds = lds + 64;            // (+ the flag word of the device-side waits, behind the images and the rings)
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp->lds));
     return NPBNN_OK;
 }
 
@@ -780,7 +792,7 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta};
+    void* chain_bufs[] = {c->d_spec, c->d_spec_pv, c->d_spec_touch, c->d_spec_tval, c->d_spec_prw, c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_delta, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -1325,7 +1337,8 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     const int D = lp.n_cand;
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
     int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : cfg->schedule;
-    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2 && schedule != NPBNN_SCHED_PERSIST) {
+    if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2 && schedule != NPBNN_SCHED_PERSIST &&
+        schedule != NPBNN_SCHED_PERSIST_SERIAL) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
         // (measured, config-2 shapes, tools/stress_schedules.py 10000 1 2 4: up to 34 % of the proposals accepted - 71 % of the passes -
         // the overlapped forms lead, 48-63 k against 45-50 k it/s; config 4 at 46 % / 84 %: serial 18.8 k against 17.4-18.4 k)
@@ -1338,13 +1351,22 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         // it also needs the two streams on hardware queues of their own, which nothing promises.)
         if (schedule == NPBNN_SCHED_OVERLAP && alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option)
             schedule = NPBNN_SCHED_PERSIST;
+        // A chain that moves: in the overlapped forms every pass that accepts something voids the pass in flight behind it (at 28 %
+        // acceptance 63 % of the passes do), and on kernel boundaries a decision between two passes costs a step kernel and two
+        // boundaries.  The persistent launch with the decision between the passes (NPBNN_SCHED_PERSIST_SERIAL) wastes no pass and
+        // decides in a few microseconds: above kPersistSerialAccept of the proposals accepted it leads (measured).
+        if (alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option && p_acc > kPersistSerialAccept && group_blocks == 0 &&
+            !cfg->slope_idx)
+            schedule = NPBNN_SCHED_PERSIST_SERIAL;
     }
     if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
+    if (schedule == NPBNN_SCHED_PERSIST_SERIAL && (ctx->sync_failed || !alone_on_device || seg_len > 0 || group_blocks > 0)) schedule = NPBNN_SCHED_SERIAL;
     // the persistent form needs every workgroup of its launch resident at once: one per compute unit at most, the GPU to itself, and
     // a plain run (an exchange run's kernels go between the passes)
     // (its grid is at most one workgroup per compute unit: the evaluating workgroups are capped at n_cu - 1 below, plus the step's)
     if (schedule == NPBNN_SCHED_PERSIST && (!alone_on_device || seg_len > 0)) schedule = NPBNN_SCHED_OVERLAP;
-    const bool persist = schedule == NPBNN_SCHED_PERSIST;
+    const bool pserial = schedule == NPBNN_SCHED_PERSIST_SERIAL;
+    const bool persist = schedule == NPBNN_SCHED_PERSIST || pserial;
     const bool overlap = schedule == NPBNN_SCHED_OVERLAP || schedule == NPBNN_SCHED_OVERLAP2 || persist;
     const bool sync = (schedule == NPBNN_SCHED_OVERLAP2 && alone_on_device) || persist;   // (several chains on one GPU: one stream each)
     if (schedule == NPBNN_SCHED_OVERLAP2 && !sync) schedule = NPBNN_SCHED_OVERLAP;
@@ -1392,6 +1414,31 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         ctx->d_pv = nullptr; ctx->pv_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_pv, (size_t)2 * kMaxCand * M * sizeof(double)));
         ctx->pv_cap = (size_t)M;
+    }
+    const bool spec = pserial && !cfg->slope_idx && !getenv("NPBNN_NO_SPEC_STEP");      // prepare the next pass ahead for every outcome
+    if (spec) {
+        if (!ctx->d_spec) HIP_TRY(ctx, hipMalloc(&ctx->d_spec, sizeof(SpecState)));
+        if ((size_t)M > ctx->spec_pv_cap) {
+            if (ctx->d_spec_pv) (void)hipFree(ctx->d_spec_pv);
+            ctx->d_spec_pv = nullptr; ctx->spec_pv_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_spec_pv, (size_t)3 * kSpecOutcomes * kMaxCand * M * sizeof(double)));
+            ctx->spec_pv_cap = (size_t)M;
+        }
+        if ((size_t)ctx->n_weights > ctx->spec_touch_cap) {
+            if (ctx->d_spec_touch) (void)hipFree(ctx->d_spec_touch);
+            if (ctx->d_spec_tval) (void)hipFree(ctx->d_spec_tval);
+            if (ctx->d_spec_prw) (void)hipFree(ctx->d_spec_prw);
+            ctx->d_spec_touch = nullptr; ctx->d_spec_tval = nullptr; ctx->d_spec_prw = nullptr; ctx->spec_touch_cap = 0;
+            ctx->spec_prw_key.clear();
+            HIP_TRY(ctx, hipMalloc(&ctx->d_spec_prw, (size_t)ctx->n_weights * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_spec_touch, (size_t)kMaxCand * ctx->n_weights * 4 * sizeof(unsigned)));
+            ctx->spec_touch_cap = (size_t)ctx->n_weights;
+            ctx->spec_gen = 0xf0000000u;         // (forces the clearing below)
+        }
+        if (ctx->spec_gen + (unsigned)K + 8u >= 0xf0000000u) {   // the batch's pass tags (one per pass, at most K + 1 passes) could repeat
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_spec_touch, 0, (size_t)kMaxCand * ctx->spec_touch_cap * 4 * sizeof(unsigned), ctx->stream));
+            ctx->spec_gen = 0;
+        }
     }
     const size_t need = (size_t)K * M;
     if (need > ctx->draw_cap) {
@@ -1488,7 +1535,23 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.image = ctx->d_image;
     c.pos = ctx->d_pos;
     c.pscale = f16 ? ctx->d_pscale : nullptr;
-    c.pv = ctx->d_pv;
+    c.pv = spec ? ctx->d_spec_pv : ctx->d_pv;      // (spec: the first step writes pass 0 into slot (parity 0, outcome 0))
+    c.spec = nullptr;
+    c.spec_pv = nullptr;
+    c.spec_touch = nullptr;
+    c.spec_touch_val = nullptr;
+    c.spec_prior_w = nullptr;
+    c.n_weights_spec = ctx->n_weights;
+    c.spec_gen = 0;
+    if (spec) {
+        c.spec = ctx->d_spec;
+        c.spec_pv = ctx->d_spec_pv;
+        c.spec_touch = ctx->d_spec_touch;
+        c.spec_touch_val = ctx->d_spec_tval;
+        c.spec_gen = (int)ctx->spec_gen;
+        ctx->spec_gen += (unsigned)K + 8u;             // (a pass decides at least one iteration)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_spec, 0, sizeof(SpecState), st));
+    }
     c.overflow = ctx->d_chain_ovf;
     B->d_stamps = nullptr;
     if (getenv("NPBNN_STEP_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the step kernel
@@ -1518,6 +1581,24 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         if (!ctx->d_pscale_w) HIP_TRY(ctx, hipMalloc(&ctx->d_pscale_w, wb));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pscale_w, cfg->prior_scale_w, wb, hipMemcpyHostToDevice, st));
         c.prior_scale_w = ctx->d_pscale_w;
+    }
+    if (spec) {
+        c.spec_prior_w = c.prior_scale_w;               // a scale per weight (already uploaded), or:
+        if (!c.prior_scale_w) {
+            std::vector<double> key{(double)cfg->prior_kind};
+            for (int l = 0; l < ctx->net.n_layers; ++l) key.push_back(cfg->prior_scale[l]);
+            if (key != ctx->spec_prw_key) {             // (changes with a Gibbs step of the scales only)
+                std::vector<double> prw((size_t)ctx->n_weights, 0.0);
+                for (int l = 0; l < ctx->net.n_layers; ++l) {
+                    const LayerMeta& L = ctx->net.L[l];
+                    const double v = cfg->prior_kind == NPBNN_PRIOR_NORMAL ? c.half_inv_s2[l] : cfg->prior_scale[l];
+                    for (int i = 0; i < L.out_dim * (L.in_dim + L.has_bias); ++i) prw[(size_t)L.w_off + i] = v;
+                }
+                HIP_TRY(ctx, hipMemcpy(ctx->d_spec_prw, prw.data(), prw.size() * sizeof(double), hipMemcpyHostToDevice));
+                ctx->spec_prw_key = key;
+            }
+            c.spec_prior_w = ctx->d_spec_prw;
+        }
     }
     c.slopes = nullptr;
     c.slope_idx = nullptr;
@@ -1567,12 +1648,12 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
     p.has_pass = 1;
-    p.pv = ctx->d_pv;
+    p.pv = spec ? ctx->d_spec_pv : ctx->d_pv;
     p.pos = ctx->d_pos;
     p.pscale = f16 ? ctx->d_pscale : nullptr;
     p.M = M;
     p.chain = overlap ? ctx->d_cparams : nullptr;
-    p.sync_mode = sync ? 1 : 0;
+    p.sync_mode = spec ? 3 : pserial ? 2 : sync ? 1 : 0;
     p.cand_slopes = c.slopes ? &ctx->d_slopes->cand[0][0][0] : nullptr;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
@@ -1770,6 +1851,13 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     const double tw2 = wall_us();
     rc = chain_finish(ctx, B, cfg, W_inout, out_accepted, out_loglik_prop, out_logprior_prop, result, K);
     if (rc) return rc;
+    if (timing && ctx->d_spec && B.schedule == NPBNN_SCHED_PERSIST_SERIAL) {
+        SpecState hs;
+        if (hipMemcpy(&hs, ctx->d_spec, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess && hs.rounds > 0)
+            fprintf(stderr, "[npbnn chain timing]   step rounds %d: touch %.2f  candidates %.2f  descriptors %.2f  wait for the pass %.2f  decide+publish %.2f  "
+                            "commit %.2f us per round\n", hs.rounds, hs.ticks[0] * 0.01 / hs.rounds, hs.ticks[1] * 0.01 / hs.rounds, hs.ticks[2] * 0.01 / hs.rounds,
+                    hs.ticks[3] * 0.01 / hs.rounds, hs.ticks[4] * 0.01 / hs.rounds, hs.ticks[5] * 0.01 / hs.rounds);
+    }
     if (timing)
         fprintf(stderr, "[npbnn chain timing] K=%d passes=%d (+%d void, %s) rounds=%d: setup %.0f us, passes %.0f us (%.2f us/pass), results %.0f us\n", K,
                 result->n_passes, result->n_void_passes, B.overlap ? "overlapped" : "serial", n_rounds, B.tw1 - B.tw0, tw2 - B.tw1,

@@ -123,6 +123,7 @@ __host__ __device__ inline double slope_prior_term(const double* s, int n) {
     return 2.302585092994046 * -sum * 10.0;       // np.log(r) * -np.sum(prm_tmp) * r, r = 10 (BNN_env.py:419-420)
 }
 
+struct SpecState;
 struct ChainParams {
     ChainDev* st;
     PassDesc* pass;            // [2] candidates of the passes in the pipeline, by pass parity (read by the evaluation kernel)
@@ -150,6 +151,12 @@ struct ChainParams {
     const int* slope_idx;      // [K] the slope iteration t proposes to move ...
     const double* slope_delta; // [K] ... and by how much (reflected at 0 and 1)
     int n_slopes, slope_term_in;   // slope_term_in: the log prior handed in at the start of the batch holds the term of the accepted slopes
+    SpecState* spec;           // NPBNN_SCHED_PERSIST_SERIAL: outcome-speculative preparation (spec_round below), else nullptr
+    double* spec_pv;           // [3][kSpecOutcomes][kMaxCand][M] candidate patch values per pass (mod 3) and outcome
+    unsigned* spec_touch;             // [kMaxCand][n_weights][4] pass tag of the last candidate j that touched the weight, -, and the value it gave it
+    double* spec_touch_val;           // (unused)
+    const double* spec_prior_w;       // [n_weights] per weight: 0.5 / scale^2 (normal prior, a scale per layer) or the scale (see spec_rounds)
+    int n_weights_spec, spec_gen;     // spec_gen: pass tags of this batch start above it (never reused: the host clears the tables first)
     int K, M, D, n_blocks;
     int sync_test_skip;        // tests only: the step of this launch never reports back (-1: none) - exercises the time-out path of
                                // the two-stream schedule
@@ -196,20 +203,21 @@ __global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__
 }
 #endif  // NPBNN_KERNELS_MAIN
 
-__device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) {
+__device__ __forceinline__ void patch_image(float* image, int pos, float scale, double v) {
     if (pos == 0x7fffffff) return;                   // an entry the image does not hold (outside the layer-0 block structure: it is 0)
     if (pos < 0) {                                   // fp16-split layer-0 entry
         const float wv = (float)(v * (double)scale);
         _Float16 hi, lo;
         split_f16(wv, hi, lo);
-        _Float16* img16 = reinterpret_cast<_Float16*>(c.image);
+        _Float16* img16 = reinterpret_cast<_Float16*>(image);
         const int h = pos & 0x7fffffff;
         img16[h] = hi;
         img16[h + 512] = lo;
     } else {
-        c.image[pos] = (float)v;
+        image[pos] = (float)v;
     }
 }
+__device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) { patch_image(c.image, pos, scale, v); }
 
 // block-wide sum of one double per thread, fixed order; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 doubles*/) {
@@ -222,6 +230,26 @@ __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 d
     if (threadIdx.x == 0)
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
     return s;
+}
+
+// the proposal of one pre-drawn entry on base value `base` (UpdateNormal, BNN_mcmc.py:64-67; mask, BNN_env.py:461-462) and its
+// change of the log prior - ONE definition for every schedule, contraction off, so that their chains agree to the bit.  The normal
+// prior with one scale per layer (the default) is two multiplies and a subtraction; everything else (Cauchy, Laplace, a scale per
+// weight) goes through a function of its own: its logarithms would otherwise be expanded at every call site.
+__device__ __attribute__((noinline)) double prior_delta_general(int kind, double v, double b, double sc) { return prior_delta(kind, v, b, sc); }
+__device__ __forceinline__ double spec_entry(double w_bound, int prior_kind, bool per_weight_scale, double base, double d, double m, double scale_w,
+                                             double his, double lsc, double& dlp) {
+#pragma clang fp contract(off)      // (no fused multiply-adds: the same bits wherever this is inlined)
+    double v = base + d;
+    if (v > w_bound) v = w_bound - (v - w_bound);
+    if (v < -w_bound) v = -w_bound + (-w_bound - v);
+    v *= m;
+    if (prior_kind != NPBNN_PRIOR_UNIFORM) {
+        if (per_weight_scale) dlp += prior_delta_general(prior_kind, v, base, scale_w);
+        else if (prior_kind == NPBNN_PRIOR_NORMAL) dlp -= (v * v - base * base) * his;
+        else dlp += prior_delta_general(prior_kind, v, base, lsc);
+    }
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -515,24 +543,16 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 sw[j][u] = (i >= 0 && c.prior_scale_w) ? c.prior_scale_w[i] : 1.0;
             }
         auto make = [&](int j, int e, int i, double base, double d, double m, int pos, float sc, double scale_w) {
-            double v = base + d;
-            if (v > c.w_bound) v = c.w_bound - (v - c.w_bound);
-            if (v < -c.w_bound) v = -c.w_bound + (-c.w_bound - v);
-            v *= m;
+            double his = half_inv_s2[0], lsc = layer_scale[0];     // (selected, not indexed: a register array indexed at run time
+#pragma unroll                                                     //  goes to scratch)
+            for (int q = 1; q < kMaxLayers; ++q) {
+                const bool past = i >= woff[q];
+                his = past ? half_inv_s2[q] : his;
+                lsc = past ? layer_scale[q] : lsc;
+            }
+            const double v = spec_entry(c.w_bound, c.prior_kind, c.prior_scale_w != nullptr, base, d, m, scale_w, his, lsc, dlp[j]);
             pv_out[(size_t)j * c.M + e] = v;
             if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
-            if (c.prior_kind != NPBNN_PRIOR_UNIFORM) {
-                double his = half_inv_s2[0], lsc = layer_scale[0];     // (selected, not indexed: a register array indexed at run time
-#pragma unroll                                                         //  goes to scratch)
-                for (int q = 1; q < kMaxLayers; ++q) {
-                    const bool past = i >= woff[q];
-                    his = past ? half_inv_s2[q] : his;
-                    lsc = past ? layer_scale[q] : lsc;
-                }
-                if (c.prior_scale_w) dlp[j] += prior_delta(c.prior_kind, v, base, scale_w);
-                else if (c.prior_kind == NPBNN_PRIOR_NORMAL) dlp[j] -= (v * v - base * base) * his;
-                else dlp[j] += prior_delta(c.prior_kind, v, base, lsc);
-            }
         };
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j) {
@@ -657,6 +677,29 @@ __device__ __forceinline__ bool sync_step_enter(const ChainParams& c, int launch
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return *lds_flag != 0;
 }
+// persistent launch with the decision BETWEEN the passes (NPBNN_SCHED_PERSIST_SERIAL): the step of round L decides pass L - 1, so all
+// it waits for is that pass's evaluating workgroups; it is the only step running (one workgroup, rounds in order)
+__device__ __forceinline__ bool sync_step_enter_serial(const ChainParams& c, int launch, int n_eval_wgs, int* lds_flag) {
+    ChainDev* st = c.st;
+    if (c.sync_test_skip == launch) return false;
+    if (threadIdx.x == 0) {
+        const int slot = (launch - 1) & 3;
+        *lds_flag = sync_wait_ge(st, &st->done[slot], ((launch - 1) / 4 + 1) * n_eval_wgs) ? 1 : 0;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *lds_flag != 0;
+}
+__device__ __forceinline__ StepPlan serial_plan(int launch) {       // round L >= 1: decide pass L - 1, prepare pass L
+    StepPlan pl;
+    pl.first = 0;
+    pl.resum = 0;
+    pl.dec = (launch - 1) & 1;
+    pl.fly = -1;
+    pl.out = launch & 1;
+    pl.launch = launch;
+    return pl;
+}
 // `wait_for_next`: launch next_launch has been enqueued and this step belongs to launch next_launch - 1.  The step then stays
 // until the step workgroup of launch next_launch has begun.  Why: launch L+1 starts when launch L-1 (same stream) is complete,
 // its evaluating workgroups wait for step L - so step L must hold a compute unit before they can take them all.  Launch L
@@ -668,6 +711,439 @@ __device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch, b
         __hip_atomic_store(&st->prepared, next_launch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (wait_for_next) (void)sync_wait_ge(st, &st->started, next_launch);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NPBNN_SCHED_PERSIST_SERIAL: evaluate pass P, decide it, evaluate pass P + 1 from the state it left (the order of the reference's
+// loop, BNN_env.py:449-494) inside ONE persistent launch - with everything the decision does NOT need done beforehand.
+// While the evaluating workgroups are busy with pass P (candidates of iterations t0 .. t0+n-1 on the current state S), the step
+// workgroup prepares the next pass for EVERY outcome pass P can have: nothing accepted (next candidates t0+n.. on S) or candidate
+// j accepted (next candidates t0+j+1.. on S + its perturbation) - n + 1 outcomes, up to D candidates each: patch lists and log
+// priors.  The accepted states themselves are never materialised ahead: a candidate entry of an accepting outcome takes its base
+// value from candidate j's patch list where j touched that weight (`touch` tables: weight -> entry of candidate j, tagged with the
+// pass so that they never need clearing) and from the current weights elsewhere.  When the last evaluating workgroup of pass P
+// reports, all that is left is: reduce the partial sums, run the accept tests in iteration order, name the outcome, publish its
+// descriptor and raise the flag - a few microseconds between two passes instead of the step's 15-20, and no pass is ever evaluated
+// in vain.  The accepted candidate is committed to the float64 weights and the global weight image AFTER the flag: the next
+// pass's evaluating workgroups, which copy that image meanwhile, apply the accepted entries to their LDS copies themselves
+// (descriptor: pad[1] = their number, pad[2] bits 8.. = where their values are) - writing the same values twice is harmless.
+// Every decision is made in iteration order on sums computed from the true current state: the sequential chain.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSpecOutcomes = kMaxCand + 1;
+constexpr int kSpecRows = 2 * kMaxCand;            // rows (iterations t0 .. t0+2D-1) a round looks at: the candidates in flight and those of every outcome
+struct SpecState {
+    double cand_lp[2][kSpecOutcomes][kMaxCand];   // log priors of the prepared candidates, by parity of their pass and outcome
+    PassDesc desc[2][kSpecOutcomes];              // their descriptors (pad[0] terminal, pad[1] accepted entries to apply first,
+                                                  // pad[2] = own patch-value slot | (slot of the accepted candidate's values + 1) << 8)
+    int ovf[2][kSpecOutcomes];                    // some candidate of that outcome leaves the fp16 range
+    int o_cur;                                    // outcome slot the candidates of the pass in flight came from
+    int rounds;                                   // diagnostics: rounds run, and wall-clock ticks (100 MHz) spent per phase:
+    unsigned long long ticks[6];                  // touch tables | candidates | descriptors | wait for the pass | decide + publish | commit
+};
+
+struct SpecShared {            // LDS scratch of spec_rounds (beside StepShared)
+    double red[kSpecOutcomes][kMaxCand][16];
+    double cand_lp[kSpecOutcomes][kMaxCand];   // log priors of the candidates being prepared, per outcome
+    double sel_lp[kMaxCand];                   // log priors of the candidates of the pass in flight
+    double cur_ll, cur_lp;                     // log-likelihood / log prior of the current state
+    double out_ll[kMaxCand];
+    PassDesc desc[kSpecOutcomes];
+    PassDesc cur;                              // descriptor of the pass in flight
+    int ovf[kSpecOutcomes];
+    int out_a[kMaxCand];
+    int outcome, accepted, n_done, o_cur, go, pad_;
+};
+
+// The rounds of the step workgroup, P0 .. P_end-1 (ends early at the batch's last pass, or when a wait times out).
+// Written for memory-level parallelism: a workgroup alone on its compute unit pays 1-2 us for every dependent global access, so each
+// stage issues ALL its loads unconditionally (indices clamped to something valid, results selected afterwards) before the first
+// use, what one round leaves for the next stays in LDS, and the parameter block is copied into registers once.
+template <bool HAS_MASK>
+__device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int P0, int P_end, int n_eval_wgs, StepShared& sh, SpecShared& sp, int* lds_flag) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    // The parameter block sits in memory and the compiler must assume that any store may change it: every use of c.<field> below a
+    // store would be a load of its own, in front of the load it feeds.  Everything the rounds need is copied out once, into
+    // scalar registers (all of it is uniform).
+    auto sg = [](auto v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto sgp = [](auto* ptr) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<decltype(ptr)>(((unsigned long long)hi << 32) | lo);
+    };
+    auto sgd = [](double v) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v)), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+        return __hiloint2double((int)hi, (int)lo);
+    };
+    ChainDev* const st = sgp(c.st);
+    SpecState* const S = sgp(c.spec);
+    PassDesc* const pass = sgp(c.pass);
+    const int lik_kind = sg(c.net.lik_kind), k_targets = sg(c.net.k_targets);
+    const int M = sg(c.M), D = sg(c.D), K = sg(c.K), n_blocks = sg(c.n_blocks), nws = sg(c.n_weights_spec);
+    const int prior_kind = sg(c.prior_kind);
+    const double w_bound = sgd(c.w_bound);
+    const int* const g_idx = sgp(c.idx);
+    const double* const g_delta = sgp(c.delta);
+    const int* const g_pos = sgp(c.pos);
+    const int* const g_cnt = sgp(c.cnt);
+    const double* const g_logu = sgp(c.log_u);
+    const double* const g_hast = sgp(c.hastings);
+    const double* const g_partials = sgp(c.partials);
+    // touch tables: one 16-byte record per weight and candidate - {pass tag, -, value} - so that a look-up is ONE gather
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* const g_touch = reinterpret_cast<u32x4*>(sgp(c.spec_touch));
+    double* const g_spec_pv = sgp(c.spec_pv);
+    double* const Wc = sgp(c.w_cur);
+    float* const g_image = sgp(c.image);
+    const double* const g_smult = sgp(c.sigma_mult);
+    unsigned char* const g_out_acc = sgp(c.out_acc);
+    double* const g_out_ll = sgp(c.out_ll);
+    double* const g_out_lp = sgp(c.out_lp);
+    int* const g_overflow = sgp(c.overflow);
+    const long long n_rows = c.n_rows;
+    const double lik_temp = sgd(c.lik_temp);
+    const int sigma_given = sg(c.sigma_given), skip_round = sg(c.sync_test_skip), gen0 = sg(c.spec_gen);
+    const bool has_sc = c.pscale != nullptr, has_psw = c.prior_scale_w != nullptr;
+    constexpr bool has_mask = HAS_MASK;
+    // arrays that may be absent read from something valid instead (the value is replaced by a constant afterwards)
+    const float* const pscale_p = has_sc ? sgp(c.pscale) : reinterpret_cast<const float*>(g_pos);
+    const double* const mask_p = has_mask ? sgp(c.mask) : Wc;
+    // per weight: 0.5 / scale^2 of its layer (normal prior, one scale per layer - the value chain_step selects from its per-layer table),
+    // else the scale itself (other priors; a scale per weight)
+    const double* const prw_p = sgp(c.spec_prior_w);
+    const bool fast_prior = prior_kind == NPBNN_PRIOR_NORMAL && !has_psw;
+    // (the default prior needs no gather for it: 0.5 / scale^2 of the weight's layer, selected by the layers' offsets)
+    int woff[kMaxLayers];
+    double l_his[kMaxLayers];
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        woff[l] = l < sg(c.net.n_layers) ? sg(c.net.L[l].w_off) : 0x7fffffff;
+        l_his[l] = sgd(c.half_inv_s2[l]);
+    }
+    const size_t slot_stride = (size_t)kMaxCand * M;
+    const int lim = sg(st->seg_end);
+    const double temperature = sgd(st->temperature);
+    const int nvals = partial_value_count(lik_kind, k_targets);
+    // what the first round starts from: the descriptor, log priors and state the previous launch (or the batch's first step) left
+    if (tid == 0) {
+        const int q0 = P0 & 1;
+        sp.cur = pass[q0];
+        const int o0 = P0 == 0 ? 0 : S->o_cur;
+        sp.o_cur = o0;
+        for (int j = 0; j < kMaxCand; ++j) sp.sel_lp[j] = P0 == 0 ? st->cand_logPrior[0][j] : S->cand_lp[q0][o0][j];
+        sp.cur_ll = st->logLik;
+        sp.cur_lp = st->logPrior;
+    }
+    __syncthreads();
+    unsigned long long tk = wall_clock64();
+#define NPBNN_SPEC_TICK(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); S->ticks[k] += now_ - tk; tk = now_; } } while (0)
+
+    for (int P = P0; P < P_end; ++P) {
+        const int q = P & 1, qn = q ^ 1;
+        const int t0 = sg(sp.cur.t0), n_pend = sg(sp.cur.n_cand);
+        if (n_pend == 0) return;
+        const int o_P = sg(sp.o_cur);
+        const int slotP = (P % 3) * kSpecOutcomes + o_P;      // (patch values rotate through three sets: the evaluation of pass P + 1 still
+                                                              //  reads the accepted candidate's of pass P while round P + 1 writes pass P + 2's)
+        const double* const pvP = g_spec_pv + (size_t)slotP * slot_stride;
+        const int slotN = ((P + 1) % 3) * kSpecOutcomes;
+        double* const pvN = g_spec_pv + (size_t)slotN * slot_stride;
+        const unsigned gen = (unsigned)(gen0 + P + 1);         // pass tag of the touch tables (never reused: the host clears them first)
+
+        // operands of the decision and of the descriptors, on their way while the candidates are prepared
+        double d_logu[kMaxCand], d_h[kMaxCand];
+        int d_cnt[kMaxCand], d_acc_cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) { d_logu[j] = 0.0; d_h[j] = 0.0; d_cnt[j] = 0; }
+        if (tid == 0) {
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                const int t = t0 + (j < n_pend ? j : 0);
+                d_logu[j] = g_logu[t];
+                d_h[j] = g_hast ? g_hast[t] : 0.0;
+            }
+        }
+        if (tid < kSpecOutcomes) {                             // thread o: entries per candidate of outcome o's pass
+            const int o = tid;
+            const int ts = o == 0 ? t0 + n_pend : t0 + o;
+#pragma unroll
+            for (int k = 0; k < kMaxCand; ++k) d_cnt[k] = g_cnt[ts + k < K ? ts + k : 0];
+            d_acc_cnt = g_cnt[o == 0 ? 0 : t0 + o - 1];
+        }
+
+        double dlp[kSpecOutcomes][kMaxCand];
+#pragma unroll
+        for (int o = 0; o < kSpecOutcomes; ++o)
+#pragma unroll
+            for (int k = 0; k < kMaxCand; ++k) dlp[o][k] = 0.0;
+        if (tid < kSpecOutcomes) sp.ovf[tid] = 0;
+
+        for (int e0 = 0; e0 < M; e0 += nthr) {            // (one trip unless a proposal is wider than the workgroup)
+            const int e = e0 + tid;
+            const bool ev = e < M;
+            // ---- stage 1: the pre-drawn entries of rows t0 .. t0+kSpecRows (row r = iteration t0 + r; entries past a row's count
+            //      are -1, as the pre-draw leaves them), and the values of the candidates in flight ----
+            int ri[kSpecRows], rpos[kSpecRows];
+            double rd[kSpecRows];
+            float rsc[kSpecRows];
+            double pvj[kMaxCand];
+#pragma unroll
+            for (int r = 0; r < kSpecRows; ++r) {
+                const int t = t0 + r;
+                const bool rowv = ev && r < n_pend + D && t < K && (r < n_pend || t < lim);
+                const size_t k = rowv ? (size_t)t * M + e : 0;
+                ri[r] = g_idx[k];
+                rd[r] = g_delta[k];
+                rpos[r] = g_pos[k];
+                rsc[r] = pscale_p[k];
+                if (!rowv) ri[r] = -1;
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) pvj[j] = pvP[(size_t)j * M + (ev ? e : 0)];
+#pragma unroll
+            for (int r = 0; r < kSpecRows; ++r)
+                if (!has_sc) rsc[r] = 1.0f;
+            // ---- A. touch tables of the candidates in flight: weight -> the value candidate j gives it, tagged with this pass ----
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j)
+                if (j < n_pend && ri[j] >= 0) {
+                    u32x4 rec;
+                    rec[0] = gen;
+                    rec[1] = 0u;
+                    rec[2] = (unsigned)__double2loint(pvj[j]);
+                    rec[3] = (unsigned)__double2hiint(pvj[j]);
+                    g_touch[(size_t)j * nws + ri[j]] = rec;
+                }
+            __syncthreads();
+            if (e0 == 0) NPBNN_SPEC_TICK(0);
+            // ---- stage 2: what the entries of rows 1.. touch; candidate j accepted = outcome j + 1, which takes rows j+1 .. j+D: its
+            //      k-th candidate's entry looks itself up in candidate j's table ----
+            double rb[kSpecRows], rm[kSpecRows], rsw[kSpecRows];
+            u32x4 rt[kMaxCand][kMaxCand];
+            double rp[kMaxCand][kMaxCand];
+#pragma unroll
+            for (int r = 1; r < kSpecRows; ++r) {
+                const int ic = ri[r] >= 0 ? ri[r] : 0;
+                rb[r] = Wc[ic];
+                rm[r] = has_mask ? mask_p[ic] : 1.0;
+                rsw[r] = fast_prior ? 0.0 : prw_p[ic];
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j)
+#pragma unroll
+                for (int k = 0; k < kMaxCand; ++k) {
+                    const int r = j + 1 + k < kSpecRows ? j + 1 + k : 0;
+                    const int ic = ri[r] >= 0 ? ri[r] : 0;
+                    rt[j][k] = g_touch[(size_t)j * nws + ic];
+                }
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j)
+#pragma unroll
+                for (int k = 0; k < kMaxCand; ++k) {
+                    const int r = j + 1 + k < kSpecRows ? j + 1 + k : 0;
+                    rp[j][k] = rt[j][k][0] == gen ? __hiloint2double((int)rt[j][k][3], (int)rt[j][k][2]) : rb[r];
+                }
+            if (fast_prior) {
+#pragma unroll
+                for (int r = 1; r < kSpecRows; ++r) {
+                    double his = l_his[0];
+#pragma unroll
+                    for (int l = 1; l < kMaxLayers; ++l) his = ri[r] >= woff[l] ? l_his[l] : his;
+                    rsw[r] = his;
+                }
+            }
+            // ---- stage 3: proposals and prior changes.  Outcome o >= 1 takes rows o .. o+D-1; outcome 0 (nothing accepted) shares the
+            //      rows of outcome n_pend - every index below is a compile-time constant, so all of this stays in registers ----
+#pragma unroll
+            for (int o = 1; o <= kMaxCand; ++o) {
+                if (o > n_pend) continue;
+#pragma unroll
+                for (int k = 0; k < kMaxCand; ++k) {
+                    const int r = o + k;
+                    if (k >= D || r >= kSpecRows) continue;
+                    const int rr = r < kSpecRows ? r : 0;
+                    const int i = ri[rr];
+                    if (i < 0) continue;
+                    const double his = rsw[rr], lsc = rsw[rr];       // (whichever the prior takes: see prw_p)
+                    const bool in16 = rpos[rr] < 0;
+                    const double sc = (double)rsc[rr];
+                    const double v = spec_entry(w_bound, prior_kind, !fast_prior && has_psw, rp[o - 1][k], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[o][k]);
+                    __hip_atomic_store(pvN + ((size_t)o * kMaxCand + k) * M + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (write-through: nothing to flush at the flag)
+                    if (in16 && !(fabs(v * sc) <= (double)kF16Safe)) atomicOr(&sp.ovf[o], 1);
+                    if (o == n_pend) {          // the same rows on the unchanged state: outcome 0
+                        const double v0 = spec_entry(w_bound, prior_kind, !fast_prior && has_psw, rb[rr], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[0][k]);
+                        __hip_atomic_store(pvN + ((size_t)k) * M + e, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (in16 && !(fabs(v0 * sc) <= (double)kF16Safe)) atomicOr(&sp.ovf[0], 1);
+                    }
+                }
+            }
+        }
+        if ((tid & ~63) < M) {                        // (a wave without entries adds exact zeros: no butterfly for it)
+#pragma unroll
+            for (int o = 0; o < kSpecOutcomes; ++o)
+#pragma unroll
+                for (int k = 0; k < kMaxCand; ++k) {
+                    double v = dlp[o][k];
+#pragma unroll
+                    for (int shf = 32; shf > 0; shf >>= 1) v += shfl_xor_f64(v, shf);
+                    if ((tid & 63) == 0) sp.red[o][k][tid >> 6] = v;
+                }
+        } else if ((tid & 63) == 0) {
+#pragma unroll
+            for (int o = 0; o < kSpecOutcomes; ++o)
+#pragma unroll
+                for (int k = 0; k < kMaxCand; ++k) sp.red[o][k][tid >> 6] = 0.0;
+        }
+        __syncthreads();
+        NPBNN_SPEC_TICK(1);
+        // ---- descriptors of the prepared passes (thread o builds outcome o's; kept in LDS until one of them is published) ----
+        if (tid < kSpecOutcomes) {
+            const int o = tid;
+            const int ts = o == 0 ? t0 + n_pend : t0 + o;
+            int n_new = lim - ts;
+            if (n_new > D) n_new = D;
+            if (n_new < 0 || o > n_pend) n_new = 0;
+            // log prior of the state outcome o leaves: unchanged, or the accepted candidate's
+            const double base_lp = o == 0 ? sp.cur_lp : sp.sel_lp[o - 1];
+            PassDesc d;
+            d.t0 = ts;
+            d.n_cand = n_new;
+#pragma unroll
+            for (int k = 0; k < kMaxCand; ++k) {
+                double sj = 0.0;
+                for (int w = 0; w < (nthr >> 6); ++w) sj += sp.red[o][k][w];
+                sp.cand_lp[o][k] = base_lp + sj;
+                d.cnt[k] = k < n_new ? d_cnt[k] : 0;
+            }
+            d.pad[0] = n_new == 0 ? 1 : 0;
+            d.pad[1] = o == 0 ? 0 : d_acc_cnt;                                 // accepted entries the evaluation applies first
+            d.pad[2] = (slotN + o) | (o == 0 ? 0 : ((slotP * kMaxCand + (o - 1) + 1) << 8));
+            sp.desc[o] = d;
+        }
+
+        // ---- C. pass P has been evaluated: decide it ----
+        NPBNN_SPEC_TICK(2);
+        if (skip_round == P + 1) return;
+        if (tid == 0) {
+            const int slot = P & 3;
+            *lds_flag = sync_wait_ge(st, &st->done[slot], (P / 4 + 1) * n_eval_wgs) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*lds_flag == 0) return;
+        NPBNN_SPEC_TICK(3);
+        {   // (the sums were stored past the caches by the evaluating workgroups: read them the same way, no acquire fence needed)
+            const int lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
+            const double* part = g_partials + (size_t)q * kMaxCand * kPartialStride * n_blocks;
+            for (int item = wave; item < n_pend * nvals; item += nwv) {
+                const int j = item / nvals, v = partial_value_index(item % nvals, k_targets);
+                const double* src = part + ((size_t)j * kPartialStride + v) * n_blocks;
+                double s = 0.0;
+                for (int b = lane; b < n_blocks; b += 64) s += __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int shf = 32; shf > 0; shf >>= 1) s += shfl_xor_f64(s, shf);
+                if (lane == 0) sh.tot[j][v] = s;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int accepted = -1, n_done = n_pend;
+            const double d_ll = sp.cur_ll, d_lp = sp.cur_lp;
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                sp.out_a[j] = 0;
+                if (j < n_pend && accepted < 0) {
+                    const int t = t0 + j;
+                    if (g_smult) {
+                        double sgm[NPBNN_MAX_TARGETS];
+                        for (int r = 0; r < k_targets; ++r) sgm[r] = st->sigma[r] * g_smult[(size_t)t * k_targets + r];
+                        loglik_from_totals(sh.tot[j], lik_kind, k_targets, n_rows, lik_temp, 1, sgm, &sh.o);
+                    } else {
+                        loglik_from_totals(sh.tot[j], lik_kind, k_targets, n_rows, lik_temp, sigma_given, c.sigma_fixed, &sh.o);
+                    }
+                    const double lp = sp.sel_lp[j];
+                    const double post_new = sh.o.loglik + lp, post_old = d_ll + d_lp;
+                    const int a = ((post_new - post_old) * temperature + d_h[j] >= d_logu[j]) ? 1 : 0;
+                    sp.out_a[j] = a;
+                    sp.out_ll[j] = sh.o.loglik;
+                    if (a) {
+                        sp.cur_ll = sh.o.loglik;
+                        sp.cur_lp = lp;
+                        if (lik_kind == NPBNN_LIK_GAUSS)
+                            for (int r = 0; r < k_targets; ++r) st->sigma[r] = sh.o.sigma[r];
+                        accepted = j;
+                        n_done = j + 1;
+                    }
+                }
+            }
+            const int o = accepted + 1;
+            // ---- D. publish the pass that outcome selects: its descriptor, then the flag; the book-keeping follows behind ----
+            const PassDesc nx = sp.desc[o];
+            {   // everything pass P + 1 reads was stored past the caches (the patch values above, the descriptor here): the flag needs
+                // no release fence - which would write this XCD's whole L2 back - only those stores to have completed
+                int* const dst = reinterpret_cast<int*>(pass + qn);
+                const int* const src = reinterpret_cast<const int*>(&nx);
+#pragma unroll
+                for (int w = 0; w < 8; ++w) __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sp.outcome = o;
+            sp.accepted = accepted;
+            sp.n_done = n_done;
+            sp.go = nx.n_cand == 0 ? 0 : 1;
+            __builtin_amdgcn_s_waitcnt(0);             // (thread 0's stores are out; the other threads' were before the barrier below the candidates)
+            __hip_atomic_store(&st->prepared, P + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        NPBNN_SPEC_TICK(4);
+        // ---- E. behind the flag: book-keeping, and the accepted candidate goes into the float64 weights and the global image ----
+        const int acc = sp.accepted, o_sel = sp.outcome, n_done = sp.n_done;
+        if (tid < kMaxCand && tid < n_done) {
+            const int j = tid, t = t0 + j;
+            g_out_acc[t] = (unsigned char)sp.out_a[j];
+            g_out_ll[t] = sp.out_ll[j];
+            g_out_lp[t] = sp.sel_lp[j];
+        }
+        if (tid >= 64 && tid < 64 + kSpecOutcomes * kMaxCand) {   // (kept in memory too: a later launch of the batch picks the chain up from there)
+            const int o = (tid - 64) / kMaxCand, k = (tid - 64) % kMaxCand;
+            S->cand_lp[qn][o][k] = sp.cand_lp[o][k];
+        }
+        if (acc >= 0) {
+            const size_t row = (size_t)(t0 + acc) * M;
+            for (int e = tid; e < M; e += nthr) {
+                const int i = g_idx[row + e];
+                const double v = pvP[(size_t)acc * M + e];
+                const int pos = g_pos[row + e];
+                const float sc = pscale_p[row + e];
+                if (i >= 0) {
+                    Wc[i] = v;
+                    patch_image(g_image, pos, has_sc ? sc : 1.0f, v);
+                }
+            }
+        }
+        __syncthreads();                               // (sel_lp is read above and rewritten below)
+        if (tid == 0) {
+            if (acc >= 0) {
+                st->logLik = sp.cur_ll;
+                st->logPrior = sp.cur_lp;
+                st->logPrior_rep = sp.cur_lp;
+                st->n_accepted += 1;
+            }
+            st->t = t0 + n_done;
+            st->n_passes += 1;
+            S->o_cur = o_sel;
+            if (sp.ovf[o_sel]) atomicOr(g_overflow, kFlagF16Range);
+            S->rounds += 1;
+            // the next round's pass in flight
+            sp.cur = sp.desc[o_sel];
+            sp.o_cur = o_sel;
+            for (int k = 0; k < kMaxCand; ++k) sp.sel_lp[k] = sp.cand_lp[o_sel][k];
+            // the committed entries sit in this XCD's L2; the evaluating workgroups of other XCDs read the image from the memory
+            // side: write them back now, off the critical path (the NEXT pass applies this accept's entries itself)
+            if (acc >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        __syncthreads();
+        NPBNN_SPEC_TICK(5);
+        if (sp.go == 0) return;
+    }
+#undef NPBNN_SPEC_TICK
 }
 
 #ifdef NPBNN_KERNELS_MAIN

@@ -473,6 +473,30 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     if (chain && bid == (sync ? 0 : G)) {
         StepShared& sh = *reinterpret_cast<StepShared*>(smem);
         int* const lds_flag = reinterpret_cast<int*>(smem + sizeof(StepShared));
+        if (uni(p.sync_mode) == 3) {     // NPBNN_SCHED_PERSIST_SERIAL: round P prepares pass P + 1 for every outcome of pass P while it is
+            // evaluated, then decides it and publishes the pass its outcome selects (spec_rounds)
+            SpecShared& sp = *reinterpret_cast<SpecShared*>(smem + ((sizeof(StepShared) + 64 + 15) & ~(size_t)15));
+            if (chain->mask) spec_rounds<true>(*chain, launch0, launch_end, G, sh, sp, lds_flag);
+            else spec_rounds<false>(*chain, launch0, launch_end, G, sh, sp, lds_flag);
+            return;
+        }
+        if (uni(p.sync_mode) == 2) {     // the same order with the plain step between the passes: round L decides pass L - 1 and prepares pass L; the evaluating
+            // workgroups wait for it (pass 0 was prepared by the batch's first step kernel)
+            for (int launch = launch0 > 1 ? launch0 : 1; launch <= launch_end; ++launch) {
+                if (!sync_step_enter_serial(*chain, launch, G, lds_flag)) return;
+                chain_step(*chain, serial_plan(launch), sh);
+                sync_step_leave(chain->st, launch);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const PassDesc& nx = chain->pass[launch & 1];
+                    *lds_flag = nx.n_cand == 0 ? 1 : 0;       // nothing in flight in this schedule: an empty pass is the end
+                }
+                __syncthreads();
+                if (*lds_flag) return;
+                __syncthreads();
+            }
+            return;
+        }
         for (int launch = launch0; launch < launch_end; ++launch) {
             if (sync && !sync_step_enter(*chain, launch, G, lds_flag)) return;
             chain_step(*chain, overlapped_plan(launch), sh);
@@ -553,64 +577,12 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const float* const g_pscale = uni(p.pscale);
     double* const g_partials = uni(p.partials);
 
-    int early_prepared = 0x7fffffff;
-    if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
-        early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int par = (chain || GN) ? (launch & 1) : 0;
-    // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
-    //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
-    int t0 = 0;
-    int cnt[D];
-    int t0g[D];                    // group pass: the iteration each chain's candidate belongs to
-#pragma unroll
-    for (int j = 0; j < D; ++j) { cnt[j] = 0; t0g[j] = 0; }
-    const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
-    const double* const pv = uni(p.pv) + (size_t)par * kMaxCand * M;
-    if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem), early_prepared)) return;
-    if (GN) {
-        int alive = 0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const PassDesc* const dj = uni(p.group[j].pass) + par;
-            const int nc = uni(dj->n_cand);
-            alive |= nc;
-            cnt[j] = nc > 0 ? uni(dj->cnt[0]) : 0;           // (a chain that has finished its iterations idles: an unpatched copy)
-            t0g[j] = uni(dj->t0);
-        }
-        if (!alive) return;                                   // every chain is through
-    } else if (pass) {
-        if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
-            const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand: an empty pass
-                if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
-                // one pass per launch: this launch is over.  Persistent form: over only at the terminal pass (PassDesc.pad[0]); an
-                // empty pass before that means the pass in flight may still accept and start the chain's tail again
-                if (n_loop <= 1 || __builtin_amdgcn_readlane(w, 5) == 1) return;
-                __syncthreads();
-                continue;
-            }
-            t0 = __builtin_amdgcn_readlane(w, 0);
-#pragma unroll
-            for (int j = 0; j < D; ++j) cnt[j] = __builtin_amdgcn_readlane(w, 2 + (j < kMaxCand ? j : 0));
-        } else {
-            if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
-            t0 = uni(pass->t0);
-#pragma unroll
-            for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
-        }
-    }
-
-    // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
-    // this pass is then evaluated from a state that no longer exists and nobody will read its sums: polled once per tile
-    // (device-scope load, issued before the tile's tail and looked at after it), the waves skip their remaining tiles
-    const int* const void_flag = chain ? uni(&chain->st->void_launch) : nullptr;
-    int void_seen = -3;
     char* const ring = smem + D * IB + (size_t)wave * uni(p.lay.wave_lds);
     char* const aux = ring + kRing * 1024;
     float* const row_scratch = reinterpret_cast<float*>(aux + (aux_mask + 1) * aux_sz);   // [16 rows][16 outputs], generic likelihoods
 
     // ---- stage the weight image of the current state into LDS, once per candidate: lane-linear DMA copies ----
-    {
+    auto stage_images = [&]() {
         const int n_pieces = (image_floats + 255) >> 8;   // 1-KiB pieces; the last one may be partial (the image is a multiple of 256 B)
         const float* const image = uni(p.image);
         const size_t set_stride = hp.weight_sets ? (size_t)image_floats : 0;
@@ -623,7 +595,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     else dma16(img_j + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
                 }
         }
-    }
+    };
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to SIMD m % 4 and, there, to the
     //      waves of that SIMD in turn (wave w sits on SIMD w % 4): the SIMDs of a CU - whose issue ports are what the tile
@@ -668,8 +640,88 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         ++pf_q;
         if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
-    for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
+    // NPBNN_SCHED_PERSIST_SERIAL with the next pass prepared ahead (sync_mode 3): nothing the image copy and the first pieces of X
+    // depend on changes at the hand-over - the global image is only written right AFTER a flag, and the pass applies the accepted
+    // candidate's entries to its LDS copies itself - so both are requested BEFORE the wait for the step workgroup's flag and have
+    // landed when it comes.  Everywhere else the image is committed before the flag: copy after it.
+    const bool early_copy = uni(p.sync_mode) == 3;
+    if (early_copy) {
+        stage_images();
+        for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
+    }
 
+    int early_prepared = 0x7fffffff;
+    if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
+        early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int par = (chain || GN) ? (launch & 1) : 0;
+    // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
+    //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
+    int t0 = 0;
+    int cnt[D];
+    int t0g[D];                    // group pass: the iteration each chain's candidate belongs to
+#pragma unroll
+    for (int j = 0; j < D; ++j) { cnt[j] = 0; t0g[j] = 0; }
+    const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
+    int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
+    // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
+    if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
+        NPBNN_WAIT_VMCNT(0);
+        return;
+    }
+    if (GN) {
+        int alive = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const PassDesc* const dj = uni(p.group[j].pass) + par;
+            const int nc = uni(dj->n_cand);
+            alive |= nc;
+            cnt[j] = nc > 0 ? uni(dj->cnt[0]) : 0;           // (a chain that has finished its iterations idles: an unpatched copy)
+            t0g[j] = uni(dj->t0);
+        }
+        if (!alive) return;                                   // every chain is through
+    } else if (pass) {
+        if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
+            const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand: an empty pass
+                if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
+                // one pass per launch: this launch is over.  Persistent form: over only at the terminal pass (PassDesc.pad[0]); an
+                // empty pass before that means the pass in flight may still accept and start the chain's tail again
+                if (n_loop <= 1 || __builtin_amdgcn_readlane(w, 5) == 1 || uni(p.sync_mode) >= 2) {
+                    NPBNN_WAIT_VMCNT(0);        // (copies requested ahead of the flag must not land in LDS that is no longer ours)
+                    return;
+                }
+                NPBNN_WAIT_VMCNT(0);
+                __syncthreads();
+                continue;
+            }
+            t0 = __builtin_amdgcn_readlane(w, 0);
+#pragma unroll
+            for (int j = 0; j < D; ++j) cnt[j] = __builtin_amdgcn_readlane(w, 2 + (j < kMaxCand ? j : 0));
+            if (uni(p.sync_mode) == 3) {     // the descriptor names what this pass reads (spec_rounds): its own patch values, and - after an
+                // accept - the accepted candidate's entries, which the global image may not hold yet
+                acc_cnt = __builtin_amdgcn_readlane(w, 6);
+                const int named = __builtin_amdgcn_readlane(w, 7);
+                pv_slot = named & 0xff;
+                acc_slot = (named >> 8) - 1;
+            }
+        } else {
+            if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
+            t0 = uni(pass->t0);
+#pragma unroll
+            for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
+        }
+    }
+
+    if (!early_copy) {
+        stage_images();
+        for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
+    }
+    const double* const pv = uni(p.pv) + (size_t)pv_slot * kMaxCand * M;
+    // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
+    // this pass is then evaluated from a state that no longer exists and nobody will read its sums: polled once per tile
+    // (device-scope load, issued before the tile's tail and looked at after it), the waves skip their remaining tiles
+    const int* const void_flag = chain ? uni(&chain->st->void_launch) : nullptr;
+    int void_seen = -3;
     // ---- candidates = current state + their own touched entries: fetch the first entry per thread now (its latency
     //      hides under the image copy), meet, patch the LDS images, meet again.  The first barrier also waits for this
     //      wave's image pieces and first X pieces (needed next anyway). ----
@@ -702,9 +754,45 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             if (psc_row) psc[j] = psc_row[tid];
         }
     }
+    int apos = kSkipPos;
+    double aval = 0.0;
+    float asc = 1.0f;
+    if (acc_cnt > 0 && tid < acc_cnt) {       // the accepted iteration is the one before this pass's first
+        const size_t arow = (size_t)(t0 - 1) * M;
+        apos = g_pos[arow + tid];
+        aval = __hip_atomic_load(uni(p.pv) + (size_t)acc_slot * M + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g_pscale) asc = g_pscale[arow + tid];
+    }
     NPBNN_ESTAMP(1);
     __syncthreads();
     NPBNN_ESTAMP(2);
+    if (acc_cnt > 0) {                        // every candidate starts from the accepted state
+        auto put = [&](int pos, double v, float sc) {
+            if (pos == kSkipPos) return;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float* imgj = reinterpret_cast<float*>(smem + j * IB);
+                if (pos < 0) {
+                    _Float16 hi, lo;
+                    split_f16((float)(v * (double)sc), hi, lo);
+                    _Float16* i16 = reinterpret_cast<_Float16*>(imgj);
+                    const int hpos = pos & 0x7fffffff;
+                    i16[hpos] = hi;
+                    i16[hpos + 512] = lo;
+                } else {
+                    imgj[pos] = (float)v;
+                }
+            }
+        };
+        if (tid < acc_cnt) put(apos, aval, asc);
+        if ((int)blockDim.x < acc_cnt) {
+            const size_t arow = (size_t)(t0 - 1) * M;
+            for (int e = tid + blockDim.x; e < acc_cnt; e += blockDim.x)
+                put(g_pos[arow + e], __hip_atomic_load(uni(p.pv) + (size_t)acc_slot * M + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    g_pscale ? g_pscale[arow + e] : 1.0f);
+        }
+        __syncthreads();
+    }
     if (pass || GN) {
         auto patch = [&](int j, int pos, double v, float sc) {
             if (pos == 0x7fffffff) return;                  // superseded entry (a later draw of the same position wins)

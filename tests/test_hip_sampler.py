@@ -175,10 +175,11 @@ def test_speculative_passes_do_not_change_the_chain(name):
     """1, 2 or 3 candidates per pass over the data, decided between the passes (serial schedule) or inside the launch
     that already evaluates the next pass (overlapped schedule): identical accept/reject sequence, weights and
     log-likelihood - the speculation only changes how many passes the same chain needs.  Schedule 3 is the overlapped
-    schedule with the launches alternating between two streams, ordered by device-side flags instead of kernel boundaries."""
+    schedule with the launches alternating between two streams, ordered by device-side flags instead of kernel boundaries, 4 its
+    persistent form (one launch loops over the passes), 5 the persistent launch with the decision between the passes."""
     cfg = cases.TRACES[name]
     out = []
-    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0), (3, 3), (1, 3), (2, 3), (3, 4), (1, 4), (2, 4)):
+    for d, sched in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2), (3, 0), (3, 3), (1, 3), (2, 3), (3, 4), (1, 4), (2, 4), (3, 5), (1, 5), (2, 5)):
         bnn, mcmc = build(cfg)
         mcmc.n_candidates = d
         mcmc.device_schedule = sched
@@ -429,10 +430,10 @@ def test_persistent_schedule_never_times_out_in_a_million_iterations():
     bnn, m = chain()                               # schedule left to the library
     for _ in range(9):
         m.run_steps(bnn, 100_000)
-        assert m._device_schedule_used == 4 and m._backend.ctx.sync_fallbacks == 0
+        assert m._device_schedule_used in (4, 5) and m._backend.ctx.sync_fallbacks == 0      # (5: batches after a stretch of many accepts)
     for _ in range(1000):
         m.run_steps(bnn, 100)
-    assert m._device_schedule_used == 4 and m._backend.ctx.sync_fallbacks == 0 and m._current_iteration == 1_000_000
+    assert m._device_schedule_used in (4, 5) and m._backend.ctx.sync_fallbacks == 0 and m._current_iteration == 1_000_000
     assert 0.001 < m._device_accepted / 1e6 < 0.3
     # the same chain on kernel boundaries (first 20 000 iterations)
     (ba, ma), (bb, mb) = chain(), chain()

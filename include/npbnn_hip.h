@@ -291,6 +291,53 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
                     const double* log_u, uint8_t* out_accepted, double* out_loglik_prop, double* out_logprior_prop,
                     npbnn_chain_result* result);
 
+/* ---- the general device chain: K iterations of MCMC.mh_step (np_bnn/BNN_env.py:381-532) for the sampler settings whose proposal is
+ * more than a list of perturbed weights - the other proposal kernels (UpdateUniform np_bnn/BNN_mcmc.py:86-96: perturbations drawn from
+ * numpy's global stream; UpdateFixedNormal :27-42: values replaced, Hastings term from every draw; UpdateNormalNormalized :71-82: the
+ * perturbed layer divided by its sum), weight indicators (BNN_env.py:460,464: layer 0 multiplied by 0/1 indicators, flipped by
+ * UpdateBinomial, BNN_mcmc.py:98-99, in the iterations that do not perturb layer 0; their Bernoulli prior, BNN_env.py:190-193) and
+ * feature indicators (BNN_env.py:424-433: a switched-off feature reads as its mean, data_transform_obj :9-17).  Every iteration the
+ * device builds the full candidate (weights, indicators, override, log prior in full, Hastings term), packs its weight image,
+ * evaluates it (one pass over X) and decides it; nothing returns to the host in between.  All random numbers are pre-drawn by the
+ * caller, in the reference's order, from the streams the reference uses:
+ *   idx / val / cnt   per iteration the UNIQUE weights the proposal touches (the last draw of a position wins, as numpy's indexed
+ *                     assignment does) and, per entry, the perturbation to add (NPBNN_PROP_NORMAL / _UNIFORM / _NORMAL_NORMALIZED) or
+ *                     the value to install (NPBNN_PROP_FIXED_NORMAL)
+ *   h_idx / h_val / h_fac / h_cnt   NPBNN_PROP_FIXED_NORMAL: EVERY draw - weight, drawn value, 0.5 / d^2 of its proposal width - for
+ *                     the Hastings term sum(logpdf(old) - logpdf(drawn))
+ *   layer_mask[t]     bit l: layer l was perturbed at iteration t (NPBNN_PROP_NORMAL_NORMALIZED renormalises those layers)
+ *   ind_*             weight indicators: ind_inout the current 0/1 matrix of layer 0 (in / out), the flips of iteration t are
+ *                     ind_pos[ind_ptr[t] .. ind_ptr[t+1])
+ *   find_*            feature indicators likewise; find_use[t] = 1 where the override applies (iterations after adapt_stop)
+ * cfg as for npbnn_chain_run (schedule, n_candidates, slopes unused: one candidate per pass, decided before the next). */
+enum { NPBNN_PROP_NORMAL = 0, NPBNN_PROP_UNIFORM = 1, NPBNN_PROP_FIXED_NORMAL = 2, NPBNN_PROP_NORMAL_NORMALIZED = 3 };
+typedef struct {
+    int32_t proposal_kind;
+    int32_t M;                                 /* capacity per iteration of the entry lists */
+    const int32_t* idx;
+    const double* val;
+    const int32_t* cnt;
+    const int32_t* h_idx;
+    const double* h_val;
+    const double* h_fac;
+    const int32_t* h_cnt;
+    const int32_t* layer_mask;
+    double* ind_inout;                         /* or NULL: no weight indicators */
+    const int32_t* ind_ptr;
+    const int32_t* ind_pos;
+    double prior_ind1;                         /* npBNN._prior_ind1 */
+    int32_t has_indicator_prior;               /* npBNN._freq_indicator > 0 */
+    int32_t reserved_;
+    double* find_inout;                        /* or NULL: no feature indicators */
+    const double* feature_means;
+    const int32_t* find_ptr;
+    const int32_t* find_pos;
+    const int32_t* find_use;
+} npbnn_general_cfg;
+int npbnn_chain_run_general(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const npbnn_general_cfg* gcfg, double* W_inout,
+                            const double* mask_packed, int32_t K, const double* log_u, uint8_t* out_accepted,
+                            double* out_loglik_prop, double* out_logprior_prop, npbnn_chain_result* result);
+
 /* ---- stand-alone operators on host arrays (float64): the reference's call-surface helpers when user code calls them on an
  * explicit matrix instead of through the sampler.  Each call uploads, runs one device kernel and downloads.
  *   npbnn_op_activation  relu_f / leaky_relu_f / swish_f / tanh_f (BNN_lib.py:50-66); kind 4 = SoftPlus (:170-172); in place

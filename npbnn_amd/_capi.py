@@ -73,6 +73,20 @@ class ChainResult(C.Structure):
                 ("iterations_done", C.c_int32), ("overflow", C.c_int32), ("slopes", C.c_double * MAX_LAYERS)]
 
 
+class GeneralCfg(C.Structure):
+    """npbnn_general_cfg: the pre-drawn proposals of the general device chain (npbnn_chain_run_general)."""
+    _fields_ = [("proposal_kind", C.c_int32), ("M", C.c_int32), ("idx", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double)),
+                ("cnt", C.POINTER(C.c_int32)), ("h_idx", C.POINTER(C.c_int32)), ("h_val", C.POINTER(C.c_double)),
+                ("h_fac", C.POINTER(C.c_double)), ("h_cnt", C.POINTER(C.c_int32)), ("layer_mask", C.POINTER(C.c_int32)),
+                ("ind_inout", C.POINTER(C.c_double)), ("ind_ptr", C.POINTER(C.c_int32)), ("ind_pos", C.POINTER(C.c_int32)),
+                ("prior_ind1", C.c_double), ("has_indicator_prior", C.c_int32), ("reserved_", C.c_int32),
+                ("find_inout", C.POINTER(C.c_double)), ("feature_means", C.POINTER(C.c_double)),
+                ("find_ptr", C.POINTER(C.c_int32)), ("find_pos", C.POINTER(C.c_int32)), ("find_use", C.POINTER(C.c_int32))]
+
+
+PROP_NORMAL, PROP_UNIFORM, PROP_FIXED_NORMAL, PROP_NORMAL_NORMALIZED = 0, 1, 2, 3
+
+
 class ChainJob(C.Structure):
     """One chain's share of npbnn_chains_run_exchange (npbnn_chain_job)."""
     _fields_ = [("ctx", C.c_void_p), ("cfg", C.POINTER(ChainCfg)), ("W_inout", C.POINTER(C.c_double)),
@@ -123,6 +137,8 @@ SIGNATURES = {
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), _DP, C.c_double, _DP,
                                             C.POINTER(C.c_int32)]),
     "npbnn_chains_run_batched": (C.c_int, [C.POINTER(ChainJob), C.c_int32, C.c_int32]),
+    "npbnn_chain_run_general": (C.c_int, [_P, C.POINTER(ChainCfg), C.POINTER(GeneralCfg), _DP, _DP, C.c_int32, _DP, C.POINTER(C.c_uint8),
+                                          _DP, _DP, C.POINTER(ChainResult)]),
     "npbnn_op_activation": (C.c_int, [C.c_int, C.c_int, C.c_double, _DP, C.c_int64]),
     "npbnn_op_output": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.c_int32]),
     "npbnn_op_likelihood": (C.c_int, [C.c_int, C.c_int, _DP, C.c_int64, C.c_int32, C.POINTER(C.c_int64), _DP, C.c_int32, _DP, _DP,

@@ -6,6 +6,7 @@ numerics of the hot path run in the hand-written HIP kernels behind it.
 """
 import ctypes as C
 import os
+from time import perf_counter as _now
 
 import numpy as np
 
@@ -60,6 +61,7 @@ class HipContext:
         self.arch = None
         self.n_rows = {}
         self.n_out = None
+        self.seconds_in_chain_run = 0.0
         self.sync_fallbacks = 0      # batches of the (opt-in) two-stream schedule that timed out and were repeated on one stream
 
     # -- lifecycle --------------------------------------------------------------------
@@ -327,8 +329,10 @@ class HipContext:
         attempt, sync_retried = 0, False
         while True:
             cfg.force_f32 = attempt
+            t_in = _now()
             rc = run(self._ctx, C.byref(cfg), addr[0], addr[1], K, M, addr[2], addr[3], addr[4], addr[5], addr[6], addr[7], addr[8],
                      C.byref(res))
+            self.seconds_in_chain_run += _now() - t_in          # (what a dispatch spends inside the library: tools/profile_dispatch.py)
             if rc == capi.E_RANGE and attempt == 0:
                 attempt = 1
                 continue        # a weight left the fp16 range: same batch again on the float32 path (state untouched)
@@ -345,6 +349,55 @@ class HipContext:
             self._chk(rc)
             break
         return w, acc, llp, lpp, self._result_dict(res)
+
+
+    def chain_run_general(self, weights, draws, log_u, mask=None, indicators=None, feature_indicators=None, feature_means=None,
+                          prior_ind1=0.5, has_indicator_prior=False, **cfg_kw):
+        """K iterations of the general device chain (npbnn_chain_run_general).  ``draws``: dict with ``kind`` (PROP_*), ``idx``,
+        ``val`` [K, M], ``cnt`` [K], ``layer_mask`` [K] and, as the sampler's settings need them, ``h_idx`` / ``h_val`` / ``h_fac`` /
+        ``h_cnt`` (every draw of the fixed-normal proposal), ``ind_ptr`` / ``ind_pos`` (weight-indicator flips), ``find_ptr`` /
+        ``find_pos`` / ``find_use`` (feature-indicator flips).  Returns (weights, indicators, feature indicators, accepted flags,
+        proposed logLik, proposed logPrior, result dict)."""
+        i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)       # noqa: E731
+        ip = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))        # noqa: E731
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
+        idx, cnt = i32(draws["idx"]), i32(draws["cnt"])
+        val = capi.as_f64(draws["val"])
+        K, M = idx.shape
+        cfg, res, g = capi.ChainCfg(), capi.ChainResult(), capi.GeneralCfg()
+        self._fill_chain_cfg(cfg, **cfg_kw)
+        g.proposal_kind, g.M = int(draws["kind"]), int(M)
+        keep = [idx, cnt, val]
+        g.idx, g.val, g.cnt = ip(idx), capi.dptr(val), ip(cnt)
+        lm = i32(draws.get("layer_mask") if draws.get("layer_mask") is not None else np.zeros(K))
+        g.layer_mask = ip(lm)
+        keep.append(lm)
+        if draws.get("h_idx") is not None:
+            h_idx, h_cnt = i32(draws["h_idx"]), i32(draws["h_cnt"])
+            h_val, h_fac = capi.as_f64(draws["h_val"]), capi.as_f64(draws["h_fac"])
+            g.h_idx, g.h_val, g.h_fac, g.h_cnt = ip(h_idx), capi.dptr(h_val), capi.dptr(h_fac), ip(h_cnt)
+            keep += [h_idx, h_cnt, h_val, h_fac]
+        ind = find = None
+        if indicators is not None:
+            ind = capi.as_f64(indicators).copy()
+            iptr, ipos = i32(draws["ind_ptr"]), i32(draws["ind_pos"] if len(draws["ind_pos"]) else np.zeros(1))
+            g.ind_inout, g.ind_ptr, g.ind_pos = capi.dptr(ind), ip(iptr), ip(ipos)
+            g.prior_ind1, g.has_indicator_prior = float(prior_ind1), 1 if has_indicator_prior else 0
+            keep += [iptr, ipos]
+        if feature_indicators is not None:
+            find = capi.as_f64(feature_indicators).copy()
+            means = capi.as_f64(feature_means)
+            fptr, fpos, fuse = i32(draws["find_ptr"]), i32(draws["find_pos"] if len(draws["find_pos"]) else np.zeros(1)), i32(draws["find_use"])
+            g.find_inout, g.feature_means, g.find_ptr, g.find_pos, g.find_use = capi.dptr(find), capi.dptr(means), ip(fptr), ip(fpos), ip(fuse)
+            keep += [means, fptr, fpos, fuse]
+        m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
+        log_u = capi.as_f64(log_u)
+        acc = np.empty(K, dtype=np.uint8)
+        llp, lpp = np.empty(K), np.empty(K)
+        self._chk(self._lib.npbnn_chain_run_general(self._ctx, C.byref(cfg), C.byref(g), capi.dptr(w), capi.dptr(m), K, capi.dptr(log_u),
+                                                    acc.ctypes.data_as(C.POINTER(C.c_uint8)), capi.dptr(llp), capi.dptr(lpp), C.byref(res)))
+        del keep
+        return w, ind, find, acc, llp, lpp, self._result_dict(res)
 
 
 def chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=None, launch_slack=1.25,

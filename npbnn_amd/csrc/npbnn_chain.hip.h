@@ -157,6 +157,8 @@ struct ChainParams {
     double* spec_touch_val;           // (unused)
     const double* spec_prior_w;       // [n_weights] per weight: 0.5 / scale^2 (normal prior, a scale per layer) or the scale (see spec_rounds)
     int n_weights_spec, spec_gen;     // spec_gen: pass tags of this batch start above it (never reused: the host clears the tables first)
+    const double* class_w;     // class weights for the weight image (pack_item), or nullptr
+    const float* w_scale;      // fp16-split column scales of layer 0, or nullptr
     int K, M, D, n_blocks;
     int sync_test_skip;        // tests only: the step of this launch never reports back (-1: none) - exercises the time-out path of
                                // the two-stream schedule
@@ -192,16 +194,33 @@ __device__ __forceinline__ double prior_delta(int kind, double v, double b, doub
 }
 
 // image position / fp16-split scale of every pre-drawn entry, gathered once per batch
-#ifdef NPBNN_KERNELS_MAIN
-__global__ void __launch_bounds__(256) gather_pos_kernel(const int* __restrict__ idx, long long n, const int* __restrict__ w2img,
-                                                         const float* __restrict__ w2scale, int* __restrict__ pos, float* __restrict__ pscale) {
+#ifdef NPBNN_KERNELS_CHAIN
+struct PackJob {              // what the packing blocks of gather_pos_kernel need (w == nullptr: nothing to pack)
+    const double* w;
+    const double* class_w;
+    float* image;
+    const NetMeta* net;       // (device copy: ChainParams::net of the batch)
+    const float* w_scale;
+};
+__global__ void __launch_bounds__(256) gather_pos_kernel(int* __restrict__ idx, long long n, int n_weights, const int* __restrict__ w2img,
+                                                         const float* __restrict__ w2scale, int* __restrict__ pos, float* __restrict__ pscale,
+                                                         int* __restrict__ flags, int gather_blocks, PackJob pk) {
+    if ((int)blockIdx.x >= gather_blocks) {      // the blocks behind the gather pack the weight image of the state the batch starts from
+        if (pk.w) pack_item(((int)blockIdx.x - gather_blocks) * 256 + (int)threadIdx.x, pk.w, nullptr, pk.class_w, pk.image, *pk.net, true, pk.w_scale, flags);
+        return;
+    }
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int w = idx[i];
+    int w = idx[i];
+    if (w >= n_weights) {          // an index outside the network: the entry is dropped here, the batch reports it (kFlagBadIndex)
+        atomicOr(flags, kFlagBadIndex);
+        idx[i] = -1;
+        w = -1;
+    }
     pos[i] = w >= 0 ? w2img[w] : kSkipPos;
     if (pscale) pscale[i] = (w >= 0 && w2scale) ? w2scale[w] : 1.0f;
 }
-#endif  // NPBNN_KERNELS_MAIN
+#endif  // NPBNN_KERNELS_CHAIN
 
 __device__ __forceinline__ void patch_image(float* image, int pos, float scale, double v) {
     if (pos == 0x7fffffff) return;                   // an entry the image does not hold (outside the layer-0 block structure: it is 0)
@@ -1146,7 +1165,7 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
 #undef NPBNN_SPEC_TICK
 }
 
-#ifdef NPBNN_KERNELS_MAIN
+#ifdef NPBNN_KERNELS_CHAIN
 // two-stream schedule, first pair of launches of a round (both streams are idle then, so the two launches become eligible
 // together): this one-wave kernel goes in front of the second launch on its stream and lets it through only when the step
 // workgroup of the first has begun - the same guarantee sync_step_leave gives from then on
@@ -1159,14 +1178,21 @@ __global__ void sync_gate_kernel(ChainDev* st, int first_launch) {
 __global__ void sync_gate_exchanged_kernel(ChainDev* st, int n_exchanges) {
     if (threadIdx.x == 0) (void)sync_wait_ge(st, &st->exchanged, n_exchanges, 200000000ull);
 }
-#endif  // NPBNN_KERNELS_MAIN
+#endif  // NPBNN_KERNELS_CHAIN
 
-#ifdef NPBNN_KERNELS_MAIN
+#ifdef NPBNN_KERNELS_CHAIN
 // serial schedule: the step as a kernel of its own, between two evaluation kernels (and as the first launch of every batch)
 __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __restrict__ cp, int first_launch) {
     const ChainParams& c = *cp;           // device-resident parameter block; only the per-launch scalar travels as an argument
     __shared__ StepShared sh;
     if (!first_launch && c.pass[0].n_cand == 0) return;      // launched past the end of the batch
+    if (first_launch) {
+        if (c.spec) {
+            int* z = reinterpret_cast<int*>(c.spec);
+            for (int i = threadIdx.x; i < (int)(sizeof(SpecState) / sizeof(int)); i += blockDim.x) z[i] = 0;
+        }
+        __syncthreads();
+    }
     StepPlan pl;
     pl.first = first_launch;
     pl.resum = first_launch;
@@ -1177,7 +1203,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     chain_step(c, pl, sh);
     if (first_launch) sync_step_leave(c.st, 0);       // (flag-ordered schedule: pass 0 is ready)
 }
-#endif  // NPBNN_KERNELS_MAIN
+#endif  // NPBNN_KERNELS_CHAIN
 
 // ------------------------------------------------------------------------------------------------
 // exchange run: several chains (one per ctx: on this GPU and, through RCCL, on the other ranks') advance in segments of
@@ -1202,7 +1228,7 @@ struct ExchangeParams {
     int n_weights;
 };
 
-#ifdef NPBNN_KERNELS_MAIN
+#ifdef NPBNN_KERNELS_CHAIN
 __global__ void exchange_pack_kernel(const ChainParams* __restrict__ cp, const ExchangeParams* __restrict__ xp, int s) {
     if (threadIdx.x != 0) return;
     const ChainDev* st = cp->st;
@@ -1266,6 +1292,6 @@ __global__ void __launch_bounds__(1024) exchange_apply_kernel(const ChainParams*
     sync_step_leave(c.st, next_launch);             // (flag-ordered schedule: the pass of launch next_launch is ready)
     if (threadIdx.x == 0) __hip_atomic_store(&st->exchanged, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-#endif  // NPBNN_KERNELS_MAIN
+#endif  // NPBNN_KERNELS_CHAIN
 
 }  // namespace npbnn

@@ -1,0 +1,244 @@
+// Host-side state of a chain context and the helpers the translation units of the C ABI share
+// (npbnn_capi.hip: contexts, data, architecture, evaluation, prediction, timing hooks; npbnn_chain_api.hip: device-resident
+// chains, group passes, exchange runs; npbnn_general.hip: the general device chain).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "npbnn_hip.h"
+#include "npbnn_kernels.hip.h"
+
+using namespace npbnn;
+
+// the evaluation-kernel instantiations live in npbnn_eval_inst_*.hip (compiled in parallel)
+namespace npbnn {
+eval_fn_t pick_eval_mti8_cat(int mt0, int f16);
+eval_fn_t pick_eval_mti8_gauss(int mt0, int f16);
+eval_fn_t pick_eval_mti8_gen(int mt0, int f16);
+eval_fn_t pick_eval_d1_cat(int mt0, int f16);
+eval_fn_t pick_eval_d1_gauss(int mt0, int f16);
+eval_fn_t pick_eval_d1_gen(int mt0, int f16);
+eval_fn_t pick_eval_d2_cat(int mt0, int f16);
+eval_fn_t pick_eval_d2_gauss(int mt0, int f16);
+eval_fn_t pick_eval_d3_cat(int mt0, int f16);
+eval_fn_t pick_eval_d3_gauss(int mt0, int f16);
+// the fast builds (eval_kernel<..., FAST = true>): nullptr where there is none (more than kFastMaxMT0 tiles in layer 0)
+eval_fn_t pick_eval_d1_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d1_gauss_fast(int mt0, int f16);
+eval_fn_t pick_eval_d2_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d2_gauss_fast(int mt0, int f16);
+eval_fn_t pick_eval_d3_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d3_gauss_fast(int mt0, int f16);
+}
+
+// lk: likelihood class of the build (npbnn::lik_class); the float64 row-wise class has single-candidate builds only
+static inline eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk, bool fast = false, bool blocked = false) {
+    using namespace npbnn;
+    if (fast) {
+        const bool g = lk == kLikGauss;
+        if (blocked) f16 = 2;                 // (fast_launch_ok: block structure only on the fp16-split path)
+        if (n_cand <= 1) return g ? pick_eval_d1_gauss_fast(mt0, f16) : pick_eval_d1_cat_fast(mt0, f16);
+        if (n_cand == 2) return g ? pick_eval_d2_gauss_fast(mt0, f16) : pick_eval_d2_cat_fast(mt0, f16);
+        return g ? pick_eval_d3_gauss_fast(mt0, f16) : pick_eval_d3_cat_fast(mt0, f16);
+    }
+    if (mti != 1) return lk == kLikGen ? pick_eval_mti8_gen(mt0, f16) : lk == kLikGauss ? pick_eval_mti8_gauss(mt0, f16) : pick_eval_mti8_cat(mt0, f16);
+    if (lk == kLikGen) return pick_eval_d1_gen(mt0, f16);
+    const bool g = lk == kLikGauss;
+    if (n_cand <= 1) return g ? pick_eval_d1_gauss(mt0, f16) : pick_eval_d1_cat(mt0, f16);
+    if (n_cand == 2) return g ? pick_eval_d2_gauss(mt0, f16) : pick_eval_d2_cat(mt0, f16);
+    return g ? pick_eval_d3_gauss(mt0, f16) : pick_eval_d3_cat(mt0, f16);
+}
+
+namespace npbnn_api {
+
+struct Dataset {
+    float* X = nullptr;
+    int* labels = nullptr;
+    float* targets = nullptr;
+    float* inst_w = nullptr;
+    int64_t n_rows = 0;
+    int n_tiles = 0;
+    int F = 0, Fp = 0, k = 0;
+    float* X16 = nullptr;      // fp16-split copy (built lazily on the device), row stride Fp16 floats
+    int Fp16 = 0;
+    int f16_state = 0;         // 0 not built, 1 usable, -1 not representable (inf/NaN or outside the fp16 range), -2 representable but
+                               // too coarse for some column: its entries span too many powers of two for a pair of fp16 numbers
+    int f16_worst_col = -1;    // column with the largest (max entry error / mean |entry|) of the fp16 pair, and that ratio
+    double f16_worst_ratio = 0.0;
+    bool borrowed = false;     // X / X16 belong to another ctx (npbnn_share_data)
+};
+
+}  // namespace npbnn_api
+using npbnn_api::Dataset;
+
+struct npbnn_ctx {
+    int device = 0;
+    int n_cu = 256;
+    size_t lds_limit = 160 * 1024;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Dataset ds[2];
+    double* d_classw = nullptr;
+    int n_classw = 0;
+    bool arch_set = false;
+    npbnn_arch arch{};
+    NetMeta net{};
+    int n_weights = 0;
+    int mt0_template = 1;
+    int l0_option = 0;             // NPBNN_L0_AUTO / _F32 / _F16
+    int fast_option = 1;           // NPBNN_OPT_FAST_TAILS
+    int slopes_option = 0;         // NPBNN_OPT_TRAINABLE_SLOPES: the image holds a slot per hidden layer for the activation slope
+    SlopeState* d_slopes = nullptr; // trainable slopes of the device chain (npbnn_chain_cfg.slope_idx ...)
+    int* d_sidx = nullptr;          // [slope_cap] pre-drawn slope entries ...
+    double* d_sdelta = nullptr;     // ... and steps
+    size_t slope_cap = 0;
+    bool batch_slopes = false;      // the batch in flight carries slopes (chain_finish reads them back)
+    int persist_option = 1;        // NPBNN_OPT_PERSISTENT
+    const void* attr_fn = nullptr; // kernel whose dynamic-LDS limit was raised last, and to what
+    size_t attr_lds = 0;
+    // layer-0 block structure (npbnn_set_layer_mask): which (16-node tile, 16-feature group) blocks of the mask hold a nonzero;
+    // empty = dense
+    std::vector<unsigned char> l0_blocks;      // [mt][ceil(in_dim / 16)]
+    float* d_xscale = nullptr;     // per-feature power-of-two scales of the fp16-split path (from the training matrix)
+    float* d_wscale = nullptr;
+    int scale_F = 0;
+    int* d_overflow = nullptr;
+    // parameter blocks of the kernels: device copies (kernels take a pointer) + pinned host staging
+    EvalParams* d_eparams = nullptr;
+    FinalizeParams* d_fparams = nullptr;
+    ChainParams* d_cparams = nullptr;
+    char* h_params = nullptr;      // pinned: EvalParams | FinalizeParams | ChainParams
+    float* d_w2scale = nullptr;
+    // device work buffers
+    double* d_wraw = nullptr;      // packed float64 weights
+    double* d_colov = nullptr;     // column override (in_dim doubles)
+    float* d_image = nullptr;      // float32 fragment image
+    int* d_w2img = nullptr;        // packed-weight index -> image float index
+    double* d_partials = nullptr;
+    int partial_waves = 0;
+    unsigned* d_conf = nullptr;    // NPBNN_MAX_WIDTH^2
+    npbnn_eval_out* d_out = nullptr;
+    float* d_y = nullptr;
+    size_t d_y_cap = 0;
+    // pinned host staging
+    double* h_w = nullptr;
+    size_t h_w_cap = 0;
+    npbnn_eval_out* h_out = nullptr;
+    unsigned* h_conf = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    // device-resident chain.  d_res / h_res: one block [ChainDev | overflow flag | W_cur | accepted | logLik' | logPrior'] so that a
+    // single copy brings the whole outcome of a batch to the (pinned) host side; d_chain, d_wcur, d_acc, d_llp, d_lpp point into it
+    char* d_res = nullptr;
+    char* h_res = nullptr;
+    size_t res_cap = 0, res_k = 0, res_nw = 0;
+    int* d_chain_ovf = nullptr;
+    double its_per_pass = 0.0;     // iterations a launch decided on average in the previous batch (0: unknown)
+    double accept_rate = -1.0;     // acceptance rate of the previous batch (< 0: unknown)
+    double* d_wcur = nullptr;
+    double* d_pv = nullptr;        // [kMaxCand][M] proposed values of the candidates in flight
+    size_t pv_cap = 0;
+    // NPBNN_SCHED_PERSIST_SERIAL (spec_round): outcome-speculative preparation
+    SpecState* d_spec = nullptr;
+    double* d_spec_pv = nullptr;   // [3][kSpecOutcomes][kMaxCand][M]
+    size_t spec_pv_cap = 0;        // M capacity
+    unsigned* d_spec_touch = nullptr;   // [kMaxCand][n_weights] touch tables: pass tags (cleared before they could repeat) ...
+    double* d_spec_tval = nullptr;      // ... and values
+    double* d_spec_prw = nullptr;       // [n_weights] per-weight prior constants of spec_rounds (ChainParams::spec_prior_w)
+    std::vector<double> spec_prw_key;   // what d_spec_prw was built from: prior kind, the per-layer scales
+    size_t spec_touch_cap = 0;     // weights capacity
+    unsigned spec_gen = 0;         // pass tags handed out so far
+    double* d_mask = nullptr;
+    ChainDev* d_chain = nullptr;
+    int* d_idx = nullptr;
+    double* d_delta = nullptr;
+    int* d_pos = nullptr;
+    float* d_pscale = nullptr;
+    size_t draw_cap = 0;        // K*M capacity of d_idx / d_delta
+    int* d_cnt = nullptr;
+    double* d_logu = nullptr;
+    unsigned char* d_acc = nullptr;
+    double* d_llp = nullptr;
+    double* d_lpp = nullptr;
+    size_t iter_cap = 0;        // K capacity
+    EvalParams* d_gparams = nullptr;   // parameter block of a group pass led by this context (npbnn_chains_run_batched)
+    EvalParams* h_gparams = nullptr;   // its page-locked staging twin
+    double* d_pscale_w = nullptr;  // [n_weights] per-weight prior scales of the current batch (npbnn_chain_cfg.prior_scale_w)
+    double* d_smult = nullptr;  // [K][k_targets] sigma multipliers, [K] Hastings terms (regression with an estimated error parameter)
+    double* d_hast = nullptr;
+    size_t smult_cap = 0;       // K capacity of the two
+    // exchange run (npbnn_chains_run_exchange): [ExchangeParams | swap_j | swap_k | swap_logu || state | records | cold weights]
+    char* d_xbuf = nullptr;
+    char* h_xbuf = nullptr;
+    size_t xbuf_cap = 0;
+    hipEvent_t ev_x = nullptr;
+    // feature matrices shared between the chains of one run (npbnn_share_data): a borrower points at its owner, an owner
+    // counts its borrowers and outlives them (a destroyed owner lingers until the last borrower lets go)
+    // flag-ordered overlapped chain schedule: the launches alternate between these two streams
+    hipStream_t stream_e[2] = {nullptr, nullptr};
+    bool sync_failed = false;      // a wait timed out once: the schedule stays off for this context
+    int debug_sync_skip = -1;      // npbnn_debug_sync_skip_ (diagnostics, not part of the ABI)
+    npbnn_ctx* data_owner = nullptr;
+    int n_borrowers = 0;
+    bool zombie = false;
+};
+
+static_assert(sizeof(EvalParams) % 8 == 0 && sizeof(FinalizeParams) % 8 == 0, "parameter blocks are laid out back to back");
+
+namespace npbnn_api {
+
+constexpr double kPersistSerialAccept = 0.07;   // NPBNN_SCHED_AUTO: acceptance rate above which the persistent launch decides between the passes
+constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
+
+int fail(npbnn_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, NPBNN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct LaunchPlan {
+    eval_fn_t fn;
+    int n_cand;
+    int grid, wpb;
+    size_t lds;
+    int n_waves;
+    bool fast;
+};
+
+int max_inner_tiles(const NetMeta& net);
+WaveLayout layout_for(const npbnn_ctx* ctx, const Dataset& d, bool predict_only = false);
+int pick_waves_per_block(const npbnn_ctx* ctx, size_t* lds_bytes, int n_cand, const WaveLayout& lay, bool predict_only = false, bool fast = false);
+int ensure_x16(npbnn_ctx* ctx, int which, int* usable);
+int rebuild_net(npbnn_ctx* ctx, bool f16);
+bool l0_blocked(const NetMeta& net);
+bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d);
+// lik_only: the caller wants the likelihood terms and nothing else from the launch (no statistics, no predictions)
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false, bool lik_only = false);
+int ensure_work_buffers(npbnn_ctx* ctx, int n_waves);
+int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const double* col_override);
+int push_eval_params(npbnn_ctx* ctx, const EvalParams& p);
+int push_finalize_params(npbnn_ctx* ctx, const FinalizeParams& f);
+int push_chain_params(npbnn_ctx* ctx, const ChainParams& c);
+EvalParams make_params(npbnn_ctx* ctx, const Dataset& d);
+int check_dataset_for_lik(npbnn_ctx* ctx, const Dataset& d, int lik);
+double wall_us();
+// launches of kernels that live in npbnn_capi.hip, for the other translation units: the weight image of device-resident float64
+// weights (col_override may be nullptr) into `image`, and the reduction of the partial sums of the last evaluation
+void launch_pack_weights(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, float* image, int* flags);
+void launch_finalize(npbnn_ctx* ctx);
+
+}  // namespace npbnn_api
+using namespace npbnn_api;

@@ -27,6 +27,7 @@ constexpr float kF16Safe = 60000.0f;   // |value| above this does not survive fp
 // bits of the flag word the packing / chain kernels raise (EvalParams / ChainParams `overflow`)
 constexpr int kFlagF16Range = 1;       // a scaled layer-0 weight left the fp16 range: the caller repeats on the float32 path
 constexpr int kFlagStructure = 2;      // a weight is not zero where the layer-0 block structure says there are none
+constexpr int kFlagBadIndex = 4;       // a pre-drawn weight index of a chain batch lies outside the network
 
 // 16-byte fragment entries of a layer in the image (layer 1 on fp16-split products: a high and a low block per K-step of two
 // layer-0 tiles; its output is one tile)

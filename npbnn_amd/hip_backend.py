@@ -100,6 +100,13 @@ class HipBackend:
             self._pinned = PinnedPool(self.ctx._lib)
         return self._pinned.empty(shape, dtype)
 
+    def host_empty_group(self, specs):
+        """Several page-locked arrays in one block (PinnedPool.empty_group)."""
+        if self._pinned is None:
+            from .pinned import PinnedPool
+            self._pinned = PinnedPool(self.ctx._lib)
+        return self._pinned.empty_group(specs)
+
     def _configure(self, weights):
         shapes = tuple(w.shape for w in weights)
         # slopes that the sampler proposes AND the forward pass uses (ActFun(fun="genReLU", trainable=True)): the device chain gives
@@ -135,6 +142,11 @@ class HipBackend:
         """Device-resident Metropolis-Hastings iterations; see HipContext.chain_run."""
         self._configure(weights)
         return self.ctx.chain_run(weights, **kw)
+
+    def run_chain_general(self, weights, **kw):
+        """Iterations of the general device chain; see HipContext.chain_run_general."""
+        self._configure(weights)
+        return self.ctx.chain_run_general(weights, **kw)
 
     exchange_slack = 1.5     # launches given to a swap interval of an exchange run, relative to the expected number (adapts)
     exchange_slack_floor = 1.15

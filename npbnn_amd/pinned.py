@@ -36,10 +36,23 @@ class PinnedPool:
         except Exception:       # interpreter shutdown
             pass
 
+    def empty_group(self, specs):
+        """Uninitialised arrays ``[(shape, dtype), ...]`` in ONE page-locked block, each starting at the next multiple of 256
+        bytes: npbnn_chain_run uploads neighbours laid out like this (indices, then deviates) in a single copy."""
+        offsets, total = [], 0
+        for shape, dtype in specs:
+            total = (total + 255) // 256 * 256
+            offsets.append(total)
+            total += int(np.prod(shape)) * np.dtype(dtype).itemsize
+        raw = self._raw(total)
+        return [np.ndarray(shape, dtype=np.dtype(dtype), buffer=raw, offset=off) for (shape, dtype), off in zip(specs, offsets)]
+
     def empty(self, shape, dtype):
         """An uninitialised C-contiguous array in page-locked memory (returned to the pool when the last view dies)."""
         dtype = np.dtype(dtype)
-        n = int(np.prod(shape)) * dtype.itemsize
+        return np.ndarray(shape, dtype=dtype, buffer=self._raw(int(np.prod(shape)) * dtype.itemsize))
+
+    def _raw(self, n):
         nbytes = 1 << max(12, (max(n, 1) - 1).bit_length())
         with self._lock:
             lst = self._free.get(nbytes)
@@ -53,4 +66,4 @@ class PinnedPool:
             ptr = out.value
         raw = (C.c_char * nbytes).from_address(ptr)
         raw._npbnn_block = _Block(self, ptr, nbytes)       # lives as long as any array built on `raw`
-        return np.ndarray(shape, dtype=dtype, buffer=raw)
+        return raw

@@ -43,7 +43,7 @@ def load_host_library():
 
 
 def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, update_ws, freq_layer_update, empty=None,
-            sigma_k=0, sigma_f=0.5, n_slopes=0, slope_d=0.05):
+            sigma_k=0, sigma_f=0.5, n_slopes=0, slope_d=0.05, empty_group=None):
     """Draw K iterations' proposals.  ``rs`` is the chain's numpy Generator (advanced in place unless
     ``randomize_seed``).  Returns (idx [K,M] int32, delta [K,M] float64, cnt [K], u [K], layer_mask [K]).
     ``empty(shape, dtype)`` allocates the four arrays that travel to the device (page-locked memory, pinned.py);
@@ -69,12 +69,12 @@ def predraw(rs, randomize_seed, first_iteration, mcmc_id, K, weights, update_n, 
         spec.update_ws[i] = ws.ctypes.data_as(C.POINTER(C.c_double))
         spec.freq_layer_update[i] = float(freq_layer_update[i])
     M = int(sum(int(n) for n in update_n))
-    idx = empty((K, M), np.int32)
+    if empty_group is not None:       # indices and deviates side by side: they travel to the device in one copy
+        idx, delta, cnt, u = empty_group([((K, M), np.int32), ((K, M), np.float64), ((K,), np.int32), ((K,), np.float64)])
+    else:
+        idx, delta, cnt, u = empty((K, M), np.int32), empty((K, M), np.float64), empty((K,), np.int32), empty((K,), np.float64)
     idx.fill(-1)
-    delta = empty((K, M), np.float64)
     delta.fill(0.0)
-    cnt = empty((K,), np.int32)
-    u = empty((K,), np.float64)
     lmask = np.empty(K, dtype=np.int32)
     bitgen = None
     if not randomize_seed:

@@ -20,9 +20,13 @@ from .likelihoods import (CalcAccuracy, CalcAccuracyRegression, CalcLabelAccurac
                           calc_likelihood_regression, calc_likelihood_regression_error, likelihood_kind,
                           stat_kind, stats_from_confusion)
 from .model import data_transform_obj, npBNN
-from .proposals import UpdateBinomial, UpdateNormal, UpdateNormal1D, multiplier_proposal_vector
+from .proposals import (UpdateBinomial, UpdateFixedNormal, UpdateNormal, UpdateNormal1D, UpdateNormalNormalized,
+                        multiplier_proposal_vector)
 
 _LAZY = ("_y", "_y_test", "_accuracy", "_test_accuracy", "_label_acc", "_label_freq")
+# proposal kernels the general device chain knows (npbnn_general_cfg.proposal_kind)
+_GENERAL_PROPOSALS = {UpdateNormal: capi.PROP_NORMAL, UpdateFixedNormal: capi.PROP_FIXED_NORMAL,
+                      UpdateNormalNormalized: capi.PROP_NORMAL_NORMALIZED}
 
 _POOL = None
 
@@ -35,6 +39,14 @@ def _draw_pool():
         from concurrent.futures import ThreadPoolExecutor
         _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="npbnn-predraw")
     return _POOL
+
+
+def _same_ends(copy, live):
+    """Cheap test for an in-place edit of a step-size matrix since it was copied (``mcmc._update_ws[i] *= 0.5``): such edits
+    rescale the whole matrix, so its first and last entries tell; a full comparison per dispatch costs more than the dispatch's
+    other book-keeping together."""
+    a, b = copy.flat, live.flat
+    return a[0] == b[0] and a[-1] == b[-1]
 
 
 def _make_backend(bnn_obj, likelihood_f):
@@ -414,20 +426,24 @@ class MCMC():
     # K iterations with the chain resident on the device
     # ------------------------------------------------------------------------------------------
     def _device_loop_ok(self, bnn_obj, k):
-        """True when the next k iterations can run as a device-resident chain: the default proposal and no
-        feature of mh_step whose random draws depend on the chain state."""
+        """True when the next k iterations can run on the patch-list device chain (npbnn_chain_run): the default proposal and no
+        feature of mh_step that changes more than a list of weights."""
+        return self._device_mode(bnn_obj, k) == "patch"
+
+    def _device_mode(self, bnn_obj, k):
+        """How the next k iterations run: ``"patch"`` - the device chain whose proposals are lists of perturbed weights
+        (npbnn_chain_run: speculative passes, every schedule); ``"general"`` - the general device chain (npbnn_chain_run_general:
+        the full candidate built on the device every iteration - the fixed-normal and normalising proposals, weight indicators,
+        feature indicators); ``None`` - one :meth:`mh_step` after the other (custom proposal / likelihood callables, sampling from
+        the prior, and the settings upstream itself cannot run: UpdateUniform takes no ``rs``, BNN_mcmc.py:86, and weight indicators
+        read ``_update_f[3]``, BNN_env.py:460, which needs four weight matrices)."""
         be = self._backend
         if be is None or not hasattr(be, "run_chain") or not getattr(be, "fused_likelihood", False):
-            return False
-        if self.update_function is not UpdateNormal or self._sample_from_prior:
-            return False
-        if bnn_obj._feature_indicators is not None or bnn_obj._freq_indicator:
-            return False
-        if bnn_obj._act_fun._trainable and (bnn_obj._act_fun._function != "genReLU" or not hasattr(be, "ctx")
-                                            or len(bnn_obj._act_fun._acc_prm) != bnn_obj._n_layers - 1):
-            return False        # (slopes that are proposed but never used by the forward pass, or not one per hidden layer: mh_step)
+            return None
+        if self._sample_from_prior:
+            return None
         if likelihood_kind(self._likelihood_f) in (None, capi.LIK_NONE):
-            return False
+            return None
         # (prior scales - one per layer, per input node or per weight, hyper_p 1-3 - change in gibbs_step only, between calls: the
         # device takes them as constants of the batch)
         if bnn_obj._estimation_mode == "regression" and not bnn_obj._empirical_error:
@@ -435,10 +451,25 @@ class MCMC():
             # must lie on one side (run_steps cuts there); the proposals need the Gaussian likelihood on the device
             first, last = self._current_iteration, self._current_iteration + k - 1
             if first <= self._estimate_error < last:
-                return False
+                return None
             if first > self._estimate_error and likelihood_kind(self._likelihood_f) != capi.LIK_GAUSS:
-                return False
-        return True
+                return None
+        whole_candidate = bnn_obj._feature_indicators is not None or bool(bnn_obj._freq_indicator)
+        if self.update_function is UpdateNormal and not whole_candidate:
+            if bnn_obj._act_fun._trainable and (bnn_obj._act_fun._function != "genReLU" or not hasattr(be, "ctx")
+                                                or len(bnn_obj._act_fun._acc_prm) != bnn_obj._n_layers - 1):
+                return None     # (slopes that are proposed but never used by the forward pass, or not one per hidden layer: mh_step)
+            return "patch"
+        if (self.update_function in _GENERAL_PROPOSALS and hasattr(be, "run_chain_general") and not bnn_obj._act_fun._trainable):
+            if bnn_obj._freq_indicator and bnn_obj._n_layers < 4:
+                return None
+            if bnn_obj._feature_indicators is not None:
+                boundary = self._adapt_stop          # the override switches on after it: a batch lies on one side
+                first, last = self._current_iteration, self._current_iteration + k - 1
+                if first <= boundary < last:
+                    return None
+            return "general"
+        return None
 
     def _plain_device_batches(self, bnn_obj):
         """May the chain take part in an exchange run or a group pass?  Those entry points run plain batches only: chain state that
@@ -476,9 +507,16 @@ class MCMC():
                 seg = min(seg, boundary - self._current_iteration)
             if bnn_obj._estimation_mode == "regression" and self._current_iteration <= self._estimate_error:
                 seg = min(seg, int(np.floor(self._estimate_error)) + 1 - self._current_iteration)    # sigma proposals start after it
-            if not self._device_loop_ok(bnn_obj, seg):
+            if bnn_obj._feature_indicators is not None and self._current_iteration <= self._adapt_stop:
+                seg = min(seg, int(self._adapt_stop) + 1 - self._current_iteration)          # the column override starts after it
+            mode = self._device_mode(bnn_obj, seg)
+            if mode is None:
                 self.mh_step(bnn_obj)
                 remaining -= 1
+                continue
+            if mode == "general":
+                self._run_general(bnn_obj, seg)
+                remaining -= seg
                 continue
             self._adapt(bnn_obj)
             sizes = self._sub_batches(seg)
@@ -520,18 +558,19 @@ class MCMC():
         cache = self._ws_copies
         if cache is None or len(cache[0]) != len(src) or any(a is not b for a, b in zip(cache[0], src)) \
                 or any(c.shape != w.shape for c, w in zip(cache[2], bnn_obj._w_layers)) \
-                or not all(np.array_equal(c, a) for c, a in zip(cache[1], src)):       # (an in-place edit of _update_ws[i])
+                or not all(_same_ends(c, a) for c, a in zip(cache[1], src)):       # (an in-place edit of _update_ws[i])
             cache = self._ws_copies = (src, [np.array(w, dtype=np.float64) for w in src], [np.empty(w.shape) for w in bnn_obj._w_layers])
         update_ws, shapes = cache[1], cache[2]                         # (predraw only needs the shapes of the layers)
         freq = [float(f) for f in self._freq_layer_update]
         empty = getattr(self._backend, "host_empty", None)
+        empty_group = getattr(self._backend, "host_empty_group", None)
         saved = rs.bit_generator.state if (rewindable and not randomize) else None
         sigma_k = self._sigma_proposal_columns(bnn_obj, first_it)
         n_slopes = self._n_trainable_slopes(bnn_obj)
 
         def draw():
             out = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty, sigma_k=sigma_k,
-                             n_slopes=n_slopes, slope_d=0.05)
+                             n_slopes=n_slopes, slope_d=0.05, empty_group=empty_group)
             idx, delta, cnt, u = out[:4]
             np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
             smult = hast = None
@@ -552,7 +591,7 @@ class MCMC():
         spec = self._speculation
         if (spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k) and len(spec[3]) == len(self._update_ws)
                 and all(a is b for a, b in zip(spec[3], self._update_ws))       # (the very arrays the draw was made with ...
-                and self._ws_copies is not None and all(np.array_equal(c, a) for c, a in zip(self._ws_copies[1], self._update_ws))):   # ... unedited)
+                and self._ws_copies is not None and all(_same_ends(c, a) for c, a in zip(self._ws_copies[1], self._update_ws))):   # ... unedited)
             self._speculation = None
             return spec[1]
         self._cancel_speculation()
@@ -674,6 +713,122 @@ class MCMC():
         self._current_iteration += k
         if self._randomize_seed:        # (assigning _gen, not _rs: draws made ahead for the next call stay valid)
             self._gen = np.random.default_rng(self._current_iteration - 1 + self._mcmc_id)
+
+    # ------------------------------------------------------------------------------------------
+    # the general device chain: proposals that change more than a list of weights
+    # ------------------------------------------------------------------------------------------
+    def _draw_general(self, bnn_obj, first_it, k):
+        """The random numbers of iterations first_it .. first_it+k-1 in the order mh_step consumes them - the chain's Generator
+        for the weight proposals and the accept test, numpy's global stream for the indicator flips (UpdateBinomial) - turned into
+        what npbnn_chain_run_general takes.  Nothing here depends on the chain's state."""
+        n_layers = bnn_obj._n_layers
+        shapes = [w.shape for w in bnn_obj._w_layers]
+        offs = np.concatenate([[0], np.cumsum([w.size for w in bnn_obj._w_layers])]).astype(np.int64)
+        kind = _GENERAL_PROPOSALS[self.update_function]
+        M = int(max(1, sum(int(n) for n in self._update_n)))
+        idx = np.full((k, M), -1, dtype=np.int32)
+        val = np.zeros((k, M))
+        cnt = np.zeros(k, dtype=np.int32)
+        fixed = kind == capi.PROP_FIXED_NORMAL
+        h_idx = np.full((k, M), -1, dtype=np.int32) if fixed else None
+        h_val, h_fac = (np.zeros((k, M)), np.zeros((k, M))) if fixed else (None, None)
+        h_cnt = np.zeros(k, dtype=np.int32) if fixed else None
+        layer_mask = np.zeros(k, dtype=np.int32)
+        log_u = np.empty(k)
+        has_ind = bool(bnn_obj._freq_indicator)
+        has_find = bnn_obj._feature_indicators is not None
+        ind_ptr, ind_pos = np.zeros(k + 1, dtype=np.int32), []
+        find_ptr, find_pos, find_use = np.zeros(k + 1, dtype=np.int32), [], np.zeros(k, dtype=np.int32)
+        sigma_k = self._sigma_proposal_columns(bnn_obj, first_it)
+        smult = np.ones((k, sigma_k)) if sigma_k else None
+        hast = np.zeros(k) if sigma_k else None
+        for t in range(k):
+            it = first_it + t
+            rs = np.random.default_rng(it + self._mcmc_id) if self._randomize_seed else self._gen
+            if has_find and it > self._adapt_stop:
+                find_use[t] = 1
+                if rs.random() < 0.2:          # UpdateBinomial(ind, 0.5, shape): |ind - binomial(1, random() * 0.5, shape)|
+                    flips = np.random.binomial(1, np.random.random() * 0.5, bnn_obj._feature_indicators.shape)
+                    find_pos.extend(np.nonzero(flips)[0].tolist())
+            find_ptr[t + 1] = len(find_pos)
+            if sigma_k:                        # multiplier_proposal_vector(q, d=1.1, f=0.5, rs) (BNN_mcmc.py:101-113)
+                chosen = rs.binomial(1, 0.5, sigma_k)
+                u = rs.random(sigma_k)
+                m = np.exp(2 * np.log(1.1) * (u - .5))
+                m[chosen == 0] = 1.
+                smult[t] = m
+                hast[t] = np.sum(np.log(m))
+            rr = rs.random(n_layers)
+            rr[np.argmin(rr)] = 0
+            used = h_used = 0
+            for i in range(n_layers):
+                if rr[i] >= bnn_obj._freq_indicator or i > 0:
+                    if rr[i] < self._freq_layer_update[i]:
+                        n = int(self._update_n[i])
+                        d = self._update_ws[i]
+                        rows = rs.integers(0, shapes[i][0], n)
+                        cols = rs.integers(0, shapes[i][1], n)
+                        z = rs.normal(0, d[rows, cols], n)
+                        flat = offs[i] + rows * shapes[i][1] + cols
+                        # numpy's indexed assignment keeps the LAST draw of a position
+                        _, last = np.unique(flat[::-1], return_index=True)
+                        keep = np.sort(n - 1 - last)
+                        idx[t, used:used + len(keep)] = flat[keep]
+                        val[t, used:used + len(keep)] = z[keep]
+                        used += len(keep)
+                        if fixed:              # the Hastings term runs over every draw: logpdf(old) - logpdf(drawn), width d
+                            h_idx[t, h_used:h_used + n] = flat
+                            h_val[t, h_used:h_used + n] = z
+                            h_fac[t, h_used:h_used + n] = 0.5 / (d[rows, cols] ** 2)
+                            h_used += n
+                        layer_mask[t] |= 1 << i
+                else:                          # layer 0 keeps its weights and proposes new indicators instead (BNN_env.py:457-460)
+                    flips = np.random.binomial(1, np.random.random() * self._update_f[3], bnn_obj._indicators.shape)
+                    ind_pos.extend(np.nonzero(flips.ravel())[0].tolist())
+            cnt[t] = used
+            if fixed:
+                h_cnt[t] = h_used
+            ind_ptr[t + 1] = len(ind_pos)
+            log_u[t] = np.log(rs.random())
+        draws = dict(kind=kind, idx=idx, val=val, cnt=cnt, layer_mask=layer_mask, h_idx=h_idx, h_val=h_val, h_fac=h_fac, h_cnt=h_cnt)
+        if has_ind:
+            draws.update(ind_ptr=ind_ptr, ind_pos=np.array(ind_pos, dtype=np.int32))
+        if has_find:
+            draws.update(find_ptr=find_ptr, find_pos=np.array(find_pos, dtype=np.int32), find_use=find_use)
+        return draws, log_u, smult, hast
+
+    def _run_general(self, bnn_obj, seg):
+        """``seg`` iterations on the general device chain (proposal settings constant over them): sub-batches, the draws of the
+        next one made by the helper thread while the GPU runs the current one - within this call only, because the indicator
+        flips come from numpy's GLOBAL stream, which other code may use between calls."""
+        self._cancel_speculation()
+        self._adapt(bnn_obj)
+        sizes = self._sub_batches(seg)
+        it = self._current_iteration
+        pending = _draw_pool().submit(self._draw_general, bnn_obj, it, sizes[0])
+        for n, k in enumerate(sizes):
+            draws, log_u, smult, hast = pending.result()
+            it += k
+            if n + 1 < len(sizes):
+                pending = _draw_pool().submit(self._draw_general, bnn_obj, it, sizes[n + 1])
+            has_ind = bool(bnn_obj._freq_indicator)
+            has_find = bnn_obj._feature_indicators is not None
+            w_new, ind, find, acc, _, _, res = self._backend.run_chain_general(
+                bnn_obj._w_layers, draws=draws, log_u=log_u, mask=bnn_obj._mask,
+                indicators=bnn_obj._indicators if has_ind else None,
+                feature_indicators=bnn_obj._feature_indicators if has_find else None,
+                feature_means=bnn_obj._feature_means if has_find else None, prior_ind1=bnn_obj._prior_ind1, has_indicator_prior=has_ind,
+                **self._device_chain_cfg(bnn_obj, smult, hast))
+            first_it = self._current_iteration
+            self._absorb_device_batch(bnn_obj, k, w_new, acc, res)
+            if res["n_accepted"] > 0:
+                if has_ind:
+                    bnn_obj.reset_indicators(np.array(ind).reshape(bnn_obj._indicators.shape))
+                if has_find:
+                    bnn_obj._feature_indicators = np.array(find).astype(bnn_obj._feature_indicators.dtype)
+                    last_acc = first_it + int(np.nonzero(acc[:k])[0][-1])
+                    if last_acc > self._adapt_stop:      # what mh_step keeps for the statistics of the accepted state
+                        self._accepted_override = data_transform_obj(bnn_obj._feature_indicators, bnn_obj._feature_means).column_override()
 
     def gibbs_step(self, bnn_obj):
         self._cancel_speculation()

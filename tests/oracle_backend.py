@@ -108,6 +108,82 @@ class OracleChainBackend(OracleBackend):
         return cur, acc, llp, lpp, dict(loglik=ll, logprior=lp, sigma=sig, n_accepted=n_acc, n_passes=K, n_candidates=1)
 
 
+    def run_chain_general(self, weights, draws, log_u, mask=None, indicators=None, feature_indicators=None, feature_means=None,
+                          prior_ind1=0.5, has_indicator_prior=False, prior_kind=1, prior_scale=None, w_bound=np.inf, temperature=1.0,
+                          lik_temp=1.0, cur_loglik=0.0, cur_logprior=0.0, cur_sigma=None, sigma=None, n_candidates=0, schedule=0,
+                          sigma_mult=None, hastings=None):
+        """numpy stand-in for npbnn_chain_run_general: every iteration builds the full candidate from the pre-drawn numbers."""
+        import scipy.stats
+        shapes = [w.shape for w in weights]
+        sizes = [int(np.prod(sh)) for sh in shapes]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        cur = np.concatenate([np.asarray(w, dtype=float).ravel() for w in weights])
+        m = None if mask is None else np.concatenate([np.asarray(x, dtype=float).ravel() for x in mask])
+        ind = None if indicators is None else np.asarray(indicators, dtype=float).ravel().copy()
+        find = None if feature_indicators is None else np.asarray(feature_indicators, dtype=float).copy()
+        kind = draws["kind"]
+        K = len(log_u)
+        acc = np.zeros(K, dtype=np.uint8)
+        llp, lpp = np.zeros(K), np.zeros(K)
+        ll, lp, sig, n_acc = cur_loglik, cur_logprior, cur_sigma, 0
+
+        def layers(v):
+            return [v[offs[i]:offs[i + 1]].reshape(shapes[i]) for i in range(len(shapes))]
+
+        for t in range(K):
+            prop = cur.copy()
+            n = draws["cnt"][t]
+            i_t, v_t = draws["idx"][t, :n], draws["val"][t, :n]
+            new = v_t if kind == 2 else cur[i_t] + v_t
+            if kind != 3:
+                new = np.where(new > w_bound, w_bound - (new - w_bound), new)
+                new = np.where(new < -w_bound, -w_bound + (-w_bound - new), new)
+            prop[i_t] = new
+            if kind == 3:
+                for li in range(len(shapes)):
+                    if (draws["layer_mask"][t] >> li) & 1:
+                        lay = prop[offs[li]:offs[li + 1]].reshape(shapes[li])
+                        prop[offs[li]:offs[li + 1]] = (lay / np.sum(lay)).ravel()
+            if m is not None:
+                prop = prop * m
+            ind_p, find_p = ind, find
+            if ind is not None:
+                fl = draws["ind_pos"][draws["ind_ptr"][t]:draws["ind_ptr"][t + 1]]
+                ind_p = ind.copy()
+                ind_p[fl] = np.abs(ind[fl] - 1)
+            override = None
+            if find is not None:
+                fl = draws["find_pos"][draws["find_ptr"][t]:draws["find_ptr"][t + 1]]
+                find_p = find.copy()
+                find_p[fl] = np.abs(find[fl] - 1)
+                if draws["find_use"][t]:
+                    override = np.where(find_p == 0, feature_means, np.nan)
+            wl = layers(prop)
+            fw = [wl[0] * ind_p.reshape(shapes[0])] + wl[1:] if ind is not None else wl
+            h = 0.0
+            if kind == 2:
+                hn = draws["h_cnt"][t]
+                hi, hv, hf = draws["h_idx"][t, :hn], draws["h_val"][t, :hn], draws["h_fac"][t, :hn]
+                dd = np.sqrt(0.5 / hf)
+                h = np.sum(scipy.stats.norm.logpdf(cur[hi], 0, dd) - scipy.stats.norm.logpdf(hv, 0, dd))
+            if sigma_mult is not None:
+                r = self.evaluate(fw, col_override=override, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
+                h += hastings[t]
+            else:
+                r = self.evaluate(fw, col_override=override, lik_temp=lik_temp, sigma=sigma)
+            p = orc.log_prior(wl, prior_kind, prior_scale)
+            if has_indicator_prior and ind is not None:
+                n_on = np.sum(ind_p)
+                p = p + (n_on * np.log(prior_ind1) + (ind_p.size - n_on) * np.log(1 - prior_ind1))
+            llp[t], lpp[t] = r["loglik"], p
+            if ((r["loglik"] + p) - (ll + lp)) * temperature + h >= log_u[t]:
+                cur, ll, lp, acc[t], ind, find = prop, r["loglik"], p, 1, ind_p, find_p
+                n_acc += 1
+                if r["sigma"] is not None:
+                    sig = r["sigma"]
+        return cur, ind, find, acc, llp, lpp, dict(loglik=ll, logprior=lp, sigma=sig, n_accepted=n_acc, n_passes=K, n_candidates=1)
+
+
 class OracleExchangeBackend(OracleChainBackend):
     """Adds a numpy stand-in for npbnn_chains_run_exchange (swap intervals with the temperature swaps between them) so
     that the exchange driver (npbnn_amd/exchange.py) and MC3's logging from saved cold-chain states run on CPU, over gloo

@@ -444,3 +444,70 @@ def test_persistent_schedule_never_times_out_in_a_million_iterations():
     assert (ma._logLik, ma._logPrior) == (mb._logLik, mb._logPrior)
     for wa, wb in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+# ---- the general device chain (npbnn_chain_run_general): proposals that change more than a list of weights ----------------------
+def _general_pair(kind, randomize_seed):
+    import contextlib, io
+    kw = dict(update_function=bn.UpdateNormal, n_nodes=[24, 9], freq_indicator=0, feature_indicators=None, w_bound=np.inf, unit_sums=False,
+              regression=False, mcmc={})
+    kw.update({"fixed_normal": dict(update_function=bn.UpdateFixedNormal, w_bound=0.4),
+               "normal_normalized": dict(update_function=bn.UpdateNormalNormalized, unit_sums=True),
+               "weight_indicators": dict(n_nodes=[24, 9, 6], freq_indicator=0.3),
+               "feature_indicators": dict(feature_indicators=True),
+               "feature_and_weight_indicators": dict(n_nodes=[24, 9, 6], freq_indicator=0.3, feature_indicators=True,
+                                                     update_function=bn.UpdateFixedNormal, w_bound=0.5),
+               "regression_sigma_and_features": dict(regression=True, feature_indicators=True, mcmc=dict(estimate_error=True))}[kind])
+    out = []
+    for _ in range(2):
+        if kw["regression"]:
+            dat = cases.regression_data(9, 3000, 40, 2, 200)
+            extra = dict(estimation_mode="regression")
+        else:
+            dat = cases.classification_data(9, 3000, 40, 4, 200)
+            extra = {}
+        np.random.seed(1234)
+        init = None
+        if kw["unit_sums"]:
+            init = [np.abs(w) / np.sum(np.abs(w)) for w in bn.init_weight_prm(kw["n_nodes"], 40, 4, bias_node=2)]
+        bnn = quiet(bn.npBNN, dat, n_nodes=kw["n_nodes"], use_bias_node=2, actFun=bn.ActFun(fun="tanh"), freq_indicator=kw["freq_indicator"],
+                    feature_indicators=kw["feature_indicators"], w_bound=kw["w_bound"], init_weights=init, **extra)
+        nl = bnn._n_layers
+        mcmc = bn.MCMC(bnn, update_function=kw["update_function"], update_f=[0.003 if kw["update_function"] is bn.UpdateFixedNormal else 0.05] * nl, update_ws=[0.02 if kw["unit_sums"] else 0.05] * nl,
+                       randomize_seed=randomize_seed, mcmc_id=3, n_iteration=1000, adapt_stop=20, **kw["mcmc"])
+        out.append((bnn, mcmc))
+    return out
+
+
+@pytest.mark.parametrize("kind", ["fixed_normal", "normal_normalized", "weight_indicators", "feature_indicators",
+                                  "feature_and_weight_indicators", "regression_sigma_and_features"])
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_run_steps_on_the_general_device_chain_is_the_mh_step_loop(kind, randomize_seed):
+    """UpdateFixedNormal / UpdateNormalNormalized (np_bnn/BNN_mcmc.py:27-42,71-82), weight indicators (BNN_env.py:457-464), feature
+    indicators (:424-433): run_steps builds every candidate in full on the device (npbnn_chain_run_general) and must leave what the
+    same number of mh_step calls leave - weights, indicators and feature indicators exactly, log values to rounding - having
+    consumed the chain's Generator and numpy's global stream identically."""
+    (ba, ma), (bb, mb) = _general_pair(kind, randomize_seed)
+    assert mb._device_mode(bb, 5) == "general"
+    n = 150
+    np.random.seed(77)
+    for _ in range(n):
+        ma.mh_step(ba)
+    state_a = np.random.get_state()[1].copy()
+    np.random.seed(77)
+    mb.SUB_BATCH = 40
+    mb.run_steps(bb, 60)
+    mb.run_steps(bb, n - 60)
+    assert ma._current_iteration == mb._current_iteration == n and mb._device_iterations == n
+    assert ma._last_accepted_mem == mb._last_accepted_mem and sum(ma._last_accepted_mem) >= 2
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(ba._indicators, bb._indicators)
+    if ba._feature_indicators is not None:
+        np.testing.assert_array_equal(ba._feature_indicators, bb._feature_indicators)
+    np.testing.assert_allclose(mb._logLik, ma._logLik, rtol=1e-11)
+    np.testing.assert_allclose(mb._logPrior, ma._logPrior, rtol=1e-11)
+    np.testing.assert_array_equal(np.random.get_state()[1], state_a)
+    np.testing.assert_allclose(mb._accuracy, ma._accuracy, rtol=1e-9)
+    if kind.startswith("regression"):
+        np.testing.assert_array_equal(np.asarray(ba._error_prm, dtype=float), np.asarray(bb._error_prm, dtype=float))

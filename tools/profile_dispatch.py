@@ -17,11 +17,24 @@ bnn, mcmc = workload(int(os.environ.get("NPBNN_CONFIG", "2"))).build()
 mcmc.run_steps(bnn, 3000)
 for _ in range(20):
     mcmc.run_steps(bnn, 100)
+ctx = mcmc._backend.ctx
+c0 = ctx.seconds_in_chain_run
 t0 = time.perf_counter()
 for _ in range(calls):
     mcmc.run_steps(bnn, 100)
 el = time.perf_counter() - t0
-print("run_steps(100): %.1f us per call (%d calls)" % (1e6 * el / calls, calls))
+inside = ctx.seconds_in_chain_run - c0
+print("run_steps(100): %.1f us per call (%d calls): %.1f us inside npbnn_chain_run, %.1f us of Python around it"
+      % (1e6 * el / calls, calls, 1e6 * inside / calls, 1e6 * (el - inside) / calls))
+for n in (1, 3, 10):
+    c0 = ctx.seconds_in_chain_run
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        mcmc.run_steps(bnn, n)
+    el = time.perf_counter() - t0
+    inside = ctx.seconds_in_chain_run - c0
+    print("run_steps(%d): %.1f us per call: %.1f us inside npbnn_chain_run, %.1f us of Python around it"
+          % (n, 1e6 * el / calls, 1e6 * inside / calls, 1e6 * (el - inside) / calls))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(calls):

@@ -8,14 +8,15 @@ step    one chain dispatch = ITERATIONS_PER_STEP (100) Metropolis-Hastings itera
         the end of every step.  With the driver's ``--steps 20 --warmup 5`` that is BASELINE.md's protocol: 500 warm-up
         and 2 000 timed iterations, starting from the freshly initialised chain.  ``value`` = iterations per second.
 config  BASELINE.json config 2 by default (synthetic 100k x 256, 10 classes, hidden [32, 8], tanh, bias nodes in input and
-        hidden layers); ``--config 4`` (1M x 64 regression, [16, 4], empirical sigma) and ``--config 5`` (50k x 512, layer 0 in
-        8 blocks of 64 inputs x 4 nodes, [32, 8]) time those shapes the same way.
+        hidden layers) - the line's ``value``; the same run then times config 4 (1M x 64 regression, [16, 4], empirical sigma)
+        and config 5 (50k x 512, layer 0 in 8 blocks of 64 inputs x 4 nodes, [32, 8]) the same way and reports them under
+        ``other_configs`` (``--only`` skips that; ``--config 4`` / ``--config 5`` make one of them the line's subject).
 N GPUs  ``--gpus N``: N chains, one per GPU, MC3 layout (config 3; weak scaling); every step ends with the temperature-swap
         proposal (np_bnn/BNN_mc3.py:98-112), whose only exchange is an all-gather of [logPost, temperature] per chain over
         RCCL.  Launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) - or by this script
         itself: without WORLD_SIZE it starts the N rank processes before anything touches a GPU and relays rank 0's line.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--no-cpu-baseline]
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--only] [--no-cpu-baseline]
 """
 import argparse
 import csv
@@ -42,6 +43,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only", action="store_true", help="the named config alone: without the other single-GPU configurations that the "
+                                                         "default run (config 2) adds under other_configs")
     return ap.parse_args()
 
 
@@ -207,7 +210,10 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
-    mcmc._backend.close()
+    try:
+        mcmc._backend.close()
+    except Exception:       # noqa: BLE001 - (already closed by the report)
+        pass
 
 
 def make_comm(dist_backend, rank, world, local_rank, device_index):
@@ -229,29 +235,145 @@ def make_comm(dist_backend, rank, world, local_rank, device_index):
     return TorchDistComm(), "%s (torch.distributed), %d ranks" % ("rccl" if dist_backend == "nccl" else dist_backend, world)
 
 
+SCHEDULES = {1: "serial: evaluate a pass, decide it, evaluate the next",
+             2: "overlapped: the launch that evaluates pass L also decides pass L-1 (one workgroup); a pass overtaken by an "
+                "accept is dropped and re-evaluated",
+             3: "overlapped, launches alternating between two streams (opt-in)",
+             4: "overlapped, persistent: one launch per batch round, its workgroups loop over the passes (a workgroup that is "
+                "through with pass L starts pass L+1), device-side flags order what kernel boundaries used to; bounded waits, "
+                "falls back to (2) on a time-out",
+             5: "persistent launch with the decision between the passes: the step workgroup prepares the next pass for every outcome "
+                "of the pass in flight, then decides it and raises a flag; no pass is evaluated in vain"}
+
+
+def profiled_kernel_ms(config, cand):
+    """Mean duration (ms) of the pass kernel with ``cand`` candidates in the newest rocprofv3 --kernel-trace --stats summary under
+    profiles/ for this config, or (None, reason)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg%d_pass%d_kernel_stats.csv" % (config, cand))), reverse=True)
+    for path in files:
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                m = re.search(r"eval_kernel<\d+, \d+, \w+, (\d+),", row.get("Name", "") or row.get("Kernel_Name", ""))
+                if m and int(m.group(1)) == cand:
+                    for key in ("AverageNs", "Average", "AverageDuration"):
+                        if row.get(key):
+                            return float(row[key]) * 1e-6, os.path.relpath(path, ROOT)
+    return None, "no profiles/*_cfg%d_pass%d_kernel_stats.csv" % (config, cand)
+
+
+def kernel_roofline(config, wl, ctx, bnn, mcmc, useful=None):
+    """The dominant kernel of a chain - the pass kernel: one launch streams X once and evaluates ``cand`` proposals against it -
+    timed live with HIP events on the chain's stream (npbnn_time_pass), priced with the HBM bytes the PMC passes under profiles/
+    recorded for it."""
+    ms_kernel, cand = ctx.time_pass(bnn._w_layers, n_candidates=mcmc.n_candidates, iters=200)
+    ms_single, _ = ctx.time_eval(bnn._w_layers, iters=200)
+    l0 = ctx.l0_mode()
+    alg = wl.bytes_per_proposal
+    traffic, traffic_src = measured_traffic(config, cand)
+    physical = traffic if traffic is not None else alg          # (no counter file: one read of X is the model)
+    achieved = physical / (ms_kernel * 1e-3)
+    ms_prof, prof_src = profiled_kernel_ms(config, cand)
+    out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK,
+           "frac_live": achieved / HBM_PEAK,
+           "frac_profiles": (physical / (ms_prof * 1e-3) / HBM_PEAK) if ms_prof else None,
+           "kernel_ms_profiles": ms_prof, "kernel_ms_profiles_source": prof_src,
+           "traffic": traffic, "traffic_source": traffic_src,
+           "traffic_note": "a RECORDED measurement (separate rocprofv3 --pmc passes of the round the file name carries), not re-measured "
+                           "by this run; kernel_ms is measured live",
+           "kernel": wl.kernel_name(ctx, cand), "kernel_ms": ms_kernel,
+           "note": "achieved = HBM bytes one launch moves (the PMC traffic; one streaming read of X whatever the number of "
+                   "candidates) / its mean duration: the share of the HBM peak the kernel really uses.  The reference reads "
+                   "X once PER PROPOSAL; that byte model (SURVEY 8d) is under algorithmic_equivalent",
+           "algorithmic_equivalent": {"proposals_per_launch": cand, "bytes_per_proposal": alg,
+                                      "GBps": alg * cand / (ms_kernel * 1e-3) / 1e9,
+                                      "x_hbm_peak": alg * cand / (ms_kernel * 1e-3) / HBM_PEAK},
+           "single_candidate_kernel_ms": ms_single,
+           "single_candidate_frac": alg / (ms_single * 1e-3) / HBM_PEAK}
+    if useful is not None:
+        out["useful_iterations_per_launch"] = useful
+    if l0 == "f16-split":        # the same launches with layer 0 on float32 matrix cores (bit-exact float32 products)
+        try:
+            ctx.set_l0_precision("f32")
+            ms32, cand32 = ctx.time_pass(bnn._w_layers, n_candidates=mcmc.n_candidates, iters=100)
+            ms32_single, _ = ctx.time_eval(bnn._w_layers, iters=100)
+            out["f32_path"] = {"kernel_ms": ms32, "candidates": cand32, "frac": physical / (ms32 * 1e-3) / HBM_PEAK,
+                               "single_candidate_kernel_ms": ms32_single, "single_candidate_frac": alg / (ms32_single * 1e-3) / HBM_PEAK,
+                               "note": "NPBNN_L0=f32: v_mfma_f32_16x16x4_f32 for layer 0 instead of three fp16 products per term"}
+        finally:
+            ctx.set_l0_precision("auto")
+            ctx.time_eval(bnn._w_layers, iters=1)      # (back on the default layout before the chain goes on)
+    return out, cand
+
+
+def moving_chain(wl):
+    """A chain that moves: the same model with proposals small enough that about a quarter of them is accepted (the reference
+    drivers adapt towards 0.2-0.4: adapt_f / adapt_fM, np_bnn/BNN_env.py:392-413)."""
+    if wl.moving_update_f is None:
+        return None
+    bnn_q, mcmc_q = wl.build(update_f=list(wl.moving_update_f))
+    mcmc_q.run_steps(bnn_q, 2000)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        mcmc_q.run_steps(bnn_q, ITERATIONS_PER_STEP)
+    el4 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mcmc_q.run_steps(bnn_q, 4000)
+    el5 = time.perf_counter() - t0
+    out = {"value": 20 * ITERATIONS_PER_STEP / el4, "unit": "iterations/s", "one_call_of_4000": 4000 / el5,
+           "accept_rate_last_100": float(mcmc_q._acceptance_rate),
+           "accept_rate": float(mcmc_q._device_accepted) / max(1, mcmc_q._device_iterations),
+           "schedule": int(mcmc_q._device_schedule_used),
+           "iterations_per_pass": mcmc_q._device_iterations / max(1, mcmc_q._device_passes),
+           "note": "20 dispatches of %d iterations after 2000 of warm-up, then one call of 4000; update_f = %s"
+                   % (ITERATIONS_PER_STEP, list(wl.moving_update_f))}
+    mcmc_q._backend.close()
+    return out
+
+
+def other_config(args, config):
+    """BASELINE.json's other single-GPU configurations, timed the way the headline is (same step, same warm-up, from the freshly
+    initialised chain) so that the driver's run covers them."""
+    from bench_support import workload
+    wl = workload(config)
+    bnn, mcmc = wl.build()
+    for _ in range(args.warmup):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    book = dict(acc=mcmc._device_accepted, passes=mcmc._device_passes, voids=mcmc._device_void_passes, its=mcmc._device_iterations)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    el = time.perf_counter() - t0
+    passes = max(1, mcmc._device_passes - book["passes"])
+    voids = mcmc._device_void_passes - book["voids"]
+    done = mcmc._device_iterations - book["its"]
+    roof, cand = kernel_roofline(config, wl, mcmc._backend.ctx, bnn, mcmc, useful=done / (passes + voids))
+    out = {"workload": wl.description, "value": args.steps * ITERATIONS_PER_STEP / el, "unit": "iterations/s",
+           "ms_per_step": 1e3 * el / args.steps, "roofline_it_per_s_one_read_per_proposal": HBM_PEAK / wl.bytes_per_proposal,
+           "accept_rate": float(mcmc._device_accepted - book["acc"]) / max(1, done), "iterations_per_pass": done / passes,
+           "schedule": int(mcmc._device_schedule_used), "candidates_per_pass": cand, "layer0": mcmc._backend.ctx.l0_mode(),
+           "roofline": roof, "parity": wl.parity(bnn, mcmc)}
+    t0 = time.perf_counter()
+    mcmc.run_steps(bnn, 4000)
+    out["one_call_of_4000"] = 4000 / (time.perf_counter() - t0)
+    mcmc._backend.close()
+    mv = moving_chain(wl)
+    if mv is not None:
+        out["moving_chain"] = mv
+    return out
+
+
 def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, device_swaps):
     from npbnn_amd import _capi as capi
     ctx = mcmc._backend.ctx
-    # dominant kernel: the evaluation kernel of a chain pass.  One launch streams X once and evaluates `cand` proposals
-    # against it (speculative Metropolis-Hastings: iteration t and t+1.. assuming the earlier ones are rejected; the step
-    # stops at the first accept, so the chain is the sequential one).  Timed here with HIP events on the chain's stream.
-    ms_kernel, cand = ctx.time_pass(bnn._w_layers, n_candidates=mcmc.n_candidates, iters=200)
-    ms_single, _ = ctx.time_eval(bnn._w_layers, iters=200)
-    alg = wl.bytes_per_proposal
-    traffic, traffic_src = measured_traffic(args.config, cand)
-    physical = traffic if traffic is not None else alg          # (no counter file: one read of X is the model)
-    achieved = physical / (ms_kernel * 1e-3)
     passes = max(1, mcmc._device_passes - book["passes"])
     voids = mcmc._device_void_passes - book["voids"]
     done = mcmc._device_iterations - book["its"]
     used = getattr(mcmc, "_device_schedule_used", 0)
-    schedule = {1: "serial: evaluate a pass, decide it, evaluate the next",
-                2: "overlapped: the launch that evaluates pass L also decides pass L-1 (one workgroup); a pass overtaken by an "
-                   "accept is dropped and re-evaluated",
-                3: "overlapped, launches alternating between two streams (opt-in)",
-                4: "overlapped, persistent: one launch per batch round, its workgroups loop over the passes (a workgroup that is "
-                   "through with pass L starts pass L+1), device-side flags order what kernel boundaries used to; bounded waits, "
-                   "falls back to (2) on a time-out"}.get(used, "host loop")
+    accept_rate = float(mcmc._device_accepted - book["acc"]) / max(1, done)
+    accept_last = float(mcmc._acceptance_rate)
+    loglik = float(mcmc._logLik)
+    roof, cand = kernel_roofline(args.config, wl, ctx, bnn, mcmc, useful=done / (passes + voids))
     line = {
         "metric": "MCMC iterations/sec (full fwd+lik per proposal)",
         "value": world * its / el,
@@ -263,7 +385,10 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f16x3-split/f32" if ctx.l0_mode() == "f16-split" else "f32",
+        "dtype_note": "layer 0 (and layer 1 of tanh networks) as three fp16 matrix-core products per term on hi/lo pairs of the float32 "
+                      "operands (~22 significant bits), float32 accumulation; later layers and the likelihood terms float32; every "
+                      "cross-row sum float64.  roofline.f32_path: the same kernel with float32 matrix cores",
         "data": "synthetic",
         "config": {"workload": wl.description + "; one chain per GPU",
                    "step": "%d Metropolis-Hastings iterations of every chain (one MC3 chain dispatch, np_bnn/BNN_mc3.py:80-85), state "
@@ -276,24 +401,12 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                                           else "host: one device batch per interval, all-gather of [logPost, temperature] and decision on the host"),
                    "layer0": ctx.l0_mode(), "fast_tails": bool(ctx.info(capi.INFO_FAST_TAILS)),
                    "loop": "device-resident chain (npbnn_chain_run), proposals pre-drawn on the host",
-                   "candidates_per_pass": cand, "iterations_per_pass": done / passes, "schedule": schedule,
+                   "candidates_per_pass": cand, "iterations_per_pass": done / passes, "schedule": SCHEDULES.get(used, "host loop"),
                    "void_pass_fraction": voids / (passes + voids)},
-        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": wl.kernel_name(ctx, cand), "kernel_ms": ms_kernel,
-                     "note": "achieved = HBM bytes one launch moves (the PMC traffic; one streaming read of X whatever the number of "
-                             "candidates) / its mean duration: the share of the HBM peak the kernel really uses.  The reference reads "
-                             "X once PER PROPOSAL; that byte model (SURVEY 8d) is under algorithmic_equivalent",
-                     "algorithmic_equivalent": {"proposals_per_launch": cand, "bytes_per_proposal": alg,
-                                                "GBps": alg * cand / (ms_kernel * 1e-3) / 1e9,
-                                                "x_hbm_peak": alg * cand / (ms_kernel * 1e-3) / HBM_PEAK},
-                     "single_candidate_kernel_ms": ms_single,
-                     "single_candidate_frac": alg / (ms_single * 1e-3) / HBM_PEAK,
-                     "useful_iterations_per_launch": done / (passes + voids)},
-        "accept_rate": float(mcmc._device_accepted - book["acc"]) / max(1, done),          # rank 0, timed region
-        "accept_rate_last_100": float(mcmc._acceptance_rate),
-        "loglik": float(mcmc._logLik),
+        "roofline": roof,
+        "accept_rate": accept_rate,          # rank 0, timed region
+        "accept_rate_last_100": accept_last,
+        "loglik": loglik,
         "schedule_timeouts": int(ctx.sync_fallbacks),
         "torch_imported": "torch" in sys.modules,
     }
@@ -301,7 +414,6 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
         line["cpu_baseline"] = cpu_baseline(wl)
         line["parity"] = wl.parity(bnn, mcmc)
         # the same chain once it has settled (acceptance of the default proposal falls to a few per cent): steady-state rate
-        t0 = time.perf_counter()
         n_more = 40
         mcmc.run_steps(bnn, 3000)
         t0 = time.perf_counter()
@@ -312,30 +424,31 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                                  "after_iterations": int(mcmc._current_iteration), "accept_rate_last_100": float(mcmc._acceptance_rate),
                                  "note": "same dispatches of %d iterations, measured after 3000 further iterations" % ITERATIONS_PER_STEP}
         # what a dispatch costs beyond its iterations: the same chain in ONE call of 10 000 iterations against the dispatches above
+        c0 = ctx.seconds_in_chain_run
+        t0 = time.perf_counter()
+        for _ in range(n_more):
+            mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+        el2b = time.perf_counter() - t0
+        inside = ctx.seconds_in_chain_run - c0
         t0 = time.perf_counter()
         mcmc.run_steps(bnn, 10000)
         el3 = time.perf_counter() - t0
         line["call_cost"] = {"long_call_iterations_per_s": 10000 / el3, "us_per_iteration_in_a_long_call": 1e2 * el3,
                              "us_per_dispatch_of_%d" % ITERATIONS_PER_STEP: 1e6 * el2 / n_more,
                              "us_fixed_per_dispatch": 1e6 * el2 / n_more - ITERATIONS_PER_STEP * 1e2 * el3,
+                             "us_of_python_per_dispatch": 1e6 * (el2b - inside) / n_more,
                              "note": "upload of state and draws, first step kernel (full prior re-sum), result copy, synchronisation, host Python"}
-        # and a chain that moves: the same model with proposals small enough that about a quarter of them is accepted (the
-        # reference drivers adapt towards 0.2-0.4: adapt_f / adapt_fM, np_bnn/BNN_env.py:392-413)
-        if wl.moving_update_f is not None:
-            bnn_q, mcmc_q = wl.build(update_f=list(wl.moving_update_f))
-            mcmc_q.run_steps(bnn_q, 2000)
-            t0 = time.perf_counter()
-            for _ in range(20):
-                mcmc_q.run_steps(bnn_q, ITERATIONS_PER_STEP)
-            el4 = time.perf_counter() - t0
-            line["moving_chain"] = {"value": 20 * ITERATIONS_PER_STEP / el4, "unit": "iterations/s",
-                                    "accept_rate_last_100": float(mcmc_q._acceptance_rate),
-                                    "accept_rate": float(mcmc_q._device_accepted) / max(1, mcmc_q._device_iterations),
-                                    "schedule": int(mcmc_q._device_schedule_used),
-                                    "iterations_per_pass": mcmc_q._device_iterations / max(1, mcmc_q._device_passes),
-                                    "note": "20 dispatches of %d iterations after 2000 of warm-up, update_f = %s"
-                                            % (ITERATIONS_PER_STEP, list(wl.moving_update_f))}
-            mcmc_q._backend.close()
+        mv = moving_chain(wl)
+        if mv is not None:
+            line["moving_chain"] = mv
+        if args.config == 2 and not args.only:          # the other single-GPU configurations of BASELINE.json, in the same run
+            mcmc._backend.close()
+            line["other_configs"] = {}
+            for cfg in (4, 5):
+                try:
+                    line["other_configs"]["config %d" % cfg] = other_config(args, cfg)
+                except Exception as e:        # noqa: BLE001 - the headline must not be lost to a side measurement
+                    line["other_configs"]["config %d" % cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
     else:
         line["cpu_baseline"] = None
     return line

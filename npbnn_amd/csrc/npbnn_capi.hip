@@ -345,7 +345,7 @@ bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d) {
 }
 
 // lik_only: the caller wants the likelihood terms and nothing else from the launch (no statistics, no predictions)
-int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int want_cand, bool predict_only, bool lik_only) {
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int want_cand, bool predict_only, bool lik_only, bool plain) {
     Dataset& d = ctx->ds[which];
     bool want_f16 = false;
     if (!force_f32 && ctx->l0_option != NPBNN_L0_F32) {
@@ -380,7 +380,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
     lp->fn = predict_only ? npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand, kLikCat)
                           : npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand,
-                                                   lik_class(ctx->net.lik_kind), fast, fast && l0_blocked(ctx->net));
+                                                   lik_class(ctx->net.lik_kind), fast, fast && l0_blocked(ctx->net), plain && fast);
     if (!lp->fn) return fail(ctx, NPBNN_E_STATE, "no evaluation kernel for this shape (internal error)");
     lp->wpb = wpb;
     lp->lds = lds;
@@ -874,7 +874,7 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     const int lik = ctx->net.lik_kind;
     Dataset& d = ctx->ds[which];
     LaunchPlan lp;
-    int rc = plan_launch(ctx, which, &lp, force_f32, 1, false, confusion == nullptr);
+    int rc = plan_launch(ctx, which, &lp, force_f32, 1, false, confusion == nullptr, true);
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;
@@ -1196,7 +1196,7 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchPlan lp;
-    rc = plan_launch(ctx, 0, &lp, 0, 1, false, true);
+    rc = plan_launch(ctx, 0, &lp, 0, 1, false, true, true);      // (the build npbnn_eval runs)
     if (rc) return rc;
     rc = ensure_work_buffers(ctx, lp.n_waves);
     if (rc) return rc;

@@ -256,6 +256,7 @@ __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 d
 // prior with one scale per layer (the default) is two multiplies and a subtraction; everything else (Cauchy, Laplace, a scale per
 // weight) goes through a function of its own: its logarithms would otherwise be expanded at every call site.
 __device__ __attribute__((noinline)) double prior_delta_general(int kind, double v, double b, double sc) { return prior_delta(kind, v, b, sc); }
+template <bool OUT_OF_LINE>
 __device__ __forceinline__ double spec_entry(double w_bound, int prior_kind, bool per_weight_scale, double base, double d, double m, double scale_w,
                                              double his, double lsc, double& dlp) {
 #pragma clang fp contract(off)      // (no fused multiply-adds: the same bits wherever this is inlined)
@@ -264,9 +265,11 @@ __device__ __forceinline__ double spec_entry(double w_bound, int prior_kind, boo
     if (v < -w_bound) v = -w_bound + (-w_bound - v);
     v *= m;
     if (prior_kind != NPBNN_PRIOR_UNIFORM) {
-        if (per_weight_scale) dlp += prior_delta_general(prior_kind, v, base, scale_w);
+        // (OUT_OF_LINE: spec_rounds, which has two dozen call sites; chain_step, inlined into every evaluation kernel, keeps its one
+        // site inline - a call inside a kernel costs the kernel's whole body registers.  Same arithmetic either way.)
+        if (per_weight_scale) dlp += OUT_OF_LINE ? prior_delta_general(prior_kind, v, base, scale_w) : prior_delta(prior_kind, v, base, scale_w);
         else if (prior_kind == NPBNN_PRIOR_NORMAL) dlp -= (v * v - base * base) * his;
-        else dlp += prior_delta_general(prior_kind, v, base, lsc);
+        else dlp += OUT_OF_LINE ? prior_delta_general(prior_kind, v, base, lsc) : prior_delta(prior_kind, v, base, lsc);
     }
     return v;
 }
@@ -569,7 +572,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 his = past ? half_inv_s2[q] : his;
                 lsc = past ? layer_scale[q] : lsc;
             }
-            const double v = spec_entry(c.w_bound, c.prior_kind, c.prior_scale_w != nullptr, base, d, m, scale_w, his, lsc, dlp[j]);
+            const double v = spec_entry<false>(c.w_bound, c.prior_kind, c.prior_scale_w != nullptr, base, d, m, scale_w, his, lsc, dlp[j]);
             pv_out[(size_t)j * c.M + e] = v;
             if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
         };
@@ -896,17 +899,44 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
             for (int k = 0; k < kMaxCand; ++k) dlp[o][k] = 0.0;
         if (tid < kSpecOutcomes) sp.ovf[tid] = 0;
 
+        // ---- A. touch tables of the candidates in flight: weight -> the value candidate j gives it, tagged with this pass.  ALL of a
+        //      candidate's entries go in before anything is looked up (a proposal may be wider than the workgroup) ----
+        for (int e0 = 0; e0 < M; e0 += nthr) {
+            const int e = e0 + tid;
+            const bool ev = e < M;
+            int ti[kMaxCand];
+            double tv[kMaxCand];
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                const bool v = ev && j < n_pend;
+                ti[j] = g_idx[v ? (size_t)(t0 + j) * M + e : 0];
+                tv[j] = pvP[(size_t)j * M + (ev ? e : 0)];
+                if (!v) ti[j] = -1;
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j)
+                if (ti[j] >= 0) {
+                    u32x4 rec;
+                    rec[0] = gen;
+                    rec[1] = 0u;
+                    rec[2] = (unsigned)__double2loint(tv[j]);
+                    rec[3] = (unsigned)__double2hiint(tv[j]);
+                    g_touch[(size_t)j * nws + ti[j]] = rec;
+                }
+        }
+        __syncthreads();
+        NPBNN_SPEC_TICK(0);
         for (int e0 = 0; e0 < M; e0 += nthr) {            // (one trip unless a proposal is wider than the workgroup)
             const int e = e0 + tid;
             const bool ev = e < M;
-            // ---- stage 1: the pre-drawn entries of rows t0 .. t0+kSpecRows (row r = iteration t0 + r; entries past a row's count
-            //      are -1, as the pre-draw leaves them), and the values of the candidates in flight ----
+            // ---- stage 1: the pre-drawn entries of rows t0+1 .. (row r = iteration t0 + r; entries past a row's count are -1, as
+            //      the pre-draw leaves them) ----
             int ri[kSpecRows], rpos[kSpecRows];
             double rd[kSpecRows];
             float rsc[kSpecRows];
-            double pvj[kMaxCand];
+            ri[0] = -1; rpos[0] = 0; rd[0] = 0.0; rsc[0] = 1.0f;
 #pragma unroll
-            for (int r = 0; r < kSpecRows; ++r) {
+            for (int r = 1; r < kSpecRows; ++r) {
                 const int t = t0 + r;
                 const bool rowv = ev && r < n_pend + D && t < K && (r < n_pend || t < lim);
                 const size_t k = rowv ? (size_t)t * M + e : 0;
@@ -917,26 +947,12 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
                 if (!rowv) ri[r] = -1;
             }
 #pragma unroll
-            for (int j = 0; j < kMaxCand; ++j) pvj[j] = pvP[(size_t)j * M + (ev ? e : 0)];
-#pragma unroll
-            for (int r = 0; r < kSpecRows; ++r)
+            for (int r = 1; r < kSpecRows; ++r)
                 if (!has_sc) rsc[r] = 1.0f;
-            // ---- A. touch tables of the candidates in flight: weight -> the value candidate j gives it, tagged with this pass ----
-#pragma unroll
-            for (int j = 0; j < kMaxCand; ++j)
-                if (j < n_pend && ri[j] >= 0) {
-                    u32x4 rec;
-                    rec[0] = gen;
-                    rec[1] = 0u;
-                    rec[2] = (unsigned)__double2loint(pvj[j]);
-                    rec[3] = (unsigned)__double2hiint(pvj[j]);
-                    g_touch[(size_t)j * nws + ri[j]] = rec;
-                }
-            __syncthreads();
-            if (e0 == 0) NPBNN_SPEC_TICK(0);
             // ---- stage 2: what the entries of rows 1.. touch; candidate j accepted = outcome j + 1, which takes rows j+1 .. j+D: its
             //      k-th candidate's entry looks itself up in candidate j's table ----
             double rb[kSpecRows], rm[kSpecRows], rsw[kSpecRows];
+            rb[0] = 0.0; rm[0] = 1.0; rsw[0] = 0.0;
             u32x4 rt[kMaxCand][kMaxCand];
             double rp[kMaxCand][kMaxCand];
 #pragma unroll
@@ -985,11 +1001,11 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
                     const double his = rsw[rr], lsc = rsw[rr];       // (whichever the prior takes: see prw_p)
                     const bool in16 = rpos[rr] < 0;
                     const double sc = (double)rsc[rr];
-                    const double v = spec_entry(w_bound, prior_kind, !fast_prior && has_psw, rp[o - 1][k], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[o][k]);
+                    const double v = spec_entry<true>(w_bound, prior_kind, !fast_prior && has_psw, rp[o - 1][k], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[o][k]);
                     __hip_atomic_store(pvN + ((size_t)o * kMaxCand + k) * M + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (write-through: nothing to flush at the flag)
                     if (in16 && !(fabs(v * sc) <= (double)kF16Safe)) atomicOr(&sp.ovf[o], 1);
                     if (o == n_pend) {          // the same rows on the unchanged state: outcome 0
-                        const double v0 = spec_entry(w_bound, prior_kind, !fast_prior && has_psw, rb[rr], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[0][k]);
+                        const double v0 = spec_entry<true>(w_bound, prior_kind, !fast_prior && has_psw, rb[rr], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[0][k]);
                         __hip_atomic_store(pvN + ((size_t)k) * M + e, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (in16 && !(fabs(v0 * sc) <= (double)kF16Safe)) atomicOr(&sp.ovf[0], 1);
                     }

@@ -100,8 +100,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         // acceptance 63 % of the passes do), and on kernel boundaries a decision between two passes costs a step kernel and two
         // boundaries.  The persistent launch with the decision between the passes (NPBNN_SCHED_PERSIST_SERIAL) wastes no pass and
         // decides in a few microseconds: above kPersistSerialAccept of the proposals accepted it leads (measured).
+        // (its step workgroup must keep pace with the evaluation: with proposals much wider than a few hundred weights it does not)
         if (alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option && p_acc > kPersistSerialAccept && group_blocks == 0 &&
-            !cfg->slope_idx)
+            !cfg->slope_idx && M <= kPersistSerialMaxWidth)
             schedule = NPBNN_SCHED_PERSIST_SERIAL;
     }
     if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;

@@ -32,6 +32,8 @@ eval_fn_t pick_eval_d3_cat(int mt0, int f16);
 eval_fn_t pick_eval_d3_gauss(int mt0, int f16);
 // the fast builds (eval_kernel<..., FAST = true>): nullptr where there is none (more than kFastMaxMT0 tiles in layer 0)
 eval_fn_t pick_eval_d1_cat_fast(int mt0, int f16);
+eval_fn_t pick_eval_d1_cat_plain(int mt0, int f16);      // (plain evaluations: no chain pass)
+eval_fn_t pick_eval_d1_gauss_plain(int mt0, int f16);
 eval_fn_t pick_eval_d1_gauss_fast(int mt0, int f16);
 eval_fn_t pick_eval_d2_cat_fast(int mt0, int f16);
 eval_fn_t pick_eval_d2_gauss_fast(int mt0, int f16);
@@ -40,11 +42,12 @@ eval_fn_t pick_eval_d3_gauss_fast(int mt0, int f16);
 }
 
 // lk: likelihood class of the build (npbnn::lik_class); the float64 row-wise class has single-candidate builds only
-static inline eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk, bool fast = false, bool blocked = false) {
+static inline eval_fn_t npbnn_pick_eval_kernel(int mt0, int mti, int f16, int n_cand, int lk, bool fast = false, bool blocked = false, bool plain = false) {
     using namespace npbnn;
     if (fast) {
         const bool g = lk == kLikGauss;
         if (blocked) f16 = 2;                 // (fast_launch_ok: block structure only on the fp16-split path)
+        if (n_cand <= 1 && plain) return g ? pick_eval_d1_gauss_plain(mt0, f16) : pick_eval_d1_cat_plain(mt0, f16);
         if (n_cand <= 1) return g ? pick_eval_d1_gauss_fast(mt0, f16) : pick_eval_d1_cat_fast(mt0, f16);
         if (n_cand == 2) return g ? pick_eval_d2_gauss_fast(mt0, f16) : pick_eval_d2_cat_fast(mt0, f16);
         return g ? pick_eval_d3_gauss_fast(mt0, f16) : pick_eval_d3_cat_fast(mt0, f16);
@@ -195,6 +198,7 @@ static_assert(sizeof(EvalParams) % 8 == 0 && sizeof(FinalizeParams) % 8 == 0, "p
 namespace npbnn_api {
 
 constexpr double kPersistSerialAccept = 0.07;   // NPBNN_SCHED_AUTO: acceptance rate above which the persistent launch decides between the passes
+constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 
 int fail(npbnn_ctx* ctx, int code, const char* fmt, ...);
@@ -226,7 +230,9 @@ int rebuild_net(npbnn_ctx* ctx, bool f16);
 bool l0_blocked(const NetMeta& net);
 bool fast_launch_ok(const npbnn_ctx* ctx, const Dataset& d);
 // lik_only: the caller wants the likelihood terms and nothing else from the launch (no statistics, no predictions)
-int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false, bool lik_only = false);
+// plain: the launch is a plain evaluation - no pass descriptor, no chain (the builds without that code)
+int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32 = 0, int want_cand = 1, bool predict_only = false, bool lik_only = false,
+                bool plain = false);
 int ensure_work_buffers(npbnn_ctx* ctx, int n_waves);
 int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const double* col_override);
 int push_eval_params(npbnn_ctx* ctx, const EvalParams& p);

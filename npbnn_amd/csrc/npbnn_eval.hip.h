@@ -433,8 +433,11 @@ __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int 
 // BLK (fast builds only): layer 0 has a block structure (NetMeta::l0_begin ...) and the loop skips the (K-unit, tile) pairs
 // without weights; the fast builds without it are for dense first layers and carry no test for it.  The general builds always
 // honour the structure.
-template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false, bool BLK = false>
+// CHAIN = false: the build for plain evaluations (npbnn_eval: MCMC.__init__, mh_step, statistics) - no pass descriptor, no patch
+// lists, no step workgroup, no device-side waits: none of that code, and none of the registers it keeps alive, is in the kernel.
+template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false, bool BLK = false, bool CHAIN = true>
 __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg, int n_loop) {
+    static_assert(CHAIN || D == 1, "plain builds evaluate one weight set");
     static_assert(!FAST || (MTI == 1 && LK != kLikGen), "fast builds: narrow later layers, categorical or Gaussian likelihood");
     static_assert(!BLK || (FAST && MT0 >= 2), "block-structure builds are fast builds of layers with several output tiles");
     constexpr bool SKIP = !FAST || BLK;          // this build tests which tiles have weights in a K-unit
@@ -458,8 +461,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
-    const ChainParams* const chain = uni(p.chain);
-    const int GN = D > 1 ? uni(p.group_n) : 0;          // group pass: candidate j belongs to chain j, whose step runs in workgroup G + j
+    const ChainParams* const chain = CHAIN ? uni(p.chain) : nullptr;
+    const int GN = (CHAIN && D > 1) ? uni(p.group_n) : 0;          // group pass: candidate j belongs to chain j, whose step runs in workgroup G + j
     const int G = (int)gridDim.x - (GN ? GN : chain ? 1 : 0);     // workgroups that evaluate
     if (GN && bid >= G) {
         StepShared& sh = *reinterpret_cast<StepShared*>(smem);
@@ -644,7 +647,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // depend on changes at the hand-over - the global image is only written right AFTER a flag, and the pass applies the accepted
     // candidate's entries to its LDS copies itself - so both are requested BEFORE the wait for the step workgroup's flag and have
     // landed when it comes.  Everywhere else the image is committed before the flag: copy after it.
-    const bool early_copy = uni(p.sync_mode) == 3;
+#ifdef NPBNN_EXP_NO_EARLY
+    constexpr bool early_copy = false;
+#else
+    const bool early_copy = CHAIN && uni(p.sync_mode) == 3;
+#endif
     if (early_copy) {
         stage_images();
         for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
@@ -661,7 +668,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int t0g[D];                    // group pass: the iteration each chain's candidate belongs to
 #pragma unroll
     for (int j = 0; j < D; ++j) { cnt[j] = 0; t0g[j] = 0; }
-    const PassDesc* const pass = uni(p.has_pass) ? &p.pass_desc[par] : nullptr;
+    const PassDesc* const pass = (CHAIN && uni(p.has_pass)) ? &p.pass_desc[par] : nullptr;
     int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
     // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
     if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
@@ -757,6 +764,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int apos = kSkipPos;
     double aval = 0.0;
     float asc = 1.0f;
+#ifdef NPBNN_EXP_NO_EARLY
+    acc_cnt = 0;
+#endif
     if (acc_cnt > 0 && tid < acc_cnt) {       // the accepted iteration is the one before this pass's first
         const size_t arow = (size_t)(t0 - 1) * M;
         apos = g_pos[arow + tid];

@@ -511,3 +511,24 @@ def test_run_steps_on_the_general_device_chain_is_the_mh_step_loop(kind, randomi
     np.testing.assert_allclose(mb._accuracy, ma._accuracy, rtol=1e-9)
     if kind.startswith("regression"):
         np.testing.assert_array_equal(np.asarray(ba._error_prm, dtype=float), np.asarray(bb._error_prm, dtype=float))
+
+
+def test_proposals_wider_than_the_workgroup_on_every_schedule():
+    """More perturbed weights per iteration than the evaluation kernel has threads (two or three trips through every patch loop,
+    in the evaluating workgroups and in the step): all schedules give the chain of the serial one."""
+    cfg = dict(cases.TRACES["cfg1"], n_nodes=[32, 8], n_rows=3000)
+    out = []
+    for sched in (1, 2, 4, 5):
+        bnn, mcmc = build(cfg, update_f=[0.5, 0.5, 0.5], update_ws=[0.001] * 3, adapt_f=0, adapt_fM=1)
+        assert int(sum(mcmc._update_n)) > 2048
+        mcmc.device_schedule = sched
+        mcmc.run_steps(bnn, 120)
+        out.append((bnn, mcmc))
+    b1, m1 = out[0]
+    assert 5 < sum(m1._last_accepted_mem) < 110
+    for b, m in out[1:]:
+        assert m._backend.ctx.sync_fallbacks == 0
+        assert m._last_accepted_mem == m1._last_accepted_mem
+        assert (m._logLik, m._logPrior) == (m1._logLik, m1._logPrior)
+        for wa, wb in zip(b1._w_layers, b._w_layers):
+            np.testing.assert_array_equal(wa, wb)

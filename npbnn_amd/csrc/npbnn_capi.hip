@@ -382,6 +382,13 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
                           : npbnn_pick_eval_kernel(ctx->net.L[0].mt, max_inner_tiles(ctx->net) == 1 ? 1 : 8, ctx->net.l0_f16, n_cand,
                                                    lik_class(ctx->net.lik_kind), fast, fast && l0_blocked(ctx->net), plain && fast);
     if (!lp->fn) return fail(ctx, NPBNN_E_STATE, "no evaluation kernel for this shape (internal error)");
+    lp->fn_spec = nullptr;
+    if (fast && !plain && !predict_only && !l0_blocked(ctx->net) && (n_cand == 1 || n_cand == 3)) {
+        const bool g = lik_class(ctx->net.lik_kind) == kLikGauss;
+        const int mt0 = ctx->net.L[0].mt, f16 = ctx->net.l0_f16;
+        lp->fn_spec = n_cand == 1 ? (g ? pick_eval_d1_gauss_spec(mt0, f16) : pick_eval_d1_cat_spec(mt0, f16))
+                                  : (g ? pick_eval_d3_gauss_spec(mt0, f16) : pick_eval_d3_cat_spec(mt0, f16));
+    }
     lp->wpb = wpb;
     lp->lds = lds;
     int grid = (d.n_tiles + wpb - 1) / wpb;
@@ -392,6 +399,8 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
     lp->lds = lds + 64;            // (+ the flag word of the device-side waits, behind the images and the rings)
     if (ctx->attr_fn != reinterpret_cast<const void*>(lp->fn) || ctx->attr_lds < lp->lds) {      // (not free: once per kernel and size)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp->lds));
+        if (lp->fn_spec)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lp->fn_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp->lds));
         ctx->attr_fn = reinterpret_cast<const void*>(lp->fn);
         ctx->attr_lds = lp->lds;
     }
@@ -596,7 +605,7 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_spec, c->d_spec_pv, c->d_spec_touch, c->d_spec_tval, c->d_spec_prw, c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta};
+    void* chain_bufs[] = {c->d_spec, c->d_spec_pv, c->d_spec_touch, c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);

@@ -154,8 +154,6 @@ struct ChainParams {
     SpecState* spec;           // NPBNN_SCHED_PERSIST_SERIAL: outcome-speculative preparation (spec_round below), else nullptr
     double* spec_pv;           // [3][kSpecOutcomes][kMaxCand][M] candidate patch values per pass (mod 3) and outcome
     unsigned* spec_touch;             // [kMaxCand][n_weights][4] pass tag of the last candidate j that touched the weight, -, and the value it gave it
-    double* spec_touch_val;           // (unused)
-    const double* spec_prior_w;       // [n_weights] per weight: 0.5 / scale^2 (normal prior, a scale per layer) or the scale (see spec_rounds)
     int n_weights_spec, spec_gen;     // spec_gen: pass tags of this batch start above it (never reused: the host clears the tables first)
     const double* class_w;     // class weights for the weight image (pack_item), or nullptr
     const float* w_scale;      // fp16-split column scales of layer 0, or nullptr
@@ -255,8 +253,10 @@ __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 d
 // change of the log prior - ONE definition for every schedule, contraction off, so that their chains agree to the bit.  The normal
 // prior with one scale per layer (the default) is two multiplies and a subtraction; everything else (Cauchy, Laplace, a scale per
 // weight) goes through a function of its own: its logarithms would otherwise be expanded at every call site.
-__device__ __attribute__((noinline)) double prior_delta_general(int kind, double v, double b, double sc) { return prior_delta(kind, v, b, sc); }
-template <bool OUT_OF_LINE>
+// NORMAL_ONLY: the caller has made sure that the prior is uniform or normal with one scale per layer (spec_rounds: the other
+// priors' logarithms, at its two dozen call sites, would not fit beside an evaluation kernel's hot loop - such chains run on the
+// other schedules).  Same arithmetic either way.
+template <bool NORMAL_ONLY>
 __device__ __forceinline__ double spec_entry(double w_bound, int prior_kind, bool per_weight_scale, double base, double d, double m, double scale_w,
                                              double his, double lsc, double& dlp) {
 #pragma clang fp contract(off)      // (no fused multiply-adds: the same bits wherever this is inlined)
@@ -264,12 +264,12 @@ __device__ __forceinline__ double spec_entry(double w_bound, int prior_kind, boo
     if (v > w_bound) v = w_bound - (v - w_bound);
     if (v < -w_bound) v = -w_bound + (-w_bound - v);
     v *= m;
-    if (prior_kind != NPBNN_PRIOR_UNIFORM) {
-        // (OUT_OF_LINE: spec_rounds, which has two dozen call sites; chain_step, inlined into every evaluation kernel, keeps its one
-        // site inline - a call inside a kernel costs the kernel's whole body registers.  Same arithmetic either way.)
-        if (per_weight_scale) dlp += OUT_OF_LINE ? prior_delta_general(prior_kind, v, base, scale_w) : prior_delta(prior_kind, v, base, scale_w);
+    if constexpr (NORMAL_ONLY) {
+        if (prior_kind == NPBNN_PRIOR_NORMAL) dlp -= (v * v - base * base) * his;
+    } else if (prior_kind != NPBNN_PRIOR_UNIFORM) {
+        if (per_weight_scale) dlp += prior_delta(prior_kind, v, base, scale_w);
         else if (prior_kind == NPBNN_PRIOR_NORMAL) dlp -= (v * v - base * base) * his;
-        else dlp += OUT_OF_LINE ? prior_delta_general(prior_kind, v, base, lsc) : prior_delta(prior_kind, v, base, lsc);
+        else dlp += prior_delta(prior_kind, v, base, lsc);
     }
     return v;
 }
@@ -699,29 +699,6 @@ __device__ __forceinline__ bool sync_step_enter(const ChainParams& c, int launch
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return *lds_flag != 0;
 }
-// persistent launch with the decision BETWEEN the passes (NPBNN_SCHED_PERSIST_SERIAL): the step of round L decides pass L - 1, so all
-// it waits for is that pass's evaluating workgroups; it is the only step running (one workgroup, rounds in order)
-__device__ __forceinline__ bool sync_step_enter_serial(const ChainParams& c, int launch, int n_eval_wgs, int* lds_flag) {
-    ChainDev* st = c.st;
-    if (c.sync_test_skip == launch) return false;
-    if (threadIdx.x == 0) {
-        const int slot = (launch - 1) & 3;
-        *lds_flag = sync_wait_ge(st, &st->done[slot], ((launch - 1) / 4 + 1) * n_eval_wgs) ? 1 : 0;
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return *lds_flag != 0;
-}
-__device__ __forceinline__ StepPlan serial_plan(int launch) {       // round L >= 1: decide pass L - 1, prepare pass L
-    StepPlan pl;
-    pl.first = 0;
-    pl.resum = 0;
-    pl.dec = (launch - 1) & 1;
-    pl.fly = -1;
-    pl.out = launch & 1;
-    pl.launch = launch;
-    return pl;
-}
 // `wait_for_next`: launch next_launch has been enqueued and this step belongs to launch next_launch - 1.  The step then stays
 // until the step workgroup of launch next_launch has begun.  Why: launch L+1 starts when launch L-1 (same stream) is complete,
 // its evaluating workgroups wait for step L - so step L must hold a compute unit before they can take them all.  Launch L
@@ -763,6 +740,9 @@ struct SpecState {
     unsigned long long ticks[6];                  // touch tables | candidates | descriptors | wait for the pass | decide + publish | commit
 };
 
+#ifndef NPBNN_SPEC_INLINE
+#define NPBNN_SPEC_INLINE __attribute__((noinline))
+#endif
 struct SpecShared {            // LDS scratch of spec_rounds (beside StepShared)
     double red[kSpecOutcomes][kMaxCand][16];
     double cand_lp[kSpecOutcomes][kMaxCand];   // log priors of the candidates being prepared, per outcome
@@ -781,7 +761,7 @@ struct SpecShared {            // LDS scratch of spec_rounds (beside StepShared)
 // stage issues ALL its loads unconditionally (indices clamped to something valid, results selected afterwards) before the first
 // use, what one round leaves for the next stays in LDS, and the parameter block is copied into registers once.
 template <bool HAS_MASK>
-__device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int P0, int P_end, int n_eval_wgs, StepShared& sh, SpecShared& sp, int* lds_flag) {
+__device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int P_end, int n_eval_wgs, StepShared& sh, SpecShared& sp, int* lds_flag) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     // The parameter block sits in memory and the compiler must assume that any store may change it: every use of c.<field> below a
     // store would be a load of its own, in front of the load it feeds.  Everything the rounds need is copied out once, into
@@ -824,16 +804,13 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
     const long long n_rows = c.n_rows;
     const double lik_temp = sgd(c.lik_temp);
     const int sigma_given = sg(c.sigma_given), skip_round = sg(c.sync_test_skip), gen0 = sg(c.spec_gen);
-    const bool has_sc = c.pscale != nullptr, has_psw = c.prior_scale_w != nullptr;
+    const bool has_sc = c.pscale != nullptr;
     constexpr bool has_mask = HAS_MASK;
     // arrays that may be absent read from something valid instead (the value is replaced by a constant afterwards)
     const float* const pscale_p = has_sc ? sgp(c.pscale) : reinterpret_cast<const float*>(g_pos);
     const double* const mask_p = has_mask ? sgp(c.mask) : Wc;
-    // per weight: 0.5 / scale^2 of its layer (normal prior, one scale per layer - the value chain_step selects from its per-layer table),
-    // else the scale itself (other priors; a scale per weight)
-    const double* const prw_p = sgp(c.spec_prior_w);
-    const bool fast_prior = prior_kind == NPBNN_PRIOR_NORMAL && !has_psw;
-    // (the default prior needs no gather for it: 0.5 / scale^2 of the weight's layer, selected by the layers' offsets)
+    // the priors this schedule runs with (the host checks): uniform, or normal with one scale per layer - 0.5 / scale^2 of a weight's
+    // layer is selected by the layers' offsets, as chain_step does
     int woff[kMaxLayers];
     double l_his[kMaxLayers];
 #pragma unroll
@@ -960,7 +937,6 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
                 const int ic = ri[r] >= 0 ? ri[r] : 0;
                 rb[r] = Wc[ic];
                 rm[r] = has_mask ? mask_p[ic] : 1.0;
-                rsw[r] = fast_prior ? 0.0 : prw_p[ic];
             }
 #pragma unroll
             for (int j = 0; j < kMaxCand; ++j)
@@ -977,14 +953,12 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
                     const int r = j + 1 + k < kSpecRows ? j + 1 + k : 0;
                     rp[j][k] = rt[j][k][0] == gen ? __hiloint2double((int)rt[j][k][3], (int)rt[j][k][2]) : rb[r];
                 }
-            if (fast_prior) {
 #pragma unroll
-                for (int r = 1; r < kSpecRows; ++r) {
-                    double his = l_his[0];
+            for (int r = 1; r < kSpecRows; ++r) {
+                double his = l_his[0];
 #pragma unroll
-                    for (int l = 1; l < kMaxLayers; ++l) his = ri[r] >= woff[l] ? l_his[l] : his;
-                    rsw[r] = his;
-                }
+                for (int l = 1; l < kMaxLayers; ++l) his = ri[r] >= woff[l] ? l_his[l] : his;
+                rsw[r] = his;
             }
             // ---- stage 3: proposals and prior changes.  Outcome o >= 1 takes rows o .. o+D-1; outcome 0 (nothing accepted) shares the
             //      rows of outcome n_pend - every index below is a compile-time constant, so all of this stays in registers ----
@@ -998,14 +972,14 @@ __device__ __attribute__((noinline)) void spec_rounds(const ChainParams& c, int 
                     const int rr = r < kSpecRows ? r : 0;
                     const int i = ri[rr];
                     if (i < 0) continue;
-                    const double his = rsw[rr], lsc = rsw[rr];       // (whichever the prior takes: see prw_p)
+                    const double his = rsw[rr];
                     const bool in16 = rpos[rr] < 0;
                     const double sc = (double)rsc[rr];
-                    const double v = spec_entry<true>(w_bound, prior_kind, !fast_prior && has_psw, rp[o - 1][k], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[o][k]);
+                    const double v = spec_entry<true>(w_bound, prior_kind, false, rp[o - 1][k], rd[rr], rm[rr], 1.0, his, 1.0, dlp[o][k]);
                     __hip_atomic_store(pvN + ((size_t)o * kMaxCand + k) * M + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (write-through: nothing to flush at the flag)
                     if (in16 && !(fabs(v * sc) <= (double)kF16Safe)) atomicOr(&sp.ovf[o], 1);
                     if (o == n_pend) {          // the same rows on the unchanged state: outcome 0
-                        const double v0 = spec_entry<true>(w_bound, prior_kind, !fast_prior && has_psw, rb[rr], rd[rr], rm[rr], rsw[rr], his, lsc, dlp[0][k]);
+                        const double v0 = spec_entry<true>(w_bound, prior_kind, false, rb[rr], rd[rr], rm[rr], 1.0, his, 1.0, dlp[0][k]);
                         __hip_atomic_store(pvN + ((size_t)k) * M + e, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (in16 && !(fabs(v0 * sc) <= (double)kF16Safe)) atomicOr(&sp.ovf[0], 1);
                     }

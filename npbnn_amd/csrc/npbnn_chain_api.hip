@@ -102,11 +102,17 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         // decides in a few microseconds: above kPersistSerialAccept of the proposals accepted it leads (measured).
         // (its step workgroup must keep pace with the evaluation: with proposals much wider than a few hundred weights it does not)
         if (alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option && p_acc > kPersistSerialAccept && group_blocks == 0 &&
-            !cfg->slope_idx && M <= kPersistSerialMaxWidth)
+            !cfg->slope_idx && M <= kPersistSerialMaxWidth && lp.fn_spec != nullptr &&
+            (cfg->prior_kind == NPBNN_PRIOR_UNIFORM || (cfg->prior_kind == NPBNN_PRIOR_NORMAL && !cfg->prior_scale_w)))
             schedule = NPBNN_SCHED_PERSIST_SERIAL;
     }
     if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
-    if (schedule == NPBNN_SCHED_PERSIST_SERIAL && (ctx->sync_failed || !alone_on_device || seg_len > 0 || group_blocks > 0)) schedule = NPBNN_SCHED_SERIAL;
+    // (asked for by name where it cannot run - no build with the speculative step for this launch, another prior, trainable slopes, a
+    // shared GPU: the persistent overlapped form where that can, else kernel boundaries)
+    if (schedule == NPBNN_SCHED_PERSIST_SERIAL &&
+        (ctx->sync_failed || !alone_on_device || seg_len > 0 || group_blocks > 0 || lp.fn_spec == nullptr || cfg->slope_idx || getenv("NPBNN_NO_SPEC_STEP") ||
+         !(cfg->prior_kind == NPBNN_PRIOR_UNIFORM || (cfg->prior_kind == NPBNN_PRIOR_NORMAL && !cfg->prior_scale_w))))
+        schedule = (alone_on_device && seg_len == 0 && !ctx->sync_failed && group_blocks == 0) ? NPBNN_SCHED_PERSIST : NPBNN_SCHED_OVERLAP;
     // the persistent form needs every workgroup of its launch resident at once: one per compute unit at most, the GPU to itself, and
     // a plain run (an exchange run's kernels go between the passes)
     // (its grid is at most one workgroup per compute unit: the evaluating workgroups are capped at n_cu - 1 below, plus the step's)
@@ -161,7 +167,8 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         HIP_TRY(ctx, hipMalloc(&ctx->d_pv, (size_t)2 * kMaxCand * M * sizeof(double)));
         ctx->pv_cap = (size_t)M;
     }
-    const bool spec = pserial && !cfg->slope_idx && !getenv("NPBNN_NO_SPEC_STEP");      // prepare the next pass ahead for every outcome
+    const bool spec = pserial;             // (every condition was checked where the schedule was fixed)
+    if (spec) lp.fn = lp.fn_spec;          // (the builds that carry spec_rounds)      // prepare the next pass ahead for every outcome
     if (spec) {
         if (!ctx->d_spec) HIP_TRY(ctx, hipMalloc(&ctx->d_spec, sizeof(SpecState)));
         if ((size_t)M > ctx->spec_pv_cap) {
@@ -172,11 +179,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         }
         if ((size_t)ctx->n_weights > ctx->spec_touch_cap) {
             if (ctx->d_spec_touch) (void)hipFree(ctx->d_spec_touch);
-            if (ctx->d_spec_tval) (void)hipFree(ctx->d_spec_tval);
-            if (ctx->d_spec_prw) (void)hipFree(ctx->d_spec_prw);
-            ctx->d_spec_touch = nullptr; ctx->d_spec_tval = nullptr; ctx->d_spec_prw = nullptr; ctx->spec_touch_cap = 0;
-            ctx->spec_prw_key.clear();
-            HIP_TRY(ctx, hipMalloc(&ctx->d_spec_prw, (size_t)ctx->n_weights * sizeof(double)));
+            ctx->d_spec_touch = nullptr; ctx->spec_touch_cap = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->d_spec_touch, (size_t)kMaxCand * ctx->n_weights * 4 * sizeof(unsigned)));
             ctx->spec_touch_cap = (size_t)ctx->n_weights;
             ctx->spec_gen = 0xf0000000u;         // (forces the clearing below)
@@ -285,15 +288,12 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.spec = nullptr;
     c.spec_pv = nullptr;
     c.spec_touch = nullptr;
-    c.spec_touch_val = nullptr;
-    c.spec_prior_w = nullptr;
     c.n_weights_spec = ctx->n_weights;
     c.spec_gen = 0;
     if (spec) {
         c.spec = ctx->d_spec;
         c.spec_pv = ctx->d_spec_pv;
         c.spec_touch = ctx->d_spec_touch;
-        c.spec_touch_val = ctx->d_spec_tval;
         c.spec_gen = (int)ctx->spec_gen;
         ctx->spec_gen += (unsigned)K + 8u;             // (a pass decides at least one iteration)
     }
@@ -326,24 +326,6 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         if (!ctx->d_pscale_w) HIP_TRY(ctx, hipMalloc(&ctx->d_pscale_w, wb));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pscale_w, cfg->prior_scale_w, wb, hipMemcpyHostToDevice, st));
         c.prior_scale_w = ctx->d_pscale_w;
-    }
-    if (spec) {
-        c.spec_prior_w = c.prior_scale_w;               // a scale per weight (already uploaded), or:
-        if (!c.prior_scale_w) {
-            std::vector<double> key{(double)cfg->prior_kind};
-            for (int l = 0; l < ctx->net.n_layers; ++l) key.push_back(cfg->prior_scale[l]);
-            if (key != ctx->spec_prw_key) {             // (changes with a Gibbs step of the scales only)
-                std::vector<double> prw((size_t)ctx->n_weights, 0.0);
-                for (int l = 0; l < ctx->net.n_layers; ++l) {
-                    const LayerMeta& L = ctx->net.L[l];
-                    const double v = cfg->prior_kind == NPBNN_PRIOR_NORMAL ? c.half_inv_s2[l] : cfg->prior_scale[l];
-                    for (int i = 0; i < L.out_dim * (L.in_dim + L.has_bias); ++i) prw[(size_t)L.w_off + i] = v;
-                }
-                HIP_TRY(ctx, hipMemcpy(ctx->d_spec_prw, prw.data(), prw.size() * sizeof(double), hipMemcpyHostToDevice));
-                ctx->spec_prw_key = key;
-            }
-            c.spec_prior_w = ctx->d_spec_prw;
-        }
     }
     c.slopes = nullptr;
     c.slope_idx = nullptr;
@@ -398,7 +380,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     p.pscale = f16 ? ctx->d_pscale : nullptr;
     p.M = M;
     p.chain = overlap ? ctx->d_cparams : nullptr;
-    p.sync_mode = spec ? 3 : pserial ? 2 : sync ? 1 : 0;
+    p.sync_mode = spec ? 3 : sync ? 1 : 0;
     p.cand_slopes = c.slopes ? &ctx->d_slopes->cand[0][0][0] : nullptr;
     c.class_w = ctx->n_classw ? ctx->d_classw : nullptr;
     c.w_scale = f16 ? ctx->d_wscale : nullptr;

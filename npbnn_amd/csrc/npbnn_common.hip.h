@@ -149,7 +149,6 @@ struct EvalParams {
     int sync_mode;             // overlapped schedule with the launches alternating between two streams: no kernel boundary orders a
     int pad_sync_;             // launch after the one before it - device-side flags do (ChainDev.prepared / .done, npbnn_chain.hip.h)
                                // 1: the step of launch L decides pass L - 1 while pass L is evaluated (NPBNN_SCHED_OVERLAP2 / _PERSIST);
-                               // 2: persistent launch, pass L - 1 is decided BEFORE pass L starts (chain_step between the passes);
                                // 3: the same with the next pass prepared ahead for every outcome (spec_round; NPBNN_SCHED_PERSIST_SERIAL):
                                //    the descriptor names the patch values the pass reads (pad[2]) and, after an accept, the accepted entries (pad[1])
     unsigned long long* stamps;   // diagnostics only (NPBNN_EVAL_STAMPS=1 in npbnn_time_pass): [workgroup][8] wall-clock stamps, else nullptr

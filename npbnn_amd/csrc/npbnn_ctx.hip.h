@@ -33,6 +33,10 @@ eval_fn_t pick_eval_d3_gauss(int mt0, int f16);
 // the fast builds (eval_kernel<..., FAST = true>): nullptr where there is none (more than kFastMaxMT0 tiles in layer 0)
 eval_fn_t pick_eval_d1_cat_fast(int mt0, int f16);
 eval_fn_t pick_eval_d1_cat_plain(int mt0, int f16);      // (plain evaluations: no chain pass)
+eval_fn_t pick_eval_d1_cat_spec(int mt0, int f16);       // (NPBNN_SCHED_PERSIST_SERIAL: with the outcome-speculative step; nullptr where none)
+eval_fn_t pick_eval_d1_gauss_spec(int mt0, int f16);
+eval_fn_t pick_eval_d3_cat_spec(int mt0, int f16);
+eval_fn_t pick_eval_d3_gauss_spec(int mt0, int f16);
 eval_fn_t pick_eval_d1_gauss_plain(int mt0, int f16);
 eval_fn_t pick_eval_d1_gauss_fast(int mt0, int f16);
 eval_fn_t pick_eval_d2_cat_fast(int mt0, int f16);
@@ -152,10 +156,7 @@ struct npbnn_ctx {
     SpecState* d_spec = nullptr;
     double* d_spec_pv = nullptr;   // [3][kSpecOutcomes][kMaxCand][M]
     size_t spec_pv_cap = 0;        // M capacity
-    unsigned* d_spec_touch = nullptr;   // [kMaxCand][n_weights] touch tables: pass tags (cleared before they could repeat) ...
-    double* d_spec_tval = nullptr;      // ... and values
-    double* d_spec_prw = nullptr;       // [n_weights] per-weight prior constants of spec_rounds (ChainParams::spec_prior_w)
-    std::vector<double> spec_prw_key;   // what d_spec_prw was built from: prior kind, the per-layer scales
+    unsigned* d_spec_touch = nullptr;   // [kMaxCand][n_weights][4] touch tables: pass tag (cleared before it could repeat), -, value
     size_t spec_touch_cap = 0;     // weights capacity
     unsigned spec_gen = 0;         // pass tags handed out so far
     double* d_mask = nullptr;
@@ -215,6 +216,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct LaunchPlan {
     eval_fn_t fn;
+    eval_fn_t fn_spec;       // the same launch's build with the outcome-speculative step (NPBNN_SCHED_PERSIST_SERIAL), or nullptr
     int n_cand;
     int grid, wpb;
     size_t lds;

@@ -435,9 +435,13 @@ __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int 
 // honour the structure.
 // CHAIN = false: the build for plain evaluations (npbnn_eval: MCMC.__init__, mh_step, statistics) - no pass descriptor, no patch
 // lists, no step workgroup, no device-side waits: none of that code, and none of the registers it keeps alive, is in the kernel.
-template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false, bool BLK = false, bool CHAIN = true>
+// SPEC = true: the builds NPBNN_SCHED_PERSIST_SERIAL launches - they carry the step workgroup's outcome-speculative rounds
+// (spec_rounds) and the evaluating workgroups' side of it (image copy ahead of the flag, accepted entries applied from the
+// descriptor).  Builds of their own, because that code beside the tile loop costs the tightest builds registers in the loop.
+template <int MT0, int MTI, bool F16, int D, int LK, bool FAST = false, bool BLK = false, bool CHAIN = true, bool SPEC = false>
 __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64) eval_kernel(const EvalParams* __restrict__ pp, int launch_arg, int n_loop) {
     static_assert(CHAIN || D == 1, "plain builds evaluate one weight set");
+    static_assert(!SPEC || (CHAIN && FAST && !BLK), "spec builds: fast chain builds of dense first layers");
     static_assert(!FAST || (MTI == 1 && LK != kLikGen), "fast builds: narrow later layers, categorical or Gaussian likelihood");
     static_assert(!BLK || (FAST && MT0 >= 2), "block-structure builds are fast builds of layers with several output tiles");
     constexpr bool SKIP = !FAST || BLK;          // this build tests which tiles have weights in a K-unit
@@ -476,28 +480,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     if (chain && bid == (sync ? 0 : G)) {
         StepShared& sh = *reinterpret_cast<StepShared*>(smem);
         int* const lds_flag = reinterpret_cast<int*>(smem + sizeof(StepShared));
-        if (uni(p.sync_mode) == 3) {     // NPBNN_SCHED_PERSIST_SERIAL: round P prepares pass P + 1 for every outcome of pass P while it is
+        if (SPEC && uni(p.sync_mode) == 3) {     // NPBNN_SCHED_PERSIST_SERIAL (spec builds): round P prepares pass P + 1 for every outcome of pass P while it is
             // evaluated, then decides it and publishes the pass its outcome selects (spec_rounds)
             SpecShared& sp = *reinterpret_cast<SpecShared*>(smem + ((sizeof(StepShared) + 64 + 15) & ~(size_t)15));
             if (chain->mask) spec_rounds<true>(*chain, launch0, launch_end, G, sh, sp, lds_flag);
             else spec_rounds<false>(*chain, launch0, launch_end, G, sh, sp, lds_flag);
-            return;
-        }
-        if (uni(p.sync_mode) == 2) {     // the same order with the plain step between the passes: round L decides pass L - 1 and prepares pass L; the evaluating
-            // workgroups wait for it (pass 0 was prepared by the batch's first step kernel)
-            for (int launch = launch0 > 1 ? launch0 : 1; launch <= launch_end; ++launch) {
-                if (!sync_step_enter_serial(*chain, launch, G, lds_flag)) return;
-                chain_step(*chain, serial_plan(launch), sh);
-                sync_step_leave(chain->st, launch);
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const PassDesc& nx = chain->pass[launch & 1];
-                    *lds_flag = nx.n_cand == 0 ? 1 : 0;       // nothing in flight in this schedule: an empty pass is the end
-                }
-                __syncthreads();
-                if (*lds_flag) return;
-                __syncthreads();
-            }
             return;
         }
         for (int launch = launch0; launch < launch_end; ++launch) {
@@ -647,11 +634,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // depend on changes at the hand-over - the global image is only written right AFTER a flag, and the pass applies the accepted
     // candidate's entries to its LDS copies itself - so both are requested BEFORE the wait for the step workgroup's flag and have
     // landed when it comes.  Everywhere else the image is committed before the flag: copy after it.
-#ifdef NPBNN_EXP_NO_EARLY
-    constexpr bool early_copy = false;
-#else
-    const bool early_copy = CHAIN && uni(p.sync_mode) == 3;
-#endif
+    const bool early_copy = SPEC && uni(p.sync_mode) == 3;
     if (early_copy) {
         stage_images();
         for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
@@ -672,7 +655,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
     // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
     if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
-        NPBNN_WAIT_VMCNT(0);
+        if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);     // (copies requested ahead of the flag must not land in LDS that is no longer ours)
         return;
     }
     if (GN) {
@@ -693,18 +676,18 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
                 // one pass per launch: this launch is over.  Persistent form: over only at the terminal pass (PassDesc.pad[0]); an
                 // empty pass before that means the pass in flight may still accept and start the chain's tail again
-                if (n_loop <= 1 || __builtin_amdgcn_readlane(w, 5) == 1 || uni(p.sync_mode) >= 2) {
-                    NPBNN_WAIT_VMCNT(0);        // (copies requested ahead of the flag must not land in LDS that is no longer ours)
+                if (n_loop <= 1 || __builtin_amdgcn_readlane(w, 5) == 1 || (SPEC && uni(p.sync_mode) == 3)) {
+                    if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);
                     return;
                 }
-                NPBNN_WAIT_VMCNT(0);
+                if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);
                 __syncthreads();
                 continue;
             }
             t0 = __builtin_amdgcn_readlane(w, 0);
 #pragma unroll
             for (int j = 0; j < D; ++j) cnt[j] = __builtin_amdgcn_readlane(w, 2 + (j < kMaxCand ? j : 0));
-            if (uni(p.sync_mode) == 3) {     // the descriptor names what this pass reads (spec_rounds): its own patch values, and - after an
+            if (SPEC && uni(p.sync_mode) == 3) {     // the descriptor names what this pass reads (spec_rounds): its own patch values, and - after an
                 // accept - the accepted candidate's entries, which the global image may not hold yet
                 acc_cnt = __builtin_amdgcn_readlane(w, 6);
                 const int named = __builtin_amdgcn_readlane(w, 7);
@@ -764,9 +747,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int apos = kSkipPos;
     double aval = 0.0;
     float asc = 1.0f;
-#ifdef NPBNN_EXP_NO_EARLY
-    acc_cnt = 0;
-#endif
+    if constexpr (!SPEC) acc_cnt = 0;
     if (acc_cnt > 0 && tid < acc_cnt) {       // the accepted iteration is the one before this pass's first
         const size_t arow = (size_t)(t0 - 1) * M;
         apos = g_pos[arow + tid];

@@ -1,0 +1,9 @@
+// eval_kernel fast builds for NPBNN_SCHED_PERSIST_SERIAL (SPEC: the step workgroup prepares the next pass for every outcome): 2- or 3-layer
+// networks with later layers <= 16 nodes, dense first layer, 1 candidate(s) per launch, likelihood class Gaussian
+#define NPBNN_INST_NAME pick_eval_d1_gauss_spec
+#define NPBNN_INST_MTI 1
+#define NPBNN_INST_D 1
+#define NPBNN_INST_LK 1
+#define NPBNN_INST_FAST 1
+#define NPBNN_INST_SPEC true
+#include "npbnn_eval_inst.inc"

@@ -377,6 +377,24 @@ int npbnn_comm_runtime(int* runtime_version, int* header_version, char* path, in
  * region with it, next to a barrier of the communicator). */
 int npbnn_device_synchronize(int device_id);
 
+/* ---- one chain over several GPUs: the ROWS of the training matrix split over the processes of `comm` (rank r holds a contiguous
+ * share as its ordinary training set), every process running the same chain from the same draws.  The reference evaluates the
+ * likelihood of a proposal as one sum over all rows (np_bnn/BNN_lib.py:100-143 called from MCMC.mh_step, BNN_env.py:467-491); here a
+ * pass leaves one record of partial sums per candidate on every rank (log-likelihood sum or residual moments), the records are
+ * all-gathered - ncclAllGather on the chain's stream, kMaxCand x 33 doubles per rank - and every rank adds them in RANK ORDER and
+ * takes the same decision: the chains stay bit-identical without another word between the ranks.  n_rows_total replaces the local
+ * row count wherever the likelihood needs N (the empirical sigma of a regression).  After this call npbnn_chain_run runs on kernel
+ * boundaries (NPBNN_SCHED_SERIAL: pass, gather, step) whatever schedule is asked for; npbnn_eval / npbnn_predict keep returning the
+ * LOCAL rows' sums (the host adds what it needs across ranks: npbnn_amd/rowshard.py).  npbnn_chain_run_general, the batched and the
+ * exchange runs refuse a sharded context.
+ *   comm != NULL: the gather is enqueued on the stream (RCCL).  comm == NULL, gather != NULL: host-staged - the record comes to the
+ *   host, gather(user, send, recv, count) must fill recv[n_ranks][count] (rank order) and return 0, the result goes back; the form
+ *   the CPU-launched rehearsals use (processes that share one GPU cannot form an RCCL communicator).  n_ranks == 1: no gather.
+ *   n_ranks == 0 switches sharding off. */
+typedef int (*npbnn_gather_fn)(void* user, const double* send, double* recv, int32_t count);
+int npbnn_set_row_shard(npbnn_ctx* ctx, npbnn_comm* comm, npbnn_gather_fn gather, void* user, int32_t rank, int32_t n_ranks,
+                        int64_t n_rows_total);
+
 /* ---- exchange run: the chains of an MC3 run (np_bnn/BNN_mc3.py:87-126) advance n_seg swap intervals of seg_len iterations with
  * the temperature swaps between them done on the GPU: replaces n_seg rounds of  pool.map(run_single_mcmc) -> read
  * [logPost, temperature] of every chain -> swap the temperatures of chains j, k when

@@ -153,7 +153,11 @@ SIGNATURES = {
     "npbnn_comm_destroy": (None, [_P]),
     "npbnn_comm_runtime": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "npbnn_device_synchronize": (C.c_int, [C.c_int]),
+    "npbnn_set_row_shard": (C.c_int, [_P, _P, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64]),
 }
+
+# npbnn_gather_fn: int (*)(void* user, const double* send, double* recv, int32_t count)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32)
 
 _lib = None
 

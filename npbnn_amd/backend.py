@@ -97,6 +97,11 @@ class HipContext:
             self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_TRAINABLE_SLOPES, 1 if on else 0))
             self._trainable_slopes = on
 
+    def set_row_shard(self, comm_handle, gather_cb, rank, n_ranks, n_rows_total):
+        """npbnn_set_row_shard: ``comm_handle`` an npbnn_comm* (ctypes void pointer) or None, ``gather_cb`` a capi.GATHER_FN or None."""
+        cb = C.cast(gather_cb, C.c_void_p) if gather_cb is not None else None
+        self._chk(self._lib.npbnn_set_row_shard(self._ctx, comm_handle, cb, None, int(rank), int(n_ranks), int(n_rows_total)))
+
     def set_persistent(self, on):
         """May the library pick the persistent form of the overlapped chain schedule by itself (default on)?"""
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_PERSISTENT, 1 if on else 0))

@@ -52,6 +52,57 @@ static void stage_mark(npbnn_ctx* ctx, const char* what, double* t_last) {
     *t_last = wall_us();
 }
 
+// ---- rows split over ranks (npbnn_set_row_shard) ----
+// this rank's record of a pass: per candidate and value in use, the sum of the pass's per-wave partials in the order the step kernel
+// itself would add them (lanes take records lane, lane + 64, ... in turn, then a fixed butterfly) - written to the rank's own place in
+// the gather buffer [rank][candidate][value]
+__global__ void __launch_bounds__(1024) shard_sum_kernel(const double* __restrict__ partials, int n_blocks, int D, int lik_kind, int k_targets,
+                                                         double* __restrict__ mine) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nvals = partial_value_count(lik_kind, k_targets);
+    for (int item = wave; item < D * nvals; item += nw) {
+        const int j = item / nvals, v = partial_value_index(item % nvals, k_targets);
+        const double* src = partials + ((size_t)j * kPartialStride + v) * n_blocks;
+        double s = 0.0;
+        for (int b = lane; b < n_blocks; b += 64) s += src[b];
+#pragma unroll
+        for (int shf = 32; shf > 0; shf >>= 1) s += shfl_xor_f64(s, shf);
+        if (lane == 0) mine[j * kPartialStride + v] = s;
+    }
+}
+// the gathered records [rank][candidate][value] in the layout the step kernel sums: [candidate][value][rank] (rank order = the order
+// of the addition, the same on every rank)
+__global__ void __launch_bounds__(256) shard_spread_kernel(const double* __restrict__ gathered, int n_ranks, double* __restrict__ part) {
+    const int rec = kMaxCand * kPartialStride;
+    for (int i = threadIdx.x; i < rec * n_ranks; i += blockDim.x) {
+        const int r = i / rec, e = i % rec;
+        part[(size_t)e * n_ranks + r] = gathered[i];
+    }
+}
+
+// between a pass and its step: every rank's record to every rank, on the chain's stream (RCCL) or through the host (gather callback)
+int shard_exchange(npbnn_ctx* ctx, const LaunchPlan& lp, int D) {
+    hipStream_t st = ctx->stream;
+    const int rec = kMaxCand * kPartialStride;
+    hipLaunchKernelGGL(shard_sum_kernel, dim3(1), dim3(1024), 0, st, (const double*)ctx->d_partials, lp.n_waves, D, ctx->net.lik_kind, ctx->net.k_targets,
+                       ctx->d_shard_recv + (size_t)ctx->shard_rank * rec);
+    if (ctx->shard_n > 1) {
+        if (ctx->shard_comm) {
+            const int rc = npbnn_comm_allgather_inplace_stream_(ctx->shard_comm, ctx->d_shard_recv, rec, st);
+            if (rc) return fail(ctx, NPBNN_E_COMM, "chain_run: the gather of the row shards' sums failed");
+        } else {
+            double* mine = ctx->h_shard + (size_t)ctx->shard_n * rec;          // (send block behind the receive block)
+            HIP_TRY(ctx, hipMemcpyAsync(mine, ctx->d_shard_recv + (size_t)ctx->shard_rank * rec, rec * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (ctx->shard_gather(ctx->shard_user, mine, ctx->h_shard, rec) != 0)
+                return fail(ctx, NPBNN_E_COMM, "chain_run: the gather callback of the row shards failed");
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_shard_recv, ctx->h_shard, (size_t)ctx->shard_n * rec * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+    }
+    hipLaunchKernelGGL(shard_spread_kernel, dim3(1), dim3(256), 0, st, (const double*)ctx->d_shard_recv, ctx->shard_n, ctx->d_shard_part);
+    return NPBNN_OK;
+}
+
 // seg_len > 0: the chain stops deciding at iteration seg_len until an exchange kernel moves the limit (exchange run)
 int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in, const double* mask_packed, int32_t K, int32_t M,
                   const int32_t* idx, const double* delta, const int32_t* cnt, const double* log_u, int seg_len, ChainBatch* B,
@@ -80,8 +131,11 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand, false, true);
     if (rc) return rc;
     const int D = lp.n_cand;
+    const bool sharded = ctx->shard_n > 0;
+    if (sharded && (group_blocks > 0 || seg_len > 0))
+        return fail(ctx, NPBNN_E_STATE, "chain_run: a context whose rows are split over ranks runs plain batches only (no group pass, no exchange run)");
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
-    int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : cfg->schedule;
+    int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : sharded ? NPBNN_SCHED_SERIAL : cfg->schedule;      // (row shards: a gather between pass and step)
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2 && schedule != NPBNN_SCHED_PERSIST &&
         schedule != NPBNN_SCHED_PERSIST_SERIAL) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
@@ -280,7 +334,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.out_acc = ctx->d_acc;
     c.out_ll = ctx->d_llp;
     c.out_lp = ctx->d_lpp;
-    c.partials = ctx->d_partials;
+    c.partials = sharded ? ctx->d_shard_part : ctx->d_partials;
     c.image = ctx->d_image;
     c.pos = ctx->d_pos;
     c.pscale = f16 ? ctx->d_pscale : nullptr;
@@ -307,7 +361,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.K = K;
     c.M = M;
     c.D = D;
-    c.n_blocks = lp.n_waves;
+    c.n_blocks = sharded ? ctx->shard_n : lp.n_waves;      // (row shards: one record per rank, gathered)
     c.stop_on_overflow = seg_len > 0 ? 1 : 0;
     c.sync_test_skip = -1;
     if (sync && ctx->debug_sync_skip >= 0) {       // (npbnn_debug_sync_skip_: provoke the time-out of the two-stream schedule, once)
@@ -368,7 +422,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.lik_temp = cfg->lik_temp;
     c.sigma_given = cfg->sigma_given;
     for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) c.sigma_fixed[j] = cfg->sigma[j];
-    c.n_rows = d.n_rows;
+    c.n_rows = sharded ? ctx->shard_rows_total : d.n_rows;
     c.net = ctx->net;
     EvalParams p = make_params(ctx, d);
     p.partials = ctx->d_partials;
@@ -492,6 +546,10 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     } else {
         for (int i = 0; i < n; ++i, ++B.launch) {
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0, 1);
+            if (ctx->shard_n > 0) {
+                const int rc = shard_exchange(ctx, lp, B.D);
+                if (rc) return rc;
+            }
             hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 0);
         }
     }
@@ -569,7 +627,6 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     hipStream_t st = ctx->stream;
     int t_done = 0, n_rounds = 0;
     const ChainDev* now = reinterpret_cast<const ChainDev*>(ctx->h_res);
-    double t_enq = 0.0, t_wait = 0.0;
     while (t_done < K) {       // launch the least number of passes that can finish, look at the counter, repeat if short
         ++n_rounds;
         const double ta = timing ? wall_us() : 0.0;
@@ -583,11 +640,14 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, B.RL.total, hipMemcpyDeviceToHost, st));   // state + results, one copy
         stage_mark(ctx, "copy of the results", &t_stage);
         const double tb = timing ? wall_us() : 0.0;
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (ctx->shard_comm && ctx->shard_n > 1) {      // (collectives in the stream: a bounded wait - a peer that is gone must not hang this rank)
+            if (npbnn_comm_wait_stream_(ctx->shard_comm, st, "the row-sharded chain batch") != 0)
+                return fail(ctx, NPBNN_E_COMM, "chain_run: the row-sharded batch did not complete (a peer failed?)");
+        } else {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
         if (timing) {
             const double tc = wall_us();
-            t_enq += tb - ta;
-            t_wait += tc - tb;
             fprintf(stderr, "[npbnn chain timing]   round %d: %d launches enqueued in %.0f us, waited %.0f us, t=%d of %d\n", n_rounds, n_launch, tb - ta,
                     tc - tb, reinterpret_cast<const ChainDev*>(ctx->h_res)->t, K);
         }
@@ -965,6 +1025,47 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
             }
     }
     *out_segments_done = seg_done;
+    return NPBNN_OK;
+}
+
+int npbnn_set_row_shard(npbnn_ctx* ctx, npbnn_comm* comm, npbnn_gather_fn gather, void* user, int32_t rank, int32_t n_ranks, int64_t n_rows_total) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (n_ranks == 0) {
+        ctx->shard_n = 0;
+        ctx->shard_comm = nullptr;
+        ctx->shard_gather = nullptr;
+        return NPBNN_OK;
+    }
+    if (n_ranks < 0 || n_ranks > 4096 || rank < 0 || rank >= n_ranks || n_rows_total < 1)
+        return fail(ctx, NPBNN_E_ARG, "set_row_shard: rank %d of %d, %lld rows in all", rank, n_ranks, (long long)n_rows_total);
+    if (n_ranks > 1 && !comm && !gather) return fail(ctx, NPBNN_E_ARG, "set_row_shard: %d ranks need a communicator or a gather callback", n_ranks);
+    if (comm) {
+        int device = -1, crank = -1, cworld = 0;
+        if (npbnn_comm_info_(comm, &device, &crank, &cworld) != 0) return fail(ctx, NPBNN_E_COMM, "set_row_shard: the communicator is not usable");
+        if (crank != rank || cworld != n_ranks || device != ctx->device)
+            return fail(ctx, NPBNN_E_ARG, "set_row_shard: communicator is rank %d of %d on device %d, asked for rank %d of %d on device %d", crank, cworld,
+                        device, rank, n_ranks, ctx->device);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t rec = (size_t)kMaxCand * kPartialStride;
+    if (ctx->d_shard_recv) { (void)hipFree(ctx->d_shard_recv); ctx->d_shard_recv = nullptr; }
+    if (ctx->d_shard_part) { (void)hipFree(ctx->d_shard_part); ctx->d_shard_part = nullptr; }
+    if (ctx->h_shard) { (void)hipHostFree(ctx->h_shard); ctx->h_shard = nullptr; }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_shard_recv, rec * n_ranks * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_shard_part, rec * n_ranks * sizeof(double)));
+    HIP_TRY(ctx, hipMemset(ctx->d_shard_recv, 0, rec * n_ranks * sizeof(double)));       // (values not in use stay zero)
+    HIP_TRY(ctx, hipMemset(ctx->d_shard_part, 0, rec * n_ranks * sizeof(double)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_shard, rec * (n_ranks + 1) * sizeof(double)));
+    memset(ctx->h_shard, 0, rec * (n_ranks + 1) * sizeof(double));
+    ctx->shard_n = n_ranks;
+    ctx->shard_rank = rank;
+    ctx->shard_rows_total = n_rows_total;
+    ctx->shard_comm = comm;
+    ctx->shard_gather = comm ? nullptr : gather;
+    ctx->shard_user = user;
+    ctx->its_per_pass = 0.0;          // (the ranks must agree on the number of launches: start from the same history)
+    ctx->accept_rate = -1.0;
     return NPBNN_OK;
 }
 

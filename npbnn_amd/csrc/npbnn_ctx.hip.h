@@ -159,6 +159,15 @@ struct npbnn_ctx {
     unsigned* d_spec_touch = nullptr;   // [kMaxCand][n_weights][4] touch tables: pass tag (cleared before it could repeat), -, value
     size_t spec_touch_cap = 0;     // weights capacity
     unsigned spec_gen = 0;         // pass tags handed out so far
+    // rows split over the ranks of a communicator (npbnn_set_row_shard): the records of partial sums are gathered before every step
+    int shard_n = 0, shard_rank = 0;
+    long long shard_rows_total = 0;
+    npbnn_comm* shard_comm = nullptr;
+    npbnn_gather_fn shard_gather = nullptr;
+    void* shard_user = nullptr;
+    double* d_shard_recv = nullptr;   // [shard_n][kMaxCand][kPartialStride]: this rank's record at its own place, the peers' after the gather
+    double* d_shard_part = nullptr;   // [kMaxCand][kPartialStride][shard_n]: the same in the layout the step kernel sums
+    double* h_shard = nullptr;        // pinned, as d_shard_recv (host-staged gather)
     double* d_mask = nullptr;
     ChainDev* d_chain = nullptr;
     int* d_idx = nullptr;

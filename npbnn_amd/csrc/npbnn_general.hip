@@ -253,6 +253,7 @@ extern "C" int npbnn_chain_run_general(npbnn_ctx* ctx, const npbnn_chain_cfg* cf
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
     if (!cfg || !gc || !W_inout || K < 1 || !log_u || !out_accepted || !result) return fail(ctx, NPBNN_E_ARG, "chain_run_general: bad arguments");
     if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "chain_run_general: call npbnn_set_arch first");
+    if (ctx->shard_n > 0) return fail(ctx, NPBNN_E_STATE, "chain_run_general: the context's rows are split over ranks (npbnn_set_row_shard): npbnn_chain_run only");
     if (gc->proposal_kind < NPBNN_PROP_NORMAL || gc->proposal_kind > NPBNN_PROP_NORMAL_NORMALIZED)
         return fail(ctx, NPBNN_E_ARG, "chain_run_general: proposal_kind=%d", gc->proposal_kind);
     if (gc->M < 1 || !gc->idx || !gc->val || !gc->cnt) return fail(ctx, NPBNN_E_ARG, "chain_run_general: the proposal's entry lists are missing");

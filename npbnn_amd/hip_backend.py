@@ -138,6 +138,22 @@ class HipBackend:
         return self.ctx.predict(weights, act_prm=slopes, col_override=col_override, which=which,
                                 apply_out_fn=apply_out_fn and self.out_kind is not None)
 
+    def train_rows(self):
+        return int(self.ctx.n_rows[capi.TRAIN])
+
+    def refresh_row_weights(self, bnn):
+        """The model's class weights changed (a row-sharded sampler recomputes them from all ranks' label counts)."""
+        if self.lik_kind == capi.LIK_CATEGORICAL and len(bnn._class_w):
+            self.ctx.set_row_weights(instance_w=bnn._instance_weights, class_w=bnn._class_w)
+
+    def set_row_shard(self, sharded):
+        """This context holds one rank's share of the rows (npbnn_amd.rowshard.RowShardedBackend): npbnn_chain_run gathers the
+        per-pass sums of all ranks before every step - on the stream through RCCL when the communicator offers a handle on this
+        GPU, else through the host."""
+        self._sharded = sharded             # (keeps the gather callback alive as long as the context may call it)
+        self.ctx.set_row_shard(sharded.rccl_handle(), None if sharded.rccl_handle() else sharded.gather_callback(),
+                               sharded.rank, sharded.world, sharded.n_rows_total)
+
     def run_chain(self, weights, **kw):
         """Device-resident Metropolis-Hastings iterations; see HipContext.chain_run."""
         self._configure(weights)

@@ -76,7 +76,9 @@ class MCMC():
                  update_function=UpdateNormal, sample_from_prior=0, run_ID="", init_additional_prob=0,
                  likelihood_tempering=1, mcmc_id=0, randomize_seed=False, adapt_f=0, estimate_error=True,
                  adapt_fM=1, adapt_freq=1000, adapt_stop=None, likelihood_f=None, adapt_verbose=False,
-                 accuracy_f=None, accuracy_lab_f=None):
+                 accuracy_f=None, accuracy_lab_f=None, row_comm=None):
+        # row_comm (no reference counterpart): a communicator over whose ranks the ROWS of the data are split - bnn_obj holds this
+        # rank's share (npbnn_amd.rowshard.shard_rows), every rank runs this same chain, the likelihood sums are added across ranks
         n_layers = bnn_obj._n_layers
         if update_ws is None:
             update_ws = [0.075] * n_layers
@@ -114,6 +116,8 @@ class MCMC():
 
         self._bnn = bnn_obj
         self._backend = get_backend(bnn_obj, self._likelihood_f)
+        if row_comm is not None:
+            self.shard_over(row_comm)
         self._lazy = {}
         self._accepted_override = None      # column override of the last accepted state (feature indicators)
         self._lik_temp = likelihood_tempering
@@ -143,6 +147,16 @@ class MCMC():
         self._max_n = np.array([bnn_obj._w_layers[i].size for i in range(n_layers)]).astype(int)
         # with estimate_error the regression sigma stays at 1 for the first iterations (BNN_env.py:375-379)
         self._estimate_error = np.min([20000, 0.1 * self._n_iterations]) if estimate_error else self._n_iterations
+
+    def shard_over(self, comm):
+        """The model's data are this rank's share of the rows; sum the likelihood over the ranks of ``comm`` (npbnn_amd/rowshard.py).
+        Called by the constructor for ``row_comm=``; call it again on a sampler that came out of a pickle."""
+        from .rowshard import RowShardedBackend
+        be = self._backend if self._backend is not None else get_backend(self._bnn, self._likelihood_f)
+        if isinstance(be, RowShardedBackend):
+            be = be._inner
+        self._backend = RowShardedBackend(be, comm, self._bnn)
+        self._invalidate()
 
     # ------------------------------------------------------------------------------------------
     # device evaluation
@@ -460,6 +474,8 @@ class MCMC():
                                                 or len(bnn_obj._act_fun._acc_prm) != bnn_obj._n_layers - 1):
                 return None     # (slopes that are proposed but never used by the forward pass, or not one per hidden layer: mh_step)
             return "patch"
+        if getattr(be, "row_sharded", False):
+            return None         # (rows split over ranks: plain batches on the device, everything else through the sharded mh_step)
         if (self.update_function in _GENERAL_PROPOSALS and hasattr(be, "run_chain_general") and not bnn_obj._act_fun._trainable):
             if bnn_obj._freq_indicator and bnn_obj._n_layers < 4:
                 return None
@@ -474,7 +490,7 @@ class MCMC():
     def _plain_device_batches(self, bnn_obj):
         """May the chain take part in an exchange run or a group pass?  Those entry points run plain batches only: chain state that
         rides along with extra per-iteration draws (trainable activation slopes) stays on :meth:`run_steps`."""
-        return not bnn_obj._act_fun._trainable
+        return not bnn_obj._act_fun._trainable and not getattr(self._backend, "row_sharded", False)
 
     def _sigma_proposal_columns(self, bnn_obj, first_it):
         """Columns of the error parameter that every iteration from ``first_it`` on proposes to change (0: none)."""

@@ -14,6 +14,29 @@ class OracleBackend:
         self.out_kind = out_kind
         self.n_eval = 0
 
+    # -- rows split over ranks (npbnn_amd/rowshard.py): the stand-in's chain asks the wrapper for the sums over all rows --
+    _sharded = None
+
+    @property
+    def lik_kind(self):
+        return 0 if self.bnn._estimation_mode == "classification" else 1        # (capi.LIK_CATEGORICAL / LIK_GAUSS)
+
+    @property
+    def n_targets(self):
+        return 0 if self.bnn._estimation_mode == "classification" else self.bnn._labels.shape[1]
+
+    def train_rows(self):
+        return len(self.bnn._data)
+
+    def set_row_shard(self, sharded):
+        self._sharded = sharded
+
+    def refresh_row_weights(self, bnn):
+        pass                              # (the stand-in reads bnn._class_w at every evaluation)
+
+    def _chain_evaluate(self, *a, **k):
+        return (self._sharded.evaluate if self._sharded is not None else self.evaluate)(*a, **k)
+
     def _act(self, slopes):
         fun = self.bnn._act_fun._function
         trainable = self.bnn._act_fun._trainable
@@ -94,10 +117,10 @@ class OracleChainBackend(OracleBackend):
             wl = unpack(prop)
             h = 0.0
             if sigma_mult is not None:             # sigma' = current sigma * pre-drawn factors (BNN_env.py:435-442)
-                r = self.evaluate(wl, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
+                r = self._chain_evaluate(wl, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
                 h = hastings[t]
             else:
-                r = self.evaluate(wl, lik_temp=lik_temp, sigma=sigma)
+                r = self._chain_evaluate(wl, lik_temp=lik_temp, sigma=sigma)
             p = orc.log_prior(wl, prior_kind, prior_scale)
             llp[t], lpp[t] = r["loglik"], p
             if ((r["loglik"] + p) - (ll + lp)) * temperature + h >= log_u[t]:

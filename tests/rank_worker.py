@@ -2,6 +2,7 @@
 
     python tests/rank_worker.py mc3 <tmpdir> <backend: oracle|hip> <comm: socket|rccl> <device_exchange: 0|1|none> [fail=<rank>:<mode>]
     python tests/rank_worker.py idle <seconds> [fail=<rank>:<mode>]
+    python tests/rank_worker.py rowshard <backend: oracle|hip> <comm: socket|rccl> <case: cls|clsw|reg|regsig>
 
 ``mc3``: the reference's golden MC3 run (tests/golden/mc3.npz: 4 chains, swaps every 20 iterations) with chain i on rank
 i % world.  oracle backend (CPU stand-in, float64): the golden swap sequence, final states and log rows exactly; hip backend
@@ -122,6 +123,74 @@ def run_mc3(argv):
     print("RANK %d OK" % rank, flush=True)
 
 
+def run_rowshard(argv):
+    """rowshard <backend: oracle|hip> <comm: socket|rccl> <case: cls|clsw|reg|regsig>: ONE chain whose rows are split over the ranks
+    (MCMC(row_comm=...)) against the same chain on all rows in this very process: the same accept decisions, the same weights, the
+    same statistics."""
+    import numpy as np
+    import cases
+    import npbnn_amd as bn
+    from npbnn_amd.rowshard import shard_rows
+    backend, comm_kind, case = argv[:3]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = make_comm(comm_kind, rank, world)
+    if backend == "oracle":
+        from oracle_backend import OracleChainBackend, serve_from_oracle
+        serve_from_oracle(lambda b: OracleChainBackend(b, 0 if b._estimation_mode == "classification" else 1))
+    if case in ("cls", "clsw"):
+        dat = cases.classification_data(5, 403, 12, 4, n_test=61)
+        model = dict(n_nodes=[8, 5], use_bias_node=2, seed=3, use_class_weights=int(case == "clsw"))
+        sampler = dict(update_f=[0.05, 0.1, 0.2], update_ws=[0.05, 0.05, 0.05], n_iteration=2000, sampling_f=10, adapt_f=0.3, adapt_freq=25)
+    else:
+        dat = cases.regression_data(7, 389, 10, 2, n_test=50)
+        model = dict(n_nodes=[6, 4], use_bias_node=2, seed=3, estimation_mode="regression", empirical_error=(case == "reg"),
+                     actFun=bn.ActFun(fun="tanh"))
+        sampler = dict(update_f=[0.05, 0.1, 0.2], update_ws=[0.03, 0.03, 0.03], n_iteration=200, sampling_f=10, estimate_error=(case == "regsig"))
+
+    def run(data, **extra):
+        np.random.seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            bnn = bn.npBNN(data, **model)
+            mcmc = bn.MCMC(bnn, **sampler, **extra)
+            trail = [float(mcmc._logLik)]
+            mcmc.run_steps(bnn, 30)
+            trail.append(float(mcmc._logLik))
+            for _ in range(4):
+                mcmc.mh_step(bnn)
+            trail.append(float(mcmc._logLik))
+            mcmc.run_steps(bnn, 45)
+            trail.append(float(mcmc._logLik))
+            stats = [float(mcmc._accuracy), float(mcmc._test_accuracy)]
+        return bnn, mcmc, trail, stats
+
+    bnn0, mcmc0, trail0, stats0 = run(dat)
+    bnn1, mcmc1, trail1, stats1 = run(shard_rows(dat, rank, world), row_comm=comm)
+    assert mcmc1._backend.row_sharded and mcmc1._backend.n_rows_total == len(dat["data"])
+    assert len(bnn1._data) < len(dat["data"])
+    assert mcmc0._current_iteration == mcmc1._current_iteration == 79
+    tol = 1e-10 if backend == "oracle" else 2e-6
+    np.testing.assert_allclose(trail1, trail0, rtol=tol)
+    assert mcmc1._last_accepted_mem == mcmc0._last_accepted_mem, "the sharded chain took other decisions"
+    assert sum(mcmc0._last_accepted_mem) >= 5, "a chain that never moves proves nothing"
+    for a, b in zip(bnn1._w_layers, bnn0._w_layers):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(stats1, stats0, rtol=1e-9 if backend == "oracle" else 1e-5)
+    if case == "clsw":
+        np.testing.assert_allclose(bnn1._class_w, bnn0._class_w, rtol=1e-14)
+    if np.size(bnn0._error_prm):
+        np.testing.assert_allclose(bnn1._error_prm, bnn0._error_prm, rtol=tol * 100)
+    # every rank holds the same chain
+    mine = np.concatenate([w.ravel() for w in bnn1._w_layers])
+    allw = comm.allgather_f64(mine)
+    assert np.all(allw == allw[0]), "ranks disagree on the chain"
+    if backend == "hip":
+        used = getattr(mcmc1, "_device_schedule_used", None)
+        assert used == 1, "a row-sharded batch runs on kernel boundaries (schedule %r)" % used
+    comm.barrier()
+    comm.close()
+    print("RANK %d OK" % rank, flush=True)
+
+
 def run_idle(argv):
     fail_rank, fail_mode = planted(argv)
     rank = int(os.environ["RANK"])
@@ -133,4 +202,4 @@ def run_idle(argv):
 
 
 if __name__ == "__main__":
-    {"mc3": run_mc3, "idle": run_idle}[sys.argv[1]](sys.argv[2:])
+    {"mc3": run_mc3, "idle": run_idle, "rowshard": run_rowshard}[sys.argv[1]](sys.argv[2:])

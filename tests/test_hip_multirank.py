@@ -98,3 +98,24 @@ def test_bench_two_ranks_without_torch(tmp_path):
     assert line["torch_imported"] is False and line["value"] > 0
     if n_gpus() >= 2:
         assert "rccl" in line["config"]["swap_exchange"] and "/opt/rocm" in line["config"]["swap_exchange"]
+
+
+# ---- one chain, rows split over ranks (npbnn_set_row_shard; npbnn_amd/rowshard.py) ----
+@pytest.mark.parametrize("case", ["cls", "clsw", "reg", "regsig"])
+def test_row_sharded_chain_two_processes_on_one_gpu(case):
+    """Two ranks on GPU 0, each holding half of the rows; the per-pass records travel through the host (TCP communicator - RCCL refuses
+    two ranks on one device): npbnn_chain_run's sharded batches (pass, record, gather, step) and the sharded single evaluations take
+    the decisions of the same chain on all rows in one context."""
+    status, out0, outs = spawn_ranks(WORKER + ["rowshard", "hip", "socket", case], 2, capture_all=True, timeout=600)
+    assert status == 0, "\n".join(outs)
+    assert "RANK 0 OK" in out0 and "RANK 1 OK" in outs[1]
+
+
+@needs_two
+@pytest.mark.parametrize("case", ["cls", "reg"])
+def test_row_sharded_chain_over_rccl(case):
+    """The same with one GPU per rank and the records all-gathered by RCCL on the chains' streams."""
+    for world in rank_counts():
+        status, out0, outs = spawn_ranks(WORKER + ["rowshard", "hip", "rccl", case], world, capture_all=True, timeout=600)
+        assert status == 0, "\n".join(outs)
+        assert all("RANK %d OK" % r in outs[r] for r in range(world))

@@ -203,17 +203,67 @@ def main():
     if comm is not None:
         el = float(np.max(comm.allgather_f64(np.array([el]))))          # the slowest rank's clock
 
+    line = None
     if rank == 0:
         its = args.steps * ITERATIONS_PER_STEP
         line = report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, device_swaps)
+    if world > 1 and not os.environ.get("NPBNN_BENCH_NO_ROW_SHARD"):
+        # after the timed region: the other way several GPUs serve this path - ONE chain, its rows split over the ranks.  Nothing in
+        # here may cost the headline line: every failure is caught and reported inside it, on every rank
+        try:
+            leg = row_sharded_chain(comm, rank, world, device_index)
+        except Exception as e:      # noqa: BLE001
+            leg = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if line is not None:
+            line["row_sharded_chain"] = leg
+    if line is not None:
         print(json.dumps(line), flush=True)
     if comm is not None:
-        comm.barrier()
-        comm.close()
+        try:
+            comm.barrier()
+            comm.close()
+        except Exception as e:      # noqa: BLE001 - (a rank that failed in the leg above: the line is out, end quietly)
+            print("[bench rank %d] closing the communicator: %s" % (rank, e), file=sys.stderr)
     try:
         mcmc._backend.close()
     except Exception:       # noqa: BLE001 - (already closed by the report)
         pass
+
+
+def row_sharded_chain(comm, rank, world, device_index, config=4, n_steps=10):
+    """ONE chain of BASELINE config 4 (1M rows) with its rows split over the ranks (MCMC(row_comm=...), npbnn_set_row_shard): every
+    rank evaluates its share, the per-pass records are all-gathered (RCCL on the chain's stream when the communicator is the C
+    ABI's, else through the host) and every rank takes the same decision.  Dispatches of 100 iterations, the slowest rank's clock."""
+    import numpy as np
+    from bench_support import workload
+    from npbnn_amd import _capi as capi
+    from npbnn_amd.rowshard import shard_bounds
+    wl = workload(config)
+    lo, hi = shard_bounds(wl.n, rank, world)
+    bnn, mcmc = wl.build(rows=(lo, hi), row_comm=comm)
+    lib = capi.load_library()
+    for _ in range(3):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    book = dict(passes=mcmc._device_passes, its=mcmc._device_iterations, acc=mcmc._device_accepted)
+    comm.barrier()
+    capi.check(lib, None, lib.npbnn_device_synchronize(device_index))
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    capi.check(lib, None, lib.npbnn_device_synchronize(device_index))
+    el = float(np.max(comm.allgather_f64(np.array([time.perf_counter() - t0]))))
+    state = comm.allgather_f64(np.concatenate([[float(mcmc._logLik)], np.concatenate([w.ravel() for w in bnn._w_layers])]))
+    done = mcmc._device_iterations - book["its"]
+    be = mcmc._backend
+    out = {"workload": wl.description + "; ONE chain, rows split over %d ranks" % world, "value": n_steps * ITERATIONS_PER_STEP / el,
+           "unit": "iterations/s", "ms_per_step": 1e3 * el / n_steps, "ranks": world, "rows_per_rank": be.rows_per_rank,
+           "schedule": int(mcmc._device_schedule_used), "iterations_per_pass": done / max(1, mcmc._device_passes - book["passes"]),
+           "accept_rate": float(mcmc._device_accepted - book["acc"]) / max(1, done),
+           "gather": "ncclAllGather of the per-pass records on the chain's stream" if be.rccl_handle() else "through the host (communicator without a device handle)",
+           "loglik": float(mcmc._logLik), "ranks_hold_the_same_chain": bool(np.all(state == state[0])),
+           "note": "kernel boundaries: pass on this rank's rows, record, gather, step (npbnn_chain_run on a context with npbnn_set_row_shard)"}
+    be.close()
+    return out
 
 
 def make_comm(dist_backend, rank, world, local_rank, device_index):

@@ -37,11 +37,12 @@ class Config2(Workload):
         self.y = rs.integers(0, self.c, self.n)
         self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n
 
-    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, rows=None, **sampler_kw):
         """np.random.seed(1234); npBNN(n_nodes=[32,8], tanh, bias nodes in input+hidden layers, N(0,1) prior); MCMC defaults
-        (update_f 0.05 -> update_n [411,13,4])."""
-        x32 = self.x.astype(np.float32)
-        dat = dict(data=x32, labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
+        (update_f 0.05 -> update_n [411,13,4]).  rows = (lo, hi): this rank's share of the rows (with MCMC's row_comm=)."""
+        lo, hi = rows if rows is not None else (0, self.n)
+        x32 = self.x[lo:hi].astype(np.float32)
+        dat = dict(data=x32, labels=self.y[lo:hi], test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
         np.random.seed(1234)
         bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
         mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **sampler_kw)
@@ -108,10 +109,12 @@ class Config4(_Regression):
         self.y = self._targets(rs, self.x, self.k)
         self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n * self.k
 
-    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, rows=None, **sampler_kw):
         """bnn_regress.py:33-52: npBNN(regression, tanh, p_scale 1, bias 2, empirical_error); MCMC(update_ws [.025,.025,.05],
-        update_f [.005,.005,.05], adapt_f .3, estimate_error False)."""
-        dat = dict(data=self.x.astype(np.float32), labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros((0, self.k)))
+        update_f [.005,.005,.05], adapt_f .3, estimate_error False).  rows = (lo, hi): this rank's share of the rows (row_comm=)."""
+        lo, hi = rows if rows is not None else (0, self.n)
+        dat = dict(data=self.x[lo:hi].astype(np.float32), labels=self.y[lo:hi], test_data=np.zeros((0, self.f)),
+                   test_labels=np.zeros((0, self.k)))
         np.random.seed(1234)
         bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, estimation_mode="regression", actFun=bn.ActFun(fun="tanh"), p_scale=1,
                      use_bias_node=2, empirical_error=True)

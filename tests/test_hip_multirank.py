@@ -98,6 +98,10 @@ def test_bench_two_ranks_without_torch(tmp_path):
     assert line["torch_imported"] is False and line["value"] > 0
     if n_gpus() >= 2:
         assert "rccl" in line["config"]["swap_exchange"] and "/opt/rocm" in line["config"]["swap_exchange"]
+    leg = line["row_sharded_chain"]          # the other multi-GPU form: ONE chain of config 4, its rows split over the two ranks
+    assert "error" not in leg, leg
+    assert leg["ranks"] == 2 and sum(leg["rows_per_rank"]) == 1_000_000 and leg["ranks_hold_the_same_chain"] and leg["value"] > 0
+    assert leg["schedule"] == 1 and ("ncclAllGather" in leg["gather"]) == (n_gpus() >= 2)
 
 
 # ---- one chain, rows split over ranks (npbnn_set_row_shard; npbnn_amd/rowshard.py) ----

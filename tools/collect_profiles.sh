@@ -21,3 +21,20 @@ for c in 2 4 5; do
   done
 done
 find $out -name "*.csv" | head -50
+# the summaries under the names profiles/ keeps them by (bench.py reads the newest r*_cfg<c>_pass<d>_kernel_stats.csv / _pmc_*.csv)
+keep=$out/keep
+mkdir -p $keep
+first() { find "$1" -name "$2" 2>/dev/null | head -1; }
+for c in 2 4 5; do
+  f=$(first $out/bench_c$c "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_bench_cfg${c}_kernel_stats.csv
+  f=$(first $out/bench_c${c}_persistent "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_bench_cfg${c}_persistent_kernel_stats.csv
+  cp $out/bench_c${c}_under_rocprof.json $keep/${tag}_bench_cfg${c}_under_rocprof.json 2>/dev/null
+  cp $out/bench_c${c}_persistent_under_rocprof.json $keep/${tag}_bench_cfg${c}_persistent_under_rocprof.json 2>/dev/null
+  for cand in 3 1; do
+    f=$(first $out/pass_c${c}_d${cand} "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_cfg${c}_pass${cand}_kernel_stats.csv
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      f=$(first $out/pmc_c${c}_d${cand}_$ctr "*counter_collection.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_cfg${c}_pass${cand}_pmc_$ctr.csv
+    done
+  done
+done
+ls $keep

@@ -6,6 +6,7 @@ numerics of the hot path run in the hand-written HIP kernels behind it.
 """
 import ctypes as C
 import os
+from operator import is_ as _is
 from time import perf_counter as _now
 
 import numpy as np
@@ -13,10 +14,25 @@ import numpy as np
 from . import _capi as capi
 
 
+_PACKED_VIEWS = {}      # id(first layer) -> (the layer arrays, the packed vector they are consecutive views of); strong references: ids stay valid
+
+
+def note_packed_views(layers, base):
+    """``layers`` were just made as the consecutive views of the packed vector ``base`` (the state a device batch returns): the next
+    pack_weights of exactly these objects is one copy of ``base``."""
+    if len(_PACKED_VIEWS) >= 32:
+        _PACKED_VIEWS.clear()
+    _PACKED_VIEWS[id(layers[0])] = (tuple(layers), base)
+
+
 def pack_weights(weights):
     """Concatenate the layer matrices (each row-major) into the packed float64 vector the C ABI takes (always a fresh array).
-    Layers that are consecutive views of one packed vector - what a device batch leaves in the model - are copied in one piece."""
+    Layers that are consecutive views of one packed vector - what a device batch leaves in the model - are copied in one piece;
+    a set of layer objects once found to be such views is recognised by identity afterwards (a view cannot be moved)."""
     first = weights[0]
+    known = _PACKED_VIEWS.get(id(first))
+    if known is not None and len(known[0]) == len(weights) and all(map(_is, known[0], weights)):
+        return known[1].copy()
     base = getattr(first, "base", None)
     if (isinstance(base, np.ndarray) and base.ndim == 1 and base.dtype == np.float64 and base.flags.c_contiguous
             and base.size == sum(w.size for w in weights)):
@@ -26,11 +42,22 @@ def pack_weights(weights):
                 break
             at += w.nbytes
         else:
+            if len(_PACKED_VIEWS) >= 32:
+                _PACKED_VIEWS.clear()
+            _PACKED_VIEWS[id(first)] = (tuple(weights), base)
             return base.copy()
     return np.concatenate([np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights])
 
 
 _NO_SIGMA = np.zeros(0)
+
+
+def _addr(a):
+    """Address of an array's first element (a third of the cost of ``a.ctypes.data``, which builds a helper object per use)."""
+    try:
+        return C.addressof(C.c_char.from_buffer(a))
+    except (TypeError, ValueError):          # read-only or empty buffers
+        return a.ctypes.data
 
 
 def default_device():
@@ -248,6 +275,26 @@ class HipContext:
 
     def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
                         cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None, slopes=None):
+        # the settings of a plain batch rarely change between dispatches: when they are the ones this struct already holds, only the
+        # chain's state goes in
+        plain = (slopes is None and sigma_mult is None and type(prior_scale) is np.ndarray and prior_scale.ndim == 1
+                 and prior_scale.dtype == np.float64)
+        key = None
+        if plain:
+            key = (prior_kind, prior_scale.tobytes(), w_bound, temperature, lik_temp, n_candidates, schedule, sigma is None, cur_sigma is None)
+            if cfg.__dict__.get("_plain_key") == key:
+                cfg.cur_loglik, cfg.cur_logprior = cur_loglik, cur_logprior
+                cfg.force_f32 = 0
+                if sigma is not None or cur_sigma is not None:
+                    k = self.arch.n_targets
+                    if sigma is not None:
+                        for j, v in enumerate(np.broadcast_to(sigma, (k,))):
+                            cfg.sigma[j] = float(v)
+                    if cur_sigma is not None:
+                        for j, v in enumerate(np.broadcast_to(cur_sigma, (k,))):
+                            cfg.cur_sigma[j] = float(v)
+                return
+        cfg._plain_key = key
         cfg.slope_idx = cfg.slope_delta = None
         cfg.n_slopes = cfg.slope_term_in_prior = 0
         cfg._keep_slopes = None
@@ -329,8 +376,8 @@ class HipContext:
         llp, lpp = np.empty(K), np.empty(K)
         res = self._chain_res
         run = capi.chain_run_by_address(self._lib)
-        addr = (w.ctypes.data, None if m is None else m.ctypes.data, idx.ctypes.data, delta.ctypes.data, cnt.ctypes.data,
-                log_u.ctypes.data, acc.ctypes.data, llp.ctypes.data, lpp.ctypes.data)
+        addr = (_addr(w), None if m is None else _addr(m), _addr(idx), _addr(delta), _addr(cnt), _addr(log_u), _addr(acc), _addr(llp),
+                _addr(lpp))
         attempt, sync_retried = 0, False
         while True:
             cfg.force_f32 = attempt
@@ -345,6 +392,7 @@ class HipContext:
                 sync_retried = True
                 if cfg.schedule in (capi.SCHED_OVERLAP2, capi.SCHED_PERSIST, capi.SCHED_PERSIST_SERIAL):
                     cfg.schedule = capi.SCHED_OVERLAP
+                    cfg._plain_key = None      # (the struct no longer holds what the caller asked for)
                 self.sync_fallbacks += 1
                 if self.sync_fallbacks == 1:
                     import warnings

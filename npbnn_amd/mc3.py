@@ -116,7 +116,7 @@ class MC3():
                 small = {name: getattr(mcmc_i, name) for name in ("_accuracy", "_test_accuracy", "_label_acc",
                                                                    "_label_freq")}
                 light = {k: v for k, v in bnn_i.__dict__.items() if k not in _SHARED and k != "_npbnn_backend"}
-                state = {k: v for k, v in mcmc_i.__dict__.items() if k not in ("_backend", "_bnn", "_lazy", "_speculation")}
+                state = {k: v for k, v in mcmc_i.__dict__.items() if k not in ("_backend", "_bnn", "_lazy", "_speculation", "_ws_copies")}
                 state["_lazy"] = small
                 view = (light, state)
             view = self.comm.bcast_obj(view, root=owner)

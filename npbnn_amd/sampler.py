@@ -12,9 +12,16 @@ reference draws for the same seed).  What changed is where the arithmetic happen
     accepted weights instead of after every accepted step: they are functions of the accepted state
     only, so the values are the same, and nothing is downloaded while nobody looks.
 """
+import _thread
+import functools
+import operator
+import queue
+import threading
+
 import numpy as np
 
 from . import _capi as capi
+from .backend import note_packed_views
 from .likelihoods import (CalcAccuracy, CalcAccuracyRegression, CalcLabelAccuracy,
                           CalcLabelAccuracyRegression, SkipAccuracy, SkipAccuracyVec, calc_likelihood,
                           calc_likelihood_regression, calc_likelihood_regression_error, likelihood_kind,
@@ -31,14 +38,61 @@ _GENERAL_PROPOSALS = {UpdateNormal: capi.PROP_NORMAL, UpdateFixedNormal: capi.PR
 _POOL = None
 
 
-def _draw_pool():
+class _DrawJob:
+    """A call handed to the helper thread and, later, its outcome (``result()`` waits for it).  What a dispatch needs of a
+    concurrent.futures.Future, at a tenth of its cost per use."""
+    __slots__ = ("fn", "done", "value", "error")
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.done = _thread.allocate_lock()
+        self.done.acquire()
+        self.value = self.error = None
+
+    def run(self):
+        try:
+            self.value = self.fn()
+        except BaseException as e:      # noqa: BLE001 - (handed to whoever asks for the result)
+            self.error = e
+        finally:
+            self.fn = None
+            self.done.release()
+
+    def result(self):
+        self.done.acquire()
+        self.done.release()
+        if self.error is not None:
+            raise self.error
+        return self.value
+
+
+class _DrawThread:
     """One helper thread that pre-draws the next sub-batch of random numbers while the GPU runs the current one
     (both the pre-draw and the device call release the GIL)."""
+
+    def __init__(self):
+        self._jobs = queue.SimpleQueue()
+        self._thread = threading.Thread(target=self._serve, name="npbnn-predraw", daemon=True)
+        self._thread.start()
+
+    def _serve(self):
+        while True:
+            self._jobs.get().run()
+
+    def submit(self, fn, *args):
+        job = _DrawJob(functools.partial(fn, *args) if args else fn)
+        self._jobs.put(job)
+        return job
+
+
+def _draw_pool():
     global _POOL
     if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="npbnn-predraw")
+        _POOL = _DrawThread()
     return _POOL
+
+
+_is = operator.is_
 
 
 def _same_ends(copy, live):
@@ -273,10 +327,10 @@ class MCMC():
         state = dict(self.__dict__)
         state.pop("_backend", None)
         state.pop("_light_pickle", None)
+        state["_speculation"] = None
+        state["_ws_copies"] = None       # (holds the pre-draw plan: pointers into this process)
         if light:       # a checkpoint view (postLogger): no prediction matrices, no model reference beside the pickled one
             state["_lazy"] = {k: v for k, v in self._lazy.items() if k not in ("_y", "_y_test")}
-            state["_speculation"] = None
-            state["_ws_copies"] = None
         return state
 
     def _light_view(self, bnn_view):
@@ -302,7 +356,10 @@ class MCMC():
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = v if k == "_backend" else copy.deepcopy(v, memo)
+            if k == "_ws_copies":        # (the pre-draw plan holds pointers into its own step-size copies: the copy builds its own)
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = v if k == "_backend" else copy.deepcopy(v, memo)
         return new
 
     # ------------------------------------------------------------------------------------------
@@ -551,12 +608,13 @@ class MCMC():
             remaining -= seg
 
     _speculation = None      # (key, future, generator state before the draw, step-size arrays used) of draws made ahead of the next call
-    _ws_copies = None        # (step-size arrays, private copies of them, layer shapes) the helper thread works from
+    _ws_copies = None        # (step-size arrays, private copies of them, the pre-draw plan built on the copies, the settings it holds)
 
     def _draw_key(self, bnn_obj, first_it, k):
-        return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id), tuple(int(n) for n in self._update_n),
-                tuple(float(f) for f in self._freq_layer_update), tuple(w.shape for w in bnn_obj._w_layers),
-                self._sigma_proposal_columns(bnn_obj, first_it), self._n_trainable_slopes(bnn_obj))
+        """What the draws of iterations first_it .. first_it+k-1 depend on besides the generator's state and the step sizes."""
+        return (int(first_it), int(k), bool(self._randomize_seed), int(self._mcmc_id),
+                np.asarray(self._update_n, dtype=np.int64).tobytes(), np.asarray(self._freq_layer_update, dtype=np.float64).tobytes(),
+                tuple([w.shape for w in bnn_obj._w_layers]), self._sigma_proposal_columns(bnn_obj, first_it), self._n_trainable_slopes(bnn_obj))
 
     @staticmethod
     def _n_trainable_slopes(bnn_obj):
@@ -565,28 +623,30 @@ class MCMC():
 
     def _submit_draw(self, bnn_obj, first_it, k, rewindable=False):
         """Start the pre-draw of iterations first_it .. first_it+k-1 on the helper thread."""
-        from . import predraw as pd
         rs, randomize, mcmc_id = self._gen, self._randomize_seed, self._mcmc_id
-        update_n = [int(n) for n in self._update_n]
-        # private copies of the step sizes (the draw runs later), made once per set of source arrays: _adapt and reset_update_ws
-        # install NEW arrays, so the same objects mean the same values
-        src = list(self._update_ws)
+        key = self._draw_key(bnn_obj, first_it, k)
+        # private copies of the step sizes (the draw runs later) and the proposal description built from them (predraw.PredrawPlan),
+        # made once per set of source arrays and proposal settings: _adapt and reset_update_ws install NEW arrays, so the same
+        # objects mean the same values
+        src = self._update_ws
         cache = self._ws_copies
-        if cache is None or len(cache[0]) != len(src) or any(a is not b for a, b in zip(cache[0], src)) \
-                or any(c.shape != w.shape for c, w in zip(cache[2], bnn_obj._w_layers)) \
-                or not all(_same_ends(c, a) for c, a in zip(cache[1], src)):       # (an in-place edit of _update_ws[i])
-            cache = self._ws_copies = (src, [np.array(w, dtype=np.float64) for w in src], [np.empty(w.shape) for w in bnn_obj._w_layers])
-        update_ws, shapes = cache[1], cache[2]                         # (predraw only needs the shapes of the layers)
-        freq = [float(f) for f in self._freq_layer_update]
-        empty = getattr(self._backend, "host_empty", None)
-        empty_group = getattr(self._backend, "host_empty_group", None)
+        if cache is None or len(cache[0]) != len(src) or not all(map(_is, cache[0], src)) or cache[3] != key[4:7] \
+                or not all(map(_same_ends, cache[1], src)):                       # (an in-place edit of _update_ws[i])
+            from . import predraw as pd
+            copies = [np.array(w, dtype=np.float64) for w in src]
+            plan = pd.PredrawPlan([np.empty(w.shape) for w in bnn_obj._w_layers], [int(n) for n in self._update_n], copies,
+                                  [float(f) for f in self._freq_layer_update])
+            cache = self._ws_copies = (list(src), copies, plan, key[4:7])
+        src, plan = cache[0], cache[2]
+        be = self._backend
+        empty = getattr(be, "host_empty", None)
+        empty_group = getattr(be, "host_empty_group", None)
         saved = rs.bit_generator.state if (rewindable and not randomize) else None
-        sigma_k = self._sigma_proposal_columns(bnn_obj, first_it)
-        n_slopes = self._n_trainable_slopes(bnn_obj)
+        sigma_k, n_slopes = key[7], key[8]
 
         def draw():
-            out = pd.predraw(rs, randomize, first_it, mcmc_id, k, shapes, update_n, update_ws, freq, empty=empty, sigma_k=sigma_k,
-                             n_slopes=n_slopes, slope_d=0.05, empty_group=empty_group)
+            out = plan.run(rs, randomize, first_it, mcmc_id, k, empty=empty, sigma_k=sigma_k, n_slopes=n_slopes, slope_d=0.05,
+                           empty_group=empty_group)
             idx, delta, cnt, u = out[:4]
             np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
             smult = hast = None
@@ -599,15 +659,15 @@ class MCMC():
                 return idx, delta, cnt, u, smult, hast, out[-2], out[-1]
             return idx, delta, cnt, u, smult, hast
 
-        return self._draw_key(bnn_obj, first_it, k), _draw_pool().submit(draw), saved, src
+        return key, _draw_pool().submit(draw), saved, src
 
     def _claim_draw(self, bnn_obj, first_it, k):
         """The draws for iterations first_it .. first_it+k-1: the ones made ahead by the previous call when they
         are exactly these, else fresh ones."""
         spec = self._speculation
         if (spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k) and len(spec[3]) == len(self._update_ws)
-                and all(a is b for a, b in zip(spec[3], self._update_ws))       # (the very arrays the draw was made with ...
-                and self._ws_copies is not None and all(_same_ends(c, a) for c, a in zip(self._ws_copies[1], self._update_ws))):   # ... unedited)
+                and all(map(_is, spec[3], self._update_ws))                     # (the very arrays the draw was made with ...
+                and self._ws_copies is not None and all(map(_same_ends, self._ws_copies[1], self._update_ws))):   # ... unedited)
             self._speculation = None
             return spec[1]
         self._cancel_speculation()
@@ -714,6 +774,8 @@ class MCMC():
             for w in bnn_obj._w_layers:
                 layers.append(w_new[off:off + w.size].reshape(w.shape))
                 off += w.size
+            if off == w_new.size and w_new.dtype == np.float64:
+                note_packed_views(layers, w_new)
             bnn_obj.reset_weights(layers)
             self._logLik, self._logPrior = res["loglik"], res["logprior"]
             self._logPost = self._logLik + self._logPrior

@@ -461,6 +461,64 @@ int push_chain_params(npbnn_ctx* ctx, const ChainParams& c) {
     return NPBNN_OK;
 }
 
+// diagnostics (NPBNN_EVAL_STAMPS): what the evaluating workgroups of the last launch (or, in a persistent launch, of its last pass)
+// stamped - [grid][8] phases of wave 0, [grid][16] tile-loop ends per wave, [grid][8] prologue points (NPBNN_EXP_PROLOGUE_STAMPS builds).
+// first_wg: workgroups before it do not evaluate (the step workgroup of the flag-ordered schedules).  Frees the buffer.
+void report_eval_stamps(unsigned long long* d_stamps, int grid, int wpb, int first_wg) {
+    std::vector<unsigned long long> hs((size_t)grid * 32);
+    (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_stamps);
+    const int nwg = grid - first_wg;
+    if (nwg < 1) return;
+    if (getenv("NPBNN_EVAL_STAMPS") && atoi(getenv("NPBNN_EVAL_STAMPS")) >= 2) {
+        const int b = first_wg;
+        fprintf(stderr, "[npbnn eval stamps] raw, workgroup %d:", b);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %llu", hs[(size_t)b * 8 + k]);
+        fprintf(stderr, " | prologue:");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %llu", hs[(size_t)grid * 24 + (size_t)b * 8 + k]);
+        fprintf(stderr, "\n");
+    }
+    {   // when each wave of a workgroup finished its tiles, relative to the workgroup's tile-loop start (mean over workgroups)
+        double done[16] = {0};
+        for (int b = first_wg; b < grid; ++b)
+            for (int w = 0; w < wpb && w < 16; ++w)
+                done[w] += (double)(hs[(size_t)grid * 8 + (size_t)b * 16 + w] - hs[(size_t)b * 8 + 3]) * 0.01;
+        fprintf(stderr, "[npbnn eval stamps] tiles done per wave, us after the tile loop starts:");
+        for (int w = 0; w < wpb && w < 16; ++w) fprintf(stderr, " %.1f", done[w] / nwg);
+        fprintf(stderr, "\n");
+    }
+    unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
+    double acc[8] = {0};
+    for (int b = first_wg; b < grid; ++b) {
+        const unsigned long long* q = &hs[(size_t)b * 8];
+        if (q[0] < first) first = q[0];
+        if (q[6] > last) last = q[6];
+        if (q[6] < first_end) first_end = q[6];
+        for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;      // 100 MHz wall clock -> us
+        acc[7] += (double)q[7] * 0.01;
+    }
+    if (hs[(size_t)grid * 24 + (size_t)first_wg * 8] || hs[(size_t)grid * 24 + (size_t)first_wg * 8 + 3]) {      // (a build with NPBNN_EXP_PROLOGUE_STAMPS)
+        double px[5] = {0};
+        for (int b = first_wg; b < grid; ++b)
+            for (int k = 0; k < 5; ++k) px[k] += (double)(hs[(size_t)grid * 24 + (size_t)b * 8 + k] - hs[(size_t)b * 8]) * 0.01;
+        double period = 0, pmax = 0;
+        int np_ = 0;
+        for (int b = first_wg; b < grid; ++b) {
+            const unsigned long long prev = hs[(size_t)grid * 24 + (size_t)b * 8 + 5];
+            if (prev) { const double d = (double)(hs[(size_t)b * 8] - prev) * 0.01; period += d; if (d > pmax) pmax = d; ++np_; }
+        }
+        if (np_) fprintf(stderr, "[npbnn eval stamps] persistent launch: start of the pass before -> start of this one, us: mean %.2f, slowest workgroup %.2f\n", period / np_, pmax);
+        fprintf(stderr, "[npbnn eval stamps] prologue of wave 0, us after its start: parameters read %.2f, pass descriptor %.2f, image copies requested %.2f, "
+                        "first X pieces requested %.2f; end of the pass (sums out, workgroup reported done) %.2f\n", px[0] / nwg, px[1] / nwg, px[2] / nwg, px[3] / nwg, px[4] / nwg);
+    }
+    double late = 0;
+    for (int b = first_wg; b < grid; ++b) late += (double)(hs[(size_t)b * 8] - first) * 0.01;
+    fprintf(stderr, "[npbnn eval stamps] wave 0 of a workgroup, mean us: start skew %.2f | issue %.2f  barrier1 %.2f  patch %.2f  tiles %.2f  "
+                    "barrier2 %.2f  partials %.2f | tails within tiles %.2f | first start -> first end %.2f, -> last end %.2f\n",
+            late / nwg, acc[1] / nwg, acc[2] / nwg, acc[3] / nwg, acc[4] / nwg, acc[5] / nwg, acc[6] / nwg, acc[7] / nwg,
+            (double)(first_end - first) * 0.01, (double)(last - first) * 0.01);
+}
+
 EvalParams make_params(npbnn_ctx* ctx, const Dataset& d) {
     EvalParams p{};
     p.X = ctx->net.l0_f16 ? d.X16 : d.X;
@@ -1131,8 +1189,8 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     p.M = 0;
     unsigned long long* d_stamps = nullptr;
     if (getenv("NPBNN_EVAL_STAMPS")) {      // diagnostics: per-phase wall-clock stamps of the last launch
-        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)lp.grid * 24 * sizeof(unsigned long long)));     // [grid][8] wave 0 + [grid][16] per wave
-        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)lp.grid * 24 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMalloc(&d_stamps, (size_t)lp.grid * 32 * sizeof(unsigned long long)));     // [grid][8] wave 0 + [grid][16] per wave + [grid][8] prologue
+        HIP_TRY(ctx, hipMemset(d_stamps, 0, (size_t)lp.grid * 32 * sizeof(unsigned long long)));
         p.stamps = d_stamps;
     }
     rc = push_eval_params(ctx, p);
@@ -1163,36 +1221,7 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
         }
         for (int i = 0; i < n_streams; ++i) (void)hipStreamDestroy(ss[i]);
     }
-    if (d_stamps) {
-        std::vector<unsigned long long> hs((size_t)lp.grid * 24);
-        (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(d_stamps);
-        {   // when each wave of a workgroup finished its tiles, relative to the workgroup's tile-loop start (mean over workgroups)
-            double done[16] = {0};
-            for (int b = 0; b < lp.grid; ++b)
-                for (int w = 0; w < lp.wpb && w < 16; ++w)
-                    done[w] += (double)(hs[(size_t)lp.grid * 8 + (size_t)b * 16 + w] - hs[(size_t)b * 8 + 3]) * 0.01;
-            fprintf(stderr, "[npbnn eval stamps] tiles done per wave, us after the tile loop starts:");
-            for (int w = 0; w < lp.wpb && w < 16; ++w) fprintf(stderr, " %.1f", done[w] / lp.grid);
-            fprintf(stderr, "\n");
-        }
-        unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
-        double acc[8] = {0};
-        for (int b = 0; b < lp.grid; ++b) {
-            const unsigned long long* q = &hs[(size_t)b * 8];
-            if (q[0] < first) first = q[0];
-            if (q[6] > last) last = q[6];
-            if (q[6] < first_end) first_end = q[6];
-            for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;      // 100 MHz wall clock -> us
-            acc[7] += (double)q[7] * 0.01;
-        }
-        double late = 0;
-        for (int b = 0; b < lp.grid; ++b) late += (double)(hs[(size_t)b * 8] - first) * 0.01;
-        fprintf(stderr, "[npbnn eval stamps] wave 0 of a workgroup, mean us: start skew %.2f | issue %.2f  barrier1 %.2f  patch %.2f  tiles %.2f  "
-                        "barrier2 %.2f  partials %.2f | tails within tiles %.2f | first start -> first end %.2f, -> last end %.2f\n",
-                late / lp.grid, acc[1] / lp.grid, acc[2] / lp.grid, acc[3] / lp.grid, acc[4] / lp.grid, acc[5] / lp.grid, acc[6] / lp.grid, acc[7] / lp.grid,
-                (double)(first_end - first) * 0.01, (double)(last - first) * 0.01);
-    }
+    if (d_stamps) report_eval_stamps(d_stamps, lp.grid, lp.wpb, 0);
     return NPBNN_OK;
 }
 

@@ -668,8 +668,9 @@ __device__ __forceinline__ bool sync_eval_enter(ChainDev* st, int launch, int* l
     // loads); nearly always it already says "ready".
     if (threadIdx.x == 0) {
         int ok = 1;
+        // (ready already: no look at ChainDev.aborted - a round trip per pass - here: a pass that is prepared may be evaluated whatever
+        // happened elsewhere, and a batch that was aborted never prepares the next one: the wait for that one sees the flag)
         if (early_prepared < launch || early_prepared == 0x7fffffff) ok = sync_wait_ge(st, &st->prepared, launch) ? 1 : 0;
-        else if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
         *lds_flag = ok;
     }
     __syncthreads();

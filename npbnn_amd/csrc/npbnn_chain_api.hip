@@ -38,6 +38,7 @@ struct ChainBatch {
     size_t wb = 0;
     int launch = 0;                            // launches enqueued so far (overlapped schedule: the pass parity follows it)
     unsigned long long* d_stamps = nullptr;    // diagnostics
+    unsigned long long* d_estamps = nullptr;   // diagnostics (NPBNN_EVAL_STAMPS: the evaluating workgroups' phases, last pass of the batch)
     double tw0 = 0.0, tw1 = 0.0;
 };
 
@@ -429,6 +430,11 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     p.inst_w = d.inst_w;
     p.use_classw = ctx->n_classw > 0 ? 1 : 0;
     p.has_pass = 1;
+    if (getenv("NPBNN_EVAL_STAMPS") && group_blocks == 0) {
+        HIP_TRY(ctx, hipMalloc(&B->d_estamps, (size_t)(lp.grid + 1) * 32 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(B->d_estamps, 0, (size_t)(lp.grid + 1) * 32 * sizeof(unsigned long long)));
+        p.stamps = B->d_estamps;
+    }
     p.pv = spec ? ctx->d_spec_pv : ctx->d_pv;
     p.pos = ctx->d_pos;
     p.pscale = f16 ? ctx->d_pscale : nullptr;
@@ -577,6 +583,10 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         }
         if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
                        acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
+    }
+    if (B.d_estamps) {
+        report_eval_stamps(B.d_estamps, B.lp.grid + (B.overlap ? 1 : 0), B.lp.wpb, (B.sync || B.persist) ? 1 : 0);
+        B.d_estamps = nullptr;
     }
     const int flags = *reinterpret_cast<const int*>(ctx->h_res + 448);
     if (flags & kFlagStructure) return fail(ctx, NPBNN_E_ARG, "chain_run: a layer-0 weight is not zero where the mask given to npbnn_set_layer_mask is");

@@ -250,6 +250,7 @@ int push_eval_params(npbnn_ctx* ctx, const EvalParams& p);
 int push_finalize_params(npbnn_ctx* ctx, const FinalizeParams& f);
 int push_chain_params(npbnn_ctx* ctx, const ChainParams& c);
 EvalParams make_params(npbnn_ctx* ctx, const Dataset& d);
+void report_eval_stamps(unsigned long long* d_stamps, int grid, int wpb, int first_wg);
 int check_dataset_for_lik(npbnn_ctx* ctx, const Dataset& d, int lik);
 double wall_us();
 // launches of kernels that live in npbnn_capi.hip, for the other translation units: the weight image of device-resident float64

@@ -426,6 +426,24 @@ __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int 
 }
 #define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// The parameter block of a launch is read with scalar loads scattered over the prologue (the network description, the layout, the
+// pass descriptor, pointers): each is a round trip of 0.6-0.9 us to the L2 when it misses the scalar cache, and they depend on one
+// another (measured, NPBNN_EXP_PROLOGUE_STAMPS: 3.6 us before the first X piece is requested).  This asks for every line of the
+// block at once, first thing in the kernel - one round trip - so that the loads that follow hit the scalar cache.  The values are
+// not used (the destinations overlap on purpose: only the cache lines matter).
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void warm_scalar_cache(const EvalParams* pp) {
+    static_assert(sizeof(EvalParams) <= 16 * 64, "one s_load_dwordx16 per 64-byte line");
+    i32x16_t a, b, c, d;
+    asm volatile(
+        "s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0\n\t"
+        "s_load_dwordx16 %0, %4, 0x100\n\ts_load_dwordx16 %1, %4, 0x140\n\ts_load_dwordx16 %2, %4, 0x180\n\ts_load_dwordx16 %3, %4, 0x1c0\n\t"
+        "s_load_dwordx16 %0, %4, 0x200\n\ts_load_dwordx16 %1, %4, 0x240\n\ts_load_dwordx16 %2, %4, 0x280\n\ts_load_dwordx16 %3, %4, 0x2c0\n\t"
+        "s_load_dwordx16 %0, %4, 0x300\n\ts_load_dwordx16 %1, %4, 0x340\n\ts_load_dwordx16 %2, %4, 0x380\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(pp) : "memory");
+}
+
 // FAST: the build for launches that want nothing but the likelihood terms of a 2- or 3-layer network with narrow later layers
 // (`fast_launch_ok` below says which: every chain pass and plain evaluation of the BASELINE configs).  It holds only the
 // shape-specialised tails and none of the scalars the general epilogue keeps alive (statistics, predictions, row weights ...),
@@ -455,11 +473,18 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const int launch_end = launch0 + (n_loop > 1 ? n_loop : 1);
     // the parameter block lives in device memory (warm in L2 across the thousands of launches of a chain); a by-value
     // kernel argument of this size costs several microseconds of cold scalar loads per launch
+#ifndef NPBNN_EXP_NO_WARM
+    warm_scalar_cache(pp);
+#endif
     const EvalParams& p = *pp;
     const int bid = uni((int)blockIdx.x);      // (pinned to a scalar register before the first lane-dependent branch)
     unsigned long long* const stamps = uni(p.stamps);
 #define NPBNN_ESTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + (k)] = wall_clock64(); } while (0)
-    NPBNN_ESTAMP(0);
+#ifdef NPBNN_EXP_PROLOGUE_STAMPS      // (diagnostic builds only: finer stamps inside the prologue, a second block behind the per-wave ones)
+#define NPBNN_ESTAMPX(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)gridDim.x * 24 + (size_t)bid * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define NPBNN_ESTAMPX(k) do { } while (0)
+#endif
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
     constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -504,18 +529,34 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         }
         return;
     }
+#ifdef NPBNN_EXP_PROLOGUE_STAMPS
+    unsigned long long t_prev_pass0 = 0;
+#endif
     for (int launch = launch0; launch < launch_end; ++launch) {         // (one pass, but for the persistent form: see n_loop)
     // Every pass reads its parameters afresh, through a pointer the compiler cannot see through: otherwise it hoists the dozens of
     // launch-invariant scalars of the pass out of this loop and keeps them alive across it - far more than the scalar register file
     // holds (70 spilled scalars against 33).
+#ifdef NPBNN_EXP_PROLOGUE_STAMPS   // (kept in a register until the pass turns out to be a real one: a persistent launch ends with an empty turn)
+    const unsigned long long t_pass0 = stamps ? wall_clock64() : 0;
+#else
+    NPBNN_ESTAMP(0);          // (start of this pass: of the launch, or of its turn in a persistent launch)
+#endif
     const EvalParams* pp_pass = pp;
     asm volatile("" : "+s"(pp_pass));
-    const EvalParams& p = *pp_pass;
+    // The parameter block does not change while a launch runs (but for the pass descriptors, which a flag-ordered launch reads with
+    // vector loads of their own): read through the CONSTANT address space its fields come in by scalar loads that hit the scalar
+    // cache.  Through the generic pointer every one of them is a vector load + readfirstlane - the compiler cannot rule out that the
+    // kernel's own stores change the block - and their dependent round trips cost a persistent launch 3.3 us at the top of every pass
+    // (measured, NPBNN_EXP_PROLOGUE_STAMPS).
+    typedef const __attribute__((address_space(4))) EvalParams ConstEvalParams;
+    ConstEvalParams& p = *(ConstEvalParams*)pp_pass;
+    const EvalParams& p_generic = *pp_pass;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
-    const NetMeta& net = p.net;
+    const auto& net = p.net;
+    const NetMeta& net_generic = p_generic.net;          // (for the tails' signature; what they read of it is in `hp`)
     const int wpb = blockDim.x >> 6;
     const int image_floats = uni(net.image_floats);
     const size_t IB = (size_t)image_floats * 4;                     // bytes of one weight image
@@ -567,6 +608,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const float* const g_pscale = uni(p.pscale);
     double* const g_partials = uni(p.partials);
 
+    NPBNN_ESTAMPX(0);
     char* const ring = smem + D * IB + (size_t)wave * uni(p.lay.wave_lds);
     char* const aux = ring + kRing * 1024;
     float* const row_scratch = reinterpret_cast<float*>(aux + (aux_mask + 1) * aux_sz);   // [16 rows][16 outputs], generic likelihoods
@@ -651,7 +693,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int t0g[D];                    // group pass: the iteration each chain's candidate belongs to
 #pragma unroll
     for (int j = 0; j < D; ++j) { cnt[j] = 0; t0g[j] = 0; }
-    const PassDesc* const pass = (CHAIN && uni(p.has_pass)) ? &p.pass_desc[par] : nullptr;
+    const PassDesc* const pass = (CHAIN && uni(p.has_pass)) ? &p_generic.pass_desc[par] : nullptr;
     int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
     // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
     if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
@@ -702,10 +744,13 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         }
     }
 
+    NPBNN_ESTAMPX(1);
     if (!early_copy) {
         stage_images();
+        NPBNN_ESTAMPX(2);
         for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
     }
+    NPBNN_ESTAMPX(3);
     const double* const pv = uni(p.pv) + (size_t)pv_slot * kMaxCand * M;
     // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
     // this pass is then evaluated from a state that no longer exists and nobody will read its sums: polled once per tile
@@ -754,6 +799,13 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         aval = __hip_atomic_load(uni(p.pv) + (size_t)acc_slot * M + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g_pscale) asc = g_pscale[arow + tid];
     }
+#ifdef NPBNN_EXP_PROLOGUE_STAMPS
+    if (stamps && threadIdx.x == 0) {
+        stamps[(size_t)bid * 8] = t_pass0;
+        stamps[(size_t)gridDim.x * 24 + (size_t)bid * 8 + 5] = t_prev_pass0;     // (start of the pass before: the period of a persistent launch)
+    }
+    t_prev_pass0 = t_pass0;
+#endif
     NPBNN_ESTAMP(1);
     __syncthreads();
     NPBNN_ESTAMP(2);
@@ -879,11 +931,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             constexpr int NLC = decltype(nlc)::value, ACTC = decltype(actc)::value;
             constexpr bool PL = decltype(plain)::value;
             if constexpr (DT == D) {
-                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                tile_tail<MT0, MTI, LK, D, D, 0, NLC, ACTC, PL, F16, GI>(net_generic, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
             } else {
-                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
-                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL, F16, GI>(net, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                tile_tail<MT0, MTI, LK, 1, D, 0, NLC, ACTC, PL, F16, GI>(net_generic, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 1) tile_tail<MT0, MTI, LK, 1, D, 1, NLC, ACTC, PL, F16, GI>(net_generic, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
+                if constexpr (D > 2) tile_tail<MT0, MTI, LK, 1, D, 2, NLC, ACTC, PL, F16, GI>(net_generic, hp, imgs, image_floats, acc0, lane, n, kq, a_slot, row_scratch, row, row < hp.n_rows, A);
                 static_assert(D <= 3, "add a call per candidate");
             }
         };
@@ -1150,7 +1202,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             }
         }
         __syncthreads();
-        for (int item = tid; item < D * nvals; item += blockDim.x) {
+        // (the LAST wave adds them up and writes them: in a flag-ordered launch it is also the one that reports the workgroup done,
+        // after waiting for these very stores)
+        for (int item = tid - ((int)blockDim.x - 64); item >= 0 && item < D * nvals; item += 64) {
             const int j = item / nvals, v = item % nvals;
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
@@ -1164,8 +1218,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     NPBNN_ESTAMP(6);
     if (sync) {                                  // this workgroup's sums are out: tell the step of the next launch
         __syncthreads();
-        if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
+        // (by the LAST wave: it waits for the stores to be acknowledged, a round trip that wave 0 - which reads the next pass's flag
+        // and descriptor for everybody - does not have to sit through)
+        if (threadIdx.x == blockDim.x - 64) sync_eval_leave(chain->st, launch);
     }
+    NPBNN_ESTAMPX(4);
     }       // (next pass of the persistent form)
 #undef NPBNN_ESTAMP
 }

@@ -1,6 +1,7 @@
 // C ABI of the gfx950 backend (see include/npbnn_hip.h for the contract and the reference
 // functions each entry point replaces).  Host-side orchestration only: device buffers, launches,
 // the HIP stream of the chain.  No torch, no BLAS library, no CPU fallback for the numerics.
+#include <algorithm>
 #define NPBNN_KERNELS_MAIN
 #include "npbnn_ctx.hip.h"
 
@@ -471,6 +472,24 @@ void report_eval_stamps(unsigned long long* d_stamps, int grid, int wpb, int fir
     const int nwg = grid - first_wg;
     if (nwg < 1) return;
     if (getenv("NPBNN_EVAL_STAMPS") && atoi(getenv("NPBNN_EVAL_STAMPS")) >= 2) {
+        // per workgroup: pass start -> end of the pass (prologue stamp 4), the tile phase of wave 0, by (b - first_wg) % 8 (its place in the
+        // round-robin over the 8 XCDs)
+        double by_xcd[8] = {0}, tiles_xcd[8] = {0};
+        int n_xcd[8] = {0};
+        std::vector<std::pair<double, int>> dur;
+        for (int b = first_wg; b < grid; ++b) {
+            const double d = (double)(hs[(size_t)grid * 24 + (size_t)b * 8 + 4] - hs[(size_t)b * 8]) * 0.01;
+            const double t = (double)(hs[(size_t)b * 8 + 4] - hs[(size_t)b * 8 + 3]) * 0.01;
+            dur.push_back({d, b});
+            by_xcd[b % 8] += d; tiles_xcd[b % 8] += t; ++n_xcd[b % 8];
+        }
+        std::sort(dur.begin(), dur.end());
+        fprintf(stderr, "[npbnn eval stamps] pass start -> end per workgroup, us: fastest %.2f (wg %d), median %.2f, slowest", dur.front().first, dur.front().second,
+                dur[dur.size() / 2].first);
+        for (size_t i = dur.size() >= 6 ? dur.size() - 6 : 0; i < dur.size(); ++i) fprintf(stderr, " %.2f (wg %d)", dur[i].first, dur[i].second);
+        fprintf(stderr, "\n[npbnn eval stamps] mean by blockIdx %% 8:");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.2f/%.2f", n_xcd[x] ? by_xcd[x] / n_xcd[x] : 0.0, n_xcd[x] ? tiles_xcd[x] / n_xcd[x] : 0.0);
+        fprintf(stderr, " (pass/tile phase)\n");
         const int b = first_wg;
         fprintf(stderr, "[npbnn eval stamps] raw, workgroup %d:", b);
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %llu", hs[(size_t)b * 8 + k]);

@@ -532,6 +532,15 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 #ifdef NPBNN_EXP_PROLOGUE_STAMPS
     unsigned long long t_prev_pass0 = 0;
 #endif
+    // Persistent launch, looking one pass ahead (LOOK builds): a workgroup that has finished the tiles of pass L reads the flag and
+    // the descriptor of pass L + 1 while its sums go out and, if that pass is ready and real, requests its weight images at once:
+    // the next turn of the loop starts with the descriptor in registers and the images on their way (a flag round trip, a descriptor
+    // round trip and the images' latency - 3 us - off every pass's critical path).  ahead_t0 >= 0: pass `launch` was looked at that way.
+    constexpr bool LOOK = CHAIN && !SPEC;
+    int ahead_t0 = -1;
+    int ahead_cnt[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) ahead_cnt[j] = 0;
     for (int launch = launch0; launch < launch_end; ++launch) {         // (one pass, but for the persistent form: see n_loop)
     // Every pass reads its parameters afresh, through a pointer the compiler cannot see through: otherwise it hoists the dozens of
     // launch-invariant scalars of the pass out of this loop and keeps them alive across it - far more than the scalar register file
@@ -682,8 +691,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
     }
 
+    const bool ahead = LOOK && ahead_t0 >= 0;      // (wave-uniform, the same in every wave: it came out of LDS behind a barrier)
     int early_prepared = 0x7fffffff;
-    if (sync && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
+    if (sync && !ahead && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
         early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int par = (chain || GN) ? (launch & 1) : 0;
     // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
@@ -696,7 +706,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const PassDesc* const pass = (CHAIN && uni(p.has_pass)) ? &p_generic.pass_desc[par] : nullptr;
     int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
     // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
-    if (sync && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
+    if (sync && !ahead && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
         if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);     // (copies requested ahead of the flag must not land in LDS that is no longer ours)
         return;
     }
@@ -711,6 +721,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             t0g[j] = uni(dj->t0);
         }
         if (!alive) return;                                   // every chain is through
+    } else if (pass && ahead) {
+        t0 = ahead_t0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cnt[j] = ahead_cnt[j];
     } else if (pass) {
         if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
             const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -746,10 +760,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 
     NPBNN_ESTAMPX(1);
     if (!early_copy) {
-        stage_images();
+        if (!ahead) stage_images();
         NPBNN_ESTAMPX(2);
         for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
     }
+    ahead_t0 = -1;
     NPBNN_ESTAMPX(3);
     const double* const pv = uni(p.pv) + (size_t)pv_slot * kMaxCand * M;
     // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
@@ -1167,6 +1182,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 
     NPBNN_ESTAMP(4);
     if (stamps && lane == 0) stamps[(size_t)gridDim.x * 8 + (size_t)bid * 16 + wave] = wall_clock64();   // every wave: tiles done
+    const bool look = LOOK && sync && n_loop > 1 && launch + 1 < launch_end && !GN && g_partials != nullptr;
+    int* const look_words = reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds));       // (the flag word's 64 bytes)
     // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
     if (g_partials || GN) {
         constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
@@ -1182,8 +1199,20 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 A[j].ll = wave_sum_f64(A[j].ll);
             }
         }
+        // (looking ahead: the flag of the pass after this one, asked for before the barrier, read behind it)
+        int nx_prepared = -1;
+        if (look && wave == 0)
+            nx_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                   // every wave is done with its ring: reuse the rings as scratch
         NPBNN_ESTAMP(5);
+        int nx_desc = 0;
+        bool nx_ready = false;
+        if (look && wave == 0) {
+            nx_ready = uni(nx_prepared) >= launch + 1;      // (ready: its descriptor is final - asked for only now, after the flag was seen)
+            if (nx_ready)
+                nx_desc = __hip_atomic_load(reinterpret_cast<const int*>(&p_generic.pass_desc[(launch + 1) & 1]) + (lane & 7), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+        }
         double* wsum = reinterpret_cast<double*>(smem + D * IB);    // [candidate][wave][kPartialStride]
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -1201,6 +1230,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 if (lane == 0) ws[0] = A[j].ll;
             }
         }
+        if (look && wave == 0 && lane < 8)                 // n_cand, t0, cnt ... of the pass ahead; n_cand = 0 when it is not to be started early
+            look_words[lane] = nx_ready ? nx_desc : 0;
         __syncthreads();
         // (the LAST wave adds them up and writes them: in a flag-ordered launch it is also the one that reports the workgroup done,
         // after waiting for these very stores)
@@ -1221,6 +1252,16 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         // (by the LAST wave: it waits for the stores to be acknowledged, a round trip that wave 0 - which reads the next pass's flag
         // and descriptor for everybody - does not have to sit through)
         if (threadIdx.x == blockDim.x - 64) sync_eval_leave(chain->st, launch);
+        if constexpr (LOOK) {
+            // (look_words were written before the barrier two above: every wave reads the same descriptor)
+            if (look && look_words[1] > 0) {     // word 1: n_cand
+                ahead_t0 = uni(look_words[0]);
+#pragma unroll
+                for (int j = 0; j < D; ++j) ahead_cnt[j] = uni(look_words[2 + (j < kMaxCand ? j : 0)]);
+                stage_images();                 // (every wave is past its tiles: the image slots are free; the step of the pass ahead does
+                                                //  not touch the global image before every workgroup - this one too - has reported done)
+            }
+        }
     }
     NPBNN_ESTAMPX(4);
     }       // (next pass of the persistent form)

@@ -154,12 +154,21 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         // A chain that moves: in the overlapped forms every pass that accepts something voids the pass in flight behind it (at 28 %
         // acceptance 63 % of the passes do), and on kernel boundaries a decision between two passes costs a step kernel and two
         // boundaries.  The persistent launch with the decision between the passes (NPBNN_SCHED_PERSIST_SERIAL) wastes no pass and
-        // decides in a few microseconds: above kPersistSerialAccept of the proposals accepted it leads (measured).
+        // decides in a few microseconds: it leads where the predicted cost per decided pass says so (npbnn_ctx.hip.h, kSpecTurnExtraUs).
         // (its step workgroup must keep pace with the evaluation: with proposals much wider than a few hundred weights it does not)
-        if (alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option && p_acc > kPersistSerialAccept && group_blocks == 0 &&
+        if (alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option && p_acc > 0.0 && group_blocks == 0 &&
             !cfg->slope_idx && M <= kPersistSerialMaxWidth && lp.fn_spec != nullptr &&
-            (cfg->prior_kind == NPBNN_PRIOR_UNIFORM || (cfg->prior_kind == NPBNN_PRIOR_NORMAL && !cfg->prior_scale_w)))
-            schedule = NPBNN_SCHED_PERSIST_SERIAL;
+            (cfg->prior_kind == NPBNN_PRIOR_UNIFORM || (cfg->prior_kind == NPBNN_PRIOR_NORMAL && !cfg->prior_scale_w))) {
+            const double a = 1.0 - std::pow(1.0 - p_acc, D);                 // share of the passes that accept something
+            const double extra = kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M;
+            double t_over = ctx->turn_us[0], t_serial = ctx->turn_us[1];
+            if (t_over <= 0.0 && t_serial <= 0.0) t_over = kTurnUsGuess;
+            if (t_over <= 0.0) t_over = t_serial - extra > 5.0 ? t_serial - extra : 5.0;
+            if (t_serial <= 0.0) t_serial = t_over + extra;
+            // (3 % in favour of the form the chain is on: no flipping on noise)
+            const bool on_serial = ctx->last_schedule == NPBNN_SCHED_PERSIST_SERIAL;
+            if (t_serial * (on_serial ? 0.97 : 1.03) < t_over * (1.0 + a)) schedule = NPBNN_SCHED_PERSIST_SERIAL;
+        }
     }
     if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
     // (asked for by name where it cannot run - no build with the speculative step for this launch, another prior, trainable slopes, a
@@ -567,6 +576,7 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
                  double* out_logprior_prop, npbnn_chain_result* result, int k_take, bool exchange_run = false) {
     const ChainDev fin = *reinterpret_cast<const ChainDev*>(ctx->h_res);
     if (fin.n_passes + fin.n_void > 0 && k_take > 0) ctx->its_per_pass = (double)k_take / (fin.n_passes + fin.n_void);
+    ctx->last_schedule = B.schedule;
     if (k_take > 0) ctx->accept_rate = (double)fin.n_accepted / k_take;
     if (B.d_stamps) {
         std::vector<unsigned long long> hs(1024 * 8);
@@ -673,6 +683,11 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     const double tw2 = wall_us();
     rc = chain_finish(ctx, B, cfg, W_inout, out_accepted, out_loglik_prop, out_logprior_prop, result, K);
     if (rc) return rc;
+    if (B.persist && n_rounds == 1 && result->n_passes + result->n_void_passes >= 8) {      // what a turn of this form takes here (NPBNN_SCHED_AUTO)
+        double& t = ctx->turn_us[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0];
+        const double now_us = (tw2 - B.tw1) / (result->n_passes + result->n_void_passes);
+        t = t > 0.0 ? 0.75 * t + 0.25 * now_us : now_us;
+    }
     if (timing && ctx->d_spec && B.schedule == NPBNN_SCHED_PERSIST_SERIAL) {
         SpecState hs;
         if (hipMemcpy(&hs, ctx->d_spec, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess && hs.rounds > 0)

@@ -147,6 +147,8 @@ struct npbnn_ctx {
     char* h_res = nullptr;
     size_t res_cap = 0, res_k = 0, res_nw = 0;
     int* d_chain_ovf = nullptr;
+    int last_schedule = 0;         // schedule of the previous batch
+    double turn_us[2] = {0.0, 0.0}; // measured time of a launch turn (pass, decided or void) of the persistent forms: overlapped, decision between passes
     double its_per_pass = 0.0;     // iterations a launch decided on average in the previous batch (0: unknown)
     double accept_rate = -1.0;     // acceptance rate of the previous batch (< 0: unknown)
     double* d_wcur = nullptr;
@@ -207,7 +209,14 @@ static_assert(sizeof(EvalParams) % 8 == 0 && sizeof(FinalizeParams) % 8 == 0, "p
 
 namespace npbnn_api {
 
-constexpr double kPersistSerialAccept = 0.07;   // NPBNN_SCHED_AUTO: acceptance rate above which the persistent launch decides between the passes
+// NPBNN_SCHED_AUTO between the two persistent forms.  Overlapped (PERSIST): a pass that accepts voids the pass in flight behind it - a
+// decided pass costs (1 + a) turns, a = 1 - (1 - p)^D the share of passes that accept something.  Decision between the passes
+// (PERSIST_SERIAL): no pass in vain, but every turn is longer by the decision and by what the step workgroup cannot hide of preparing
+// the next pass for every outcome - more, the wider the proposals.  The context keeps the turn times it measured (npbnn_ctx.turn_us) and
+// picks the form with the lower predicted cost per decided pass; a form not measured yet is predicted from the other one with
+// kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M (measured on config-2 shapes: 33.2 against 28.5 us per turn at M = 33, 40 at M = 428).
+constexpr double kSpecTurnExtraUs = 4.5, kSpecTurnExtraUsPerWeight = 0.0175;
+constexpr double kTurnUsGuess = 30.0;           // before anything has been measured
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 

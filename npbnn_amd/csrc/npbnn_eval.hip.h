@@ -560,6 +560,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     typedef const __attribute__((address_space(4))) EvalParams ConstEvalParams;
     ConstEvalParams& p = *(ConstEvalParams*)pp_pass;
     const EvalParams& p_generic = *pp_pass;
+    // (the chain's parameter block sits behind this one in the same buffer and is as constant: its state pointer by a scalar load too -
+    // through the generic pointer it was a vector load whose readfirstlane waited for every image and X piece requested before it)
+    typedef const __attribute__((address_space(4))) ChainParams ConstChainParams;
+    ChainDev* const st_dev = chain ? uni(((ConstChainParams*)chain)->st) : nullptr;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -645,7 +649,16 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const int first_tile = ebid + G * wave;
     const int simd_waves = (wpb - (wave & 3) + 3) >> 2;      // waves of this workgroup on this wave's SIMD
     const int stride = G * 4 * simd_waves;
-    const int my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0;
+    // (counted, not divided, when it is a handful: an integer division runs on the vector unit, and the first vector instruction at
+    // the top of a pass waits for every vector memory operation still in flight - the image copies of the look-ahead among them)
+    int my_tiles = 0;
+    if (first_tile < n_tiles) {
+        if (n_tiles - first_tile <= 32 * stride) {
+            for (int t = first_tile; t < n_tiles; t += stride) ++my_tiles;
+        } else {
+            my_tiles = (n_tiles - first_tile + stride - 1) / stride;
+        }
+    }
     const int Q = my_tiles * KT0;                       // 1-KiB X pieces this wave consumes
     int Dp = PIPE ? kRing : DEPTH;                      // prefetch distance in pieces
     if (Dp > 2 * KT0) Dp = 2 * KT0;                     // at most 3 tiles in flight (aux slots)
@@ -694,7 +707,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const bool ahead = LOOK && ahead_t0 >= 0;      // (wave-uniform, the same in every wave: it came out of LDS behind a barrier)
     int early_prepared = 0x7fffffff;
     if (sync && !ahead && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
-        early_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        early_prepared = __hip_atomic_load(&st_dev->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int par = (chain || GN) ? (launch & 1) : 0;
     // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
     //      pads the tail of a batch with unperturbed copies, cnt = 0, whose sums nobody reads): no per-candidate branches ----
@@ -706,7 +719,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const PassDesc* const pass = (CHAIN && uni(p.has_pass)) ? &p_generic.pass_desc[par] : nullptr;
     int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
     // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
-    if (sync && !ahead && !sync_eval_enter(chain->st, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
+    if (sync && !ahead && !sync_eval_enter(st_dev, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
         if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);     // (copies requested ahead of the flag must not land in LDS that is no longer ours)
         return;
     }
@@ -729,7 +742,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
             const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand: an empty pass
-                if (threadIdx.x == 0) sync_eval_leave(chain->st, launch);
+                if (threadIdx.x == 0) sync_eval_leave(st_dev, launch);
                 // one pass per launch: this launch is over.  Persistent form: over only at the terminal pass (PassDesc.pad[0]); an
                 // empty pass before that means the pass in flight may still accept and start the chain's tail again
                 if (n_loop <= 1 || __builtin_amdgcn_readlane(w, 5) == 1 || (SPEC && uni(p.sync_mode) == 3)) {
@@ -770,7 +783,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // overlapped schedule: the step running in this launch raises ChainDev.void_launch when the pass before this one accepts -
     // this pass is then evaluated from a state that no longer exists and nobody will read its sums: polled once per tile
     // (device-scope load, issued before the tile's tail and looked at after it), the waves skip their remaining tiles
-    const int* const void_flag = chain ? uni(&chain->st->void_launch) : nullptr;
+    const int* const void_flag = chain ? uni(&st_dev->void_launch) : nullptr;
     int void_seen = -3;
     // ---- candidates = current state + their own touched entries: fetch the first entry per thread now (its latency
     //      hides under the image copy), meet, patch the LDS images, meet again.  The first barrier also waits for this
@@ -1202,7 +1215,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         // (looking ahead: the flag of the pass after this one, asked for before the barrier, read behind it)
         int nx_prepared = -1;
         if (look && wave == 0)
-            nx_prepared = __hip_atomic_load(&chain->st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nx_prepared = __hip_atomic_load(&st_dev->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                   // every wave is done with its ring: reuse the rings as scratch
         NPBNN_ESTAMP(5);
         int nx_desc = 0;
@@ -1251,7 +1264,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         __syncthreads();
         // (by the LAST wave: it waits for the stores to be acknowledged, a round trip that wave 0 - which reads the next pass's flag
         // and descriptor for everybody - does not have to sit through)
-        if (threadIdx.x == blockDim.x - 64) sync_eval_leave(chain->st, launch);
+        if (threadIdx.x == blockDim.x - 64) sync_eval_leave(st_dev, launch);
         if constexpr (LOOK) {
             // (look_words were written before the barrier two above: every wave reads the same descriptor)
             if (look && look_words[1] > 0) {     // word 1: n_cand

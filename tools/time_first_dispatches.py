@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Wall time of the first 40 dispatches of 100 iterations of a FRESH config-2 chain (the region bench.py times: warm-up 5, then 20) with the
+schedule each ran on - how NPBNN_SCHED_AUTO behaves while the acceptance rate falls from 8 % to 1 %.  NPBNN_CHAIN_TIMING=1 adds the library's phases.
+   python tools/time_first_dispatches.py"""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 from bench_support import workload

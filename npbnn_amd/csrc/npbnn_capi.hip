@@ -1226,6 +1226,21 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     *ms_kernel = (double)ms / iters;
     if (used_candidates) *used_candidates = lp.n_cand;
+    if (getenv("NPBNN_TIME_PASS_ONE_BY_ONE")) {      // diagnostics: every launch between events of its own, the stream idle before it (what a profiler's trace shows)
+        double sum = 0.0, mn = 1e30, mx = 0.0;
+        for (int i = 0; i < iters; ++i) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            float one = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&one, ctx->ev[0], ctx->ev[1]));
+            sum += one; if (one < mn) mn = one; if (one > mx) mx = one;
+        }
+        fprintf(stderr, "[npbnn time_pass] %d launches one by one: %.2f us mean (%.2f-%.2f); back to back %.2f us per launch\n", iters, 1e3 * sum / iters, 1e3 * mn,
+                1e3 * mx, 1e3 * (double)ms / iters);
+    }
     if (const char* ns = getenv("NPBNN_TIME_PASS_STREAMS")) {      // diagnostics: the same independent launches dealt over several streams
         const int n_streams = atoi(ns) > 1 ? (atoi(ns) > 4 ? 4 : atoi(ns)) : 1;
         hipStream_t ss[4];

@@ -375,7 +375,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
     while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only, fast) < 8) --n_cand;
     lp->n_cand = n_cand;
     lp->fast = fast;
-    const int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only, fast);
+    int wpb = pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only, fast);
     if (wpb == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
                     ctx->net.image_floats * 4 / 1024, ctx->lds_limit / 1024);
@@ -389,6 +389,21 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
         const int mt0 = ctx->net.L[0].mt, f16 = ctx->net.l0_f16;
         lp->fn_spec = n_cand == 1 ? (g ? pick_eval_d1_gauss_spec(mt0, f16) : pick_eval_d1_cat_spec(mt0, f16))
                                   : (g ? pick_eval_d3_gauss_spec(mt0, f16) : pick_eval_d3_cat_spec(mt0, f16));
+    }
+    {
+        // A thin second round of tiles: when a workgroup's share is just over one tile per wave (config 5 with three candidates: 12.25
+        // tiles for 12 waves) the leftover tile runs alone after the others are through - a lone wave streams X at a ring's worth per
+        // memory latency.  Two waves fewer spread the leftovers over several SIMDs and give the first round less contention: measured
+        // 36.4 -> 33.4 us per pass there (9 or 10 waves; 11: 35.0, 8: 35.0, 7: 41.9); single-candidate launches and shares of two rounds
+        // or more are best at the build's full count (config 2: 30.6 us at 12 waves, 31.3 at 10).  NPBNN_WAVES: A/B switch.
+        int w_use = wpb;
+        const double share = (double)d.n_tiles / (double)(ctx->n_cu > 0 ? ctx->n_cu : 1);
+        if (n_cand > 1 && share > (double)w_use && share < 1.25 * (double)w_use && w_use - 2 >= 8) w_use -= 2;
+        if (const char* e = getenv("NPBNN_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= wpb) w_use = v; }
+        if (w_use != wpb) {
+            wpb = w_use;
+            lds = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)wpb * lay.wave_lds;
+        }
     }
     lp->wpb = wpb;
     lp->lds = lds;

@@ -593,6 +593,20 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         }
         if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
                        acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
+        {   // start of a step -> start of the next one (the period of a pass where the step is what the passes wait for), and what of it the
+            // step workgroup spent between two steps (waiting for the evaluating workgroups' sums, flag-ordered schedules)
+            double period = 0, idle = 0;
+            int m = 0;
+            for (int r = 1; r + 1 < 1024; ++r) {
+                const unsigned long long* q = &hs[(size_t)r * 8];
+                const unsigned long long* q2 = q + 8;
+                if (!q[0] || !q[6] || !q2[0] || !q2[6] || q2[0] < q[6]) continue;
+                period += (double)(q2[0] - q[0]) * 0.01;
+                idle += (double)(q2[0] - q[6]) * 0.01;
+                ++m;
+            }
+            if (m) fprintf(stderr, "[npbnn step stamps] step start -> next step start %.2f us, of which between steps %.2f us (mean of %d)\n", period / m, idle / m, m);
+        }
     }
     if (B.d_estamps) {
         report_eval_stamps(B.d_estamps, B.lp.grid + (B.overlap ? 1 : 0), B.lp.wpb, (B.sync || B.persist) ? 1 : 0);

@@ -211,12 +211,19 @@ __device__ __forceinline__ float softplus_f(float z) {   // np.logaddexp(0, z), 
 // v_permlane16_swap exchanges odd and even 16-lane rows, v_permlane32_swap the two 32-lane halves; after a swap of two
 // copies of v the pair (r[0], r[1]) holds v[l] and v[l^16] (resp. v[l^32]) in every lane.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// (after a lane swap the compiler no longer knows its operands to be canonical numbers and turns max_nn back into a canonicalising max -
+// three instructions; the median with the largest FINITE float stays one v_med3 and is the same maximum for every finite pair)
+__device__ __forceinline__ float max_fin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.402823466e38f); }
 __device__ __forceinline__ float quad_max(float v) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = max_nn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    v = max_fin(__uint_as_float(r[0]), __uint_as_float(r[1]));
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return max_nn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return max_fin(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// natural logarithm of a number in [1, 2^20] (the softmax denominator after the maximum has been taken out: between 1 and the number
+// of outputs): the hardware's log2 (1 ulp) times ln 2 - two instructions; logf's general form spends ten more on denormal inputs and a
+// correction term that such arguments never need
+__device__ __forceinline__ float log_1_to_n(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float quad_sum(float v) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);

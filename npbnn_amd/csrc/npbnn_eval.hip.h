@@ -251,7 +251,10 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < D; ++j) se[j] += __expf(h[j][mt][i] - m[j]);
+                        for (int j = 0; j < D; ++j) {
+                            const float e = __expf(h[j][mt][i] - m[j]);
+                            se[j] = (mt == 0 && i == 0) ? e : se[j] + e;      // (0 + e is not e for the compiler: e could be -0)
+                        }
         } else {
 #pragma unroll
             for (int mt = 0; mt < MTI; ++mt)
@@ -275,7 +278,7 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 #pragma unroll
         for (int j = 0; j < D; ++j) se[j] = quad_sum(se[j]);
 #pragma unroll
-        for (int j = 0; j < D; ++j) lse[j] = m[j] + __logf(se[j]);
+        for (int j = 0; j < D; ++j) lse[j] = m[j] + log_1_to_n(se[j]);
         if (!PLAIN && hp.confusion && primary) {   // np.argmax: first maximum wins (BNN_lib.py:207); statistics of the first candidate only
             float bv = -INFINITY;
             int bi = 0x7fffffff;
@@ -424,7 +427,10 @@ __host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int 
 __host__ __device__ constexpr int max_waves_for(int mt0, int mti, bool f16, int d, int lk, bool fast = false) {
     return mti != 1 ? 8 : d == 1 ? 16 : d == 2 ? (fast ? 12 : 14) : fast ? (NPBNN_FAST3_WAVES) : (lk == kLikCat && pipelined_l0(mt0, mti, f16, d)) ? 13 : 11;
 }
-#define NPBNN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// s_waitcnt lgkmcnt(0) as an instruction the compiler's own wait-count bookkeeping sees (the builtin, not inline assembly): with an
+// opaque asm statement the compiler added a full wait of its own in front of every unit's first MFMA - behind the LDS reads just
+// requested for the NEXT unit, which therefore never ran underneath the MFMAs - and moved the statement itself up between them
+#define NPBNN_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
 
 // The parameter block of a launch is read with scalar loads scattered over the prologue (the network description, the layout, the
 // pass descriptor, pointers): each is a round trip of 0.6-0.9 us to the L2 when it misses the scalar cache, and they depend on one
@@ -631,15 +637,24 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         const int n_pieces = (image_floats + 255) >> 8;   // 1-KiB pieces; the last one may be partial (the image is a multiple of 256 B)
         const float* const image = uni(p.image);
         const size_t set_stride = hp.weight_sets ? (size_t)image_floats : 0;
+        // pieces outermost, candidates innermost: the copies of a chain pass all read the one committed image - one lane address serves
+        // the D copies of a piece - and there is ONE loop: behind a loop of LDS-DMAs the compiler waits for every copy in flight before it
+        // reuses the address registers, so a loop per candidate made the images arrive one after the other (three round trips)
+        const float* img[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const float* const img_j = GN ? uni(p.group[j].image) : image + j * set_stride;     // (group pass: chain j's own image)
+        for (int j = 0; j < D; ++j) img[j] = GN ? uni(p.group[j].image) : image + j * set_stride;     // (group pass: chain j's own image)
+        auto copy_all = [&](auto coherent) {
             for (int i = wave; i < n_pieces; i += wpb)
                 if (i * 256 + lane * 4 < image_floats) {    // (an LDS-DMA writes only its active lanes' 16 bytes)
-                    if (sync) dma16_coherent(img_j + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
-                    else dma16(img_j + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        if constexpr (decltype(coherent)::value) dma16_coherent(img[j] + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                        else dma16(img[j] + (size_t)i * 256 + lane * 4, smem + j * IB + (size_t)i * 1024);
+                    }
                 }
-        }
+        };
+        if (sync) copy_all(std::true_type{});
+        else copy_all(std::false_type{});
     };
 
     // ---- tile schedule: workgroup b owns tiles b, b+G, b+2G, ...; its m-th tile goes to SIMD m % 4 and, there, to the
@@ -694,6 +709,34 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         ++pf_q;
         if (++pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
     };
+    // fp16-split mode: the two pieces of a K-step at once.  They are consecutive 64-byte column groups of the same rows (a tile has an
+    // even number of pieces, the ring an even number of slots, and pieces are only ever requested in such pairs): one lane address - the
+    // second copy reaches its columns through the instruction's offset, which moves the LDS side by the same 64 bytes, hence the - 64 -
+    // and one round of cursor arithmetic.  The scalar unit is one per compute unit: a dozen waves queue for it, and a piece requested on
+    // its own costs ~25 scalar instructions (SQ counters: more scalar than vector instructions per tile).
+    auto issue_pair = [&]() {
+        if (pf_kt == 0) issue_aux();
+        const float* const g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pf_ptr) + pf_lane);
+        dma16(g, ring + pf_slot);
+        __builtin_amdgcn_global_load_lds((gvoid*)g, (lvoid*)(ring + pf_slot + (1024 - 64)), 16, 64, 0);
+        pf_ptr += 32;
+        pf_slot += 2048;
+        if (pf_slot == kRing * 1024) pf_slot = 0;
+        pf_q += 2;
+        pf_kt += 2;
+        if (pf_kt == KT0) { pf_kt = 0; pf_tile += stride; ++pf_seq; pf_ptr += tile_jump; }
+    };
+    auto issue_first = [&](int depth) {       // the first `depth` pieces of the wave (fewer when it has fewer)
+        if constexpr (F16) {
+            // (no loop: in front of a loop of LDS-DMAs - stores and no loads, to its bookkeeping - the compiler drains every memory
+            // operation in flight, the image copies among them, when a register it believes pending is used inside)
+            static_assert(kRing <= 4, "one statement per pair of ring slots");
+            if (0 < depth && pf_q < Q) issue_pair();
+            if (2 < depth && pf_q < Q) issue_pair();
+        } else {
+            for (int i = 0; i < depth && pf_q < Q; ++i) issue_next();
+        }
+    };
     // NPBNN_SCHED_PERSIST_SERIAL with the next pass prepared ahead (sync_mode 3): nothing the image copy and the first pieces of X
     // depend on changes at the hand-over - the global image is only written right AFTER a flag, and the pass applies the accepted
     // candidate's entries to its LDS copies itself - so both are requested BEFORE the wait for the step workgroup's flag and have
@@ -701,7 +744,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const bool early_copy = SPEC && uni(p.sync_mode) == 3;
     if (early_copy) {
         stage_images();
-        for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
+        issue_first(Dp);
     }
 
     const bool ahead = LOOK && ahead_t0 >= 0;      // (wave-uniform, the same in every wave: it came out of LDS behind a barrier)
@@ -723,6 +766,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);     // (copies requested ahead of the flag must not land in LDS that is no longer ours)
         return;
     }
+    asm volatile("" :: "v"(early_prepared));      // (looked at on every path, for the compiler's wait-count bookkeeping: see the end of the tile loop)
     if (GN) {
         int alive = 0;
 #pragma unroll
@@ -764,10 +808,14 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 acc_slot = (named >> 8) - 1;
             }
         } else {
-            if (uni(pass->n_cand) == 0) return;                         // the chain batch is finished
-            t0 = uni(pass->t0);
+            // (launches ordered by kernel boundaries: the descriptor was final before this launch began - the step that runs beside this
+            // launch writes the OTHER parity's - so it comes in with the rest of the block, by scalar loads that hit the warmed scalar
+            // cache; through the generic pointer it was a vector load and a round trip to the L2 ahead of the image copies)
+            const auto& cpass = p.pass_desc[par];
+            if (uni(cpass.n_cand) == 0) return;                         // the chain batch is finished
+            t0 = uni(cpass.t0);
 #pragma unroll
-            for (int j = 0; j < D; ++j) cnt[j] = uni(pass->cnt[j < kMaxCand ? j : 0]);
+            for (int j = 0; j < D; ++j) cnt[j] = uni(cpass.cnt[j < kMaxCand ? j : 0]);
         }
     }
 
@@ -775,7 +823,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     if (!early_copy) {
         if (!ahead) stage_images();
         NPBNN_ESTAMPX(2);
-        for (int i = 0; i < Dp && pf_q < Q; ++i) issue_next();
+        issue_first(Dp);
     }
     ahead_t0 = -1;
     NPBNN_ESTAMPX(3);
@@ -806,15 +854,28 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             pv_row = pv + (size_t)j * M;
         }
     };
+    // Every load of the thread is requested before any of them is waited for (the values are used behind the barrier): through
+    // global-address-space pointers - a generic agent-scope load came out with a full wait for everything in flight in front of it,
+    // image copies and X pieces included, once per candidate - and with the conversions the compiler would hoist in front of the
+    // barrier pinned behind it (below).  Before: 3 us at the top of every pass of a persistent launch, most of it these round trips.
+    {
+        typedef const __attribute__((address_space(1))) int gint_t;
+        typedef const __attribute__((address_space(1))) float gfloat_t;
+        typedef const __attribute__((address_space(1))) double gdouble_t;
+        const int* pos_rows[D]; const float* psc_rows[D]; const double* pv_rows[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
-        if ((pass || GN) && tid < cnt[j]) {
-            const int* pos_row; const float* psc_row; const double* pv_row;
-            patch_src(j, pos_row, psc_row, pv_row);
-            ppos[j] = pos_row[tid];
-            pval[j] = sync ? __hip_atomic_load(pv_row + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pv_row[tid];
-            if (psc_row) psc[j] = psc_row[tid];
+        for (int j = 0; j < D; ++j) {
+            pos_rows[j] = nullptr; psc_rows[j] = nullptr; pv_rows[j] = nullptr;
+            if (pass || GN) patch_src(j, pos_rows[j], psc_rows[j], pv_rows[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            ppos[j] = 0; pval[j] = 0.0; psc[j] = 1.0f;
+            if ((pass || GN) && tid < cnt[j]) {
+                ppos[j] = ((gint_t*)pos_rows[j])[tid];
+                pval[j] = sync ? __hip_atomic_load((gdouble_t*)pv_rows[j] + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((gdouble_t*)pv_rows[j])[tid];
+                if (psc_rows[j]) psc[j] = ((gfloat_t*)psc_rows[j])[tid];
+            }
         }
     }
     int apos = kSkipPos;
@@ -837,6 +898,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     NPBNN_ESTAMP(1);
     __syncthreads();
     NPBNN_ESTAMP(2);
+#pragma unroll
+    for (int j = 0; j < D; ++j) asm volatile("" : "+v"(ppos[j]), "+v"(pval[j]), "+v"(psc[j]));      // (nothing computed from them in front of the barrier)
     if (acc_cnt > 0) {                        // every candidate starts from the accepted state
         auto put = [&](int pos, double v, float sc) {
             if (pos == kSkipPos) return;
@@ -1045,8 +1108,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     WFrag& wn = Wb[(PAR * D + j + 1) & 1];
                     NPBNN_WAIT_LGKM0();                   // this unit's fragments are complete
                     if (j == 0 && pf_q < Q) {             // the x fragments of step s are in registers: refill its slots (step s+2)
-                        issue_next();
-                        issue_next();
+                        issue_pair();
                         issued = true;
                     }
                     if (j == D - 1) {
@@ -1073,6 +1135,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 #else
                     acc0[j][0][0] += (float)wc.wh[0][0] + (float)wc.wl[MT0 - 1][7] + (float)Xb[PAR].xh[0] + (float)Xb[PAR].xl[7];
 #endif
+                    __builtin_amdgcn_sched_barrier(0);    // ... and the next unit's wait behind them
                 }
                 ++s;
                 ks = ks_next;
@@ -1167,8 +1230,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             int n_issue = Q - pf_q;
             if (n_issue > KT0) n_issue = KT0;
             for (int kt = 0; kt < n_issue; kt += STEP) {
-                issue_next();                           // targets the slot(s) consumed one step ago
-                if constexpr (F16) issue_next();
+                if constexpr (F16) issue_pair();        // targets the slot(s) consumed one step ago
+                else issue_next();
                 wait_depth<DEPTH>();
                 consume();
             }
@@ -1179,8 +1242,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             q += KT0;
         } else {
             for (int kt = 0; kt < KT0; kt += STEP, q += STEP) {
-                for (int i = 0; i < STEP; ++i)
-                    if (pf_q < Q) issue_next();
+                if (pf_q < Q) {
+                    if constexpr (F16) issue_pair();
+                    else issue_next();
+                }
                 wait_younger(pf_q - q - STEP);
                 consume();
             }
@@ -1191,7 +1256,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         run_tail(acc0, tseq, tile);
     }
     }
-    if (void_flag) NPBNN_WAIT_VMCNT(0);       // (a wave that left early still has X pieces on their way into its ring)
+    // (a wave that left early still has X pieces on their way into its ring.  As an instruction the compiler's wait-count bookkeeping
+    // sees, on every path: a load whose value is looked at on some paths only - the void flag of the last tile - stays "pending" for it,
+    // and the next write to that register, a pass later and behind freshly requested copies, is made to wait for everything in flight)
+    __builtin_amdgcn_s_waitcnt(0x0f70);       // s_waitcnt vmcnt(0)
 
     NPBNN_ESTAMP(4);
     if (stamps && lane == 0) stamps[(size_t)gridDim.x * 8 + (size_t)bid * 16 + wave] = wall_clock64();   // every wave: tiles done
@@ -1245,6 +1313,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         }
         if (look && wave == 0 && lane < 8)                 // n_cand, t0, cnt ... of the pass ahead; n_cand = 0 when it is not to be started early
             look_words[lane] = nx_ready ? nx_desc : 0;
+        asm volatile("" :: "v"(nx_prepared), "v"(nx_desc));      // (both loads are through for the compiler's bookkeeping on every path, see above)
         __syncthreads();
         // (the LAST wave adds them up and writes them: in a flag-ordered launch it is also the one that reports the workgroup done,
         // after waiting for these very stores)

@@ -38,8 +38,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
         const int v = partial_value_index(it, k_targets);
         double s = 0.0;
         for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)v * n_blocks + b];
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) s += shfl_xor_f64(s, sh);
+        s = butterfly_sum_f64(s);
         if (lane == 0) tot[v] = s;
     }
     __syncthreads();
@@ -238,8 +237,7 @@ __device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos
 
 // block-wide sum of one double per thread, fixed order; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 doubles*/) {
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) v += shfl_xor_f64(v, sh);
+    v = butterfly_sum_f64(v);
     __syncthreads();                                  // `red` may still be read from a previous call
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -406,8 +404,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 const double* src = part + ((size_t)j * kPartialStride + v) * c.n_blocks;
                 double s = 0.0;
                 for (int b = lane; b < c.n_blocks; b += 64) s += src[b];
-#pragma unroll
-                for (int shf = 32; shf > 0; shf >>= 1) s += shfl_xor_f64(s, shf);
+                s = butterfly_sum_f64(s);
                 if (lane == 0) sh.tot[j][v] = s;
             }
         }
@@ -546,7 +543,9 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
             for (int u = 0; u < ES; ++u) {
                 const int e = tid + u * (int)blockDim.x;
                 ii[j][u] = -1; pp[j][u] = 0; dd[j][u] = 0.0; ss[j][u] = 1.0f;
-                if (e < cn[j]) {
+                // (asked for with the row's count, not behind it: the rows are touched once per batch - every level of dependent loads here
+                // is a cold miss of 2-3 us on the step's critical path; slots past the count are inside the [K][M] arrays and are dropped below)
+                if (j < n_new && e < c.M) {
                     const size_t k = (size_t)(t_new + j) * c.M + e;
                     ii[j][u] = c.idx[k];
                     dd[j][u] = c.delta[k];
@@ -555,6 +554,11 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j)
+#pragma unroll
+            for (int u = 0; u < ES; ++u)
+                if (!(tid + u * (int)blockDim.x < cn[j])) { ii[j][u] = -1; pp[j][u] = 0; dd[j][u] = 0.0; ss[j][u] = 1.0f; }
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j)
 #pragma unroll
@@ -594,8 +598,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     NPBNN_STAMP(5);
 #pragma unroll
     for (int j = 0; j < kMaxCand; ++j) {
-#pragma unroll
-        for (int shf = 32; shf > 0; shf >>= 1) dlp[j] += shfl_xor_f64(dlp[j], shf);
+        dlp[j] = butterfly_sum_f64(dlp[j]);
         if ((tid & 63) == 0) sh.red3[j][tid >> 6] = dlp[j];
     }
     __syncthreads();
@@ -993,8 +996,7 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
 #pragma unroll
                 for (int k = 0; k < kMaxCand; ++k) {
                     double v = dlp[o][k];
-#pragma unroll
-                    for (int shf = 32; shf > 0; shf >>= 1) v += shfl_xor_f64(v, shf);
+                    v = butterfly_sum_f64(v);
                     if ((tid & 63) == 0) sp.red[o][k][tid >> 6] = v;
                 }
         } else if ((tid & 63) == 0) {
@@ -1048,8 +1050,7 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
                 const double* src = part + ((size_t)j * kPartialStride + v) * n_blocks;
                 double s = 0.0;
                 for (int b = lane; b < n_blocks; b += 64) s += __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int shf = 32; shf > 0; shf >>= 1) s += shfl_xor_f64(s, shf);
+                s = butterfly_sum_f64(s);
                 if (lane == 0) sh.tot[j][v] = s;
             }
         }

@@ -66,8 +66,7 @@ __global__ void __launch_bounds__(1024) shard_sum_kernel(const double* __restric
         const double* src = partials + ((size_t)j * kPartialStride + v) * n_blocks;
         double s = 0.0;
         for (int b = lane; b < n_blocks; b += 64) s += src[b];
-#pragma unroll
-        for (int shf = 32; shf > 0; shf >>= 1) s += shfl_xor_f64(s, shf);
+        s = butterfly_sum_f64(s);
         if (lane == 0) mine[j * kPartialStride + v] = s;
     }
 }
@@ -594,15 +593,21 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         if (n) fprintf(stderr, "[npbnn step stamps] prefetch %.2f  reduce %.2f  decide %.2f  commit %.2f  prepare %.2f  finish %.2f us (mean of %d)\n",
                        acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, n);
         {   // start of a step -> start of the next one (the period of a pass where the step is what the passes wait for), and what of it the
-            // step workgroup spent between two steps (waiting for the evaluating workgroups' sums, flag-ordered schedules)
+            // step workgroup spent between two steps (waiting for the evaluating workgroups' sums, flag-ordered schedules).  Rows are
+            // indexed by the first iteration of the decided pass: in time order
+            std::vector<std::pair<unsigned long long, unsigned long long>> se;
+            for (int r = 1; r < 1024; ++r) {
+                const unsigned long long* q = &hs[(size_t)r * 8];
+                if (q[0] && q[6] && q[6] > q[0]) se.push_back({q[0], q[6]});
+            }
+            std::sort(se.begin(), se.end());
             double period = 0, idle = 0;
             int m = 0;
-            for (int r = 1; r + 1 < 1024; ++r) {
-                const unsigned long long* q = &hs[(size_t)r * 8];
-                const unsigned long long* q2 = q + 8;
-                if (!q[0] || !q[6] || !q2[0] || !q2[6] || q2[0] < q[6]) continue;
-                period += (double)(q2[0] - q[0]) * 0.01;
-                idle += (double)(q2[0] - q[6]) * 0.01;
+            for (size_t i = 0; i + 1 < se.size(); ++i) {
+                const double d = (double)(se[i + 1].first - se[i].first) * 0.01;
+                if (se[i + 1].first < se[i].second || d > 200.0) continue;      // (a row overwritten by a later lap of the table; a batch boundary)
+                period += d;
+                idle += (double)(se[i + 1].first - se[i].second) * 0.01;
                 ++m;
             }
             if (m) fprintf(stderr, "[npbnn step stamps] step start -> next step start %.2f us, of which between steps %.2f us (mean of %d)\n", period / m, idle / m, m);

@@ -284,6 +284,32 @@ __device__ __forceinline__ double wave_sum_f64(double v) {     // over all 64 la
     return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
 }
 
+// v += v[lane ^ 32]; ^ 16; ^ 8; ^ 4; ^ 2; ^ 1 - the xor butterfly the step's float64 reductions have always used (every lane ends with the
+// total; the partners and their order are part of the result's bits), without its twelve ds_bpermute round trips per sum: the halves
+// and rows meet through the permlane swaps, lanes inside a row through DPP (xor 8 is a rotation by 8; xor 4 is the rotation by 4 one way
+// or the other, chosen by the lane's bit 2; xor 2 and xor 1 are quad permutations).  Same partners, same additions, same bits.
+__device__ __forceinline__ double butterfly_sum_f64(double v) {
+    {
+        const u32x2 rl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        const u32x2 rh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    {
+        const u32x2 rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        const u32x2 rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    v += dpp_f64<0x128>(v);                                   // row_ror:8
+    {
+        const double down = dpp_f64<0x124>(v);                // row_ror:4: the value of lane - 4 (mod 16)
+        const double up = dpp_f64<0x12c>(v);                  // row_ror:12: the value of lane + 4 (mod 16)
+        v += (threadIdx.x & 4) ? down : up;
+    }
+    v += dpp_f64<0x4e>(v);                                    // quad_perm [2, 3, 0, 1]
+    v += dpp_f64<0xb1>(v);                                    // quad_perm [1, 0, 3, 2]
+    return v;
+}
+
 #define NPBNN_WAIT_VMCNT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define NPBNN_WAIT_VMCNT(n) NPBNN_WAIT_VMCNT_(n)
 #define NPBNN_DEPTH (NPBNN_RING - 1)

@@ -92,8 +92,7 @@ __device__ double numpy_sum(const double* a0, int n0) {             // the recur
 }
 
 __device__ __forceinline__ double block_sum_all(double v, double* red) {      // fixed order; every thread gets the result
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) v += shfl_xor_f64(v, sh);
+    v = butterfly_sum_f64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

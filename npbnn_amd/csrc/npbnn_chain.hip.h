@@ -323,7 +323,13 @@ struct StepShared {            // LDS scratch of chain_step
     int s_accepted, s_t, s_start, s_lim;
 };
 
-__device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan pl, StepShared& sh) {
+__device__ __forceinline__ void chain_step(const ChainParams& c_generic, const StepPlan pl, StepShared& sh) {
+    // The step's parameter block does not change while a launch runs (what its pointers point at does): read through the CONSTANT
+    // address space its fields are scalar loads the compiler may keep - through the generic reference every field was fetched again
+    // after every store (it cannot rule out that the store hit the block), a dependent round trip each time: a patch value stored,
+    // the block's pointers re-read, waited for - six times over in the prepare phase (8 of its 11 us), and all through the decision.
+    typedef const __attribute__((address_space(4))) ChainParams ConstChainParams;
+    ConstChainParams& c = *(ConstChainParams*)&c_generic;
     const int tid = threadIdx.x;
     ChainDev* st = c.st;
     const int lik_kind = c.net.lik_kind;
@@ -338,7 +344,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
     if (pl.resum && c.prior_kind != NPBNN_PRIOR_UNIFORM) {
         double lp = 0.0;
         for (int l = 0; l < c.net.n_layers; ++l) {
-            const LayerMeta& L = c.net.L[l];
+            const auto& L = c.net.L[l];
             const int n = L.out_dim * (L.in_dim + L.has_bias);
             const double sc = c.prior_scale[l];
             if (c.prior_scale_w) {            // a scale per weight: the density entry by entry
@@ -421,7 +427,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                         for (int q = 0; q < c.net.k_targets; ++q) sg[q] = st->sigma[q] * c.sigma_mult[(size_t)t * c.net.k_targets + q];
                         loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, 1, sg, &sh.o);
                     } else {
-                        loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c.sigma_fixed, &sh.o);
+                        loglik_from_totals(sh.tot[j], lik_kind, c.net.k_targets, c.n_rows, c.lik_temp, c.sigma_given, c_generic.sigma_fixed, &sh.o);
                     }
                     const double lp = d_cand[j];
                     const double post_new = sh.o.loglik + lp, post_old = d_ll + d_lp;
@@ -477,7 +483,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c, const StepPlan 
                 if (i >= 0) {
                     const double v = pv[(size_t)a * c.M + e];
                     c.w_cur[i] = v;
-                    patch_global_image(c, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, v);
+                    patch_global_image(c_generic, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, v);
                 }
             }
         }

@@ -532,3 +532,31 @@ def test_proposals_wider_than_the_workgroup_on_every_schedule():
         assert (m._logLik, m._logPrior) == (m1._logLik, m1._logPrior)
         for wa, wb in zip(b1._w_layers, b._w_layers):
             np.testing.assert_array_equal(wa, wb)
+
+
+def test_thin_second_round_runs_on_fewer_waves_and_is_the_same_chain(monkeypatch):
+    """plan_launch gives a workgroup whose share is just over one tile per wave two waves fewer (config 5: 12.25 tiles for 12
+    waves; the lone 13th tile ran alone behind the others).  Same proposals, same decisions, same weights as on the build's
+    full count - only the order of the float64 sums changes (np_bnn/BNN_env.py:467-491 is one sum over all rows either way)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_support import workload
+    from npbnn_amd import _capi
+    wl = workload(5)
+    out = {}
+    for tag, waves in (("rule", None), ("full", "12")):
+        if waves is None:
+            monkeypatch.delenv("NPBNN_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("NPBNN_WAVES", waves)
+        bnn, mcmc = wl.build()
+        ll0 = mcmc._logLik
+        mcmc.run_steps(bnn, 300)
+        out[tag] = (ll0, mcmc._logLik, mcmc._logPrior, np.concatenate([w.ravel() for w in bnn._w_layers]).copy(), mcmc._device_accepted,
+                    mcmc._backend.ctx.info(_capi.INFO_WAVES_PER_BLOCK))
+        mcmc._backend.close()
+    a, b = out["rule"], out["full"]
+    assert a[4] == b[4] and a[4] > 0                      # the same proposals were accepted
+    assert np.array_equal(a[3], b[3])                     # the same weights, bit for bit
+    assert abs(a[1] - b[1]) <= 1e-9 * abs(b[1]) and abs(a[0] - b[0]) <= 1e-9 * abs(b[0])
+    assert a[2] == b[2]

@@ -4,11 +4,17 @@ A pre-drawn batch is K x M indices and deviates (5 KB per iteration on BASELINE 
 page-locked memory it is uploaded asynchronously at link speed.  Blocks are recycled through a small pool, because
 locking pages costs far more than a batch upload."""
 import ctypes as C
+import os
+import sys
 import threading
+import time
 
 import numpy as np
 
 from . import _capi as capi
+
+
+_TRACE = bool(os.environ.get("NPBNN_PINNED_TRACE"))      # diagnostics: every new page-locked block, its size and what locking it cost
 
 
 class _Block:
@@ -59,7 +65,11 @@ class PinnedPool:
             ptr = lst.pop() if lst else None
         if ptr is None:
             out = C.c_void_p()
+            t0 = time.perf_counter() if _TRACE else 0.0
             rc = self._lib.npbnn_pinned_alloc(nbytes, C.byref(out))
+            if _TRACE:
+                sys.stderr.write("[npbnn pinned] %d KiB page-locked in %.2f ms (thread %s)\n"
+                                 % (nbytes >> 10, (time.perf_counter() - t0) * 1e3, threading.current_thread().name))
             if rc != 0 or not out.value:
                 msg = self._lib.npbnn_last_error(None)
                 raise capi.NpbnnError(rc, "npbnn_pinned_alloc(%d): %s" % (nbytes, msg.decode() if msg else "?"))

@@ -64,10 +64,13 @@ class ActFun:
     def device_kind(self):
         return self.activate.kind
 
-    def device_slopes(self, n_hidden):
+    def device_slopes(self, n_hidden, accepted=False):
+        """Slopes of the hidden layers as the device takes them (None: the activation has none).  ``accepted``: the slopes of
+        the chain's accepted state rather than the last proposed ones - they differ while slopes are trainable, because a
+        proposal is installed in ``_prm`` whether it is accepted or not (np_bnn/BNN_env.py:421 against :502-503)."""
         if self._function != "genReLU":
             return None
-        prm = np.asarray(self._prm, dtype=float)
+        prm = np.asarray(self._acc_prm if (accepted and self._trainable) else self._prm, dtype=float)
         return np.array([prm[i] for i in range(n_hidden)], dtype=float)
 
     # -- reference API --

@@ -122,6 +122,23 @@ def get_backend(bnn_obj, likelihood_f):
     return be
 
 
+class _Candidate:
+    """The state one iteration proposes, filled in by the draw steps of :meth:`MCMC.mh_step` and scored afterwards."""
+    __slots__ = ("layers", "weight_switches", "feature_switches", "override", "sigma", "slopes_moved", "log_hastings",
+                 "log_prior_extra", "log_prior", "log_lik", "log_post")
+
+    def __init__(self, bnn_obj, log_prior_extra):
+        self.layers = []
+        self.weight_switches = bnn_obj._indicators + 0
+        self.feature_switches = None
+        self.override = None                      # column override of the forward pass (feature switches)
+        self.sigma = bnn_obj._error_prm
+        self.slopes_moved = False
+        self.log_hastings = 0
+        self.log_prior_extra = log_prior_extra    # the caller's additional_prob plus the priors of slopes and sigma
+        self.log_prior = self.log_lik = self.log_post = None
+
+
 class MCMC():
     def __init__(self,
                  bnn_obj: npBNN,
@@ -222,8 +239,13 @@ class MCMC():
     def _slopes(self, bnn_obj):
         return bnn_obj._act_fun.device_slopes(bnn_obj._n_layers - 1)
 
-    def _host_predictions(self, bnn_obj, fw, override, which=capi.TRAIN):
-        y = self._backend.predict(fw, slopes=self._slopes(bnn_obj), col_override=override, which=which)
+    def _accepted_slopes(self, bnn_obj):
+        """Slopes of the accepted state: what its statistics and prediction matrices are computed with."""
+        return bnn_obj._act_fun.device_slopes(bnn_obj._n_layers - 1, accepted=True)
+
+    def _host_predictions(self, bnn_obj, fw, override, which=capi.TRAIN, accepted=False):
+        slopes = self._accepted_slopes(bnn_obj) if accepted else self._slopes(bnn_obj)
+        y = self._backend.predict(fw, slopes=slopes, col_override=override, which=which)
         if getattr(self._backend, "out_kind", 0) is None:
             y = bnn_obj._output_act_fun(y)      # user output function on the host
         return y
@@ -262,13 +284,13 @@ class MCMC():
         ka, kl = stat_kind(self._accuracy_f), stat_kind(self._accuracy_lab_f)
         fused = getattr(self._backend, "fused_likelihood", False)
         if fused and bnn_obj._estimation_mode == "classification" and ka == "acc" and kl == "label_acc":
-            r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+            r = self._backend.evaluate(fw, slopes=self._accepted_slopes(bnn_obj), col_override=self._accepted_override,
                                        want_confusion=True)
             acc, lab_acc, freq = stats_from_confusion(r["confusion"])
             self._lazy.update(_accuracy=acc, _label_acc=lab_acc, _label_freq=freq)
             return
         if fused and bnn_obj._estimation_mode == "regression" and ka == "mse" and kl == "label_mse":
-            r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+            r = self._backend.evaluate(fw, slopes=self._accepted_slopes(bnn_obj), col_override=self._accepted_override,
                                        sigma=np.ones(bnn_obj._labels.shape[1]))
             mse_col = r["sum_r2"] / r["n_rows"]
             self._lazy.update(_accuracy=float(np.mean(mse_col)), _label_acc=mse_col)
@@ -283,21 +305,21 @@ class MCMC():
             self._backend = get_backend(bnn_obj, self._likelihood_f)
         fw = self._forward_weights(bnn_obj._w_layers, bnn_obj._indicators)
         if name == "_y":
-            return self._host_predictions(bnn_obj, fw, self._accepted_override)
+            return self._host_predictions(bnn_obj, fw, self._accepted_override, accepted=True)
         if name == "_y_test":
             if len(bnn_obj._test_data) > 0:
-                return self._host_predictions(bnn_obj, fw, self._accepted_override, which=capi.TEST)
+                return self._host_predictions(bnn_obj, fw, self._accepted_override, which=capi.TEST, accepted=True)
             return []
         if name == "_test_accuracy":
             if len(bnn_obj._test_data) == 0:
                 return 0
             fused = getattr(self._backend, "fused_likelihood", False)
             if fused and bnn_obj._estimation_mode == "classification" and stat_kind(self._accuracy_f) == "acc":
-                r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+                r = self._backend.evaluate(fw, slopes=self._accepted_slopes(bnn_obj), col_override=self._accepted_override,
                                            which=capi.TEST, want_confusion=True)
                 return stats_from_confusion(r["confusion"])[0]
             if fused and bnn_obj._estimation_mode == "regression" and stat_kind(self._accuracy_f) == "mse":
-                r = self._backend.evaluate(fw, slopes=self._slopes(bnn_obj), col_override=self._accepted_override,
+                r = self._backend.evaluate(fw, slopes=self._accepted_slopes(bnn_obj), col_override=self._accepted_override,
                                            which=capi.TEST, sigma=np.ones(bnn_obj._labels.shape[1]))
                 return float(np.mean(r["sum_r2"] / r["n_rows"]))
             return self._accuracy_f(self._y_test, bnn_obj._test_labels)
@@ -389,109 +411,153 @@ class MCMC():
                       self._update_f)
 
     # ------------------------------------------------------------------------------------------
-    # one Metropolis-Hastings iteration (reference: BNN_env.py:381-532)
+    # one Metropolis-Hastings iteration (behaviour: np_bnn/BNN_env.py:381-532)
     # ------------------------------------------------------------------------------------------
+    SLOPE_STEP, SLOPE_PRIOR_RATE = 0.05, 10          # random-walk width and Exp(rate) prior of trainable slopes (:417-419)
+    SIGMA_WINDOW, SIGMA_SHARE, SIGMA_PRIOR_RATE = 1.1, 0.5, 1     # multiplier proposal and Exp(rate) prior of sigma (:439-442)
+    FEATURE_FLIP_CHANCE, FEATURE_FLIP_SHARE = 0.2, 0.5            # feature switches (:425-426)
+
     def mh_step(self, bnn_obj, additional_prob=0, return_bnn=False):
+        """One iteration: build a candidate state, score it, accept or reject it, book the outcome.
+
+        What is contractual is the ORDER in which random numbers leave the two streams (``G`` = the chain's Generator,
+        ``np.random`` = numpy's global stream), because a chain must make the reference's draws for the reference's seed:
+
+          ====  =====================================================  ======================================  ==============
+          step  when                                                   draws                                   reference
+          ====  =====================================================  ======================================  ==============
+          0     ``randomize_seed``                                     G = default_rng(iteration + mcmc_id)     BNN_env :383
+          1     trainable activation slopes                            G.integers, G.normal                     :416-421
+          2     feature switches and iteration > adapt_stop            G.random; if < 0.2: np.random.random,    :424-433
+                                                                       np.random.binomial
+          3     regression, sigma estimated, iteration > its start     G.binomial(k), G.random(k)               :435-444
+          4     always                                                 G.random(n_layers)                       :446-447
+          5     per layer, in order: the layer's proposal function     G.integers, G.integers, G.normal         :449-459
+                (or, layer 0 in an indicator turn)                     np.random.random, np.random.binomial     :457-460
+          6     always                                                 G.random  (the accept test)              :493
+          ====  =====================================================  ======================================  ==============
+        """
+        self._enter_step(bnn_obj)
+        cand = _Candidate(bnn_obj, additional_prob)
+        self._draw_slopes(bnn_obj, cand)
+        self._draw_feature_switches(bnn_obj, cand)
+        self._draw_sigma(bnn_obj, cand)
+        self._draw_layers(bnn_obj, cand)
+        self._score(bnn_obj, cand)
+        took = (cand.log_post - self._logPost) * self._temperature + cand.log_hastings >= np.log(self._gen.random())
+        if took:
+            self._install(bnn_obj, cand)
+        self._book(took)
+        if return_bnn:
+            return bnn_obj, self
+
+    def _enter_step(self, bnn_obj):
         self._cancel_speculation()
         self._bnn = bnn_obj
         if self._backend is None:
             self._backend = get_backend(bnn_obj, self._likelihood_f)
         if self._randomize_seed:
-            self._rs = np.random.default_rng(self._current_iteration + self._mcmc_id)
-        rs = self._rs
-        hastings = 0
-        indicators_prime = bnn_obj._indicators + 0
+            self._gen = np.random.default_rng(self._current_iteration + self._mcmc_id)
         self._adapt(bnn_obj)
 
-        # trainable activation slopes: proposed from the accepted values, installed right away
-        if bnn_obj._act_fun._trainable:
-            prm_tmp, _, h = UpdateNormal1D(bnn_obj._act_fun._acc_prm, d=0.05, n=1, Mb=1, mb=0, rs=rs)
-            r = 10
-            additional_prob += np.log(r) * -np.sum(prm_tmp) * r      # exponential prior Exp(r)
-            hastings += h
-            bnn_obj._act_fun.reset_prm(prm_tmp)
+    def _draw_slopes(self, bnn_obj, cand):
+        """Step 1.  The proposed slopes go into the activation object at once - accepted or not - and the forward pass of this
+        iteration reads them from there."""
+        act = bnn_obj._act_fun
+        if not act._trainable:
+            return
+        moved, _, log_h = UpdateNormal1D(act._acc_prm, d=self.SLOPE_STEP, n=1, Mb=1, mb=0, rs=self._gen)
+        rate = self.SLOPE_PRIOR_RATE
+        cand.log_prior_extra += np.log(rate) * -np.sum(moved) * rate
+        cand.log_hastings += log_h
+        cand.slopes_moved = True
+        act.reset_prm(moved)
 
-        # feature indicators -> constant-column override of the data matrix
-        override = None
-        if bnn_obj._feature_indicators is not None and self._current_iteration > self._adapt_stop:
-            if rs.random() < 0.2:
-                feature_indicators_prime = UpdateBinomial(bnn_obj._feature_indicators + 0, 0.5,
-                                                          bnn_obj._feature_indicators.shape)
+    def _draw_feature_switches(self, bnn_obj, cand):
+        """Step 2.  Once the switches are live every candidate is evaluated through the column override, flipped or not."""
+        current = bnn_obj._feature_indicators
+        cand.feature_switches = current
+        if current is None or not self._current_iteration > self._adapt_stop:
+            return
+        cand.feature_switches = current + 0
+        if self._gen.random() < self.FEATURE_FLIP_CHANCE:
+            cand.feature_switches = UpdateBinomial(cand.feature_switches, self.FEATURE_FLIP_SHARE, current.shape)
+        cand.override = data_transform_obj(cand.feature_switches, bnn_obj._feature_means).column_override()
+
+    def _draw_sigma(self, bnn_obj, cand):
+        """Step 3.  Outside regression, and in regression while sigma is still fixed, the candidate's sigma is the scalar 1;
+        an empirical sigma comes out of the evaluation instead."""
+        if not (bnn_obj._estimation_mode == "regression" and self._current_iteration > self._estimate_error):
+            cand.sigma = 1
+            return
+        if bnn_obj._empirical_error:
+            return
+        cand.sigma, _, log_h = multiplier_proposal_vector(bnn_obj._error_prm, d=self.SIGMA_WINDOW, f=self.SIGMA_SHARE, rs=self._gen)
+        rate = self.SIGMA_PRIOR_RATE
+        cand.log_hastings += log_h
+        cand.log_prior_extra += np.log(rate) * -np.sum(cand.sigma) * rate
+
+    def _draw_layers(self, bnn_obj, cand):
+        """Steps 4 and 5.  A layer is proposed when its uniform number falls below the layer's update frequency; the layer with
+        the smallest number always is.  With weight indicators, layer 0 spends the turns whose number falls below
+        ``freq_indicator`` on flipping indicators instead of moving weights."""
+        turn = self._gen.random(bnn_obj._n_layers)
+        turn[np.argmin(turn)] = 0
+        mask = bnn_obj._mask
+        for li, current in enumerate(bnn_obj._w_layers):
+            indicator_turn = li == 0 and turn[li] < bnn_obj._freq_indicator
+            if not indicator_turn and turn[li] < self._freq_layer_update[li]:
+                layer, _, log_h = self.update_function(current, d=self._update_ws[li], n=self._update_n[li],
+                                                       Mb=bnn_obj._w_bound, mb=-bnn_obj._w_bound, rs=self._gen)
+                cand.log_hastings += log_h
             else:
-                feature_indicators_prime = bnn_obj._feature_indicators + 0
-            override = data_transform_obj(feature_indicators_prime, bnn_obj._feature_means).column_override()
-        else:
-            feature_indicators_prime = bnn_obj._feature_indicators
+                layer = current + 0
+                if indicator_turn:
+                    # (the flip share is read from the FOURTH update frequency, as upstream does, BNN_env.py:460: networks of
+                    # fewer than four weight matrices fail here with upstream's IndexError)
+                    cand.weight_switches = UpdateBinomial(bnn_obj._indicators, self._update_f[3], bnn_obj._indicators.shape)
+            if mask is not None:
+                layer *= mask[li]
+            cand.layers.append(layer)
 
-        # regression error parameter
-        error_prm_tmp = bnn_obj._error_prm
-        if bnn_obj._estimation_mode == "regression" and self._current_iteration > self._estimate_error:
-            if not bnn_obj._empirical_error:
-                error_prm_tmp, _, h = multiplier_proposal_vector(bnn_obj._error_prm, d=1.1, f=0.5, rs=rs)
-                r = 1
-                hastings += h
-                additional_prob += np.log(r) * -np.sum(error_prm_tmp) * r
-        else:
-            error_prm_tmp = 1
-
-        # weight proposals: at least one layer is always updated
-        rr = rs.random(bnn_obj._n_layers)
-        rr[np.argmin(rr)] = 0
-        w_layers_prime = []
-        for i in range(bnn_obj._n_layers):
-            if rr[i] >= bnn_obj._freq_indicator or i > 0:
-                if rr[i] < self._freq_layer_update[i]:
-                    update, _, h = self.update_function(bnn_obj._w_layers[i], d=self._update_ws[i],
-                                                        n=self._update_n[i], Mb=bnn_obj._w_bound,
-                                                        mb=-bnn_obj._w_bound, rs=rs)
-                    w_layers_prime.append(update)
-                    hastings += h
-                else:
-                    w_layers_prime.append(bnn_obj._w_layers[i] + 0)
-            else:
-                w_layers_prime.append(bnn_obj._w_layers[i] + 0)
-                indicators_prime = UpdateBinomial(bnn_obj._indicators, self._update_f[3], bnn_obj._indicators.shape)
-            if bnn_obj._mask is not None:
-                w_layers_prime[i] *= bnn_obj._mask[i]
-
-        logPrior_prime = bnn_obj.calc_prior(w=w_layers_prime, ind=indicators_prime) + additional_prob
+    def _score(self, bnn_obj, cand):
+        cand.log_prior = bnn_obj.calc_prior(w=cand.layers, ind=cand.weight_switches) + cand.log_prior_extra
         if self._sample_from_prior:
-            logLik_prime = 0
+            cand.log_lik = 0
         else:
-            logLik_prime, error_prm_tmp = self._log_likelihood(bnn_obj, w_layers_prime, indicators_prime, override,
-                                                               self._lik_temp, error_prm_tmp)
-        logPost_prime = logLik_prime + logPrior_prime
-        rrr = np.log(rs.random())
-        if (logPost_prime - self._logPost) * self._temperature + hastings >= rrr:
-            bnn_obj.reset_weights(w_layers_prime)
-            bnn_obj.reset_indicators(indicators_prime)
-            if bnn_obj._feature_indicators is not None:
-                bnn_obj._feature_indicators = feature_indicators_prime + 0
-            if bnn_obj._estimation_mode == "regression":
-                # the reference stores the bare scalar 1 here while sigma is still fixed, which later breaks its own
-                # multiplier proposal (BNN_env.py:444,501 -> BNN_mcmc.py:105); keep a vector of ones instead
-                if np.ndim(error_prm_tmp) == 0:
-                    error_prm_tmp = np.ones(bnn_obj._size_output) * error_prm_tmp
-                bnn_obj.reset_error_prm(error_prm_tmp)
-            if bnn_obj._act_fun._trainable:
-                bnn_obj._act_fun.reset_accepted_prm()
-                self._slope_term_in_prior = True        # (MCMC.__init__'s prior is without it: BNN_env.py:374 against :419-420)
-            self._logPost = logPost_prime
-            self._logLik = logLik_prime
-            self._logPrior = logPrior_prime
-            self._accepted_override = override
-            self._invalidate()
-            self._last_accepted = 1
-        else:
-            self._last_accepted = 0
+            cand.log_lik, cand.sigma = self._log_likelihood(bnn_obj, cand.layers, cand.weight_switches, cand.override,
+                                                            self._lik_temp, cand.sigma)
+        cand.log_post = cand.log_lik + cand.log_prior
 
-        self._last_accepted_mem.append(self._last_accepted)
-        self._acceptance_rate = np.mean(self._last_accepted_mem)
-        if len(self._last_accepted_mem) > 100:
-            self._last_accepted_mem = self._last_accepted_mem[-100:]
+    def _install(self, bnn_obj, cand):
+        """The candidate becomes the chain's state.  Statistics of the state (accuracies, predictions) are not computed here:
+        they are functions of what is stored now and are produced when somebody reads them."""
+        bnn_obj.reset_weights(cand.layers)
+        bnn_obj.reset_indicators(cand.weight_switches)
+        if bnn_obj._feature_indicators is not None:
+            bnn_obj._feature_indicators = cand.feature_switches + 0
+        if bnn_obj._estimation_mode == "regression":
+            # (upstream stores the bare scalar 1 while sigma is still fixed and later trips over it in its own multiplier
+            # proposal, BNN_env.py:444,501 -> BNN_mcmc.py:105; a vector of ones means the same and keeps working)
+            sigma = cand.sigma
+            bnn_obj.reset_error_prm(np.ones(bnn_obj._size_output) * sigma if np.ndim(sigma) == 0 else sigma)
+        if cand.slopes_moved:
+            bnn_obj._act_fun.reset_accepted_prm()
+            self._slope_term_in_prior = True        # (MCMC.__init__'s prior is without the term: BNN_env.py:320 against :419)
+        self._logLik, self._logPrior, self._logPost = cand.log_lik, cand.log_prior, cand.log_post
+        self._accepted_override = cand.override
+        self._invalidate()
+
+    def _book(self, took):
+        """Acceptance book-keeping (BNN_env.py:523-530): the rate is the mean over a window that holds up to 101 outcomes at
+        the moment it is taken and is cut back to 100 afterwards."""
+        self._last_accepted = 1 if took else 0
+        window = self._last_accepted_mem
+        window.append(self._last_accepted)
+        self._acceptance_rate = np.mean(window)
+        if len(window) > 100:
+            self._last_accepted_mem = window[-100:]
         self._current_iteration += 1
-        if return_bnn:
-            return bnn_obj, self
 
     # ------------------------------------------------------------------------------------------
     # K iterations with the chain resident on the device
@@ -525,6 +591,11 @@ class MCMC():
                 return None
             if first > self._estimate_error and likelihood_kind(self._likelihood_f) != capi.LIK_GAUSS:
                 return None
+        if np.isfinite(bnn_obj._w_bound) and any(np.max(np.abs(w)) > bnn_obj._w_bound for w in bnn_obj._w_layers if w.size):
+            # a weight OUTSIDE the reflecting walls (initial weights under a narrow uniform prior): upstream's proposal folds every
+            # entry of a layer it touches back inside, moved or not (BNN_mcmc.py:66-67); the device chains fold the moved ones.
+            # mh_step does it upstream's way, and after an accepted proposal per layer nothing is outside any more
+            return None
         whole_candidate = bnn_obj._feature_indicators is not None or bool(bnn_obj._freq_indicator)
         if self.update_function is UpdateNormal and not whole_candidate:
             if bnn_obj._act_fun._trainable and (bnn_obj._act_fun._function != "genReLU" or not hasattr(be, "ctx")

@@ -85,11 +85,14 @@ def count_inputs(seed=23, n_rows=211, n_features=6, n_nodes=(5, 3), n_out=2, k=1
 
 
 # ---- G4 / G5: sampler traces ------------------------------------------------
-def classification_data(seed, n_rows, n_features, n_classes, n_test=0):
-    """Learnable synthetic classification problem."""
+def classification_data(seed, n_rows, n_features, n_classes, n_test=0, n_informative=None):
+    """Learnable synthetic classification problem (``n_informative``: only the first so many features carry signal)."""
     rs = np.random.default_rng(seed)
     x = rs.standard_normal((n_rows + n_test, n_features))
     proj = rs.standard_normal((n_features, n_classes)) / np.sqrt(n_features)
+    if n_informative is not None:
+        proj[n_informative:] = 0
+        proj *= np.sqrt(n_features / n_informative)
     score = x @ proj + 0.3 * rs.standard_normal((n_rows + n_test, n_classes))
     lab = np.argmax(score, axis=1)
     lab[:n_classes] = np.arange(n_classes)
@@ -123,6 +126,163 @@ TRACES = {
                             adapt_f=0.3, estimate_error=False)),
 }
 
+# ---- G9: sampler options beyond the default path (one reference-generated trace each) ----------------------------------
+# Every entry is built through the SAME call surface on the reference (make_golden.py) and on the product (tests), by
+# ``option_chain`` below: npBNN(...) / ActFun(...) / MCMC(...) keyword for keyword.  ``gibbs_every`` = k: a gibbs_step after
+# every k-th mh_step (BNN_env.py:534-538).  ``post_init``: attributes set on the sampler after construction.
+_CLS = dict(kind="classification", seed=201, n_rows=1500, n_features=24, n_classes=4, n_test=150)
+_REG = dict(kind="regression", seed=202, n_rows=1500, n_features=16, k=2, n_test=150)
+_MC = dict(update_f=[0.05, 0.05, 0.1], update_ws=[0.075, 0.075, 0.075], n_iteration=5000)
+OPTION_TRACES = {
+    # (i) trainable activation slopes (BNN_env.py:416-421,502-503)
+    "slopes": dict(_CLS, n_nodes=[6, 5], bias=2, steps=300, act=dict(fun="genReLU", prm=[0.1, 0.2], trainable=True),
+                   bnn=dict(), mcmc=dict(_MC)),
+    # slopes proposed but never used by the forward pass: ReLU + trainable (BNN_lib.py:74-87)
+    "slopes_relu": dict(_CLS, n_nodes=[6, 5], bias=1, steps=200, act=dict(fun="ReLU", prm=[0.3], trainable=True),
+                        bnn=dict(), mcmc=dict(_MC)),
+    # (ii) feature indicators, the column override live after adapt_stop (BNN_env.py:9-17,424-433)
+    "feature_ind": dict(_CLS, seed=203, n_informative=6, n_nodes=[6, 5], bias=2, steps=300, act=dict(fun="tanh"),
+                        bnn=dict(feature_indicators=True), mcmc=dict(_MC, adapt_stop=10)),
+    # (iii) weight indicators: four weight matrices and a four-element update_f (BNN_env.py:457-464)
+    "weight_ind": dict(_CLS, seed=204, n_nodes=[6, 5, 4], bias=2, steps=300, act=dict(fun="swish"),
+                       bnn=dict(freq_indicator=0.3, prior_ind1=0.4),
+                       mcmc=dict(update_f=[0.05, 0.05, 0.05, 0.08], update_ws=[0.075] * 4, n_iteration=5000)),
+    # (iv) hyper-prior scales, a gibbs_step every 10 iterations (BNN_env.py:196-221,534-538; BNN_mcmc.py:126-150)
+    "hyper1": dict(_CLS, n_nodes=[6, 5], bias=2, steps=250, act=dict(fun="tanh"), bnn=dict(hyper_p=1), mcmc=dict(_MC),
+                   gibbs_every=10),
+    "hyper2": dict(_CLS, n_nodes=[6, 5], bias=3, steps=250, act=dict(fun="ReLU"), bnn=dict(hyper_p=2), mcmc=dict(_MC),
+                   gibbs_every=10),
+    "hyper3": dict(_REG, n_nodes=[6, 4], bias=2, steps=250, act=dict(fun="tanh"),
+                   bnn=dict(hyper_p=3, estimation_mode="regression", empirical_error=True),
+                   mcmc=dict(_MC, estimate_error=False), gibbs_every=7),
+    # (v) the other proposal kernels (BNN_mcmc.py:27-42,71-82)
+    "fixed_normal": dict(_CLS, n_nodes=[6, 5], bias=2, steps=300, act=dict(fun="tanh"), bnn=dict(),
+                         mcmc=dict(update_f=[0.02, 0.05, 0.1], update_ws=[0.1, 0.1, 0.1], n_iteration=5000),
+                         update_function="UpdateFixedNormal"),
+    # (the normalising proposal rescales a layer to unit sum: the chain starts from layers that have it)
+    "normalized": dict(_CLS, n_nodes=[6, 5], bias=0, steps=200, act=dict(fun="tanh"), bnn=dict(), init_weights="unit_sum",
+                       mcmc=dict(update_f=[0.02, 0.05, 0.1], update_ws=[0.05, 0.05, 0.05], n_iteration=5000),
+                       update_function="UpdateNormalNormalized"),
+    # (vi) the regression error parameter with multiplier proposals (BNN_env.py:435-444; BNN_mcmc.py:101-113).  Upstream
+    # stores the bare scalar 1 on an accepted step while sigma is still fixed and then fails in the multiplier proposal
+    # (SURVEY 7.3 #8b), so the proposals start at iteration 0 here.
+    "sigma": dict(_REG, n_nodes=[6, 4], bias=2, steps=300, act=dict(fun="tanh"), bnn=dict(estimation_mode="regression"),
+                  mcmc=dict(_MC), post_init=dict(_estimate_error=-1)),
+    # (vii) class weights / instance weights inside a chain (BNN_lib.py:105-119)
+    "class_w": dict(_CLS, seed=205, imbalance=True, n_nodes=[6, 5], bias=2, steps=250, act=dict(fun="tanh"),
+                    bnn=dict(use_class_weights=1), mcmc=dict(_MC)),
+    "inst_w": dict(_CLS, seed=206, n_nodes=[6, 5], bias=2, steps=250, act=dict(fun="tanh"), bnn=dict(), instance_weights=True,
+                   mcmc=dict(_MC)),
+    # the other priors (BNN_env.py:135-150), a heated chain with a tempered likelihood (BNN_env.py:493-494)
+    "cauchy": dict(_CLS, n_nodes=[6, 5], bias=2, steps=200, act=dict(fun="tanh"), bnn=dict(prior_f=2, p_scale=0.5), mcmc=dict(_MC)),
+    "laplace": dict(_CLS, n_nodes=[6, 5], bias=2, steps=200, act=dict(fun="swish"), bnn=dict(prior_f=3, p_scale=0.7), mcmc=dict(_MC)),
+    "uniform": dict(_CLS, n_nodes=[6, 5], bias=2, steps=200, act=dict(fun="tanh"), bnn=dict(prior_f=0, p_scale=0.25),
+                    mcmc=dict(_MC, update_ws=[0.15, 0.15, 0.15])),
+    "heated": dict(_CLS, n_nodes=[6, 5], bias=2, steps=200, act=dict(fun="tanh"), bnn=dict(),
+                   mcmc=dict(_MC, temperature=0.6, likelihood_tempering=0.5)),
+    # predicted-sigma regression and a count likelihood plug-in as whole chains (BNN_lib.py:134-143; BNN_lik.py:5-14,81-84)
+    "reg_error": dict(_REG, n_nodes=[6, 4], bias=2, steps=200, act=dict(fun="tanh"),
+                      bnn=dict(estimation_mode="regression-error", output_act_fun="RegressTransformError"), mcmc=dict(_MC)),
+    "poisson": dict(kind="counts", seed=207, n_rows=1500, n_features=12, n_test=150, n_nodes=[6, 4], bias=2, steps=200,
+                    act=dict(fun="swish"), bnn=dict(estimation_mode="custom", size_output=1),
+                    mcmc=dict(_MC, likelihood_f="poi_likelihood", accuracy_f="poi_acc")),
+}
+
+
+def count_data(seed, n_rows, n_features, n_test=0):
+    rs = np.random.default_rng(seed)
+    x = rs.standard_normal((n_rows + n_test, n_features))
+    eta = 0.8 + x[:, :3] @ np.array([0.5, -0.4, 0.3])
+    y = rs.poisson(np.exp(eta)).astype(float).reshape(-1, 1)
+    return dict(data=x[:n_rows], labels=y[:n_rows], test_data=x[n_rows:], test_labels=y[n_rows:])
+
+
+def option_data(cfg):
+    if cfg["kind"] == "classification":
+        dat = classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"],
+                                  n_informative=cfg.get("n_informative"))
+        if cfg.get("imbalance"):       # thin out two of the classes
+            keep = np.ones(cfg["n_rows"], dtype=bool)
+            lab = dat["labels"]
+            for c, every in ((1, 3), (2, 5)):
+                rows = np.nonzero(lab == c)[0]
+                keep[rows[np.arange(len(rows)) % every != 0]] = False
+            keep[:cfg["n_classes"]] = True
+            dat["data"], dat["labels"] = dat["data"][keep], lab[keep]
+        return dat
+    if cfg["kind"] == "regression":
+        return regression_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["k"], cfg["n_test"])
+    return count_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_test"])
+
+
+def option_chain(bn, name, **mcmc_extra):
+    """Model and sampler of OPTION_TRACES[name] through package ``bn`` (the reference ``np_bnn`` or ``npbnn_amd``: the same
+    keywords go to the same constructors).  Returns (data, model, sampler)."""
+    import contextlib
+    import io
+    cfg = OPTION_TRACES[name]
+    dat = option_data(cfg)
+    act_kw = dict(cfg["act"])
+    if "prm" in act_kw:
+        act_kw["prm"] = np.array(act_kw["prm"], dtype=float)
+    bnn_kw = dict(cfg["bnn"])
+    if isinstance(bnn_kw.get("output_act_fun"), str):
+        bnn_kw["output_act_fun"] = getattr(bn, bnn_kw["output_act_fun"])
+    if cfg.get("instance_weights"):
+        bnn_kw["instance_weights"] = np.random.default_rng(cfg["seed"] + 1000).uniform(0.2, 2.0, len(dat["labels"]))
+    if cfg.get("init_weights") == "unit_sum":
+        rs = np.random.default_rng(cfg["seed"] + 2000)
+        outputs = cfg["n_classes"] if cfg["kind"] == "classification" else cfg["k"]
+        drawn = [rs.uniform(-0.5, 1.0, shape) for shape in layer_shapes(cfg["n_features"], cfg["n_nodes"], outputs, cfg["bias"])]
+        bnn_kw["init_weights"] = [w / w.sum() for w in drawn]
+    mcmc_kw = dict(cfg["mcmc"])
+    for key in ("likelihood_f", "accuracy_f", "accuracy_lab_f"):
+        if isinstance(mcmc_kw.get(key), str):
+            mcmc_kw[key] = getattr(bn, mcmc_kw[key])
+    if "update_function" in cfg:
+        mcmc_kw["update_function"] = getattr(bn, cfg["update_function"])
+    mcmc_kw.update(mcmc_extra)
+    np.random.seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], actFun=bn.ActFun(**act_kw), use_bias_node=cfg["bias"], seed=1234, **bnn_kw)
+        mcmc = bn.MCMC(bnn, **mcmc_kw)
+    for attr, value in cfg.get("post_init", {}).items():
+        setattr(mcmc, attr, value)
+    return dat, bnn, mcmc
+
+
+def option_state(bnn, mcmc):
+    """The observable state after an iteration, as one float vector (its layout depends on the case only)."""
+    parts = [[mcmc._logLik, mcmc._logPrior, mcmc._logPost, mcmc._last_accepted, mcmc._acceptance_rate, mcmc._current_iteration]]
+    act = bnn._act_fun
+    if act._trainable:
+        parts += [np.ravel(act._prm), np.ravel(act._acc_prm)]
+    if bnn._estimation_mode == "regression":
+        parts.append(np.ravel(np.ones(bnn._size_output) * bnn._error_prm))
+    if bnn._freq_indicator:
+        parts.append([np.sum(bnn._indicators)])
+    if bnn._feature_indicators is not None:
+        parts.append(np.ravel(bnn._feature_indicators))
+    if bnn._hyper_p:
+        parts.append([np.sum([np.sum(s) for s in bnn._prior_scale])])
+    return np.concatenate([np.asarray(p, dtype=float) for p in parts])
+
+
+def option_schedule(cfg):
+    """The calls of a trace in order: ("mh", n) = n mh_step calls, ("gibbs", 1) = one gibbs_step."""
+    every = cfg.get("gibbs_every")
+    if not every:
+        return [("mh", cfg["steps"])]
+    out, left = [], cfg["steps"]
+    while left > 0:
+        n = min(every, left)
+        out.append(("mh", n))
+        left -= n
+        if n == every:
+            out.append(("gibbs", 1))
+    return out
+
+
 MC3_TRACE = dict(seed=105, n_rows=1000, n_features=32, n_classes=4, n_test=100, n_nodes=[5, 5],
                  bias=-1, n_chains=4, swap_frequency=20, n_iteration=600)
 
@@ -154,18 +314,6 @@ def posterior_inputs(seed=77, n_rows=97, n_features=11, n_nodes=(6, 5), n_classe
 
 POSTERIOR_CASES = [dict(name="tanh", fun="tanh", seed=77), dict(name="genrelu", fun="genReLU", seed=78),
                    dict(name="swish_bias3", fun="swish", seed=79, bias=3)]
-
-
-def pdp_inputs():
-    """Feature matrix for the partial-dependence vectors: column 0 continuous, column 3 ordinal, columns 8-10 one-hot."""
-    inp = posterior_inputs(**{k: v for k, v in POSTERIOR_CASES[0].items() if k != "name"})
-    xp = inp["x"].copy()
-    xp[:, 3] = np.round(np.abs(xp[:, 3]) * 2)
-    xp[:, 8:11] = np.eye(3)[np.random.default_rng(3).integers(0, 3, len(xp))]
-    return inp, xp
-
-
-PDP_FOCAL = (("cont", [0]), ("ord", [3]), ("ohe", [8, 9, 10]))
 
 
 # ---- G8: get_data / randomize_data (split indices of seeded example tables) -------------------------------------------

@@ -15,6 +15,7 @@ Groups:
   G6 masks.npz       create_mask block layouts
   G7 posterior.npz   get_posterior_cat_prob: per-sample class probabilities and the three summaries
   G8 split.npz       get_data / randomize_data: the train / test split of seeded example tables
+  G9 options.npz     one Metropolis-Hastings trace per sampler option beyond the default path (cases.OPTION_TRACES)
 """
 import contextlib
 import io
@@ -255,14 +256,6 @@ def g7_posterior():
         out["fi_%s_index" % tag] = df["feature_block_index"].to_numpy().astype(np.int64)
         out["fi_%s_values" % tag] = df.iloc[:, 2:].to_numpy().astype(np.float64)
         out["fi_%s_names" % tag] = df["feature_name"].to_numpy().astype(str)
-    # partial dependence: continuous focal feature (100 steps), an ordinal one, a one-hot block
-    inp, xp = cases.pdp_inputs()
-    weights = [s["weights"] for s in inp["samples"]]
-    alphas = [s["alphas"] for s in inp["samples"]]
-    for tag, focal in cases.PDP_FOCAL:
-        res = quiet(bn.get_pdp, xp, focal, "classification", 4, bn.ActFun(fun=inp["fun"]), bn.SoftMax, weights, alphas, None)
-        out["pdp_%s_feature" % tag] = res["feature"]
-        out["pdp_%s_pdp" % tag] = res["pdp"]
     np.savez_compressed(os.path.join(HERE, "posterior.npz"), **out)
     print("posterior.npz")
 
@@ -283,6 +276,71 @@ def g8_split():
     print("split.npz")
 
 
+class _Tally:
+    """Wraps a proposal function of the reference and adds up the Hastings terms it returns (third element)."""
+
+    def __init__(self, fn, book):
+        self.fn, self.book = fn, book
+
+    def __call__(self, *a, **k):
+        r = self.fn(*a, **k)
+        self.book[0] += float(r[2])
+        return r
+
+
+def g9_options():
+    """One trace per entry of cases.OPTION_TRACES.  Per mh_step: the proposal's log-likelihood and calc_prior value (recorded
+    at the reference's own calls), the sum of the Hastings terms its proposal functions returned, and the observable state
+    after the step (cases.option_state); per gibbs_step the state after it; the final weights, indicators, prior scales."""
+    import np_bnn.BNN_env as ref_env
+    out = {}
+    for name, cfg in cases.OPTION_TRACES.items():
+        dat, bnn, mcmc = cases.option_chain(bn, name)
+        book = [0.0]
+        lik_rec = Recorder(mcmc._likelihood_f, lambda r, a, k: float(r))
+        mcmc._likelihood_f = lik_rec
+        pri_rec = Recorder(bnn.calc_prior, lambda r, a, k: float(r))
+        bnn.calc_prior = pri_rec
+        mcmc.update_function = _Tally(mcmc.update_function, book)
+        saved = ref_env.UpdateNormal1D, ref_env.multiplier_proposal_vector
+        ref_env.UpdateNormal1D = _Tally(saved[0], book)
+        ref_env.multiplier_proposal_vector = _Tally(saved[1], book)
+        for i, w in enumerate(bnn._w_layers):
+            out["%s/w0_%d" % (name, i)] = w.copy()
+        out["%s/init" % name] = cases.option_state(bnn, mcmc)
+        out["%s/init_acc" % name] = np.array([mcmc._accuracy, mcmc._test_accuracy], dtype=float)
+        out["%s/update_n" % name] = np.asarray(mcmc._update_n)
+        rows, states, stats = [], [], []
+        try:
+            for what, n in cases.option_schedule(cfg):
+                for _ in range(n):
+                    if what == "gibbs":
+                        mcmc.gibbs_step(bnn)
+                        rows.append([np.nan, pri_rec.rows[-1], np.nan])
+                    else:
+                        book[0] = 0.0
+                        mcmc.mh_step(bnn)
+                        rows.append([lik_rec.rows[-1], pri_rec.rows[-1], book[0]])
+                    states.append(cases.option_state(bnn, mcmc))
+                    stats.append([mcmc._accuracy, mcmc._test_accuracy])
+        finally:
+            ref_env.UpdateNormal1D, ref_env.multiplier_proposal_vector = saved
+        out["%s/rows" % name] = np.array(rows, dtype=float)        # logLik', calc_prior(w', ind'), sum of Hastings terms
+        out["%s/states" % name] = np.array(states, dtype=float)    # cases.option_state after every call
+        out["%s/stats" % name] = np.array(stats, dtype=float)      # accuracy, test accuracy after every call
+        for i, w in enumerate(bnn._w_layers):
+            out["%s/wfinal_%d" % (name, i)] = w
+        out["%s/final_indicators" % name] = np.asarray(bnn._indicators, dtype=np.int8)
+        out["%s/final_label_acc" % name] = np.asarray(mcmc._label_acc, dtype=float)
+        if bnn._hyper_p:
+            for i, sc in enumerate(bnn._prior_scale):
+                out["%s/final_prior_scale_%d" % (name, i)] = np.asarray(sc, dtype=float)
+        acc = np.array(states)[:, 3]
+        print("  %-13s %3d calls, acceptance %.3f" % (name, len(rows), np.nanmean(acc)))
+    np.savez_compressed(os.path.join(HERE, "options.npz"), **out)
+    print("options.npz:", len(cases.OPTION_TRACES), "traces")
+
+
 if __name__ == "__main__":
     print("reference np_bnn", bn.__version__, "numpy", np.__version__)
     g1_grid()
@@ -293,3 +351,4 @@ if __name__ == "__main__":
     g6_masks()
     g7_posterior()
     g8_split()
+    g9_options()

@@ -56,11 +56,15 @@ class OracleBackend:
         z = orc.forward_logits(x, weights, self._act(slopes), col_override=co)
         return self._out_fn()(z) if apply_out_fn else z
 
+    _ROWWISE = {2: orc.lik_gaussian_error, 3: orc.lik_poisson, 4: orc.lik_negbin, 5: orc.lik_negbin2d, 6: orc.lik_negbin_base10}
+
     def evaluate(self, weights, slopes=None, col_override=None, lik_temp=1.0, sigma=None, which=0, want_confusion=False):
         self.n_eval += 1
         x, lab = self._data(which)
         y = self.predict(weights, slopes, col_override, which)
         out = dict(confusion=None, sigma=None, sum_r=None, sum_r2=None, n_rows=len(x))
+        from npbnn_amd.likelihoods import likelihood_kind
+        kind = likelihood_kind(getattr(self, "_lik_f", None))          # (capi.LIK_*; set by npbnn_amd.sampler.get_backend)
         if self.bnn._estimation_mode == "classification":
             iw = self.bnn._instance_weights if which == 0 else None
             cw = self.bnn._class_w if which == 0 else []
@@ -69,6 +73,8 @@ class OracleBackend:
                                                     lik_temp=lik_temp)
             if want_confusion:
                 out["confusion"] = orc.confusion_counts(y, lab)
+        elif kind in self._ROWWISE:
+            out["loglik"] = self._ROWWISE[kind](y, lab, None, lik_temp=lik_temp)
         else:
             r = lab - y[:, :lab.shape[1]]
             sig = np.std(y - lab, axis=0) if sigma is None else np.asarray(sigma, dtype=float)

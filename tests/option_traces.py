@@ -28,7 +28,7 @@ def check_initial_state(name, g, bnn, mcmc, rtol_lik, rtol_stats=None):
         np.testing.assert_allclose([mcmc._accuracy, mcmc._test_accuracy], g["init_acc"], rtol=rtol_stats, atol=rtol_stats)
 
 
-def follow(name, g, bnn, mcmc, rtol_lik, advance="mh_step", stats_every=0, rtol_stats=1e-9, chunk=None):
+def follow(name, g, bnn, mcmc, rtol_lik, advance="mh_step", stats_every=0, rtol_stats=1e-9, chunk=None, rtol_state=1e-9):
     """Run the trace's schedule.  ``advance``: "mh_step" (one call per iteration) or "run_steps" (one device batch per block of
     iterations between two gibbs steps, cut into calls of ``chunk``).  Returns the number of calls (iterations and gibbs steps)
     over which the sampler reproduced the reference's accept / reject sequence and state; raises Divergence where a state
@@ -48,7 +48,7 @@ def follow(name, g, bnn, mcmc, rtol_lik, advance="mh_step", stats_every=0, rtol_
         try:
             np.testing.assert_allclose(got[LOGLIK], want[LOGLIK], rtol=rtol_lik)
             np.testing.assert_allclose(got[LOGPRIOR], want[LOGPRIOR], rtol=1e-9, atol=1e-9)
-            np.testing.assert_allclose(got[ITERATION + 1:], want[ITERATION + 1:], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(got[ITERATION + 1:], want[ITERATION + 1:], rtol=rtol_state, atol=1e-12)
         except AssertionError as e:
             raise Divergence("%s: state after call %d differs with the same decisions\n%s" % (name, n_calls, e))
         if stats_every and (n_calls % stats_every == 0 or n_calls == len(states)):

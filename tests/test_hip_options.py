@@ -5,7 +5,7 @@ npbnn_chain_run / npbnn_chain_run_general, with mh_step inside where no device c
 
 The device computes row terms in float32, so a decision may flip where |logPost' - logPost - log u| falls below that noise,
 after which two correct chains part ways; the bar is the one of test_hip_sampler.py: the same accept / reject sequence AND
-state (log-likelihood 2e-6 relative; prior, slopes, sigma, indicators, prior scales 1e-9) over at least 150 calls - and
+state (log-likelihood and sigma 2e-6 relative; prior 1e-9; slopes, indicators, prior scales as the host keeps them) over at least 150 calls - and
 a state that differs while every decision was the same is an error wherever it happens."""
 import os
 
@@ -34,7 +34,8 @@ def test_free_running_chain_follows_the_reference_under_every_option(name, advan
     _, bnn, mcmc = cases.option_chain(bn, name)
     ot.check_initial_state(name, g, bnn, mcmc, rtol_lik=RTOL_LIK, rtol_stats=2e-3)
     n_calls = len(g["states"])
-    n = ot.follow(name, g, bnn, mcmc, rtol_lik=RTOL_LIK, advance=advance, stats_every=50, rtol_stats=2e-3, chunk=40)
+    n = ot.follow(name, g, bnn, mcmc, rtol_lik=RTOL_LIK, advance=advance, stats_every=50, rtol_stats=2e-3, chunk=40,
+                  rtol_state=2e-6)     # (an empirical sigma comes from float32 residuals)
     assert n >= min(COMMON, n_calls), "%s via %s: left the reference's accept / reject sequence after %d calls" % (name, advance, n)
     if n == n_calls:
         ot.check_final_state(name, g, bnn, mcmc, rtol_stats=2e-3)

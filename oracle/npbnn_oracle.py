@@ -29,7 +29,8 @@ __all__ = [
     "confusion_counts", "mse_all", "mse_per_column",
     "init_weights", "block_mask", "log_prior",
     "propose_normal", "propose_normal_1d", "propose_fixed_normal",
-    "propose_normal_normalized", "propose_multiplier_vector",
+    "propose_normal_normalized", "propose_multiplier_vector", "propose_binomial",
+    "gibbs_prior_scales", "gibbs_step",
     "make_chain", "mh_step", "run_chain", "mc3_make", "mc3_run",
     "posterior_cat_prob", "sample_from_categorical", "feature_importance",
 ]
@@ -544,11 +545,15 @@ def make_chain(data, labels, n_nodes, *, act=None, use_bias_node=1, prior_kind=1
                update_f=None, update_ws=None, temperature=1, n_iteration=100000,
                likelihood_tempering=1, mcmc_id=0, randomize_seed=False, adapt_f=0, adapt_fM=1,
                adapt_freq=1000, adapt_stop=None, estimate_error=True, likelihood_f=None,
-               with_stats=True):
+               with_stats=True, hyper_p=0, freq_indicator=0, prior_ind1=0.5, feature_indicators=False,
+               update_function=None, out_fn=None, size_output=None, accuracy_f=None):
     """State of one chain = what npBNN.__init__ (BNN_env.py:19-173) and
-    MCMC.__init__ (:274-379) set up, for the feature set of SURVEY.md section 8
-    (no weight/feature indicators, no trainable activation).  Weights are drawn
-    from numpy's global RNG exactly where the reference draws them (:111-115).
+    MCMC.__init__ (:274-379) set up, every sampler option included: weight
+    indicators (``freq_indicator``, ``prior_ind1``), feature indicators,
+    trainable activation slopes (``act.trainable``), hyper-prior scales
+    (``hyper_p``, changed by :func:`gibbs_step`), the proposal function.
+    Weights are drawn from numpy's global RNG exactly where the reference
+    draws them (:111-115).
     """
     st = SimpleNamespace()
     st.act = act if act is not None else Act()
@@ -571,16 +576,27 @@ def make_chain(data, labels, n_nodes, *, act=None, use_bias_node=1, prior_kind=1
         st.size_output = st.labels.shape[1] * 2
         st.out_fn = out_regress_error
         st.lik = lik_gaussian_error
+    elif mode == "custom":                                      # :72-74
+        st.size_output = size_output
+        st.out_fn = out_identity
+        st.lik = None
     else:
         raise ValueError(mode)
+    if out_fn is not None and mode != "classification":         # :57-60
+        st.out_fn = out_fn
     if likelihood_f is not None:
         st.lik = likelihood_f
+    st.accuracy_f = accuracy_f
     st.empirical_error = empirical_error
     st.n_layers = len(n_nodes) + 1
     st.sample_id = np.arange(data.shape[0])
     st.w_bound = p_scale if prior_kind == 0 else w_bound       # :135-137
     st.prior_kind = prior_kind
     st.prior_scale = np.ones(st.n_layers) * p_scale            # :154
+    st.hyper_p = hyper_p
+    st.freq_indicator = freq_indicator
+    st.prior_ind1 = prior_ind1
+    st.propose = propose_normal if update_function is None else update_function   # :278
     st.class_w = class_weights
     st.instance_weights = instance_weights
     st.mask = None
@@ -593,6 +609,14 @@ def make_chain(data, labels, n_nodes, *, act=None, use_bias_node=1, prior_kind=1
         st.mask = mask
         st.w = [st.w[i] * mask[i] for i in range(st.n_layers)]
     st.n_params = int(np.sum([np.size(i) for i in st.w]))
+    if st.act.trainable:
+        st.n_params += st.n_layers                              # :166-167
+    st.indicators = np.ones(st.w[0].shape)                      # :125
+    st.feature_ind = st.feature_means = None
+    if feature_indicators:                                      # :170-172
+        st.feature_ind = np.ones(data.shape[1]).astype(int)
+        st.feature_means = np.mean(data, axis=0)
+    st.test_override = None
     # ---- MCMC.__init__ ----
     if update_ws is None:
         update_ws = [0.075] * st.n_layers
@@ -611,7 +635,7 @@ def make_chain(data, labels, n_nodes, *, act=None, use_bias_node=1, prior_kind=1
     st.logLik = st.lik(st.y, st.labels, st.sample_id, class_weight=st.class_w,
                        instance_weight=st.instance_weights, lik_temp=st.lik_temp,
                        sig2=st.error_prm)                       # :313-319
-    st.logPrior = log_prior(st.w, st.prior_kind, st.prior_scale)
+    st.logPrior = _chain_prior(st, st.w, st.indicators)
     st.logPost = st.logLik + st.logPrior
     _refresh_stats(st)
     st.last_accepted = 1
@@ -633,28 +657,67 @@ def _refresh_stats(st):
     """Accuracy bookkeeping done at init (:344-353) and on accept (:508-518)."""
     if not st.with_stats:
         return
-    if st.mode == "classification":
-        st.accuracy = acc_classification(st.y, st.labels)
-        st.label_acc = label_acc_classification(st.y, st.labels)
-        st.label_freq = label_freq(st.y)
+    if st.accuracy_f is not None:
+        acc_f, lab_f = st.accuracy_f, (lambda y, lab: np.ones(1))
+    elif st.mode == "classification":
+        acc_f, lab_f = acc_classification, label_acc_classification
+    elif st.mode in ("regression", "regression-error"):
+        acc_f, lab_f = mse_all, mse_per_column
     else:
-        st.accuracy = mse_all(st.y, st.labels)
-        st.label_acc = mse_per_column(st.y, st.labels)
-        st.label_freq = label_freq(st.y)
+        acc_f, lab_f = (lambda y, lab: 1.0), (lambda y, lab: np.ones(1))    # SkipAccuracy*, BNN_lib.py:235-239
+    st.accuracy = acc_f(st.y, st.labels)
+    st.label_acc = lab_f(st.y, st.labels)
+    st.label_freq = label_freq(st.y)
     if st.test_data is not None and len(st.test_data) > 0:
-        st.y_test = forward(st.test_data, st.w, st.act, st.out_fn,
-                            indicators=np.ones(st.w[0].shape))
-        if st.mode == "classification":
-            st.test_accuracy = acc_classification(st.y_test, st.test_labels)
-        else:
-            st.test_accuracy = mse_all(st.y_test, st.test_labels)
+        st.y_test = forward(st.test_data, st.w, st.act, st.out_fn, indicators=st.indicators,
+                            col_override=st.test_override)     # RunPredictInd :347-349, :512-515
+        st.test_accuracy = acc_f(st.y_test, st.test_labels)
     else:
         st.y_test, st.test_accuracy = [], 0
 
 
+def _chain_prior(st, weights, indicators):
+    return log_prior(weights, st.prior_kind, st.prior_scale, indicators=indicators,
+                     freq_indicator=st.freq_indicator, prior_ind1=st.prior_ind1,
+                     n_indicators=st.indicators.size)
+
+
+def propose_binomial(ind, update_f, shape_out):
+    """UpdateBinomial (BNN_mcmc.py:98-99): numpy's GLOBAL stream, not the chain's."""
+    return np.abs(ind - np.random.binomial(1, np.random.random() * update_f, shape_out))
+
+
+def gibbs_prior_scales(w_layers, hyper_p):
+    """npBNN.sample_prior_scale (BNN_env.py:196-221) with the conjugate draws of
+    BNN_mcmc.py:126-144: the standard deviation of a zero-mean normal under a
+    gamma prior on its precision - one per layer (a=2), per input node (a=1) or
+    per weight (a=1.5), b=0.1; numpy's global stream."""
+    out = []
+    for x in w_layers:
+        if hyper_p == 1:
+            v = x.flatten()
+            tau = np.random.gamma(2 + len(v) / 2., scale=1. / (0.1 + np.sum(v ** 2) / 2.))
+        elif hyper_p == 2:
+            tau = np.random.gamma(1 + x.shape[0] / 2., scale=1. / (0.1 + np.sum(x ** 2, axis=0) / 2.))
+        else:
+            tau = np.random.gamma(1.5 + 1 / 2., scale=1. / (0.1 + (x ** 2) / 2.))
+        out.append(1 / np.sqrt(tau))
+    return out
+
+
+def gibbs_step(st):
+    """MCMC.gibbs_step (BNN_env.py:534-538): new prior scales, the prior of
+    the current state under them (without the slope term), iteration + 1."""
+    if st.hyper_p in (1, 2, 3):
+        st.prior_scale = gibbs_prior_scales(st.w, st.hyper_p)
+    st.logPrior = _chain_prior(st, st.w, st.indicators)
+    st.logPost = st.logLik + st.logPrior
+    st.it += 1
+
+
 def mh_step(st):
-    """One Metropolis-Hastings iteration, MCMC.mh_step (BNN_env.py:381-532),
-    for the section-8 feature set.  Returns a dict describing the proposal."""
+    """One Metropolis-Hastings iteration, MCMC.mh_step (BNN_env.py:381-532).
+    Returns a dict describing the proposal."""
     if st.randomize_seed:
         st.rs = np.random.default_rng(st.it + st.mcmc_id)       # :383-384
     hastings = 0
@@ -676,7 +739,22 @@ def mh_step(st):
             n[n < 1] = 1
             st.update_n = n
             st.update_ws = [i * 1.2 for i in st.update_ws]
+    # ---- trainable activation slopes :416-421 ----
+    if st.act.trainable:
+        prm_tmp, _, h = propose_normal_1d(st.act.acc_prm, d=0.05, n=1, Mb=1, mb=0, rs=st.rs)
+        additional_prob += np.log(10) * -np.sum(prm_tmp) * 10
+        hastings += h
+        st.act.prm = prm_tmp
+    # ---- feature indicators :424-433 ----
+    col_override = None
+    feature_ind_p = st.feature_ind
+    if st.feature_ind is not None and st.it > st.adapt_stop:
+        feature_ind_p = st.feature_ind + 0
+        if st.rs.random() < 0.2:
+            feature_ind_p = propose_binomial(feature_ind_p, 0.5, st.feature_ind.shape)
+        col_override = (feature_ind_p, st.feature_means)
     # ---- regression error parameter :435-444 ----
+    indicators_p = st.indicators + 0
     error_tmp = st.error_prm
     if st.mode == "regression" and st.it > st.estimate_error:
         if not st.empirical_error:
@@ -689,21 +767,28 @@ def mh_step(st):
     rr = st.rs.random(st.n_layers)
     rr[np.argmin(rr)] = 0
     for i in range(st.n_layers):                                 # :449-472
-        if rr[i] < st.freq_layer_update[i]:
-            upd, _, h = propose_normal(st.w[i], d=st.update_ws[i], n=st.update_n[i],
+        if rr[i] >= st.freq_indicator or i > 0:
+            if rr[i] < st.freq_layer_update[i]:
+                upd, _, h = st.propose(st.w[i], d=st.update_ws[i], n=st.update_n[i],
                                        Mb=st.w_bound, mb=-st.w_bound, rs=st.rs)
-            w_prime.append(upd)
-            hastings += h
-        else:
+                w_prime.append(upd)
+                hastings += h
+            else:
+                w_prime.append(st.w[i] + 0)
+        else:                                                    # :457-460
             w_prime.append(st.w[i] + 0)
+            indicators_p = propose_binomial(st.indicators, st.update_f[3], st.indicators.shape)
         if st.mask is not None:
             w_prime[i] *= st.mask[i]
         act = st.act if i < st.n_layers - 1 else None
-        tmp = hidden_layer(tmp, w_prime[i], act, i)
+        if i == 0:                                               # :463-468
+            tmp = hidden_layer(tmp, w_prime[i] * indicators_p, act, i, col_override)
+        else:
+            tmp = hidden_layer(tmp, w_prime[i], act, i)
     y_prime = st.out_fn(tmp)                                     # :473
     if st.mode == "regression" and st.empirical_error:
         error_tmp = np.std(y_prime - st.labels, axis=0)          # :475-476
-    logPrior_p = log_prior(w_prime, st.prior_kind, st.prior_scale) + additional_prob
+    logPrior_p = _chain_prior(st, w_prime, indicators_p) + additional_prob
     logLik_p = st.lik(y_prime, st.labels, st.sample_id, class_weight=st.class_w,
                       instance_weight=st.instance_weights, lik_temp=st.lik_temp,
                       sig2=error_tmp)                            # :485-491
@@ -716,6 +801,12 @@ def mh_step(st):
         info["w_prime"] = w_prime
     if accepted:                                                 # :494-519
         st.w = w_prime
+        st.indicators = indicators_p
+        if st.feature_ind is not None:
+            st.feature_ind = feature_ind_p + 0
+        st.test_override = col_override                          # the test forward of this accept uses it (:512-515)
+        if st.act.trainable:
+            st.act.acc_prm = st.act.prm + 0                      # :502-503
         if st.mode == "regression":
             st.error_prm = error_tmp
         st.logPost, st.logLik, st.logPrior = logPost_p, logLik_p, logPrior_p

@@ -239,3 +239,93 @@ def test_g7_feature_importance(tag, blocks, golden_dir):
     np.testing.assert_array_equal(order, g["fi_%s_index" % tag])
     assert [str(n) for n in names] == [str(n) for n in g["fi_%s_names" % tag]]
     np.testing.assert_allclose(table, g["fi_%s_values" % tag], rtol=1e-12, atol=1e-15)
+
+
+# ---- G9: one reference trace per sampler option beyond the default path -------------------------------------------------
+_ORACLE_NAMES = dict(UpdateFixedNormal=orc.propose_fixed_normal, UpdateNormalNormalized=orc.propose_normal_normalized,
+                     RegressTransformError=orc.out_regress_error, poi_likelihood=orc.lik_poisson,
+                     poi_acc=lambda y, lab: np.mean((np.exp(y[:, 0]) - lab.flatten()) ** 2))        # BNN_lik.py:94-96
+
+
+def _build_oracle_option_chain(name):
+    cfg = cases.OPTION_TRACES[name]
+    dat = cases.option_data(cfg)
+    a = dict(cfg["act"])
+    act = orc.Act(a["fun"], prm=np.array(a["prm"], dtype=float) if "prm" in a else None, trainable=a.get("trainable", False))
+    b, m = dict(cfg["bnn"]), dict(cfg["mcmc"])
+    kw = dict(act=act, use_bias_node=cfg["bias"], prior_kind=b.get("prior_f", 1), p_scale=b.get("p_scale", 1),
+              mode=b.get("estimation_mode", "classification"), empirical_error=b.get("empirical_error", False),
+              hyper_p=b.get("hyper_p", 0), freq_indicator=b.get("freq_indicator", 0), prior_ind1=b.get("prior_ind1", 0.5),
+              feature_indicators=b.get("feature_indicators", False), size_output=b.get("size_output"),
+              test_data=dat["test_data"], test_labels=dat["test_labels"])
+    if "output_act_fun" in b:
+        kw["out_fn"] = _ORACLE_NAMES[b["output_act_fun"]]
+    if b.get("use_class_weights"):                      # BNN_env.py:98-102
+        counts = np.unique(dat["labels"], return_counts=True)[1]
+        cw = 1 / (counts / np.max(counts))
+        kw["class_weights"] = cw / np.mean(cw)
+    if cfg.get("instance_weights"):
+        kw["instance_weights"] = np.random.default_rng(cfg["seed"] + 1000).uniform(0.2, 2.0, len(dat["labels"]))
+    if cfg.get("init_weights") == "unit_sum":
+        rs = np.random.default_rng(cfg["seed"] + 2000)
+        drawn = [rs.uniform(-0.5, 1.0, sh) for sh in cases.layer_shapes(cfg["n_features"], cfg["n_nodes"], cfg["n_classes"], cfg["bias"])]
+        kw["init_w"] = [w / w.sum() for w in drawn]
+    for key in ("likelihood_f", "accuracy_f"):
+        if key in m:
+            kw[key] = _ORACLE_NAMES[m.pop(key)]
+    if "update_function" in cfg:
+        kw["update_function"] = _ORACLE_NAMES[cfg["update_function"]]
+    np.random.seed(1234)
+    st = orc.make_chain(dat["data"], dat["labels"], cfg["n_nodes"], **kw, **m)
+    for attr, value in cfg.get("post_init", {}).items():
+        setattr(st, attr.lstrip("_"), value)
+    return st
+
+
+def _oracle_option_state(st):
+    parts = [[st.logLik, st.logPrior, st.logPost, st.last_accepted, st.acceptance_rate, st.it]]
+    if st.act.trainable:
+        parts += [np.ravel(st.act.prm), np.ravel(st.act.acc_prm)]
+    if st.mode == "regression":
+        parts.append(np.ravel(np.ones(st.size_output) * st.error_prm))
+    if st.freq_indicator:
+        parts.append([np.sum(st.indicators)])
+    if st.feature_ind is not None:
+        parts.append(np.ravel(st.feature_ind))
+    if st.hyper_p:
+        parts.append([np.sum([np.sum(s) for s in st.prior_scale])])
+    return np.concatenate([np.asarray(p, dtype=float) for p in parts])
+
+
+@pytest.mark.parametrize("name", list(cases.OPTION_TRACES))
+def test_g9_option_traces(name, golden_dir):
+    """The oracle's chain under every sampler option against the reference's own run: per proposal the log-likelihood, the
+    prior and the Hastings terms; after every call the whole observable state; at the end weights, indicators, scales."""
+    import option_traces as ot
+    g = ot.load(np.load(os.path.join(golden_dir, "options.npz")), name)
+    cfg = cases.OPTION_TRACES[name]
+    st = _build_oracle_option_chain(name)
+    for i, w in enumerate(st.w):
+        np.testing.assert_array_equal(w, g["w0_%d" % i])
+    np.testing.assert_array_equal(st.update_n, g["update_n"])
+    np.testing.assert_allclose(_oracle_option_state(st), g["init"], rtol=RTOL)
+    np.testing.assert_allclose([st.accuracy, st.test_accuracy], g["init_acc"], rtol=RTOL)
+    call = 0
+    for what, n in cases.option_schedule(cfg):
+        for _ in range(n):
+            if what == "gibbs":
+                orc.gibbs_step(st)
+            else:
+                info = orc.mh_step(st)
+                np.testing.assert_allclose(info["logLik"], g["rows"][call, 0], rtol=RTOL, err_msg="call %d" % call)
+                np.testing.assert_allclose(info["hastings"], g["rows"][call, 2], rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(_oracle_option_state(st), g["states"][call], rtol=RTOL, atol=1e-12, err_msg="call %d" % call)
+            np.testing.assert_allclose([st.accuracy, st.test_accuracy], g["stats"][call], rtol=RTOL)
+            call += 1
+    for i, w in enumerate(st.w):
+        np.testing.assert_array_equal(w, g["wfinal_%d" % i])
+    np.testing.assert_array_equal(st.indicators.astype(np.int8), g["final_indicators"])
+    np.testing.assert_allclose(st.label_acc, g["final_label_acc"], rtol=RTOL)
+    if st.hyper_p:
+        for i, sc in enumerate(st.prior_scale):
+            np.testing.assert_allclose(sc, g["final_prior_scale_%d" % i], rtol=1e-13)

@@ -967,6 +967,10 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
     if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds, 1, layout_for(ctx, ctx->ds[0])); return NPBNN_OK; }
     if (what == NPBNN_INFO_N_CU) { *out = ctx->n_cu; return NPBNN_OK; }
+    if (what == NPBNN_INFO_TURN_NS_OVERLAPPED || what == NPBNN_INFO_TURN_NS_BETWEEN) {
+        *out = (int)(1000.0 * ctx->turn_us[what == NPBNN_INFO_TURN_NS_BETWEEN ? 1 : 0]);
+        return NPBNN_OK;
+    }
     if (what == NPBNN_INFO_FAST_TAILS) { *out = (ctx->arch_set && fast_launch_ok(ctx, ctx->ds[0])) ? 1 : 0; return NPBNN_OK; }
     return fail(ctx, NPBNN_E_ARG, "get_info: unknown item %d", what);
 }

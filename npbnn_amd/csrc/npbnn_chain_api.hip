@@ -167,6 +167,15 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
             // (3 % in favour of the form the chain is on: no flipping on noise)
             const bool on_serial = ctx->last_schedule == NPBNN_SCHED_PERSIST_SERIAL;
             if (t_serial * (on_serial ? 0.97 : 1.03) < t_over * (1.0 + a)) schedule = NPBNN_SCHED_PERSIST_SERIAL;
+            // an estimate that was measured goes stale while the other form runs (the chain's acceptance rate moves, the box's clocks
+            // do): after kTurnReprobeBatches batches on one form, one batch on the other - if it is within reach (a factor 1.25)
+            const int other = schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1;
+            if (ctx->turn_us[other] > 0.0 && ctx->turn_batches[other] >= kTurnReprobeBatches) {
+                const double c_ser = t_serial, c_over = t_over * (1.0 + a);
+                const double ratio = other == 1 ? c_ser / c_over : c_over / c_ser;
+                ctx->turn_batches[other] = 0;
+                if (ratio < 1.25) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
+            }
         }
     }
     if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
@@ -704,8 +713,13 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
     if (rc) return rc;
     if (B.persist && n_rounds == 1 && result->n_passes + result->n_void_passes >= 8) {      // what a turn of this form takes here (NPBNN_SCHED_AUTO)
         double& t = ctx->turn_us[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0];
-        const double now_us = (tw2 - B.tw1) / (result->n_passes + result->n_void_passes);
+        double now_us = (tw2 - B.tw1) / (result->n_passes + result->n_void_passes);
+        // one stalled call (the host descheduled, a collector pause: 80 ms were seen) must not price a form out for good - the form
+        // that lost is not run again, so nothing would ever correct its estimate: a sample counts for at most 1.25 x the estimate
+        if (t > 0.0 && now_us > 1.25 * t) now_us = 1.25 * t;
         t = t > 0.0 ? 0.75 * t + 0.25 * now_us : now_us;
+        ctx->turn_batches[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0] = 0;
+        ctx->turn_batches[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1] += 1;
     }
     if (timing && ctx->d_spec && B.schedule == NPBNN_SCHED_PERSIST_SERIAL) {
         SpecState hs;

@@ -148,6 +148,7 @@ struct npbnn_ctx {
     size_t res_cap = 0, res_k = 0, res_nw = 0;
     int* d_chain_ovf = nullptr;
     int last_schedule = 0;         // schedule of the previous batch
+    int turn_batches[2] = {0, 0};   // batches run since that form's turn time was last measured (kTurnReprobeBatches)
     double turn_us[2] = {0.0, 0.0}; // measured time of a launch turn (pass, decided or void) of the persistent forms: overlapped, decision between passes
     double its_per_pass = 0.0;     // iterations a launch decided on average in the previous batch (0: unknown)
     double accept_rate = -1.0;     // acceptance rate of the previous batch (< 0: unknown)
@@ -217,6 +218,7 @@ namespace npbnn_api {
 // kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M (measured on config-2 shapes: 33.2 against 28.5 us per turn at M = 33, 40 at M = 428).
 constexpr double kSpecTurnExtraUs = 4.5, kSpecTurnExtraUsPerWeight = 0.0175;
 constexpr double kTurnUsGuess = 30.0;           // before anything has been measured
+constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 

@@ -502,6 +502,22 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                              "us_fixed_per_dispatch": 1e6 * el2 / n_more - ITERATIONS_PER_STEP * 1e2 * el3,
                              "us_of_python_per_dispatch": 1e6 * (el2b - inside) / n_more,
                              "note": "upload of state and draws, first step kernel (full prior re-sum), result copy, synchronisation, host Python"}
+        if "f32_path" in roof:          # the same chain with layer 0 on float32 matrix cores: a rate, not only kernel times
+            try:
+                ctx.set_l0_precision("f32")
+                for _ in range(args.warmup):
+                    mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+                el32 = time.perf_counter() - t0
+                roof["f32_path"].update({"value": args.steps * ITERATIONS_PER_STEP / el32, "unit": "iterations/s",
+                                         "ms_per_step": 1e3 * el32 / args.steps, "layer0": ctx.l0_mode(),
+                                         "value_note": "%d dispatches of %d iterations of the settled chain (compare settled_chain)"
+                                                       % (args.steps, ITERATIONS_PER_STEP)})
+            finally:
+                ctx.set_l0_precision("auto")
+                mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
         mv = moving_chain(wl)
         if mv is not None:
             line["moving_chain"] = mv

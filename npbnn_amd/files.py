@@ -51,9 +51,15 @@ def attach_data(obj, source):
 
 def load_obj(file_name, dat=None):
     """The pickled object(s) of ``file_name`` (np_bnn/BNN_files.py:260-267).  Checkpoints written by ``postLogger`` keep their
-    feature matrices in a side file; they are re-attached from it - or from ``dat``, the dictionary the model was built from."""
+    feature matrices in a side file; they are re-attached from it - or from ``dat``, the dictionary the model was built from.
+    A checkpoint in upstream's format (np_bnn's own, or written here with ``export="upstream"``) comes back as objects of this
+    package (npbnn_amd/export.py)."""
     with open(file_name, 'rb') as f:
-        obj = pickle.load(f)
+        raw = f.read()
+    from . import export
+    if export.names_upstream(raw):        # written by np_bnn itself, or by postLogger(export="upstream") / save_upstream
+        return export.loads_as_this_package(raw)
+    obj = pickle.loads(raw)
     models = [o for o in (obj if isinstance(obj, (list, tuple)) else [obj])
               if any(isinstance(v, DetachedMatrix) for v in getattr(o, "__dict__", {}).values())]
     if models:

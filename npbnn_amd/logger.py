@@ -3,9 +3,11 @@
 Same files and layouts as the reference logger (np_bnn/BNN_env.py:553-658, header built in
 np_bnn/BNN_files.py:110-187): ``<name>_l<nodes>.log`` (tab separated; any tool that reads upstream's
 log reads this one), optional ``..._W.log`` with every weight, and ``<name>_l<nodes>.pkl`` holding
-``[bnn_obj, mcmc_obj, logger]`` with the same ``_post_weight_samples`` dictionaries.  The pickle holds
-objects of THIS package (``npbnn_amd.model.npBNN`` ...): loading it needs ``npbnn_amd`` on the import
-path, upstream's classes cannot stand in.
+``[bnn_obj, mcmc_obj, logger]`` with the same ``_post_weight_samples`` dictionaries.  By default the pickle
+holds objects of THIS package (``npbnn_amd.model.npBNN`` ...) without the feature matrices; with
+``postLogger(export="upstream")`` it is written in upstream's own format (npbnn_amd/export.py): ``np_bnn.load_obj``
+opens it as np_bnn objects and ``np_bnn.predictBNN`` / ``get_posterior_est`` / ``npBNN(pickle_file=...)`` consume it.
+``load_obj`` of this package reads both.
 """
 import csv
 import os
@@ -62,11 +64,15 @@ def init_output_files(bnn_obj, filename="bnn", sample_from_prior=0, outpath="", 
 
 class postLogger():
     def __init__(self, bnn_obj, filename="BNN", wdir="", sample_from_prior=0, add_prms=None,
-                 continue_logfile=False, log_all_weights=0, pickle_data=False):
+                 continue_logfile=False, log_all_weights=0, pickle_data=False, export=None):
         """``pickle_data``: True writes the feature matrices into the checkpoint with every posterior sample, as the reference
         does (np_bnn/BNN_env.py:655-658; > 200 MB per sample at 100k x 256); the default writes them ONCE into
         ``<checkpoint>_data.npz`` and keeps the checkpoint itself to weights, sampler state and posterior samples -
-        ``load_obj`` puts them back together."""
+        ``load_obj`` puts them back together.  ``export="upstream"``: the checkpoint in upstream's own pickle format (with
+        the feature matrices, as upstream writes it), readable by np_bnn's tools without this package."""
+        if export not in (None, "upstream"):
+            raise ValueError("export=%r; expected None or 'upstream'" % (export,))
+        self._export = export
         self._logfile, self._w_file, self._pklfile = init_output_files(
             bnn_obj, filename, sample_from_prior, outpath=wdir, add_prms=add_prms,
             continue_logfile=continue_logfile, log_all_weights=log_all_weights)
@@ -163,7 +169,10 @@ class postLogger():
                 sample['additional_prm'] = list(add_prms)
             self.update_post_weight_samples(sample)
             self.control_weight_sample_length(mcmc_obj._n_post_samples)
-        if save_pickle:
+        if save_pickle and getattr(self, "_export", None) == "upstream":
+            from .export import save_upstream
+            save_upstream([bnn_obj, mcmc_obj, self] + ([add_obj] if add_obj else []), self._pklfile)
+        elif save_pickle:
             if not getattr(self, "_pickle_data", True):
                 bnn_obj, mcmc_obj = self._light_views(bnn_obj, mcmc_obj)
             objs = [bnn_obj, mcmc_obj, self] + ([add_obj] if add_obj else [])

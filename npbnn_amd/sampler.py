@@ -369,8 +369,15 @@ class MCMC():
         state = dict(state)
         if "_rs" in state:
             state["_gen"] = state.pop("_rs")
+        # statistics stored as plain attributes (an upstream-format checkpoint, npbnn_amd/export.py) are the cached values here
+        cached = dict(state.pop("_lazy", None) or {})
+        for name in _LAZY:
+            if name in state:
+                cached[name] = state.pop(name)
         self.__dict__.update(state)
-        self.__dict__.setdefault("_backend", None)
+        self._lazy = cached
+        for name in ("_backend", "_bnn", "_accepted_override"):
+            self.__dict__.setdefault(name, None)
 
     def __deepcopy__(self, memo):
         import copy

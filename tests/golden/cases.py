@@ -189,6 +189,14 @@ OPTION_TRACES = {
 }
 
 
+# ---- G10: a checkpoint in upstream's format (npbnn_amd/export.py), written here, consumed by np_bnn's own tools -----------
+EXPORT_CASE = "export_small"
+OPTION_TRACES[EXPORT_CASE] = dict(kind="classification", seed=208, n_rows=320, n_features=10, n_classes=3, n_test=60,
+                                  n_nodes=[5, 4], bias=2, steps=240, act=dict(fun="genReLU", prm=[0.05, 0.1], trainable=True),
+                                  bnn=dict(), mcmc=dict(_MC, n_iteration=120, sampling_f=20, print_f=100000))
+EXPORT_SWITCH = 120          # iterations under this package before the checkpoint is handed to upstream
+
+
 def count_data(seed, n_rows, n_features, n_test=0):
     rs = np.random.default_rng(seed)
     x = rs.standard_normal((n_rows + n_test, n_features))

@@ -16,6 +16,8 @@ Groups:
   G7 posterior.npz   get_posterior_cat_prob: per-sample class probabilities and the three summaries
   G8 split.npz       get_data / randomize_data: the train / test split of seeded example tables
   G9 options.npz     one Metropolis-Hastings trace per sampler option beyond the default path (cases.OPTION_TRACES)
+  G10 export.npz + export_upstream.pkl   a checkpoint written by npbnn_amd in upstream's format (on the oracle stand-in: no GPU
+                     here), opened by np_bnn.load_obj, continued by np_bnn's mh_step, read by np_bnn.predictBNN / get_posterior_est
 """
 import contextlib
 import io
@@ -341,6 +343,55 @@ def g9_options():
     print("options.npz:", len(cases.OPTION_TRACES), "traces")
 
 
+def g10_export():
+    """The round trip of npbnn_amd/export.py, proven against the reference itself:
+    (1) cases.EXPORT_CASE runs EXPORT_SWITCH iterations under npbnn_amd (served by the float64 oracle stand-in, the device being
+        absent here) with postLogger(export="upstream");
+    (2) np_bnn.load_obj opens the checkpoint as np_bnn objects; np_bnn's own mh_step continues the chain from it and must land,
+        call for call, on the states of np_bnn's own uninterrupted run of the same case (options.npz) - asserted here;
+    (3) np_bnn.predictBNN and np_bnn.get_posterior_est consume the file; their outputs are stored for the tests, which feed
+        the committed file to this package's predictBNN / get_posterior_est."""
+    import shutil
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))          # tests/
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))       # repository root
+    import npbnn_amd
+    from oracle_backend import OracleChainBackend, serve_from_oracle
+    name = cases.EXPORT_CASE
+    cfg = cases.OPTION_TRACES[name]
+    golden = np.load(os.path.join(HERE, "options.npz"))
+    states = golden["%s/states" % name]
+    serve_from_oracle(lambda b: OracleChainBackend(b, 0))
+    with tempfile.TemporaryDirectory() as tmp:
+        dat, bnn, mcmc = cases.option_chain(npbnn_amd, name)
+        logger = npbnn_amd.postLogger(bnn, filename="EXPORT", wdir=tmp, export="upstream")
+        quiet(npbnn_amd.run_mcmc, bnn, mcmc, logger)
+        assert mcmc._current_iteration == cases.EXPORT_SWITCH
+        np.testing.assert_allclose(cases.option_state(bnn, mcmc), states[cases.EXPORT_SWITCH - 1], rtol=1e-10)
+        b_up, m_up, l_up = bn.load_obj(logger._pklfile)
+        assert type(b_up) is bn.npBNN and type(m_up) is bn.MCMC and type(l_up) is bn.postLogger and type(b_up._act_fun) is bn.ActFun
+        for it in range(cases.EXPORT_SWITCH, cfg["steps"]):
+            m_up.mh_step(b_up)
+            np.testing.assert_allclose(cases.option_state(b_up, m_up), states[it], rtol=1e-10, err_msg="upstream continuing at %d" % it)
+        out = {}
+        res = quiet(bn.predictBNN, dat["test_data"], logger._pklfile, test_labels=dat["test_labels"], post_summary_mode=1, verbose=0)
+        out["predict_mean_prob"] = res["post_prob_predictions"]
+        out["predict_accuracy"] = np.array(res["mean_accuracy"])
+        est = bn.get_posterior_est(logger._pklfile)
+        out["est_prm_mean"] = est["prm_mean"]
+        out["est_prm_mean_test"] = est["prm_mean_test"]
+        np.random.seed(1234)
+        b_restart = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], pickle_file=logger._pklfile,
+                          actFun=bn.ActFun(fun="genReLU", prm=np.zeros(2), trainable=True))
+        out["restart_w0"] = b_restart._w_layers[0]
+        out["restart_alphas"] = np.asarray(b_restart._act_fun._prm, dtype=float)
+        shutil.copy(logger._pklfile, os.path.join(HERE, "export_upstream.pkl"))
+        for key in ("predict_mean_prob", "est_prm_mean_test"):
+            assert np.all(np.isfinite(out[key]))
+    np.savez_compressed(os.path.join(HERE, "export.npz"), **out)
+    print("export.npz + export_upstream.pkl: upstream continued the chain for %d iterations on np_bnn's own trace"
+          % (cfg["steps"] - cases.EXPORT_SWITCH))
+
+
 if __name__ == "__main__":
     print("reference np_bnn", bn.__version__, "numpy", np.__version__)
     g1_grid()
@@ -352,3 +403,4 @@ if __name__ == "__main__":
     g7_posterior()
     g8_split()
     g9_options()
+    g10_export()

@@ -5,10 +5,19 @@ import os
 import numpy as np
 import pytest
 
+import contextlib
+import io
+
 import cases
+import npbnn_amd as bn
 import oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+
+def quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
 
 TOL = 2e-5      # class probabilities, float32 forward pass vs float64
 
@@ -131,3 +140,38 @@ def test_get_posterior_est_of_a_regression_checkpoint(tmp_path):
             np.testing.assert_allclose(res[key][i], ref, atol=TOL, rtol=0)
     np.testing.assert_allclose(res['prm_mean'], res['post_est'].mean(axis=0), rtol=1e-14)
     np.testing.assert_array_equal(np.array(res['error_prm']), np.array([smp['error_prm'] for smp in samples]))
+
+
+def test_upstream_format_checkpoint_through_this_packages_tools(golden_dir, tmp_path):
+    """tests/golden/export_upstream.pkl - written by this package in upstream's format, then opened, continued and analysed by
+    np_bnn itself (make_golden.py G10) - fed to THIS package's predictBNN / get_posterior_est on the GPU: the numbers np_bnn's
+    own tools computed from the same file (export.npz)."""
+    import shutil
+    import cases
+    g = np.load(os.path.join(golden_dir, "export.npz"))
+    dat = cases.option_data(cases.OPTION_TRACES[cases.EXPORT_CASE])
+    pkl = str(tmp_path / "export_upstream.pkl")
+    shutil.copy(os.path.join(golden_dir, "export_upstream.pkl"), pkl)
+    res = quiet(bn.predictBNN, dat["test_data"], pkl, test_labels=dat["test_labels"], post_summary_mode=1, verbose=0)
+    np.testing.assert_allclose(res["post_prob_predictions"], g["predict_mean_prob"], atol=2e-6)
+    np.testing.assert_allclose(res["mean_accuracy"], g["predict_accuracy"], atol=1e-12)
+    est = bn.get_posterior_est(pkl)
+    np.testing.assert_allclose(est["prm_mean"], g["est_prm_mean"], atol=2e-6)
+    np.testing.assert_allclose(est["prm_mean_test"], g["est_prm_mean_test"], atol=2e-6)
+
+
+def test_a_gpu_chain_writes_and_rereads_an_upstream_format_checkpoint(tmp_path):
+    import cases
+    from test_host_export import _globals_named
+    _, bnn, mcmc = cases.option_chain(bn, cases.EXPORT_CASE)
+    logger = bn.postLogger(bnn, filename="GPU", wdir=str(tmp_path), export="upstream")
+    quiet(bn.run_mcmc, bnn, mcmc, logger)
+    assert not [n for n in _globals_named(logger._pklfile) if n[0].startswith("npbnn_amd")]
+    b2, m2, l2 = bn.load_obj(logger._pklfile)
+    for wa, wb in zip(bnn._w_layers, b2._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    assert m2._logLik == mcmc._logLik and m2._accuracy == mcmc._accuracy and len(l2._post_weight_samples) == 6
+    np.testing.assert_array_equal(np.asarray(m2._y), np.asarray(mcmc._y))
+    m2.run_steps(b2, 30)
+    mcmc.run_steps(bnn, 30)
+    assert m2._last_accepted_mem == mcmc._last_accepted_mem and m2._logLik == mcmc._logLik

@@ -560,3 +560,40 @@ def test_thin_second_round_runs_on_fewer_waves_and_is_the_same_chain(monkeypatch
     assert np.array_equal(a[3], b[3])                     # the same weights, bit for bit
     assert abs(a[1] - b[1]) <= 1e-9 * abs(b[1]) and abs(a[0] - b[0]) <= 1e-9 * abs(b[0])
     assert a[2] == b[2]
+
+
+def test_config5_as_benched_block_build_relu_full_size():
+    """BASELINE.json config 5 exactly as bench.py builds it (bench_support.Config5: 50k x 512, create_mask / apply_mask -> the
+    block-structured layer-0 build through npbnn_set_layer_mask, ReLU, bias on the last layer only, one Gaussian target with an
+    empirical sigma): the initial evaluation and a moved state against the float64 oracle at full size, and 300 iterations of
+    the device-resident chain against the mh_step loop from the same start."""
+    import oracle as orc
+    from bench_support import Config5
+    wl = Config5()
+    bnn, mcmc = wl.build()
+    assert mcmc._backend.ctx.info(bn._capi.INFO_FAST_TAILS) == 1
+    x64 = wl.x.astype(np.float32).astype(np.float64)
+
+    def oracle_loglik(weights):
+        pred = orc.forward(x64, [np.array(w, dtype=np.float64) for w in weights], orc.Act("ReLU"), orc.out_identity)
+        return orc.closed_gaussian_empirical(pred, wl.y)[0]
+
+    # (MCMC.__init__ evaluates with sigma = 1, BNN_env.py:313-319; the chain's proposals with the empirical one)
+    pred0 = orc.forward(x64, bnn._w_layers, orc.Act("ReLU"), orc.out_identity)
+    want0 = orc.lik_gaussian(pred0, wl.y, sig2=np.ones(1))
+    assert abs(mcmc._logLik - want0) / abs(want0) < 2e-6
+    bnn_h, mcmc_h = wl.build()
+    for _ in range(300):
+        mcmc_h.mh_step(bnn_h)
+    mcmc.run_steps(bnn, 100)
+    mcmc.run_steps(bnn, 200)
+    assert mcmc._device_iterations == 300 and mcmc._device_schedule_used in (1, 2, 4, 5)
+    assert mcmc._last_accepted_mem == mcmc_h._last_accepted_mem
+    assert sum(mcmc._last_accepted_mem) > 3
+    for wa, wb, mk in zip(bnn._w_layers, bnn_h._w_layers, bnn._mask):
+        np.testing.assert_array_equal(wa, wb)
+        assert np.all(wa[mk == 0] == 0)
+    np.testing.assert_allclose(mcmc._logLik, mcmc_h._logLik, rtol=1e-12)
+    want = oracle_loglik(bnn._w_layers)
+    assert abs(mcmc._logLik - want) / abs(want) < 2e-6
+    mcmc._backend.close()

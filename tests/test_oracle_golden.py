@@ -270,6 +270,8 @@ def _build_oracle_option_chain(name):
         rs = np.random.default_rng(cfg["seed"] + 2000)
         drawn = [rs.uniform(-0.5, 1.0, sh) for sh in cases.layer_shapes(cfg["n_features"], cfg["n_nodes"], cfg["n_classes"], cfg["bias"])]
         kw["init_w"] = [w / w.sum() for w in drawn]
+    for key in ("sampling_f", "print_f"):           # (driver cadence: nothing the chain itself reads)
+        m.pop(key, None)
     for key in ("likelihood_f", "accuracy_f"):
         if key in m:
             kw[key] = _ORACLE_NAMES[m.pop(key)]

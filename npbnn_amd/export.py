@@ -208,4 +208,9 @@ def loads_as_this_package(data):
     for o in group:
         if isinstance(o, MCMC) and o.__dict__.get("_bnn") is None and len(models) == 1:
             o._bnn = models[0]            # (upstream's sampler holds no model; here its on-demand statistics are the model's)
+        if isinstance(o, MCMC) and len(models) == 1 and models[0]._act_fun._trainable and "_slope_term_in_prior" not in o.__dict__:
+            # upstream's _logPrior carries the prior of trainable slopes from the first accepted proposal on, and not before
+            # (np_bnn/BNN_env.py:320 against :419); the device chain is told which - read it off the number itself
+            bare = models[0].calc_prior()
+            o._slope_term_in_prior = bool(abs(o._logPrior - bare) > 1e-9 * max(1.0, abs(bare)))
     return obj

@@ -370,6 +370,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
     int n_cand = (max_inner_tiles(ctx->net) == 1 && (predict_only || !lik_needs_row_scratch(ctx->net.lik_kind))) ? want_cand : 1;
     if (n_cand > kMaxCand) n_cand = kMaxCand;
+    if (n_cand > max_cand_for(ctx->net.L[0].mt)) n_cand = max_cand_for(ctx->net.L[0].mt);
     const WaveLayout lay = layout_for(ctx, d, predict_only);
     const bool fast = lik_only && !predict_only && fast_launch_ok(ctx, d);
     while (n_cand > 1 && pick_waves_per_block(ctx, &lds, n_cand, lay, predict_only, fast) < 8) --n_cand;
@@ -969,6 +970,18 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (what == NPBNN_INFO_N_CU) { *out = ctx->n_cu; return NPBNN_OK; }
     if (what == NPBNN_INFO_TURN_NS_OVERLAPPED || what == NPBNN_INFO_TURN_NS_BETWEEN) {
         *out = (int)(1000.0 * ctx->turn_us[what == NPBNN_INFO_TURN_NS_BETWEEN ? 1 : 0]);
+        return NPBNN_OK;
+    }
+    if (what == NPBNN_INFO_MAX_CANDIDATES) {        // what plan_launch would give a chain pass that asks for as many as fit
+        *out = 1;
+        if (!ctx->arch_set || !ctx->ds[0].X) return NPBNN_OK;
+        int n = (max_inner_tiles(ctx->net) == 1 && !lik_needs_row_scratch(ctx->net.lik_kind)) ? kMaxCand : 1;
+        if (n > max_cand_for(ctx->net.L[0].mt)) n = max_cand_for(ctx->net.L[0].mt);
+        const WaveLayout lay = layout_for(ctx, ctx->ds[0], false);
+        const bool fast = fast_launch_ok(ctx, ctx->ds[0]);
+        size_t lds = 0;
+        while (n > 1 && pick_waves_per_block(ctx, &lds, n, lay, false, fast) < 8) --n;
+        *out = n;
         return NPBNN_OK;
     }
     if (what == NPBNN_INFO_FAST_TAILS) { *out = (ctx->arch_set && fast_launch_ok(ctx, ctx->ds[0])) ? 1 : 0; return NPBNN_OK; }

@@ -418,8 +418,12 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 // software-pipelined layer 0 (the fragments of K-step s+1 are read from LDS while the MFMAs of step s run): builds whose two
 // fragment sets fit the register budget of their launch bounds
 __host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int d) {
-    return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && mt0 <= 1) || (d == 1 && mt0 <= 3));
+    return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && mt0 <= 1) || (d == 1 && mt0 <= 2));
 }
+// candidates per pass a layer-0 width is built for: three sets of accumulators and tails side by side spill INSIDE the tile loop from
+// three output tiles on (tools/check_hot_loop_spills.sh; measured on 100k x 64, hidden [50, 5]: 30.3 us for three candidates
+// against 18.1 us for two, chain 65-81 k against 91 k it/s) - plan_launch asks for no more, and no such build is instantiated
+__host__ __device__ constexpr int max_cand_for(int mt0) { return mt0 <= 2 ? 3 : 2; }
 // waves per workgroup a build is compiled for: more candidates keep more accumulators and weight fragments alive.  The
 // three-candidate categorical build of the narrow networks (the chain kernel of config 2) fits 128 VGPRs, i.e. 13 waves:
 // with 24-25 tiles per workgroup that is two rounds of tiles per wave instead of three for some.

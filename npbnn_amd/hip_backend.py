@@ -178,7 +178,10 @@ class HipBackend:
         return chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=comm,
                                    launch_slack=launch_slack, want_cold_w=want_cold_w)
 
-    group_size = 3           # chains a group pass evaluates together (candidate slots of the evaluation kernel)
+    @property
+    def group_size(self):
+        """Chains a group pass evaluates together: the candidate slots one launch of the evaluation kernel has for this network."""
+        return max(1, self.ctx.info(capi.INFO_MAX_CANDIDATES))
 
     @staticmethod
     def run_batched(jobs, K):

@@ -453,6 +453,43 @@ class HipContext:
         return w, ind, find, acc, llp, lpp, self._result_dict(res)
 
 
+class FastBatch:
+    """A dispatch of the patch-list device chain whose settings are fixed: the settings struct filled once, the result struct, the
+    accept flags and the packed mask kept, the C entry bound once - :meth:`run` only puts in the chain's state and the addresses of
+    this batch's draws.  (What ``HipContext.chain_run`` does per call, minus everything that does not change between calls.)"""
+
+    def __init__(self, ctx, K, M, mask, cfg_kwargs):
+        self.ctx = ctx
+        self.K, self.M = int(K), int(M)
+        self.cfg = capi.ChainCfg()
+        ctx._fill_chain_cfg(self.cfg, **cfg_kwargs)
+        self.cfg_ref = C.byref(self.cfg)
+        self.res = capi.ChainResult()
+        self.res_ref = C.byref(self.res)
+        self.acc = np.empty(self.K, dtype=np.uint8)
+        self.acc_addr = _addr(self.acc)
+        self.mask = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
+        self.mask_addr = None if self.mask is None else _addr(self.mask)
+        self.n_targets = ctx.arch.n_targets
+        self.entry = capi.chain_run_by_address(ctx._lib)
+
+    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, cur_sigma=None):
+        """0 and the results in ``self.res`` / ``self.acc`` / ``w`` - or the C ABI's error code with the state untouched (a weight
+        left the fp16 range, a device-side wait timed out ...: the caller repeats the batch through ``chain_run``, which knows the
+        remedies)."""
+        cfg = self.cfg
+        cfg.cur_loglik, cfg.cur_logprior = cur_loglik, cur_logprior
+        if cur_sigma is not None:
+            for j in range(self.n_targets):
+                cfg.cur_sigma[j] = cur_sigma[j]
+        ctx = self.ctx
+        t_in = _now()
+        rc = self.entry(ctx._ctx, self.cfg_ref, _addr(w), self.mask_addr, self.K, self.M, _addr(idx), _addr(delta), _addr(cnt), _addr(log_u),
+                        self.acc_addr, None, None, self.res_ref)
+        ctx.seconds_in_chain_run += _now() - t_in
+        return rc
+
+
 def chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_logu, comm=None, launch_slack=1.25,
                         want_cold_w=True):
     """Several chains advance ``n_seg`` swap intervals of ``seg_len`` iterations with the temperature swaps done on the GPU

@@ -15,6 +15,7 @@ reference draws for the same seed).  What changed is where the arithmetic happen
 import _thread
 import functools
 import operator
+import os
 import queue
 import threading
 
@@ -41,13 +42,14 @@ _POOL = None
 class _DrawJob:
     """A call handed to the helper thread and, later, its outcome (``result()`` waits for it).  What a dispatch needs of a
     concurrent.futures.Future, at a tenth of its cost per use."""
-    __slots__ = ("fn", "done", "value", "error")
+    __slots__ = ("fn", "done", "value", "error", "saved")
 
     def __init__(self, fn):
         self.fn = fn
         self.done = _thread.allocate_lock()
         self.done.acquire()
         self.value = self.error = None
+        self.saved = None         # state of the chain's generator before the draw, when the draw can be taken back (the job fills it in)
 
     def run(self):
         try:
@@ -83,6 +85,9 @@ class _DrawThread:
         job = _DrawJob(functools.partial(fn, *args) if args else fn)
         self._jobs.put(job)
         return job
+
+    def enqueue(self, job):
+        self._jobs.put(job)
 
 
 def _draw_pool():
@@ -120,6 +125,141 @@ def get_backend(bnn_obj, likelihood_f):
         be._lik_f = likelihood_f
         bnn_obj.__dict__["_npbnn_backend"] = be
     return be
+
+
+class _FastDispatch:
+    """A repeat of the dispatch before it: ``run_steps(bnn, k)`` on the patch-list device chain, called again with the same
+    ``k`` while nothing the dispatch depends on has changed - the call pattern of MC3's workers and of ``run_mcmc`` between two
+    samples.  Everything such a dispatch derives from the sampler's settings (which device chain, batch cuts, the pre-draw plan,
+    the C ABI's settings struct, buffers) is kept here; a dispatch then costs one comparison of what the settings are now with
+    what they were, the wait for the draws made ahead, the request for the next ones, the C call, and the book-keeping of its
+    outcome.  Any difference - another ``k``, an attribute set from outside, new step-size or weight arrays, an adaptation
+    boundary ahead, an error code from the library - sends the call down :meth:`MCMC.run_steps`'s general path, which builds a
+    new one when it applies.  The general path and this one leave the sampler in the same state, draws made ahead included."""
+    __slots__ = ("k", "objects", "scalars", "n_bytes", "freq_bytes", "scale_bytes", "ws_src", "ws_copies", "plan", "key_tail", "batch",
+                 "layers", "regression", "n_out", "adapt_possible", "empty", "empty_group")
+
+    @staticmethod
+    def _objects(mcmc, bnn):
+        return (bnn, mcmc._backend, bnn._mask, bnn._act_fun, bnn._prior_scale, mcmc._update_ws, mcmc._update_n, mcmc._freq_layer_update,
+                mcmc.update_function, mcmc._likelihood_f, None if mcmc._randomize_seed else mcmc._gen)
+
+    @staticmethod
+    def _scalars(mcmc, bnn, k):
+        return (k, mcmc._temperature, mcmc._lik_temp, bnn._w_bound, mcmc.n_candidates, mcmc.device_schedule, mcmc._randomize_seed,
+                mcmc._mcmc_id, bnn._prior, mcmc._sample_from_prior, mcmc._adapt_f, mcmc._adapt_fM, mcmc._adapt_freq, mcmc._adapt_stop,
+                bnn._estimation_mode, bnn._empirical_error, bnn._freq_indicator, bnn._feature_indicators is None,
+                bnn._act_fun._trainable, mcmc._estimate_error, mcmc.SUB_BATCH)
+
+    @classmethod
+    def build(cls, mcmc, bnn, k):
+        """The fast dispatch for ``run_steps(bnn, k)`` as the sampler stands, or None where the general path must stay: anything
+        but plain batches of the patch-list chain (trainable slopes, an estimated sigma, indicators, rows split over ranks), a
+        call longer than one sub-batch, a backend without the C ABI underneath (the CPU test stand-ins)."""
+        be = mcmc._backend
+        ctx = getattr(be, "ctx", None)
+        cache = mcmc._ws_copies
+        if ctx is None or cache is None or not 1 <= k <= mcmc.SUB_BATCH or getattr(be, "row_sharded", False):
+            return None
+        regression = bnn._estimation_mode == "regression"
+        if bnn._act_fun._trainable or (regression and not bnn._empirical_error) or mcmc._device_mode(bnn, k) != "patch":
+            return None
+        if type(bnn._prior_scale) is not np.ndarray or bnn._prior_scale.ndim != 1:
+            return None
+        from .backend import FastBatch
+        self = cls()
+        self.k = k
+        self.objects = cls._objects(mcmc, bnn)
+        self.scalars = cls._scalars(mcmc, bnn, k)
+        if type(mcmc._update_n) is not np.ndarray or type(mcmc._freq_layer_update) is not np.ndarray:
+            return None
+        self.n_bytes = mcmc._update_n.tobytes()
+        self.freq_bytes = mcmc._freq_layer_update.tobytes()
+        self.scale_bytes = bnn._prior_scale.tobytes()
+        self.ws_src, self.ws_copies, self.plan = cache[0], cache[1], cache[2]
+        if len(self.ws_src) != len(mcmc._update_ws) or not all(map(_is, self.ws_src, mcmc._update_ws)):
+            return None
+        self.key_tail = mcmc._draw_key(bnn, 0, k)[2:]
+        self.regression = regression
+        self.n_out = bnn._size_output
+        self.adapt_possible = not (mcmc._adapt_f <= 0 and mcmc._adapt_fM >= 1)
+        self.empty = getattr(be, "host_empty", None)
+        self.empty_group = getattr(be, "host_empty_group", None)
+        be._configure(bnn._w_layers)
+        self.batch = FastBatch(ctx, k, self.plan.M, bnn._mask, mcmc._device_chain_cfg(bnn))
+        self.layers = bnn._w_layers
+        return self
+
+    def matches(self, mcmc, bnn, k):
+        if k != self.k or bnn._w_layers is not self.layers:
+            return False
+        for now, then in zip(self._objects(mcmc, bnn), self.objects):
+            if now is not then:
+                return False
+        if self._scalars(mcmc, bnn, k) != self.scalars:
+            return False
+        # arrays that may be edited in place
+        if (mcmc._update_n.tobytes() != self.n_bytes or mcmc._freq_layer_update.tobytes() != self.freq_bytes
+                or bnn._prior_scale.tobytes() != self.scale_bytes):
+            return False
+        live = mcmc._update_ws
+        for src, copy, now in zip(self.ws_src, self.ws_copies, live):
+            if now is not src or not _same_ends(copy, now):
+                return False
+        if self.adapt_possible:
+            boundary = mcmc._next_adapt_boundary()
+            if mcmc._current_iteration % mcmc._adapt_freq == 0 or (boundary is not None and boundary < mcmc._current_iteration + k):
+                return False
+        return True
+
+    def _draw_ahead(self, mcmc, first_it):
+        """Start the pre-draw of iterations first_it .. first_it + k - 1 (what MCMC._submit_draw does, from the kept plan)."""
+        rs, randomize, mcmc_id, k, plan = mcmc._gen, mcmc._randomize_seed, mcmc._mcmc_id, self.k, self.plan
+        empty, empty_group = self.empty, self.empty_group
+        keep_state = not randomize
+
+        def draw():
+            if keep_state:
+                job.saved = rs.bit_generator.state
+            out = plan.run(rs, randomize, first_it, mcmc_id, k, empty=empty, empty_group=empty_group)
+            np.log(out[3], out=out[3])
+            return out[0], out[1], out[2], out[3], None, None
+
+        job = _DrawJob(draw)
+        _draw_pool().enqueue(job)
+        return (first_it, k) + self.key_tail, job, keep_state, self.ws_src, self
+
+    def run(self, mcmc, bnn):
+        """One dispatch.  False: nothing was done (the library returned an error code with the chain untouched) - the caller goes
+        the general way."""
+        k = self.k
+        it = mcmc._current_iteration
+        spec = mcmc._speculation
+        if spec is not None and len(spec) == 5 and spec[4] is self and spec[0][0] == it:
+            mcmc._speculation = None
+            job = spec[1]
+        else:
+            job = mcmc._claim_draw(bnn, it, k)
+        idx, delta, cnt, log_u = job.result()[:4]
+        mcmc._speculation = self._draw_ahead(mcmc, it + k)
+        from .backend import pack_weights
+        w = pack_weights(bnn._w_layers)
+        batch = self.batch
+        cur_sigma = (np.ones(self.n_out) * bnn._error_prm) if self.regression else None
+        rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, cur_sigma)
+        if rc != 0:
+            # (the draws of this batch are still good: hand them to the general path as the draws "made ahead")
+            mcmc._cancel_speculation()
+            done = _DrawJob(None)
+            done.value = (idx, delta, cnt, log_u, None, None)
+            done.done.release()
+            mcmc._speculation = ((it, k) + self.key_tail, done, False, self.ws_src)
+            return False
+        res = batch.res
+        sigma = np.array(res.sigma[:self.n_out]) if self.regression else None
+        mcmc._absorb(bnn, k, w, batch.acc, int(res.n_accepted), res.n_passes, res.n_void_passes, res.schedule, res.loglik, res.logprior, sigma)
+        self.layers = bnn._w_layers
+        return True
 
 
 class _Candidate:
@@ -351,6 +491,7 @@ class MCMC():
         state.pop("_light_pickle", None)
         state["_speculation"] = None
         state["_ws_copies"] = None       # (holds the pre-draw plan: pointers into this process)
+        state.pop("_fast", None)         # (ctypes structs and addresses of this process)
         if light:       # a checkpoint view (postLogger): no prediction matrices, no model reference beside the pickled one
             state["_lazy"] = {k: v for k, v in self._lazy.items() if k not in ("_y", "_y_test")}
         return state
@@ -361,6 +502,7 @@ class MCMC():
         view = self.__class__.__new__(self.__class__)
         view.__dict__.update(self.__dict__)
         view._speculation = None
+        view._fast = None
         view._bnn = bnn_view
         view._light_pickle = True
         return view
@@ -385,7 +527,7 @@ class MCMC():
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k == "_ws_copies":        # (the pre-draw plan holds pointers into its own step-size copies: the copy builds its own)
+            if k in ("_ws_copies", "_fast"):    # (the pre-draw plan holds pointers into its own step-size copies: the copy builds its own)
                 new.__dict__[k] = None
             else:
                 new.__dict__[k] = v if k == "_backend" else copy.deepcopy(v, memo)
@@ -651,6 +793,12 @@ class MCMC():
         if self._backend is None:
             self._backend = get_backend(bnn_obj, self._likelihood_f)
         remaining = int(n_steps)
+        fast = self._fast
+        if fast is not None:
+            if fast.matches(self, bnn_obj, remaining) and fast.run(self, bnn_obj):
+                return
+            self._fast = None
+            self._fast_hold = 16        # (what made it fail may last: a few dispatches the general way before another is built)
         while remaining > 0:
             seg = remaining                       # iterations over which the proposal settings stay constant
             boundary = self._next_adapt_boundary()
@@ -684,8 +832,20 @@ class MCMC():
                     self._speculation = self._submit_draw(bnn_obj, it, min(self.SUB_BATCH, int(n_steps)), rewindable=True)
                 self._run_device_batch(bnn_obj, idx, delta, cnt, log_u, smult, hast, slope_draws)
             remaining -= seg
+        # the same call twice in a row on the patch-list chain: the next one of this kind takes the short way (_FastDispatch)
+        k = int(n_steps)
+        if self._fast_hold > 0:
+            self._fast_hold -= 1
+        elif k == self._last_call and self._fast is None and not os.environ.get("NPBNN_NO_FAST_DISPATCH"):
+            self._fast = _FastDispatch.build(self, bnn_obj, k)
+            if self._fast is None:
+                self._fast_hold = 64
+        self._last_call = k
 
-    _speculation = None      # (key, future, generator state before the draw, step-size arrays used) of draws made ahead of the next call
+    _fast = None             # the kept form of the last dispatch (_FastDispatch), when calls repeat
+    _fast_hold = 0
+    _last_call = 0
+    _speculation = None      # (key, job, may the draw be taken back?, step-size arrays used[, the fast dispatch that made it]) of draws made ahead
     _ws_copies = None        # (step-size arrays, private copies of them, the pre-draw plan built on the copies, the settings it holds)
 
     def _draw_key(self, bnn_obj, first_it, k):
@@ -719,10 +879,12 @@ class MCMC():
         be = self._backend
         empty = getattr(be, "host_empty", None)
         empty_group = getattr(be, "host_empty_group", None)
-        saved = rs.bit_generator.state if (rewindable and not randomize) else None
+        keep_state = rewindable and not randomize
         sigma_k, n_slopes = key[7], key[8]
 
         def draw():
+            if keep_state:        # (here, on the helper thread, rather than in the caller: reading the state builds a nested dictionary)
+                job.saved = rs.bit_generator.state
             out = plan.run(rs, randomize, first_it, mcmc_id, k, empty=empty, sigma_k=sigma_k, n_slopes=n_slopes, slope_d=0.05,
                            empty_group=empty_group)
             idx, delta, cnt, u = out[:4]
@@ -737,7 +899,9 @@ class MCMC():
                 return idx, delta, cnt, u, smult, hast, out[-2], out[-1]
             return idx, delta, cnt, u, smult, hast
 
-        return key, _draw_pool().submit(draw), saved, src
+        job = _DrawJob(draw)
+        _draw_pool().enqueue(job)
+        return key, job, keep_state, src
 
     def _claim_draw(self, bnn_obj, first_it, k):
         """The draws for iterations first_it .. first_it+k-1: the ones made ahead by the previous call when they
@@ -759,8 +923,8 @@ class MCMC():
         try:
             spec[1].result()
         finally:
-            if spec[2] is not None:
-                self._gen.bit_generator.state = spec[2]
+            if spec[2] and spec[1].saved is not None:
+                self._gen.bit_generator.state = spec[1].saved
 
     @property
     def _rs(self):
@@ -841,13 +1005,17 @@ class MCMC():
         """Book-keeping of k device-resident iterations: what k calls of mh_step would have left behind."""
         if k <= 0:
             return
+        self._absorb(bnn_obj, k, w_new, acc, int(res.get("n_accepted", 0)), res.get("n_passes", k), res.get("n_void_passes", 0),
+                     res.get("schedule", 0), res["loglik"], res["logprior"], res.get("sigma"))
+
+    def _absorb(self, bnn_obj, k, w_new, acc, n_accepted, n_passes, n_void, schedule, loglik, logprior, sigma):
         acc = acc[:k]
-        self._device_schedule_used = res.get("schedule", 0)
-        self._device_accepted += int(res.get("n_accepted", 0))
-        self._device_passes += res.get("n_passes", k)
-        self._device_void_passes += res.get("n_void_passes", 0)
+        self._device_schedule_used = schedule
+        self._device_accepted += n_accepted
+        self._device_passes += n_passes
+        self._device_void_passes += n_void
         self._device_iterations += k
-        if res["n_accepted"] > 0:
+        if n_accepted > 0:
             layers, off = [], 0
             for w in bnn_obj._w_layers:
                 layers.append(w_new[off:off + w.size].reshape(w.shape))
@@ -855,10 +1023,10 @@ class MCMC():
             if off == w_new.size and w_new.dtype == np.float64:
                 note_packed_views(layers, w_new)
             bnn_obj.reset_weights(layers)
-            self._logLik, self._logPrior = res["loglik"], res["logprior"]
+            self._logLik, self._logPrior = loglik, logprior
             self._logPost = self._logLik + self._logPrior
             if bnn_obj._estimation_mode == "regression":
-                bnn_obj.reset_error_prm(res["sigma"])
+                bnn_obj.reset_error_prm(sigma)
             self._accepted_override = None
             self._invalidate()
         history = self._last_accepted_mem + acc.tolist()

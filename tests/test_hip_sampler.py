@@ -593,3 +593,79 @@ def test_config5_as_benched_block_build_relu_full_size():
     par = wl.parity(bnn, mcmc)            # the moved state against the oracle at full size (what bench.py's parity leg reads)
     assert par["chain_loglik_rel_err"] < 2e-6 and par["loglik_rel_err"] < 2e-6 and par["prediction_max_abs_err"] < 2e-5
     mcmc._backend.close()
+
+
+# ---- repeated dispatches of one size: the kept form of a dispatch (sampler._FastDispatch) ------------------------------
+@pytest.mark.parametrize("name", ["cfg1", "cfg4s"])
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_repeated_dispatches_take_the_short_way_and_are_the_mh_step_loop(name, randomize_seed):
+    cfg = cases.TRACES[name]
+    bnn_a, mcmc_a = build(cfg, randomize_seed=randomize_seed, mcmc_id=3)
+    bnn_b, mcmc_b = build(cfg, randomize_seed=randomize_seed, mcmc_id=3)
+    n_calls, k = 9, 60
+    for _ in range(n_calls * k):
+        mcmc_a.mh_step(bnn_a)
+    short = 0
+    for _ in range(n_calls):
+        kept = mcmc_b._fast
+        mcmc_b.run_steps(bnn_b, k)
+        short += kept is not None and mcmc_b._fast is kept
+    assert short >= n_calls - 3, "only %d of %d dispatches took the short way" % (short, n_calls)
+    assert mcmc_b._current_iteration == mcmc_a._current_iteration == n_calls * k
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem and mcmc_a._acceptance_rate == mcmc_b._acceptance_rate
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    if cfg["kind"] == "regression":
+        np.testing.assert_allclose(bnn_a._error_prm, bnn_b._error_prm, rtol=1e-12)
+    if not randomize_seed:
+        assert mcmc_a._rs.random() == mcmc_b._rs.random()
+
+
+def test_the_short_way_notices_what_changes_between_dispatches():
+    """Between dispatches of one size: a new temperature, step sizes edited in place, weights put back by hand, the generator
+    read (draws made ahead are taken back), a pickle round trip of the sampler, another batch size - the chain stays the
+    mh_step loop's through all of it."""
+    import pickle
+    cfg = cases.TRACES["cfg1"]
+    bnn_a, mcmc_a = build(cfg)
+    bnn_b, mcmc_b = build(cfg)
+    k = 50
+
+    def both(f):
+        f(bnn_a, mcmc_a)
+        f(bnn_b, mcmc_b)
+
+    def advance(n_calls):
+        for _ in range(n_calls * k):
+            mcmc_a.mh_step(bnn_a)
+        for _ in range(n_calls):
+            mcmc_b.run_steps(bnn_b, k)
+        assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem, "diverged by iteration %d" % mcmc_b._current_iteration
+        for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+            np.testing.assert_array_equal(wa, wb)
+        np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+
+    advance(4)
+    assert mcmc_b._fast is not None
+    both(lambda b, m: m.reset_temperature(0.7))
+    advance(3)
+    both(lambda b, m: m._update_ws[0].__imul__(0.5))                  # in place: the arrays stay the same objects
+    advance(3)
+    both(lambda b, m: b.reset_weights([w * 0.9 for w in b._w_layers]) or m.__setattr__("_logLik", m._logLik))
+    # (weights changed behind the sampler's back: its log-likelihood is stale in both chains alike, which is all this needs)
+    advance(3)
+    both(lambda b, m: m._rs.random())                                 # consumes a number from the chain's stream
+    advance(3)
+    mcmc_b2 = pickle.loads(pickle.dumps(mcmc_b))
+    assert mcmc_b2._fast is None
+    mcmc_b2._bnn = bnn_b
+    mcmc_b = mcmc_b2
+    advance(3)
+    for _ in range(77):
+        mcmc_a.mh_step(bnn_a)
+    mcmc_b.run_steps(bnn_b, 77)
+    advance(3)
+    assert mcmc_b._fast is not None
+    assert mcmc_a._rs.random() == mcmc_b._rs.random()

@@ -473,19 +473,24 @@ class FastBatch:
         self.n_targets = ctx.arch.n_targets
         self.entry = capi.chain_run_by_address(ctx._lib)
 
-    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, cur_sigma=None):
+    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, cur_sigma=None, just_before=None):
         """0 and the results in ``self.res`` / ``self.acc`` / ``w`` - or the C ABI's error code with the state untouched (a weight
         left the fp16 range, a device-side wait timed out ...: the caller repeats the batch through ``chain_run``, which knows the
-        remedies)."""
+        remedies).  ``just_before()`` is called as the last thing before the C entry: work for another thread is handed over there,
+        so that the other thread finds the interpreter lock free (the C call releases it) instead of taking it from this one in
+        the middle of its preparations (measured: copies of the weight vector that took 300 us instead of 4)."""
         cfg = self.cfg
         cfg.cur_loglik, cfg.cur_logprior = cur_loglik, cur_logprior
         if cur_sigma is not None:
             for j in range(self.n_targets):
                 cfg.cur_sigma[j] = cur_sigma[j]
         ctx = self.ctx
+        a_w, a_idx, a_delta, a_cnt, a_u = _addr(w), _addr(idx), _addr(delta), _addr(cnt), _addr(log_u)
+        if just_before is not None:
+            just_before()
         t_in = _now()
-        rc = self.entry(ctx._ctx, self.cfg_ref, _addr(w), self.mask_addr, self.K, self.M, _addr(idx), _addr(delta), _addr(cnt), _addr(log_u),
-                        self.acc_addr, None, None, self.res_ref)
+        rc = self.entry(ctx._ctx, self.cfg_ref, a_w, self.mask_addr, self.K, self.M, a_idx, a_delta, a_cnt, a_u, self.acc_addr, None, None,
+                        self.res_ref)
         ctx.seconds_in_chain_run += _now() - t_in
         return rc
 

@@ -22,7 +22,7 @@ import threading
 import numpy as np
 
 from . import _capi as capi
-from .backend import note_packed_views
+from .backend import note_packed_views, pack_weights
 from .likelihoods import (CalcAccuracy, CalcAccuracyRegression, CalcLabelAccuracy,
                           CalcLabelAccuracyRegression, SkipAccuracy, SkipAccuracyVec, calc_likelihood,
                           calc_likelihood_regression, calc_likelihood_regression_error, likelihood_kind,
@@ -42,13 +42,14 @@ _POOL = None
 class _DrawJob:
     """A call handed to the helper thread and, later, its outcome (``result()`` waits for it).  What a dispatch needs of a
     concurrent.futures.Future, at a tenth of its cost per use."""
-    __slots__ = ("fn", "done", "value", "error", "saved")
+    __slots__ = ("fn", "done", "value", "error", "saved", "queued")
 
     def __init__(self, fn):
         self.fn = fn
         self.done = _thread.allocate_lock()
         self.done.acquire()
         self.value = self.error = None
+        self.queued = False       # handed to the helper thread (a job nobody queued never completes: do not wait for it)
         self.saved = None         # state of the chain's generator before the draw, when the draw can be taken back (the job fills it in)
 
     def run(self):
@@ -83,10 +84,12 @@ class _DrawThread:
 
     def submit(self, fn, *args):
         job = _DrawJob(functools.partial(fn, *args) if args else fn)
+        job.queued = True
         self._jobs.put(job)
         return job
 
     def enqueue(self, job):
+        job.queued = True
         self._jobs.put(job)
 
 
@@ -125,6 +128,10 @@ def get_backend(bnn_obj, likelihood_f):
         be._lik_f = likelihood_f
         bnn_obj.__dict__["_npbnn_backend"] = be
     return be
+
+
+def _enqueue_draw(job):
+    _draw_pool().enqueue(job)
 
 
 class _FastDispatch:
@@ -226,7 +233,6 @@ class _FastDispatch:
             return out[0], out[1], out[2], out[3], None, None
 
         job = _DrawJob(draw)
-        _draw_pool().enqueue(job)
         return (first_it, k) + self.key_tail, job, keep_state, self.ws_src, self
 
     def run(self, mcmc, bnn):
@@ -241,12 +247,16 @@ class _FastDispatch:
         else:
             job = mcmc._claim_draw(bnn, it, k)
         idx, delta, cnt, log_u = job.result()[:4]
-        mcmc._speculation = self._draw_ahead(mcmc, it + k)
-        from .backend import pack_weights
         w = pack_weights(bnn._w_layers)
         batch = self.batch
         cur_sigma = (np.ones(self.n_out) * bnn._error_prm) if self.regression else None
-        rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, cur_sigma)
+        # the next call's draws are handed to the helper thread at the very last moment before the C call (FastBatch.run)
+        ahead = self._draw_ahead(mcmc, it + k)
+        try:
+            rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, cur_sigma, functools.partial(_enqueue_draw, ahead[1]))
+        finally:
+            if ahead[1].queued:
+                mcmc._speculation = ahead
         if rc != 0:
             # (the draws of this batch are still good: hand them to the general path as the draws "made ahead")
             mcmc._cancel_speculation()

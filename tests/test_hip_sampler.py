@@ -653,8 +653,12 @@ def test_the_short_way_notices_what_changes_between_dispatches():
     advance(3)
     both(lambda b, m: m._update_ws[0].__imul__(0.5))                  # in place: the arrays stay the same objects
     advance(3)
-    both(lambda b, m: b.reset_weights([w * 0.9 for w in b._w_layers]) or m.__setattr__("_logLik", m._logLik))
-    # (weights changed behind the sampler's back: its log-likelihood is stale in both chains alike, which is all this needs)
+    def shrink(b, m):      # weights changed behind the sampler's back; its prior brought up to date (the device chain re-sums it
+        b.reset_weights([w * 0.9 for w in b._w_layers])        # at the start of every batch), its log-likelihood stale in both alike
+        m._logPrior = b.calc_prior()
+        m._logPost = m._logLik + m._logPrior
+
+    both(shrink)
     advance(3)
     both(lambda b, m: m._rs.random())                                 # consumes a number from the chain's stream
     advance(3)

@@ -16,7 +16,7 @@ N GPUs  ``--gpus N``: N chains, one per GPU, MC3 layout (config 3; weak scaling)
         RCCL.  Launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) - or by this script
         itself: without WORLD_SIZE it starts the N rank processes before anything touches a GPU and relays rank 0's line.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--only] [--no-cpu-baseline]
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5|0] [--only] [--no-cpu-baseline]
 """
 import argparse
 import csv
@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5, 0), help="BASELINE.json config; 0 = config 2's data under the reference's default network [50,5]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", action="store_true", help="the named config alone: without the other single-GPU configurations that the "
                                                          "default run (config 2) adds under other_configs")
@@ -524,11 +524,12 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
         if args.config == 2 and not args.only:          # the other single-GPU configurations of BASELINE.json, in the same run
             mcmc._backend.close()
             line["other_configs"] = {}
-            for cfg in (4, 5):
+            for cfg in (4, 5, 0):         # (0: config 2's data under the reference's default network, hidden [50, 5])
+                name = "config %d" % cfg if cfg else "default network"
                 try:
-                    line["other_configs"]["config %d" % cfg] = other_config(args, cfg)
+                    line["other_configs"][name] = other_config(args, cfg)
                 except Exception as e:        # noqa: BLE001 - the headline must not be lost to a side measurement
-                    line["other_configs"]["config %d" % cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    line["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
     else:
         line["cpu_baseline"] = None
     return line

@@ -163,8 +163,41 @@ class Config5(_Regression):
                               mode="regression", init_w=w, mask=orc.block_mask(w, idx, per))
 
 
+class DefaultNetwork(Config2):
+    """Config 2's data under the reference's DEFAULT model: npBNN(n_nodes=[50, 5]), ActFun() = ReLU, use_bias_node=1
+    (np_bnn/BNN_env.py:20-23), MCMC defaults.  Layer 0 has 50 nodes = four 16-unit output tiles (MT0 = 4): one 70-KB weight image
+    per candidate, so ONE candidate per pass fits a compute unit's LDS beside the X rings."""
+    config, mt0 = 0, 4
+    hidden = [50, 5]
+    short = "default network (100k x 256, [50,5])"
+    moving_update_f = None
+    description = "config-2 data, the reference's default network: hidden [50,5], ReLU, bias 1"
+
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, rows=None, **sampler_kw):
+        lo, hi = rows if rows is not None else (0, self.n)
+        dat = dict(data=self.x[lo:hi].astype(np.float32), labels=self.y[lo:hi], test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
+        np.random.seed(1234)
+        bnn = _quiet(bn.npBNN, dat)
+        mcmc = bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **sampler_kw)
+        return bnn, mcmc
+
+    def oracle_chain(self, orc):
+        np.random.seed(1234)
+        return orc.make_chain(self.x, self.y, self.hidden, act=orc.Act("ReLU"), use_bias_node=1, prior_kind=1, p_scale=1)
+
+    def parity(self, bnn, mcmc):
+        import oracle as orc
+        w = [np.array(v, dtype=np.float64) for v in bnn._w_layers]
+        xs = self.x.astype(np.float32).astype(np.float64)
+        pred = orc.forward(xs, w, orc.Act("ReLU"), orc.out_softmax)
+        ll = orc.lik_categorical(pred, self.y, np.arange(self.n))
+        dev = mcmc._backend.evaluate(bnn._w_layers, None)["loglik"]
+        return dict(loglik_oracle=float(ll), loglik_device=float(dev), loglik_rel_err=float(abs(dev - ll) / abs(ll)),
+                    chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)), tolerance="1e-4 relative (BASELINE.json)")
+
+
 def workload(config):
-    return {2: Config2, 4: Config4, 5: Config5}[config]()
+    return {2: Config2, 4: Config4, 5: Config5, 0: DefaultNetwork}[config]()
 
 
 def build_config2(x, y, hidden, mcmc_id=0, temperature=1.0, randomize_seed=False):

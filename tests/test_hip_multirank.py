@@ -104,6 +104,24 @@ def test_bench_two_ranks_without_torch(tmp_path):
     assert leg["schedule"] == 1 and ("ncclAllGather" in leg["gather"]) == (n_gpus() >= 2)
 
 
+def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
+    """`bench.py --gpus 4`'s exact code path with every rank on GPU 0 and the TCP communicator in place of RCCL (which refuses
+    several ranks on one device): four chains, one per rank, the swap proposal after every step, max-over-ranks timing, then the
+    row-sharded chain over the four ranks.  (Four, not eight: a GPU box admits six processes on its card; the eight-rank run is
+    the driver's, on eight GPUs.)"""
+    env = dict(os.environ, NPBNN_BENCH_DIST_BACKEND="socket")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["config"]["chains"] == 4 and line["config"]["swap_exchange_nranks"] == 4
+    assert line["scaling"] == "weak" and line["torch_imported"] is False and line["value"] > 0
+    assert "tcp" in line["config"]["swap_exchange"] and line["config"]["swap_exchange_path"].startswith("host")
+    leg = line["row_sharded_chain"]
+    assert "error" not in leg, leg
+    assert leg["ranks"] == 4 and sum(leg["rows_per_rank"]) == 1_000_000 and leg["ranks_hold_the_same_chain"]
+
+
 # ---- one chain, rows split over ranks (npbnn_set_row_shard; npbnn_amd/rowshard.py) ----
 @pytest.mark.parametrize("case", ["cls", "clsw", "reg", "regsig"])
 def test_row_sharded_chain_two_processes_on_one_gpu(case):

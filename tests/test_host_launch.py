@@ -38,6 +38,15 @@ def test_mc3_two_ranks_over_tcp_match_the_reference(tmp_path):
     assert "RANK 0 OK" in out0 and "RANK 1 OK" in outs[1]
 
 
+def test_mc3_one_chain_per_rank_over_tcp_matches_the_reference(tmp_path):
+    """The layout of an 8-GPU node in small: as many ranks as chains (the golden run has four), ONE chain per rank, every swap
+    decided from an all-gather of [logPost, temperature] over all ranks, the cold chain's row shipped to rank 0 whichever rank
+    holds it - the reference's golden swap sequence, final states and log rows on every rank."""
+    status, out0, outs = spawn_ranks(WORKER + ["mc3", str(tmp_path), "oracle", "socket", "0"], 4, capture_all=True, timeout=600)
+    assert status == 0, "\n".join(outs)
+    assert all("RANK %d OK" % r in outs[r] for r in range(4))
+
+
 def test_a_rank_that_leaves_quietly_does_not_hang_its_peer(tmp_path):
     """Rank 1 exits with status 0 in the middle of the run (the launcher sees nothing wrong): rank 0 must fail by itself - its
     next exchange finds the connection closed - instead of waiting for ever."""

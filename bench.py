@@ -361,8 +361,9 @@ def kernel_roofline(config, wl, ctx, bnn, mcmc, useful=None):
 
 def _drop_the_last_leg():
     """The objects of the leg before (a model with its 100-260 MB feature matrix, its chain) sit in reference cycles: left to the
-    cyclic collector they are torn down whenever its counters say so - seen as ONE dispatch of 82 ms among the first of the next
-    leg (config 5 behind config 4: 4 ms per step on the 20 timed ones, `tools/repro_c5.py`).  Collect between the legs instead."""
+    cyclic collector they are torn down whenever its counters say so, i.e. inside the next leg's dispatches.  Collect between the
+    legs instead.  (Round 3 blamed the collector for the one 80 ms dispatch early in config 5's leg; round 4 found the device's clock
+    change after the host-only parity check - see spin_up - but an untimely collection is no better.)"""
     gc.collect()
 
 

@@ -201,7 +201,7 @@ def workload(config):
 
 
 def build_config2(x, y, hidden, mcmc_id=0, temperature=1.0, randomize_seed=False):
-    """BASELINE.json config 2 on given arrays (tools/): np.random.seed(1234); npBNN(n_nodes=[32,8], tanh, bias nodes in
+    """BASELINE.json config 2 on given arrays (tools/time_rows_sweep.py): np.random.seed(1234); npBNN(n_nodes=[32,8], tanh, bias nodes in
     input+hidden layers, N(0,1) prior); MCMC defaults (update_f 0.05 -> update_n [411,13,4])."""
     dat = dict(data=x, labels=y, test_data=np.zeros((0, x.shape[1])), test_labels=np.zeros(0))
     np.random.seed(1234)

@@ -14,8 +14,9 @@ for c in 2 4 5 0; do      # (0: config 2's data under the reference's default ne
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c${c}_persistent -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_persistent_under_rocprof.json 2> $out/bench_c${c}_persistent.err || echo "persistent bench profile of config $c failed"
   cands="3 1"; [ $c = 0 ] && cands="1"
   for cand in $cands; do
-    # full passes only (200 launches of the pass kernel, nothing idle or void among them): the mean to hold against roofline.kernel_ms
-    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pass_c${c}_d${cand} -o k -- python3 tools/profile_eval.py --config $c --cand $cand --iters 200 > $out/pass_c${c}_d${cand}.log 2>&1 || echo "pass stats of config $c D=$cand failed"
+    # full passes only (a quarter second of spin-up, then 2000 launches of the pass kernel, nothing idle or void among them): the mean to
+    # hold against roofline.kernel_ms
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pass_c${c}_d${cand} -o k -- python3 tools/profile_eval.py --config $c --cand $cand --iters 2000 --spin 0.25 > $out/pass_c${c}_d${cand}.log 2>&1 || echo "pass stats of config $c D=$cand failed"
     for ctr in FETCH_SIZE WRITE_SIZE; do
       timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_c${c}_d${cand}_$ctr -o p -- python3 tools/profile_eval.py --config $c --cand $cand --iters 3 > $out/pmc_c${c}_d${cand}_$ctr.log 2>&1 || echo "pmc $ctr of config $c D=$cand failed"
     done

@@ -116,7 +116,7 @@ class MC3():
                 small = {name: getattr(mcmc_i, name) for name in ("_accuracy", "_test_accuracy", "_label_acc",
                                                                    "_label_freq")}
                 light = {k: v for k, v in bnn_i.__dict__.items() if k not in _SHARED and k != "_npbnn_backend"}
-                state = {k: v for k, v in mcmc_i.__dict__.items() if k not in ("_backend", "_bnn", "_lazy", "_speculation", "_ws_copies", "_fast")}
+                state = {k: v for k, v in mcmc_i.__dict__.items() if k not in ("_backend", "_bnn", "_lazy", "_speculation", "_speculation2", "_ws_copies", "_fast")}
                 state["_lazy"] = small
                 view = (light, state)
             view = self.comm.bcast_obj(view, root=owner)
@@ -156,7 +156,7 @@ class MC3():
         bnn_v._w_layers = layers
         m_v = mcmc.__class__.__new__(mcmc.__class__)
         m_v.__dict__.update(mcmc.__dict__)
-        m_v._speculation = None
+        m_v._speculation = m_v._speculation2 = None
         m_v._fast = None
         m_v._bnn = bnn_v
         m_v._lazy = {}

@@ -130,8 +130,10 @@ def get_backend(bnn_obj, likelihood_f):
     return be
 
 
-def _enqueue_draw(job):
-    _draw_pool().enqueue(job)
+def _enqueue_draws(jobs):
+    pool = _draw_pool()
+    for job in jobs:
+        pool.enqueue(job)
 
 
 class _FastDispatch:
@@ -245,18 +247,35 @@ class _FastDispatch:
             mcmc._speculation = None
             job = spec[1]
         else:
-            job = mcmc._claim_draw(bnn, it, k)
+            job = mcmc._claim_draw(bnn, it, k)       # (takes back a second batch drawn ahead, if there is one)
         idx, delta, cnt, log_u = job.result()[:4]
         w = pack_weights(bnn._w_layers)
         batch = self.batch
         cur_sigma = (np.ones(self.n_out) * bnn._error_prm) if self.regression else None
-        # the next call's draws are handed to the helper thread at the very last moment before the C call (FastBatch.run)
-        ahead = self._draw_ahead(mcmc, it + k)
+        # TWO batches are kept drawn ahead: the draws of a batch (0.6 ms of numpy's routines for 100 iterations of config 2) take
+        # several times as long once in a few hundred calls, and one batch ahead of a 1-ms dispatch then makes the dispatch wait.
+        # The batch after next moves up; what is missing is handed to the helper thread at the very last moment before the C call
+        # (FastBatch.run), in stream order.
+        second = mcmc._speculation2
+        mcmc._speculation2 = None
+        fresh = []
+        if second is not None and second[4] is self and second[0][0] == it + k:
+            ahead = second
+        else:
+            if second is not None:
+                mcmc._speculation2 = second
+                mcmc._cancel_second()
+            ahead = self._draw_ahead(mcmc, it + k)
+            fresh.append(ahead[1])
+        further = self._draw_ahead(mcmc, it + 2 * k)
+        fresh.append(further[1])
         try:
-            rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, cur_sigma, functools.partial(_enqueue_draw, ahead[1]))
+            rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, cur_sigma, functools.partial(_enqueue_draws, fresh))
         finally:
             if ahead[1].queued:
                 mcmc._speculation = ahead
+                if further[1].queued:
+                    mcmc._speculation2 = further
         if rc != 0:
             # (the draws of this batch are still good: hand them to the general path as the draws "made ahead")
             mcmc._cancel_speculation()
@@ -500,6 +519,7 @@ class MCMC():
         state.pop("_backend", None)
         state.pop("_light_pickle", None)
         state["_speculation"] = None
+        state["_speculation2"] = None
         state["_ws_copies"] = None       # (holds the pre-draw plan: pointers into this process)
         state.pop("_fast", None)         # (ctypes structs and addresses of this process)
         if light:       # a checkpoint view (postLogger): no prediction matrices, no model reference beside the pickled one
@@ -511,7 +531,7 @@ class MCMC():
         prediction matrices - after loading they are computed on demand from the weights, like every other statistic."""
         view = self.__class__.__new__(self.__class__)
         view.__dict__.update(self.__dict__)
-        view._speculation = None
+        view._speculation = view._speculation2 = None
         view._fast = None
         view._bnn = bnn_view
         view._light_pickle = True
@@ -855,6 +875,7 @@ class MCMC():
     _fast = None             # the kept form of the last dispatch (_FastDispatch), when calls repeat
     _fast_hold = 0
     _last_call = 0
+    _speculation2 = None     # the batch after that one, same form (kept by the fast dispatch only)
     _speculation = None      # (key, job, may the draw be taken back?, step-size arrays used[, the fast dispatch that made it]) of draws made ahead
     _ws_copies = None        # (step-size arrays, private copies of them, the pre-draw plan built on the copies, the settings it holds)
 
@@ -916,6 +937,7 @@ class MCMC():
     def _claim_draw(self, bnn_obj, first_it, k):
         """The draws for iterations first_it .. first_it+k-1: the ones made ahead by the previous call when they
         are exactly these, else fresh ones."""
+        self._cancel_second()        # (this path keeps one batch ahead: whatever it submits next must follow the first in the stream)
         spec = self._speculation
         if (spec is not None and spec[0] == self._draw_key(bnn_obj, first_it, k) and len(spec[3]) == len(self._update_ws)
                 and all(map(_is, spec[3], self._update_ws))                     # (the very arrays the draw was made with ...
@@ -925,8 +947,20 @@ class MCMC():
         self._cancel_speculation()
         return self._submit_draw(bnn_obj, first_it, k)[1]
 
+    def _cancel_second(self):
+        """Drop the SECOND batch drawn ahead (the fast dispatch keeps two): the generator goes back to where the first one left it."""
+        spec, self._speculation2 = self._speculation2, None
+        if spec is None:
+            return
+        try:
+            spec[1].result()
+        finally:
+            if spec[2] and spec[1].saved is not None:
+                self._gen.bit_generator.state = spec[1].saved
+
     def _cancel_speculation(self):
         """Drop draws made ahead and put the generator back where the chain left it."""
+        self._cancel_second()
         spec, self._speculation = self._speculation, None
         if spec is None:
             return

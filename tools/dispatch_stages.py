@@ -33,7 +33,19 @@ def run(self, mcmc, bnn):
     t.append(now())
     idx, delta, cnt, log_u = job.result()[:4]
     t.append(now())
-    ahead = self._draw_ahead(mcmc, it + k)
+    second = mcmc._speculation2          # (two batches are kept drawn ahead, as in the product's run)
+    mcmc._speculation2 = None
+    fresh = []
+    if second is not None and second[4] is self and second[0][0] == it + k:
+        ahead = second
+    else:
+        if second is not None:
+            mcmc._speculation2 = second
+            mcmc._cancel_second()
+        ahead = self._draw_ahead(mcmc, it + k)
+        fresh.append(ahead[1])
+    further = self._draw_ahead(mcmc, it + 2 * k)
+    fresh.append(further[1])
     t.append(now())
     w = pack_weights(bnn._w_layers)
     t.append(now())
@@ -42,8 +54,9 @@ def run(self, mcmc, bnn):
     cfg.cur_loglik, cfg.cur_logprior = mcmc._logLik, mcmc._logPrior
     from npbnn_amd.backend import _addr
     a = (_addr(w), _addr(idx), _addr(delta), _addr(cnt), _addr(log_u))
-    sampler._draw_pool().enqueue(ahead[1])
-    mcmc._speculation = ahead
+    for j in fresh:
+        sampler._draw_pool().enqueue(j)
+    mcmc._speculation, mcmc._speculation2 = ahead, further
     t.append(now())
     rc = batch.entry(batch.ctx._ctx, batch.cfg_ref, a[0], batch.mask_addr, batch.K, batch.M, a[1], a[2], a[3], a[4], batch.acc_addr, None, None,
                      batch.res_ref)

@@ -294,6 +294,18 @@ def option_schedule(cfg):
 MC3_TRACE = dict(seed=105, n_rows=1000, n_features=32, n_classes=4, n_test=100, n_nodes=[5, 5],
                  bias=-1, n_chains=4, swap_frequency=20, n_iteration=600)
 
+# the same with trainable activation slopes (every chain proposes its own; MC3 deep-copies the model per chain, BNN_mc3.py:55-58)
+MC3_SLOPES_TRACE = dict(MC3_TRACE, seed=106, n_chains=3, n_iteration=400, act=dict(fun="genReLU", prm=[0.1, 0.15], trainable=True))
+MC3_TRACES = {"mc3": MC3_TRACE, "mc3_slopes": MC3_SLOPES_TRACE}
+
+
+def mc3_act(bn, cfg):
+    a = cfg.get("act")
+    if a is None:
+        return {}
+    return dict(actFun=bn.ActFun(fun=a["fun"], prm=np.array(a["prm"], dtype=float), trainable=a["trainable"]))
+
+
 BLOCK_LAYOUTS = [
     # (n_features, n_nodes, size_output, indx_input_list, nodes_per_feature_list)  -- block_bnns.py:39-41,57-59,79-81
     (3, [6, 2], 2, [[0, 1, 2], [], []], [[2, 2, 2], [], []]),

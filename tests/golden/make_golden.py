@@ -188,35 +188,37 @@ def g4_traces():
 
 
 def g5_mc3():
-    cfg = cases.MC3_TRACE
-    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
-    np.random.seed(1234)
-    with tempfile.TemporaryDirectory() as tmp:
-        bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
-        logger = bn.postLogger(bnn, filename="MC3", wdir=tmp, log_all_weights=0)
-        mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"],
-                    n_iteration=cfg["n_iteration"], n_chains=cfg["n_chains"],
-                    swap_frequency=cfg["swap_frequency"], verbose=1)
-        buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            mc3.run_mcmc()
-        log_rows = np.loadtxt(logger._logfile, skiprows=1)
-    swapped = []
-    for line in buf.getvalue().splitlines():
-        m = re.match(r"^(\d+) SWAPPED (\S+) (\S+) (\S+) (\S+)", line)
-        if m:
-            swapped.append([float(m.group(i)) for i in range(1, 6)])
-    out = dict(rseeds=np.asarray(mc3.rseeds), temperatures0=np.asarray(mc3.temperatures, dtype=float),
-               swapped=np.array(swapped, dtype=float).reshape(-1, 5), log_rows=log_rows)
-    out["final_temperature"] = np.array([c[1]._temperature for c in mc3.singleChainArgs], dtype=float)
-    out["final_logPost"] = np.array([c[1]._logPost for c in mc3.singleChainArgs], dtype=float)
-    out["final_logLik"] = np.array([c[1]._logLik for c in mc3.singleChainArgs], dtype=float)
-    out["final_acc_rate"] = np.array([c[1]._acceptance_rate for c in mc3.singleChainArgs], dtype=float)
-    for ci, c in enumerate(mc3.singleChainArgs):
-        for li, w in enumerate(c[0]._w_layers):
-            out["w_c%d_l%d" % (ci, li)] = w
-    np.savez_compressed(os.path.join(HERE, "mc3.npz"), **out)
-    print("mc3.npz: %d swaps accepted of %d" % (len(swapped), mc3.n_mc3_iteration))
+    for name, cfg in cases.MC3_TRACES.items():
+        dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+        np.random.seed(1234)
+        with tempfile.TemporaryDirectory() as tmp:
+            bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1, **cases.mc3_act(bn, cfg))
+            logger = bn.postLogger(bnn, filename="MC3", wdir=tmp, log_all_weights=0)
+            mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"],
+                        n_iteration=cfg["n_iteration"], n_chains=cfg["n_chains"],
+                        swap_frequency=cfg["swap_frequency"], verbose=1)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                mc3.run_mcmc()
+            log_rows = np.loadtxt(logger._logfile, skiprows=1)
+        swapped = []
+        for line in buf.getvalue().splitlines():
+            m = re.match(r"^(\d+) SWAPPED (\S+) (\S+) (\S+) (\S+)", line)
+            if m:
+                swapped.append([float(m.group(i)) for i in range(1, 6)])
+        out = dict(rseeds=np.asarray(mc3.rseeds), temperatures0=np.asarray(mc3.temperatures, dtype=float),
+                   swapped=np.array(swapped, dtype=float).reshape(-1, 5), log_rows=log_rows)
+        out["final_temperature"] = np.array([c[1]._temperature for c in mc3.singleChainArgs], dtype=float)
+        out["final_logPost"] = np.array([c[1]._logPost for c in mc3.singleChainArgs], dtype=float)
+        out["final_logLik"] = np.array([c[1]._logLik for c in mc3.singleChainArgs], dtype=float)
+        out["final_acc_rate"] = np.array([c[1]._acceptance_rate for c in mc3.singleChainArgs], dtype=float)
+        for ci, c in enumerate(mc3.singleChainArgs):
+            for li, w in enumerate(c[0]._w_layers):
+                out["w_c%d_l%d" % (ci, li)] = w
+            if c[0]._act_fun._trainable:
+                out["alphas_c%d" % ci] = np.asarray(c[0]._act_fun._acc_prm, dtype=float)
+        np.savez_compressed(os.path.join(HERE, "%s.npz" % name), **out)
+        print("%s.npz: %d swaps accepted of %d" % (name, len(swapped), mc3.n_mc3_iteration))
 
 
 def g6_masks():

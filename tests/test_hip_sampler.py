@@ -673,3 +673,31 @@ def test_the_short_way_notices_what_changes_between_dispatches():
     advance(3)
     assert mcmc_b._fast is not None
     assert mcmc_a._rs.random() == mcmc_b._rs.random()
+
+
+def test_mc3_with_trainable_slopes_follows_the_reference(golden_dir, tmp_path):
+    """MC3 with trainable activation slopes on the GPU (three chains in this process): such chains carry extra per-iteration
+    draws, stay off the exchange run and the group pass and advance interval by interval through run_steps; the
+    reference's swap sequence for its first accepted swaps, its first log rows, the swap log complete."""
+    cfg = cases.MC3_TRACES["mc3_slopes"]
+    g = np.load(os.path.join(golden_dir, "mc3_slopes.npz"))
+    dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
+    np.random.seed(1234)
+    bnn = quiet(bn.npBNN, dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1, **cases.mc3_act(bn, cfg))
+    logger = bn.postLogger(bnn, filename="MC3", wdir=str(tmp_path), log_all_weights=0)
+    mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=10, sampling_f=cfg["swap_frequency"], n_iteration=cfg["n_iteration"],
+                n_chains=cfg["n_chains"], swap_frequency=cfg["swap_frequency"], verbose=0)
+    np.testing.assert_array_equal(mc3.rseeds, g["rseeds"])
+    quiet(mc3.run_mcmc)
+    assert len(mc3.swap_log) == 20
+    accepted = [i for i, s in enumerate(mc3.swap_log) if s[4]]
+    want = [int(r[0]) for r in g["swapped"]]
+    n_common = 0
+    for a, b in zip(accepted, want):
+        if a != b:
+            break
+        n_common += 1
+    assert n_common >= 5, "swap sequences diverged immediately: %s vs %s" % (accepted, want)
+    rows = np.loadtxt(logger._logfile, skiprows=1)
+    np.testing.assert_allclose(rows[:3, 2], g["log_rows"][:3, 2], rtol=2e-6)
+    assert all(c[1]._device_iterations > 0 for c in mc3.singleChainArgs)          # (the device chain with slopes, not the mh_step loop)

@@ -16,12 +16,12 @@ from oracle_backend import OracleBackend, serve_from_oracle
 RTOL = 1e-9
 
 
-def build_mc3(tmpdir, comm=None):
-    cfg = cases.MC3_TRACE
+def build_mc3(tmpdir, comm=None, name="mc3"):
+    cfg = cases.MC3_TRACES[name]
     dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
     np.random.seed(1234)
     with contextlib.redirect_stdout(io.StringIO()):
-        bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1)
+        bnn = bn.npBNN(dat, n_nodes=cfg["n_nodes"], use_bias_node=cfg["bias"], seed=1, init_std=0.1, **cases.mc3_act(bn, cfg))
         rank0 = comm is None or comm.rank == 0
         logger = bn.postLogger(bnn, filename="MC3", wdir=str(tmpdir), log_all_weights=0, continue_logfile=not rank0)
         serve_from_oracle(lambda b: OracleBackend(b, 0))
@@ -45,6 +45,21 @@ def check_against_golden(mc3, g, local_only=False):
         np.testing.assert_allclose(mcmc_i._acceptance_rate, g["final_acc_rate"][i], rtol=RTOL)
         for li, w in enumerate(bnn_i._w_layers):
             np.testing.assert_array_equal(w, g["w_c%d_l%d" % (i, li)])
+        if bnn_i._act_fun._trainable:
+            np.testing.assert_array_equal(np.asarray(bnn_i._act_fun._acc_prm, dtype=float), g["alphas_c%d" % i])
+
+
+def test_mc3_with_trainable_slopes_matches_reference(golden_dir, tmp_path):
+    """MC3 whose chains propose their own activation slopes (ActFun("genReLU", trainable=True)): the reference's swap sequence,
+    final states, accepted slopes of every chain and the cold chain's log rows (alpha columns included)."""
+    g = np.load(os.path.join(golden_dir, "mc3_slopes.npz"))
+    mc3, logger = build_mc3(tmp_path, name="mc3_slopes")
+    np.testing.assert_array_equal(mc3.rseeds, g["rseeds"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        mc3.run_mcmc()
+    check_against_golden(mc3, g)
+    rows = np.loadtxt(logger._logfile, skiprows=1)
+    np.testing.assert_allclose(rows, g["log_rows"], rtol=1e-8)
 
 
 def test_mc3_in_process_matches_reference(golden_dir, tmp_path):

@@ -12,7 +12,7 @@ import pytest
 
 import cases
 import npbnn_amd as bn
-from oracle_backend import OracleBackend, serve_from_oracle
+from oracle_backend import OracleBackend, OracleChainBackend, serve_from_oracle
 
 RTOL = 1e-9
 
@@ -275,3 +275,101 @@ def test_run_steps_between_gibbs_steps_of_a_hyper_prior(hyper_p):
     np.testing.assert_allclose([mb._logLik, mb._logPrior], [ma._logLik, ma._logPrior], rtol=1e-12)
     for wa, wb in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+# ---- the kept form of a repeated dispatch (sampler._FastDispatch) on CPU: its batch object replaced by a numpy stand-in --------
+class _ShortWayBackend(OracleChainBackend):
+    """OracleChainBackend that also offers what _FastDispatch.build asks of a device backend (a ``ctx``, ``_configure``)."""
+
+    @property
+    def ctx(self):
+        return self
+
+    def _configure(self, weights):
+        pass
+
+
+class _FakeFastBatch:
+    """Stands in for backend.FastBatch: same constructor and ``run`` contract, the batch computed by the numpy chain stand-in."""
+
+    def __init__(self, ctx, K, M, mask, cfg_kwargs):
+        from types import SimpleNamespace
+        self.be, self.K, self.mask, self.kw = ctx, K, mask, dict(cfg_kwargs)
+        self.acc = np.zeros(K, dtype=np.uint8)
+        self.res = SimpleNamespace(n_accepted=0, n_passes=0, n_void_passes=0, schedule=1, loglik=0.0, logprior=0.0, sigma=[0.0] * 8)
+        self.calls = 0
+
+    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, cur_sigma=None, just_before=None):
+        if just_before is not None:
+            just_before()
+        self.calls += 1
+        shapes = [x.shape for x in self.be.bnn._w_layers]
+        layers, off = [], 0
+        for sh in shapes:
+            layers.append(w[off:off + int(np.prod(sh))].reshape(sh))
+            off += int(np.prod(sh))
+        kw = dict(self.kw, cur_loglik=cur_loglik, cur_logprior=cur_logprior)
+        if cur_sigma is not None:
+            kw["cur_sigma"] = cur_sigma
+        new, acc, _, _, res = self.be.run_chain(layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=self.mask, **kw)
+        w[:] = new
+        self.acc[:] = acc
+        r = self.res
+        r.n_accepted, r.n_passes, r.n_void_passes, r.schedule = res["n_accepted"], res["n_passes"], 0, 1
+        r.loglik, r.logprior = res["loglik"], res["logprior"]
+        if res.get("sigma") is not None:
+            r.sigma = list(np.ravel(res["sigma"])) + [0.0] * 8
+        return 0
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg4s"])
+@pytest.mark.parametrize("randomize_seed", [False, True])
+def test_repeated_dispatches_take_the_short_way_on_cpu(name, randomize_seed, monkeypatch):
+    """run_steps(bnn, k) over and over: from the third call on the kept dispatch runs (two batches drawn ahead, one comparison of the
+    settings, the batch object) - and what changes between calls (temperature, step sizes edited in place, the generator read, another
+    k) is noticed.  The chain is the mh_step loop's throughout."""
+    import npbnn_amd.backend as backend_mod
+    monkeypatch.setattr(backend_mod, "FastBatch", _FakeFastBatch)
+    cfg = cases.TRACES[name]
+    out_kind = 0 if cfg["kind"] == "classification" else 1
+    chains = []
+    for _ in range(2):
+        bnn, mcmc, _ = build(dict(cfg, mcmc=dict(cfg["mcmc"], randomize_seed=randomize_seed, mcmc_id=2)))
+        chains.append((bnn, mcmc))
+    serve_from_oracle(lambda b: _ShortWayBackend(b, out_kind))
+    (bnn_a, mcmc_a), (bnn_b, mcmc_b) = chains
+    for m, b in ((mcmc_a, bnn_a), (mcmc_b, bnn_b)):
+        m._backend = _ShortWayBackend(b, out_kind)
+        m._backend._lik_f = m._likelihood_f
+    k = 40
+
+    def advance(n_calls):
+        for _ in range(n_calls * k):
+            mcmc_a.mh_step(bnn_a)
+        for _ in range(n_calls):
+            mcmc_b.run_steps(bnn_b, k)
+        assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem, "diverged by iteration %d" % mcmc_b._current_iteration
+        for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+            np.testing.assert_array_equal(wa, wb)
+        np.testing.assert_allclose([mcmc_b._logLik, mcmc_b._logPrior], [mcmc_a._logLik, mcmc_a._logPrior], rtol=1e-12)
+
+    advance(5)
+    fast = mcmc_b._fast
+    assert fast is not None and fast.batch.calls >= 2 and mcmc_b._speculation2 is not None
+    for m in (mcmc_a, mcmc_b):
+        m.reset_temperature(0.8)
+    advance(3)
+    for m in (mcmc_a, mcmc_b):
+        m._update_ws[0] *= 0.5
+    advance(3)
+    if not randomize_seed:
+        assert mcmc_a._rs.random() == mcmc_b._rs.random()          # (takes back both batches drawn ahead)
+    advance(3)
+    for _ in range(33):
+        mcmc_a.mh_step(bnn_a)
+    mcmc_b.run_steps(bnn_b, 33)
+    assert mcmc_b._fast is None                      # (another k: the general path took the call; it waits a few dispatches ...
+    advance(20)
+    assert mcmc_b._fast is not None and mcmc_b._fast is not fast       # ... before it keeps a dispatch again)
+    if cfg["kind"] == "regression":
+        np.testing.assert_allclose(bnn_a._error_prm, bnn_b._error_prm, rtol=1e-12)

@@ -172,15 +172,18 @@ def test_g4_mh_trace(name, golden_dir):
         np.testing.assert_allclose(st.error_prm, g["final_error_prm"], rtol=RTOL)
 
 
-def test_g5_mc3_trace(golden_dir):
-    cfg = cases.MC3_TRACE
-    g = np.load(os.path.join(golden_dir, "mc3.npz"))
+@pytest.mark.parametrize("name", list(cases.MC3_TRACES))
+def test_g5_mc3_trace(name, golden_dir):
+    cfg = cases.MC3_TRACES[name]
+    g = np.load(os.path.join(golden_dir, "%s.npz" % name))
     dat = cases.classification_data(cfg["seed"], cfg["n_rows"], cfg["n_features"], cfg["n_classes"], cfg["n_test"])
     np.random.seed(1234)
     w0 = orc.init_weights(cfg["n_nodes"], cfg["n_features"], cfg["n_classes"], bias_node=cfg["bias"])
 
     def factory(i, temp):
-        return orc.make_chain(dat["data"], dat["labels"], cfg["n_nodes"], act=orc.Act(), use_bias_node=cfg["bias"],
+        a = cfg.get("act")
+        act = orc.Act() if a is None else orc.Act(a["fun"], prm=np.array(a["prm"], dtype=float), trainable=a["trainable"])
+        return orc.make_chain(dat["data"], dat["labels"], cfg["n_nodes"], act=act, use_bias_node=cfg["bias"],
                               init_w=[w + 0 for w in w0], test_data=dat["test_data"], test_labels=dat["test_labels"],
                               temperature=temp, n_iteration=cfg["swap_frequency"], mcmc_id=i, randomize_seed=True,
                               adapt_freq=50, adapt_f=0.1, adapt_fM=0.6, adapt_stop=1000)
@@ -198,6 +201,8 @@ def test_g5_mc3_trace(golden_dir):
     for ci, st in enumerate(mc.chains):
         for li, w in enumerate(st.w):
             np.testing.assert_array_equal(w, g["w_c%d_l%d" % (ci, li)])
+        if st.act.trainable:
+            np.testing.assert_array_equal(np.asarray(st.act.acc_prm, dtype=float), g["alphas_c%d" % ci])
 
 
 def test_g6_block_masks(golden_dir):

@@ -473,7 +473,7 @@ class FastBatch:
         self.n_targets = ctx.arch.n_targets
         self.entry = capi.chain_run_by_address(ctx._lib)
 
-    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, cur_sigma=None, just_before=None):
+    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, temperature, cur_sigma=None, just_before=None):
         """0 and the results in ``self.res`` / ``self.acc`` / ``w`` - or the C ABI's error code with the state untouched (a weight
         left the fp16 range, a device-side wait timed out ...: the caller repeats the batch through ``chain_run``, which knows the
         remedies).  ``just_before()`` is called as the last thing before the C entry: work for another thread is handed over there,
@@ -481,6 +481,7 @@ class FastBatch:
         the middle of its preparations (measured: copies of the weight vector that took 300 us instead of 4)."""
         cfg = self.cfg
         cfg.cur_loglik, cfg.cur_logprior = cur_loglik, cur_logprior
+        cfg.temperature = temperature        # (state, not a setting: MC3 swaps it between two dispatches)
         if cur_sigma is not None:
             for j in range(self.n_targets):
                 cfg.cur_sigma[j] = cur_sigma[j]

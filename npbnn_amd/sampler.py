@@ -155,7 +155,7 @@ class _FastDispatch:
 
     @staticmethod
     def _scalars(mcmc, bnn, k):
-        return (k, mcmc._temperature, mcmc._lik_temp, bnn._w_bound, mcmc.n_candidates, mcmc.device_schedule, mcmc._randomize_seed,
+        return (k, mcmc._lik_temp, bnn._w_bound, mcmc.n_candidates, mcmc.device_schedule, mcmc._randomize_seed,
                 mcmc._mcmc_id, bnn._prior, mcmc._sample_from_prior, mcmc._adapt_f, mcmc._adapt_fM, mcmc._adapt_freq, mcmc._adapt_stop,
                 bnn._estimation_mode, bnn._empirical_error, bnn._freq_indicator, bnn._feature_indicators is None,
                 bnn._act_fun._trainable, mcmc._estimate_error, mcmc.SUB_BATCH)
@@ -270,7 +270,7 @@ class _FastDispatch:
         further = self._draw_ahead(mcmc, it + 2 * k)
         fresh.append(further[1])
         try:
-            rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, cur_sigma, functools.partial(_enqueue_draws, fresh))
+            rc = batch.run(w, idx, delta, cnt, log_u, mcmc._logLik, mcmc._logPrior, mcmc._temperature, cur_sigma, functools.partial(_enqueue_draws, fresh))
         finally:
             if ahead[1].queued:
                 mcmc._speculation = ahead

@@ -299,7 +299,7 @@ class _FakeFastBatch:
         self.res = SimpleNamespace(n_accepted=0, n_passes=0, n_void_passes=0, schedule=1, loglik=0.0, logprior=0.0, sigma=[0.0] * 8)
         self.calls = 0
 
-    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, cur_sigma=None, just_before=None):
+    def run(self, w, idx, delta, cnt, log_u, cur_loglik, cur_logprior, temperature, cur_sigma=None, just_before=None):
         if just_before is not None:
             just_before()
         self.calls += 1
@@ -308,7 +308,7 @@ class _FakeFastBatch:
         for sh in shapes:
             layers.append(w[off:off + int(np.prod(sh))].reshape(sh))
             off += int(np.prod(sh))
-        kw = dict(self.kw, cur_loglik=cur_loglik, cur_logprior=cur_logprior)
+        kw = dict(self.kw, cur_loglik=cur_loglik, cur_logprior=cur_logprior, temperature=temperature)
         if cur_sigma is not None:
             kw["cur_sigma"] = cur_sigma
         new, acc, _, _, res = self.be.run_chain(layers, idx=idx, delta=delta, cnt=cnt, log_u=log_u, mask=self.mask, **kw)
@@ -359,6 +359,7 @@ def test_repeated_dispatches_take_the_short_way_on_cpu(name, randomize_seed, mon
     for m in (mcmc_a, mcmc_b):
         m.reset_temperature(0.8)
     advance(3)
+    assert mcmc_b._fast is fast                      # (the temperature is the chain's state, handed over with every dispatch)
     for m in (mcmc_a, mcmc_b):
         m._update_ws[0] *= 0.5
     advance(3)

@@ -52,6 +52,7 @@ def run(self, mcmc, bnn):
     batch = self.batch
     cfg = batch.cfg
     cfg.cur_loglik, cfg.cur_logprior = mcmc._logLik, mcmc._logPrior
+    cfg.temperature = mcmc._temperature
     from npbnn_amd.backend import _addr
     a = (_addr(w), _addr(idx), _addr(delta), _addr(cnt), _addr(log_u))
     for j in fresh:

@@ -512,3 +512,42 @@ def test_group_passes_are_taken_automatically_only_for_chains_that_move(monkeypa
         assert (len(calls) == 4) == expect_groups, (threshold, calls)
         assert_same(state_of(a), state_of(b), exact=False)
         monkeypatch.setattr(ex, "run_steps_batched", real)
+
+
+def test_config5_shape_four_chains_in_one_process(tmp_path, monkeypatch):
+    """BASELINE.json config 5's MC3 half in the one-GPU form: FOUR chains of the block-masked regression network (create_mask /
+    apply_mask: the block-structured layer-0 builds, ReLU, bias on the last layer, bench_support.Config5's model on a tenth of its
+    rows), swap intervals in device batches against one batch per interval with the swap on the host - same swap log, same cold-chain
+    log rows, same final weights (masked entries still zero), all chains sharing one resident copy of X."""
+    from bench_support import Config5
+    monkeypatch.setattr(bn.MCMC, "device_schedule", 2)
+    wl = Config5()
+    n = 5000
+    dat = dict(data=wl.x[:n].astype(np.float32), labels=wl.y[:n], test_data=np.zeros((0, wl.f)), test_labels=np.zeros((0, wl.k)))
+    idx, per = wl._mask_args()
+    runs = []
+    for name, device in (("host", False), ("device", True)):
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, dat, n_nodes=wl.hidden, estimation_mode="regression", p_scale=1, use_bias_node=-1)
+        quiet(bnn.apply_mask, bn.create_mask(bnn._w_layers, indx_input_list=idx, nodes_per_feature_list=per))
+        logger = bn.postLogger(bnn, filename="C5" + name, wdir=str(tmp_path), log_all_weights=0)
+        mc3 = quiet(bn.MC3, bnn, logger=logger, n_post_samples=5, sampling_f=25, n_iteration=500, n_chains=4, swap_frequency=25,
+                    verbose=0, adapt_stop=50)
+        mc3.device_exchange = device
+        mc3.exchange_batch = 6
+        quiet(mc3.run_mcmc)
+        runs.append((mc3, logger))
+    (ma, la), (mb, lb) = runs
+    assert ma.swap_log == mb.swap_log and len(ma.swap_log) == 20 and any(s[4] for s in ma.swap_log)
+    assert [c[1]._temperature for c in ma.singleChainArgs] == [c[1]._temperature for c in mb.singleChainArgs]
+    np.testing.assert_array_equal(np.loadtxt(la._logfile, skiprows=1), np.loadtxt(lb._logfile, skiprows=1))
+    owners = set()
+    for (ba, ca), (bb, cb) in zip(ma.singleChainArgs, mb.singleChainArgs):
+        assert ca._device_iterations > 0 and cb._device_iterations > 0
+        for u, v, keep in zip(ba._w_layers, bb._w_layers, ba._mask):
+            np.testing.assert_array_equal(u, v)
+            assert np.all(u[keep == 0] == 0)
+        be = cb._backend
+        owners.add(id(be.data_shared_with if be.data_shared_with is not None else be))
+        assert be.ctx.info(bn._capi.INFO_FAST_TAILS) == 1
+    assert len(owners) == 1

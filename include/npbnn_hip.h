@@ -34,6 +34,7 @@ extern "C" {
 #define NPBNN_MAX_LAYERS 8      /* weight matrices per network                    */
 #define NPBNN_MAX_WIDTH 128     /* max nodes of any hidden/output layer           */
 #define NPBNN_MAX_TARGETS 16    /* max target columns for the Gaussian/count liks */
+#define NPBNN_XSTATE_DOUBLES (4 + NPBNN_MAX_TARGETS)   /* doubles per exchange in npbnn_chain_job.out_state */
 
 enum {
     NPBNN_OK = 0,
@@ -422,7 +423,9 @@ int npbnn_set_row_shard(npbnn_ctx* ctx, npbnn_comm* comm, npbnn_gather_fn gather
  * with an error instead of pairing with unrelated ones: the handle is dead afterwards (every call on it returns NPBNN_E_COMM);
  * destroy it and start again with a new one.
  *   out_records[s][i] = {logPost, temperature (before swap s), 1.0 if chain i had finished segment s, iterations done}
- *   job.out_state[s]  = {logLik, logPrior, temperature, iterations done} of the chain after exchange s
+ *   job.out_state[s]  = {logLik, logPrior, temperature, iterations done, sigma[NPBNN_MAX_TARGETS]} of the chain after exchange s
+ *                       (NPBNN_XSTATE_DOUBLES per exchange; sigma = the regression error parameter, BNN_env.py:500-501, which the
+ *                       logger writes with the cold chain's row, :611-612)
  *   job.out_cold_w[s] = its weights at exchange s if it is the cold chain (temperature 1) afterwards (the logger's sample,
  *                       BNN_mc3.py:118-122); untouched otherwise */
 typedef struct {
@@ -438,7 +441,7 @@ typedef struct {
     uint8_t* out_accepted;
     double* out_loglik_prop;                   /* or NULL */
     double* out_logprior_prop;                 /* or NULL */
-    double* out_state;                         /* [n_seg][4] or NULL */
+    double* out_state;                         /* [n_seg][NPBNN_XSTATE_DOUBLES] or NULL */
     double* out_cold_w;                        /* [n_seg][n_weights] or NULL */
     npbnn_chain_result* result;
 } npbnn_chain_job;

@@ -12,6 +12,7 @@ import numpy as np
 MAX_LAYERS = 8
 MAX_WIDTH = 128
 MAX_TARGETS = 16
+XSTATE_DOUBLES = 4 + MAX_TARGETS      # doubles per exchange in ChainJob.out_state: logLik, logPrior, temperature, iterations, sigma[...]
 
 ACT_RELU, ACT_LEAKY, ACT_SWISH, ACT_TANH = 0, 1, 2, 3
 OUT_SOFTMAX, OUT_IDENTITY, OUT_SOFTPLUS_HALF = 0, 1, 2

@@ -531,7 +531,7 @@ def chains_run_exchange(jobs, n_chains, seg_len, n_seg, swap_j, swap_k, swap_log
         ctx._fill_chain_cfg(cfg, **job["cfg"])
         acc = np.zeros(K, dtype=np.uint8)
         llp, lpp = np.zeros(K), np.zeros(K)
-        state = np.zeros((n_seg, 4))
+        state = np.zeros((n_seg, capi.XSTATE_DOUBLES))
         cold = np.zeros((n_seg, w.size)) if want_cold_w else None
         J = arr[q]
         J.ctx = ctx._ctx

@@ -1267,8 +1267,9 @@ __global__ void __launch_bounds__(1024) exchange_apply_kernel(const ChainParams*
             if (s + 1 < x.n_seg) st->seg_end += x.seg_len;
         }
         if (x.snap_state) {
-            double* q = x.snap_state + (size_t)s * 4;
+            double* q = x.snap_state + (size_t)s * NPBNN_XSTATE_DOUBLES;
             q[0] = st->logLik; q[1] = st->logPrior_rep; q[2] = st->temperature; q[3] = (double)st->t;
+            for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) q[4 + j] = st->sigma[j];
         }
         s_go = all_done;
         // the launch after this kernel decides "the pass before it": there is none

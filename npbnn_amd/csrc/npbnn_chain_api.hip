@@ -907,7 +907,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         L.sk = L.sj + up256((size_t)n_seg * sizeof(int));
         L.su = L.sk + up256((size_t)n_seg * sizeof(int));
         L.state = L.su + up256((size_t)n_seg * sizeof(double));
-        L.rec = L.state + up256((size_t)n_seg * 4 * sizeof(double));
+        L.rec = L.state + up256((size_t)n_seg * NPBNN_XSTATE_DOUBLES * sizeof(double));
         L.cold = L.rec + (q == 0 ? up256(rec_bytes) : 0);
         L.total = L.cold + (jobs[q].out_cold_w ? up256((size_t)n_seg * ctx->n_weights * sizeof(double)) : 0);
         static_assert(sizeof(ExchangeParams) <= 256, "ExchangeParams must fit its slot");
@@ -1070,7 +1070,7 @@ int npbnn_chains_run_exchange(npbnn_comm* comm, npbnn_chain_job* jobs, int32_t n
         const ChainDev* fin = reinterpret_cast<const ChainDev*>(ctx->h_res);
         int rc = chain_finish(ctx, B[q], J.cfg, J.W_inout, J.out_accepted, J.out_loglik_prop, J.out_logprior_prop, J.result, fin->t, true);
         if (rc) return rc;
-        if (J.out_state) memcpy(J.out_state, ctx->h_xbuf + XL[q].state, (size_t)n_seg * 4 * sizeof(double));
+        if (J.out_state) memcpy(J.out_state, ctx->h_xbuf + XL[q].state, (size_t)n_seg * NPBNN_XSTATE_DOUBLES * sizeof(double));
         if (J.out_cold_w) memcpy(J.out_cold_w, ctx->h_xbuf + XL[q].cold, (size_t)n_seg * ctx->n_weights * sizeof(double));
     }
     if (out_records) {     // device order (rank-major) -> chain order

@@ -277,7 +277,7 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
             cold = []
             for q, out in enumerate(outs):
                 st = out["state"][s]
-                cold.append(dict(w=out["cold_w"][s], loglik=st[0], logprior=st[1], accepted=out["accepted"],
+                cold.append(dict(w=out["cold_w"][s], loglik=st[0], logprior=st[1], accepted=out["accepted"], sigma=st[4:],
                                  iterations=(s + 1) * seg_len, iteration0=it0[q], mem_before=mem0[q])
                             if st[2] == 1.0 and out["cold_w"] is not None else None)
             on_interval(done + s, dict(scalars=scal, swap=(j, k, float(r), float(su[s]), accepted), cold=cold,

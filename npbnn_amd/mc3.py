@@ -154,6 +154,8 @@ class MC3():
         bnn_v = bnn.__class__.__new__(bnn.__class__)
         bnn_v.__dict__.update(bnn.__dict__)
         bnn_v._w_layers = layers
+        if bnn._estimation_mode == "regression" and len(np.atleast_1d(snap.get("sigma", ()))) >= bnn._size_output:
+            bnn_v._error_prm = np.array(snap["sigma"][:bnn._size_output], dtype=float)      # (the row's sig_* columns, BNN_env.py:611-612)
         m_v = mcmc.__class__.__new__(mcmc.__class__)
         m_v.__dict__.update(mcmc.__dict__)
         m_v._speculation = m_v._speculation2 = None

@@ -238,7 +238,7 @@ class OracleExchangeBackend(OracleChainBackend):
             cfg = dict(job["cfg"])
             st.append(dict(w=[np.array(w, dtype=float) for w in job["weights"]], ll=cfg["cur_loglik"], lp=cfg["cur_logprior"],
                            temp=cfg["temperature"], t=0, acc=np.zeros(K, dtype=np.uint8), llp=np.zeros(K), lpp=np.zeros(K), n_acc=0,
-                           sigma=cfg.get("cur_sigma"), state=np.zeros((n_seg, 4)),
+                           sigma=cfg.get("cur_sigma"), state=np.zeros((n_seg, 20)),
                            cold=np.zeros((n_seg, sum(w.size for w in job["weights"]))) if want_cold_w else None, cfg=cfg))
         records = np.zeros((n_seg, n_chains, 4))
         done, poisoned = 0, False
@@ -283,7 +283,10 @@ class OracleExchangeBackend(OracleChainBackend):
                     elif job["chain_id"] == k:
                         c["temp"] = tj
             for c in st:
-                c["state"][s] = (c["ll"], c["lp"], c["temp"], c["t"])
+                c["state"][s, :4] = (c["ll"], c["lp"], c["temp"], c["t"])
+                if c["sigma"] is not None:
+                    sg = np.ravel(np.asarray(c["sigma"], dtype=float))
+                    c["state"][s, 4:4 + len(sg)] = sg
                 if c["cold"] is not None and c["temp"] == 1.0:
                     c["cold"][s] = np.concatenate([w.ravel() for w in c["w"]])
             done = s + 1

@@ -122,6 +122,24 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     assert leg["ranks"] == 4 and sum(leg["rows_per_rank"]) == 1_000_000 and leg["ranks_hold_the_same_chain"]
 
 
+def test_bench_under_the_drivers_launcher(tmp_path):
+    """The driver's command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` - the ranks take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's
+    environment (the unique-id / TCP rendezvous of this package sits beside the launcher's own store, on MASTER_PORT + 17 / + 19)
+    and still import no torch themselves.  Two ranks; on one GPU over the TCP communicator."""
+    from npbnn_amd.launch import free_port
+    env = dict(os.environ)
+    if n_gpus() < 2:
+        env["NPBNN_BENCH_DIST_BACKEND"] = "socket"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["swap_exchange_nranks"] == 2 and line["torch_imported"] is False and line["value"] > 0
+    assert "error" not in line["row_sharded_chain"], line["row_sharded_chain"]
+
+
 # ---- one chain, rows split over ranks (npbnn_set_row_shard; npbnn_amd/rowshard.py) ----
 @pytest.mark.parametrize("case", ["cls", "clsw", "reg", "regsig"])
 def test_row_sharded_chain_two_processes_on_one_gpu(case):

@@ -992,7 +992,11 @@ class MCMC():
     _device_void_passes = 0
     _device_iterations = 0
     SUB_BATCH = 128          # first sub-batch of a segment (its pre-draw is not overlapped); later ones double
-    SUB_BATCH_MAX = 2048
+    # (512, not more: the draws of sub-batch n+1 are made while the GPU runs sub-batch n, so a sub-batch twice the size of the one
+    # before it makes the GPU wait whenever drawing an iteration takes more than half of what evaluating it does - config 2: 5 of 9 us,
+    # config 5: 10 of 11 us.  One call of 10 000 iterations with sub-batches growing to 2048 / 512: 105 / 118 k it/s on config 2,
+    # 62 / 75 k on config 5, 39.5 / 39.8 k on config 4; tools/time_long_calls.py)
+    SUB_BATCH_MAX = 512
 
     def _sub_batches(self, seg):
         sizes, k = [], self.SUB_BATCH

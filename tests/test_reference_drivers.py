@@ -75,3 +75,17 @@ def test_bnn_classify_runs_unchanged_and_writes_the_references_files(tmp_path):
 def test_block_bnns_runs_unchanged(tmp_path):
     """block_bnns.py (the layouts of BASELINE.json config 5): get_data in regression mode, three masked models."""
     _run_both(tmp_path, "block_bnns.py")
+
+
+@needs_reference
+@pytest.mark.skipif(not os.environ.get("NPBNN_SLOW_TESTS"), reason="two minutes of CPU (20 000 iterations x 4 chains twice over): NPBNN_SLOW_TESTS=1")
+def test_bnn_runner_mc3_runs_unchanged_and_writes_the_references_files(tmp_path):
+    """bnn_runner_MC3.py (BASELINE.json config 3's call sequence; it seeds numpy itself): the cold chain's log file, the swap
+    messages it prints, the prediction files.  Last run in the build container (round 4): 200 log rows, 21 swaps, per-sample
+    probabilities - all equal to the run under np_bnn, max relative difference 0.0."""
+    ref_dir, our_dir = _run_both(tmp_path, "bnn_runner_MC3.py", threads="1")
+    stem = "BNNMC3_l5_5"
+    a, b = np.loadtxt(str(ref_dir / (stem + ".log")), skiprows=1), np.loadtxt(str(our_dir / (stem + ".log")), skiprows=1)
+    assert a.shape == b.shape == (200, 19)
+    np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.load(str(our_dir / (stem + "_pred_pr.npy"))), np.load(str(ref_dir / (stem + "_pred_pr.npy"))), rtol=0, atol=1e-12)

@@ -139,6 +139,147 @@ static void pcg64_bitgen(pcg64_t* r, bitgen_t* bg) {
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * The same draws without a call through a function pointer per random number ("fast path").
+ *
+ * numpy's routines reach the generator through bitgen_t's function pointers and are calls themselves: ~4.5 ns per number, 5.8 us
+ * per iteration of BASELINE config 2 (428 normals, 856 bounded integers), 10 us of config 5 - as long as the GPU takes to evaluate
+ * the iteration.  Below the generator (the PCG64 above, on a COPY of the Generator's state that the caller hands in and takes back as
+ * plain integers - no assumption about numpy's structs) and the two distributions are inlined:
+ *   - bounded integers: Lemire's multiply-shift with rejection on 32-bit halves of the 64-bit outputs (low half first), which is
+ *     what random_bounded_uint64_fill does for ranges below 2^32;
+ *   - normal deviates: the fast branch of the 256-layer ziggurat (one 64-bit output: 8 bits layer, 1 bit sign, 52 bits magnitude;
+ *     98.8 % of the draws).  Its two tables are LEARNT from numpy's own random_standard_normal by feeding it crafted outputs
+ *     (wi[layer] = the value returned for magnitude 1; ki[layer] = the first magnitude that leaves the fast branch, by bisection),
+ *     so they are the installed numpy's whatever its version; any other draw rewinds the generator by the one output and lets
+ *     numpy's routine make it.
+ * Before first use the inlined forms are run against numpy's routines on identical generator states (2^18 normals, bounded
+ * integers over a spread of ranges, uniforms); any difference disables the fast path for the life of the process.
+ * ------------------------------------------------------------------------------------------- */
+static double zig_wi[256];
+static uint64_t zig_ki[256];
+static int fast_state = 0;          /* 0 not initialised, 1 verified, -1 disabled */
+
+typedef struct { uint64_t r0, filler; int n64, ndbl; } probe_t;
+static uint64_t probe_next64(void* st) { probe_t* p = (probe_t*)st; return p->n64++ == 0 ? p->r0 : p->filler; }
+static uint32_t probe_next32(void* st) { return (uint32_t)probe_next64(st); }
+static double probe_double(void* st) { ((probe_t*)st)->ndbl++; return 0.25; }
+
+/* does numpy's routine take the fast branch for (layer, magnitude)?  *x = what it returns */
+static int probe_fast(int layer, uint64_t rabs, double* x) {
+    probe_t p;
+    bitgen_t bg;
+    p.r0 = (uint64_t)layer | (rabs << 9);                 /* sign bit (bit 8) clear */
+    p.filler = 0;                                          /* layer 0, magnitude 0: returns 0 at once (ends any retry loop) */
+    p.n64 = p.ndbl = 0;
+    bg.state = &p; bg.next_uint64 = probe_next64; bg.next_uint32 = probe_next32; bg.next_double = probe_double; bg.next_raw = probe_next64;
+    const double v = random_standard_normal(&bg);
+    if (x) *x = v;
+    return p.ndbl == 0 && p.n64 == 1;
+}
+
+static inline uint32_t fast_next32(pcg64_t* r) {
+    if (r->has_uint32) { r->has_uint32 = 0; return r->uinteger; }
+    pcg_step(r);
+    const uint64_t hi = (uint64_t)(r->state >> 64), lo = (uint64_t)r->state;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(r->state >> 122);
+    const uint64_t next = (x >> rot) | (x << ((-rot) & 63));
+    r->has_uint32 = 1;
+    r->uinteger = (uint32_t)(next >> 32);
+    return (uint32_t)(next & 0xffffffffu);
+}
+
+static inline uint64_t fast_next64(pcg64_t* r) {
+    pcg_step(r);
+    const uint64_t hi = (uint64_t)(r->state >> 64), lo = (uint64_t)r->state;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(r->state >> 122);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+static inline double fast_double(pcg64_t* r) { return (fast_next64(r) >> 11) * (1.0 / 9007199254740992.0); }
+
+/* integers in [0, rng] for rng < 2^32 - 1 (numpy: buffered_bounded_lemire_uint32) */
+static inline uint32_t fast_bounded32(pcg64_t* r, uint32_t rng) {
+    const uint32_t rng_excl = rng + 1u;
+    uint64_t m = (uint64_t)fast_next32(r) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        const uint32_t threshold = (0xffffffffu - rng) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)fast_next32(r) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+
+static inline double fast_standard_normal(pcg64_t* r, bitgen_t* own_bg) {
+    const u128 before = r->state;                       /* (the 32-bit buffer is not touched by a 64-bit draw) */
+    const uint64_t u = fast_next64(r);
+    const int layer = (int)(u & 0xff);
+    const uint64_t v = u >> 8;
+    const uint64_t rabs = (v >> 1) & 0x000fffffffffffffULL;
+    if (rabs < zig_ki[layer]) {
+        const double x = (double)rabs * zig_wi[layer];
+        return (v & 1) ? -x : x;
+    }
+    r->state = before;                                   /* the rare branches: numpy's own routine, from the same output on */
+    return random_standard_normal(own_bg);
+}
+
+static void fast_init(void) {
+    if (fast_state != 0) return;
+    fast_state = -1;
+    if (getenv("NPBNN_NO_FAST_PREDRAW")) return;
+    for (int layer = 0; layer < 256; ++layer) {
+        double w = 0.0;
+        if (!probe_fast(layer, 1, &w) || !(w > 0.0)) {       /* magnitude 1 leaves the fast branch: not the table we think it is */
+            if (!probe_fast(layer, 0, NULL)) { zig_ki[layer] = 0; zig_wi[layer] = 0.0; continue; }
+            return;
+        }
+        zig_wi[layer] = w;
+        uint64_t lo = 1, hi = (uint64_t)1 << 52;             /* fast at lo; ki in (lo, hi] */
+        if (probe_fast(layer, hi - 1, NULL)) { zig_ki[layer] = hi; continue; }
+        hi -= 1;                                             /* slow at hi */
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (probe_fast(layer, mid, NULL)) lo = mid; else hi = mid;
+        }
+        zig_ki[layer] = hi;                                  /* the first magnitude that is not fast */
+    }
+    /* verification against numpy's routines on identical states */
+    pcg64_t a, b;
+    bitgen_t bga, bgb;
+    pcg64_seed(&a, 0x9e3779b97f4a7c15ULL);
+    b = a;
+    pcg64_bitgen(&a, &bga);
+    pcg64_bitgen(&b, &bgb);
+    fast_state = 1;                                           /* (fast_standard_normal reads the tables unconditionally) */
+    for (int i = 0; i < (1 << 18); ++i) {
+        const double x = fast_standard_normal(&a, &bga), y = random_standard_normal(&bgb);
+        if (memcmp(&x, &y, sizeof x) != 0 || a.state != b.state) { fast_state = -1; return; }
+    }
+    static const uint32_t ranges[] = {1, 2, 4, 7, 9, 31, 32, 63, 255, 256, 511, 1000, 8191, 65535, 65536, 1000003, 0x7fffffffu, 0xfffffffeu};
+    for (size_t q = 0; q < sizeof ranges / sizeof ranges[0]; ++q) {
+        uint64_t want[257];
+        random_bounded_uint64_fill(&bgb, 0, ranges[q], 257, 0, want);
+        for (int i = 0; i < 257; ++i)
+            if ((uint64_t)fast_bounded32(&a, ranges[q]) != want[i]) { fast_state = -1; return; }
+        /* an odd number of 32-bit draws leaves a buffered half behind: the two generators must agree on it too */
+        if (a.state != b.state || a.has_uint32 != b.has_uint32 || a.uinteger != b.uinteger) { fast_state = -1; return; }
+        const double x = fast_double(&a), y = random_standard_uniform(&bgb);
+        if (x != y) { fast_state = -1; return; }
+    }
+}
+
+/* 1 when the inlined draws are in use (verified against numpy's routines in this process), else 0 */
+int npbnn_host_fast_predraw(void) {
+    fast_init();
+    return fast_state == 1;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * pre-draw
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -213,7 +354,10 @@ int npbnn_host_predraw2(void* bitgen, int randomize_seed, int64_t first_iteratio
  * draws of an iteration, BNN_env.py:416-421) when n_slopes > 0:
  *   slope_idx[t]     rs.integers(0, n_slopes, 1)   (no draw when n_slopes == 1: numpy returns the only value)
  *   slope_delta[t]   rs.normal(0, slope_d, 1) */
-int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+/* own_state: NULL (the draws come from `bitgen`, numpy's live generator, or - randomize_seed - from a generator seeded per iteration), or
+ * the generator to draw from and leave advanced (npbnn_host_predraw_state).  Wherever the generator is one of this file's own
+ * (own_state, or the per-iteration ones) and the inlined draws have been verified (fast_init), they are used. */
+static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
                         const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
                         int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
                         double* sigma_chosen, double* sigma_u, int n_slopes, double slope_d, int32_t* slope_idx,
@@ -221,7 +365,9 @@ int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteratio
     if (!spec || K < 0 || spec->n_layers < 1 || spec->n_layers > NPBNN_HOST_MAX_LAYERS) return -1;
     if (sigma_k < 0 || (sigma_k > 0 && (!sigma_chosen || !sigma_u))) return -1;
     if (n_slopes < 0 || (n_slopes > 0 && (!slope_idx || !slope_delta))) return -1;
-    if (!randomize_seed && !bitgen) return -1;
+    if (!randomize_seed && !bitgen && !own_state) return -1;
+    fast_init();
+    const int fast_ok = fast_state == 1;
     int total = 0, max_n = 0;
     for (int i = 0; i < spec->n_layers; ++i) {
         total += spec->update_n[i];
@@ -239,12 +385,15 @@ int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteratio
     for (int i = 0; i < n_weights; ++i) last[i] = -1;
     pcg64_t local;
     bitgen_t local_bg;
+    if (own_state) pcg64_bitgen(own_state, &local_bg);
     for (int t = 0; t < K; ++t) {
-        bitgen_t* bg = (bitgen_t*)bitgen;
+        bitgen_t* bg = own_state ? &local_bg : (bitgen_t*)bitgen;
+        pcg64_t* fr = (own_state && fast_ok) ? own_state : NULL;      /* the generator of the inlined draws, when they apply */
         if (randomize_seed) {
             pcg64_seed(&local, (uint64_t)(first_iteration + t + mcmc_id));
             pcg64_bitgen(&local, &local_bg);
             bg = &local_bg;
+            fr = fast_ok ? &local : NULL;
         }
         if (n_slopes > 0) {
             uint64_t pick = 0;
@@ -259,7 +408,8 @@ int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteratio
             random_standard_uniform_fill(bg, sigma_k, sigma_u + (size_t)t * sigma_k);
         }
         double rr[NPBNN_HOST_MAX_LAYERS];
-        random_standard_uniform_fill(bg, spec->n_layers, rr);
+        if (fr) { for (int i = 0; i < spec->n_layers; ++i) rr[i] = fast_double(fr); }
+        else random_standard_uniform_fill(bg, spec->n_layers, rr);
         int amin = 0;
         for (int i = 1; i < spec->n_layers; ++i)
             if (rr[i] < rr[amin]) amin = i;
@@ -271,14 +421,21 @@ int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteratio
             if (!(rr[i] < spec->freq_layer_update[i])) continue;
             mask |= 1 << i;
             const int n = spec->update_n[i];
-            random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->rows[i] - 1), n, 0, ix);
-            random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->cols[i] - 1), n, 0, iy);
+            if (fr) {      /* (a range of one value draws nothing, as in numpy's fill) */
+                const uint32_t rmax = (uint32_t)(spec->rows[i] - 1), cmax = (uint32_t)(spec->cols[i] - 1);
+                if (rmax == 0) { for (int j = 0; j < n; ++j) ix[j] = 0; } else { for (int j = 0; j < n; ++j) ix[j] = fast_bounded32(fr, rmax); }
+                if (cmax == 0) { for (int j = 0; j < n; ++j) iy[j] = 0; } else { for (int j = 0; j < n; ++j) iy[j] = fast_bounded32(fr, cmax); }
+            } else {
+                random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->rows[i] - 1), n, 0, ix);
+                random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->cols[i] - 1), n, 0, iy);
+            }
             const int base = used;
             for (int j = 0; j < n; ++j) {
                 const int local_pos = (int)ix[j] * spec->cols[i] + (int)iy[j];
                 const double scale = spec->update_ws[i][local_pos];
                 const int flat = spec->w_off[i] + local_pos;
-                row_delta[base + j] = random_normal(bg, 0.0, scale);
+                /* random_normal(loc, scale) = loc + scale * standard normal */
+                row_delta[base + j] = fr ? 0.0 + scale * fast_standard_normal(fr, bg) : random_normal(bg, 0.0, scale);
                 if (last[flat] >= base) row_idx[last[flat]] = -1;   /* superseded within this layer */
                 row_idx[base + j] = flat;
                 last[flat] = base + j;
@@ -287,11 +444,43 @@ int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteratio
                 if (row_idx[base + j] >= 0) last[row_idx[base + j]] = -1;
             used += n;
         }
+        for (int j = used; j < max_per_iter; ++j) { row_idx[j] = -1; row_delta[j] = 0.0; }      /* (the caller's arrays come uninitialised) */
         cnt[t] = used;
         layer_mask[t] = mask;
-        log_u[t] = random_standard_uniform(bg);
+        log_u[t] = fr ? fast_double(fr) : random_standard_uniform(bg);
     }
     free(last);
     free(ix);
     return 0;
+}
+
+int npbnn_host_predraw3(void* bitgen, int randomize_seed, int64_t first_iteration, int64_t mcmc_id, int K,
+                        const npbnn_proposal_spec* spec, int max_per_iter, int32_t* idx, double* delta,
+                        int32_t* cnt, double* log_u, int32_t* layer_mask, int n_weights, int sigma_k, double sigma_f,
+                        double* sigma_chosen, double* sigma_u, int n_slopes, double slope_d, int32_t* slope_idx,
+                        double* slope_delta) {
+    return predraw_core(bitgen, NULL, randomize_seed, first_iteration, mcmc_id, K, spec, max_per_iter, idx, delta, cnt, log_u, layer_mask,
+                        n_weights, sigma_k, sigma_f, sigma_chosen, sigma_u, n_slopes, slope_d, slope_idx, slope_delta);
+}
+
+/* The same for a chain that draws from ONE generator (randomize_seed == 0), given by value: gen = {state high, state low, increment
+ * high, increment low, has_uint32, uinteger} - the integers of numpy's PCG64 state dictionary (Generator.bit_generator.state) - read
+ * at entry, written back advanced.  The draws are numpy's to the bit (the inlined forms where verified, numpy's routines on this
+ * file's PCG64 otherwise); nothing of numpy's own structs is touched. */
+int npbnn_host_predraw_state(uint64_t* gen, int64_t first_iteration, int64_t mcmc_id, int K, const npbnn_proposal_spec* spec,
+                             int max_per_iter, int32_t* idx, double* delta, int32_t* cnt, double* log_u, int32_t* layer_mask,
+                             int n_weights, int sigma_k, double sigma_f, double* sigma_chosen, double* sigma_u, int n_slopes,
+                             double slope_d, int32_t* slope_idx, double* slope_delta) {
+    if (!gen) return -1;
+    pcg64_t g;
+    g.state = (((u128)gen[0]) << 64) | (u128)gen[1];
+    g.inc = (((u128)gen[2]) << 64) | (u128)gen[3];
+    g.has_uint32 = (int)gen[4];
+    g.uinteger = (uint32_t)gen[5];
+    const int rc = predraw_core(NULL, &g, 0, first_iteration, mcmc_id, K, spec, max_per_iter, idx, delta, cnt, log_u, layer_mask, n_weights,
+                                sigma_k, sigma_f, sigma_chosen, sigma_u, n_slopes, slope_d, slope_idx, slope_delta);
+    gen[0] = (uint64_t)(g.state >> 64); gen[1] = (uint64_t)g.state;
+    gen[2] = (uint64_t)(g.inc >> 64); gen[3] = (uint64_t)g.inc;
+    gen[4] = (uint64_t)g.has_uint32; gen[5] = (uint64_t)g.uinteger;
+    return rc;
 }

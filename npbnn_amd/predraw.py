@@ -9,6 +9,8 @@ from ._capi import LIB_DIR, BackendUnavailable
 
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libnpbnn_host.so")
 MAX_LAYERS = 8
+_M64 = (1 << 64) - 1
+_NO_STATE_HANDOVER = bool(os.environ.get("NPBNN_NO_STATE_HANDOVER"))     # A/B: draw through numpy's live generator as before
 
 
 class ProposalSpec(C.Structure):
@@ -40,6 +42,11 @@ def load_host_library():
         proto = C.CFUNCTYPE(C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.POINTER(ProposalSpec), C.c_int, vp, vp, vp, vp, vp,
                             C.c_int, C.c_int, C.c_double, vp, vp, C.c_int, C.c_double, vp, vp)
         lib.npbnn_host_predraw3_by_address = proto(("npbnn_host_predraw3", lib))
+        # the generator handed over by value (six integers of numpy's PCG64 state dictionary) and taken back advanced
+        proto_state = C.CFUNCTYPE(C.c_int, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(ProposalSpec), C.c_int, vp, vp, vp, vp, vp,
+                                  C.c_int, C.c_int, C.c_double, vp, vp, C.c_int, C.c_double, vp, vp)
+        lib.npbnn_host_predraw_state_by_address = proto_state(("npbnn_host_predraw_state", lib))
+        lib.npbnn_host_fast_predraw.restype = C.c_int
         lib.npbnn_host_selftest_doubles.restype = C.c_int
         lib.npbnn_host_selftest_doubles.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_double)]
         _lib = lib
@@ -72,7 +79,8 @@ class PredrawPlan:
         self.M = int(sum(int(n) for n in update_n))
 
     def run(self, rs, randomize_seed, first_iteration, mcmc_id, K, empty=None, sigma_k=0, sigma_f=0.5, n_slopes=0, slope_d=0.05,
-            empty_group=None):
+            empty_group=None, state=None):
+        """``state``: ``rs.bit_generator.state`` if the caller has just read it (saves reading it again)."""
         if empty is None:
             empty = np.empty
         lib = load_host_library()
@@ -81,8 +89,7 @@ class PredrawPlan:
             idx, delta, cnt, u = empty_group([((K, M), np.int32), ((K, M), np.float64), ((K,), np.int32), ((K,), np.float64)])
         else:
             idx, delta, cnt, u = empty((K, M), np.int32), empty((K, M), np.float64), empty((K,), np.int32), empty((K,), np.float64)
-        idx.fill(-1)
-        delta.fill(0.0)
+        # (unused entries of a row are set to -1 / 0 by the C routine, row by row, while the row is in cache)
         lmask = np.empty(K, dtype=np.int32)
         bitgen = None
         if not randomize_seed:
@@ -97,11 +104,31 @@ class PredrawPlan:
             slope_idx = np.zeros(K, dtype=np.int32)
             slope_delta = np.zeros(K, dtype=np.float64)
         with rs.bit_generator.lock:
-            rc = lib.npbnn_host_predraw3_by_address(
-                bitgen, 1 if randomize_seed else 0, int(first_iteration), int(mcmc_id), K, self.spec_ref, M, idx.ctypes.data,
-                delta.ctypes.data, cnt.ctypes.data, u.ctypes.data, lmask.ctypes.data, self.n_weights, sigma_k, float(sigma_f),
-                chosen.ctypes.data if sigma_k else None, u_sigma.ctypes.data if sigma_k else None, n_slopes, float(slope_d),
-                slope_idx.ctypes.data if n_slopes else None, slope_delta.ctypes.data if n_slopes else None)
+            by_value = None
+            if not randomize_seed and not _NO_STATE_HANDOVER:
+                # a PCG64 generator travels by value: its state as six integers in, the advanced state out - the C side then draws
+                # with its own inlined generator and distributions (npbnn_host.c, "fast path": 2-3x numpy's routines called through
+                # the generator's function pointers) and nothing depends on the layout of numpy's structs
+                st = rs.bit_generator.state if state is None else state
+                if st.get("bit_generator") == "PCG64":
+                    s128, i128 = st["state"]["state"], st["state"]["inc"]
+                    by_value = (C.c_uint64 * 6)(s128 >> 64, s128 & _M64, i128 >> 64, i128 & _M64, st["has_uint32"], st["uinteger"])
+            if by_value is not None:
+                rc = lib.npbnn_host_predraw_state_by_address(
+                    C.addressof(by_value), int(first_iteration), int(mcmc_id), K, self.spec_ref, M, idx.ctypes.data, delta.ctypes.data,
+                    cnt.ctypes.data, u.ctypes.data, lmask.ctypes.data, self.n_weights, sigma_k, float(sigma_f),
+                    chosen.ctypes.data if sigma_k else None, u_sigma.ctypes.data if sigma_k else None, n_slopes, float(slope_d),
+                    slope_idx.ctypes.data if n_slopes else None, slope_delta.ctypes.data if n_slopes else None)
+                if rc == 0:
+                    rs.bit_generator.state = {"bit_generator": "PCG64",
+                                              "state": {"state": (by_value[0] << 64) | by_value[1], "inc": (by_value[2] << 64) | by_value[3]},
+                                              "has_uint32": int(by_value[4]), "uinteger": int(by_value[5])}
+            else:
+                rc = lib.npbnn_host_predraw3_by_address(
+                    bitgen, 1 if randomize_seed else 0, int(first_iteration), int(mcmc_id), K, self.spec_ref, M, idx.ctypes.data,
+                    delta.ctypes.data, cnt.ctypes.data, u.ctypes.data, lmask.ctypes.data, self.n_weights, sigma_k, float(sigma_f),
+                    chosen.ctypes.data if sigma_k else None, u_sigma.ctypes.data if sigma_k else None, n_slopes, float(slope_d),
+                    slope_idx.ctypes.data if n_slopes else None, slope_delta.ctypes.data if n_slopes else None)
         if rc != 0:
             raise RuntimeError("npbnn_host_predraw failed with code %d" % rc)
         out = (idx, delta, cnt, u, lmask)

@@ -230,7 +230,7 @@ class _FastDispatch:
         def draw():
             if keep_state:
                 job.saved = rs.bit_generator.state
-            out = plan.run(rs, randomize, first_it, mcmc_id, k, empty=empty, empty_group=empty_group)
+            out = plan.run(rs, randomize, first_it, mcmc_id, k, empty=empty, empty_group=empty_group, state=job.saved)
             np.log(out[3], out=out[3])
             return out[0], out[1], out[2], out[3], None, None
 
@@ -917,7 +917,7 @@ class MCMC():
             if keep_state:        # (here, on the helper thread, rather than in the caller: reading the state builds a nested dictionary)
                 job.saved = rs.bit_generator.state
             out = plan.run(rs, randomize, first_it, mcmc_id, k, empty=empty, sigma_k=sigma_k, n_slopes=n_slopes, slope_d=0.05,
-                           empty_group=empty_group)
+                           empty_group=empty_group, state=job.saved)
             idx, delta, cnt, u = out[:4]
             np.log(u, out=u)                      # the accept test compares with log u (BNN_env.py:493)
             smult = hast = None

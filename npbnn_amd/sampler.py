@@ -146,7 +146,7 @@ class _FastDispatch:
     boundary ahead, an error code from the library - sends the call down :meth:`MCMC.run_steps`'s general path, which builds a
     new one when it applies.  The general path and this one leave the sampler in the same state, draws made ahead included."""
     __slots__ = ("k", "objects", "scalars", "n_bytes", "freq_bytes", "scale_bytes", "ws_src", "ws_copies", "plan", "key_tail", "batch",
-                 "layers", "regression", "n_out", "adapt_possible", "empty", "empty_group")
+                 "layers", "regression", "fixed_sigma", "n_out", "adapt_possible", "empty", "empty_group")
 
     @staticmethod
     def _objects(mcmc, bnn):
@@ -171,7 +171,12 @@ class _FastDispatch:
         if ctx is None or cache is None or not 1 <= k <= mcmc.SUB_BATCH or getattr(be, "row_sharded", False):
             return None
         regression = bnn._estimation_mode == "regression"
-        if bnn._act_fun._trainable or (regression and not bnn._empirical_error) or mcmc._device_mode(bnn, k) != "patch":
+        # (a regression whose sigma is estimated: kept only while sigma is still fixed at 1 - BNN_env.py:375-379,435-444 -, i.e. while the
+        # call ends at or before iteration _estimate_error; the proposals on sigma that follow bring per-batch arrays of their own)
+        fixed_sigma = regression and not bnn._empirical_error
+        if fixed_sigma and mcmc._current_iteration + k - 1 > mcmc._estimate_error:
+            return None
+        if bnn._act_fun._trainable or mcmc._device_mode(bnn, k) != "patch":
             return None
         if type(bnn._prior_scale) is not np.ndarray or bnn._prior_scale.ndim != 1:
             return None
@@ -190,6 +195,7 @@ class _FastDispatch:
             return None
         self.key_tail = mcmc._draw_key(bnn, 0, k)[2:]
         self.regression = regression
+        self.fixed_sigma = fixed_sigma
         self.n_out = bnn._size_output
         self.adapt_possible = not (mcmc._adapt_f <= 0 and mcmc._adapt_fM >= 1)
         self.empty = getattr(be, "host_empty", None)
@@ -215,6 +221,8 @@ class _FastDispatch:
         for src, copy, now in zip(self.ws_src, self.ws_copies, live):
             if now is not src or not _same_ends(copy, now):
                 return False
+        if self.fixed_sigma and mcmc._current_iteration + k - 1 > mcmc._estimate_error:
+            return False
         if self.adapt_possible:
             boundary = mcmc._next_adapt_boundary()
             if mcmc._current_iteration % mcmc._adapt_freq == 0 or (boundary is not None and boundary < mcmc._current_iteration + k):

@@ -596,10 +596,15 @@ def test_config5_as_benched_block_build_relu_full_size():
 
 
 # ---- repeated dispatches of one size: the kept form of a dispatch (sampler._FastDispatch) ------------------------------
-@pytest.mark.parametrize("name", ["cfg1", "cfg4s"])
+def _fixed_sigma_variant(cfg):
+    """cfg4s with the error parameter estimated (MCMC's default): sigma stays 1 for the first tenth of n_iteration, BNN_env.py:375-379"""
+    return dict(cfg, empirical_error=False, mcmc=dict(cfg["mcmc"], estimate_error=True))
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg4s", "cfg4s_fixed_sigma"])
 @pytest.mark.parametrize("randomize_seed", [False, True])
 def test_repeated_dispatches_take_the_short_way_and_are_the_mh_step_loop(name, randomize_seed):
-    cfg = cases.TRACES[name]
+    cfg = _fixed_sigma_variant(cases.TRACES["cfg4s"]) if name == "cfg4s_fixed_sigma" else cases.TRACES[name]
     bnn_a, mcmc_a = build(cfg, randomize_seed=randomize_seed, mcmc_id=3)
     bnn_b, mcmc_b = build(cfg, randomize_seed=randomize_seed, mcmc_id=3)
     n_calls, k = 9, 60

@@ -322,7 +322,7 @@ class _FakeFastBatch:
         return 0
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg4s"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg4s", "cfg4s_fixed_sigma"])
 @pytest.mark.parametrize("randomize_seed", [False, True])
 def test_repeated_dispatches_take_the_short_way_on_cpu(name, randomize_seed, monkeypatch):
     """run_steps(bnn, k) over and over: from the third call on the kept dispatch runs (two batches drawn ahead, one comparison of the
@@ -330,7 +330,11 @@ def test_repeated_dispatches_take_the_short_way_on_cpu(name, randomize_seed, mon
     k) is noticed.  The chain is the mh_step loop's throughout."""
     import npbnn_amd.backend as backend_mod
     monkeypatch.setattr(backend_mod, "FastBatch", _FakeFastBatch)
-    cfg = cases.TRACES[name]
+    if name == "cfg4s_fixed_sigma":     # the error parameter estimated (MCMC's default): sigma stays 1 for the first tenth of n_iteration
+        cfg = cases.TRACES["cfg4s"]
+        cfg = dict(cfg, empirical_error=False, mcmc=dict(cfg["mcmc"], estimate_error=True))
+    else:
+        cfg = cases.TRACES[name]
     out_kind = 0 if cfg["kind"] == "classification" else 1
     chains = []
     for _ in range(2):

@@ -401,10 +401,12 @@ def moving_chain(wl):
     t0 = time.perf_counter()
     mcmc_q.run_steps(bnn_q, 4000)
     el5 = time.perf_counter() - t0
+    from npbnn_amd import _capi as capi
     ctx = mcmc_q._backend.ctx
     out = {"value": 20 * ITERATIONS_PER_STEP / el4, "unit": "iterations/s", "one_call_of_4000": 4000 / el5,
            "us_per_dispatch_of_100": 1e6 * el4 / 20, "us_fixed_per_dispatch": 1e6 * (el4 / 20 - ITERATIONS_PER_STEP * el5 / 4000),
-           "auto_turn_us": {"overlapped": ctx.info(5) / 1e3, "decision_between_passes": ctx.info(6) / 1e3},
+           "auto_turn_us": {"overlapped": ctx.info(capi.INFO_TURN_NS_OVERLAPPED) / 1e3,
+                            "decision_between_passes": ctx.info(capi.INFO_TURN_NS_BETWEEN) / 1e3},
            "accept_rate_last_100": float(mcmc_q._acceptance_rate),
            "accept_rate": float(mcmc_q._device_accepted) / max(1, mcmc_q._device_iterations),
            "schedule": int(mcmc_q._device_schedule_used),

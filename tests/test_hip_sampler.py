@@ -706,3 +706,61 @@ def test_mc3_with_trainable_slopes_follows_the_reference(golden_dir, tmp_path):
     rows = np.loadtxt(logger._logfile, skiprows=1)
     np.testing.assert_allclose(rows[:3, 2], g["log_rows"][:3, 2], rtol=2e-6)
     assert all(c[1]._device_iterations > 0 for c in mc3.singleChainArgs)          # (the device chain with slopes, not the mh_step loop)
+
+
+# ---- random shapes: the device chain against the mh_step loop -------------------------------------------------------------
+def _random_case(seed):
+    rs = np.random.default_rng(seed)
+    n = int(rs.integers(40, 700))
+    f = int(rs.choice([1, 3, 15, 16, 17, 31, 33, 64, 70]))
+    depth = int(rs.integers(1, 4))
+    hidden = [int(rs.choice([1, 2, 5, 15, 16, 17, 32, 33, 48, 50, 64])) if li == 0 else int(rs.integers(1, 17)) for li in range(depth)]
+    regression = bool(rs.integers(0, 2))
+    fun = str(rs.choice(["ReLU", "tanh", "swish", "genReLU"]))
+    bias = int(rs.choice([0, 1, 2, 3, -1]))
+    x = rs.standard_normal((n, f))
+    if regression:
+        k = int(rs.integers(1, 4))
+        dat = dict(data=x, labels=rs.standard_normal((n, k)), test_data=np.zeros((0, f)), test_labels=np.zeros((0, k)))
+        extra = dict(estimation_mode="regression", empirical_error=bool(rs.integers(0, 2)))
+    else:
+        c = int(rs.integers(2, 13))
+        lab = rs.integers(0, c, n)
+        lab[:c] = np.arange(c)
+        dat = dict(data=x, labels=lab, test_data=np.zeros((0, f)), test_labels=np.zeros(0))
+        extra = {}
+    prior = int(rs.choice([0, 1, 1, 2, 3]))
+    act_kw = dict(fun=fun)
+    if fun == "genReLU":
+        act_kw["prm"] = rs.uniform(0.0, 0.3, depth)
+    update_f = [float(rs.choice([0.01, 0.05, 0.2, 0.6]))] * (depth + 1)
+    return dat, dict(n_nodes=hidden, use_bias_node=bias, prior_f=prior, p_scale=float(rs.choice([0.5, 1.0, 2.0])), **extra), act_kw, \
+        dict(update_f=update_f, update_ws=[float(rs.choice([0.02, 0.075, 0.2]))] * (depth + 1), n_iteration=100000, estimate_error=False,
+             temperature=float(rs.choice([1.0, 0.8])), likelihood_tempering=float(rs.choice([1.0, 0.6])))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_device_chain_is_the_mh_step_loop_on_random_shapes(seed):
+    """Random table sizes, depths (1-3 hidden layers), first layers from 1 to 64 nodes (one to four output tiles: three, two and one
+    candidates per pass), every activation, bias mode and prior, both estimation modes, tempered / heated chains, proposals from 1 %
+    to 60 % of a layer: 90 iterations of run_steps (in calls of 30, the last one through the kept dispatch) against 90 calls of
+    mh_step - same accept / reject sequence, same weights to the bit."""
+    dat, model_kw, act_kw, sampler_kw = _random_case(1000 + seed)
+    chains = []
+    for _ in range(2):
+        np.random.seed(77)
+        bnn = quiet(bn.npBNN, dat, actFun=bn.ActFun(**act_kw), **model_kw)
+        chains.append((bnn, bn.MCMC(bnn, **sampler_kw)))
+    (bnn_a, mcmc_a), (bnn_b, mcmc_b) = chains
+    for _ in range(90):
+        mcmc_a.mh_step(bnn_a)
+    for _ in range(3):
+        mcmc_b.run_steps(bnn_b, 30)
+    assert mcmc_b._device_iterations == 90, "the device chain did not take these iterations: %s %s" % (model_kw, sampler_kw)
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem, (model_kw, act_kw, sampler_kw)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
+    if model_kw.get("estimation_mode") == "regression":
+        np.testing.assert_allclose(np.ones(bnn_a._size_output) * bnn_a._error_prm, np.ones(bnn_b._size_output) * bnn_b._error_prm, rtol=1e-12)

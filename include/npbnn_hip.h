@@ -245,7 +245,8 @@ typedef struct {
      * log(r) * -sum(slopes') * r (r = 10) to the proposal's log prior and keeps them when the proposal is accepted.
      * cur_slopes: the accepted slopes on entry (result->slopes on return; n_slopes = hidden layers); slope_term_in_prior: 1 when
      * cur_logprior already holds that term for cur_slopes (it does after the chain's first accepted proposal: MCMC.__init__ computes
-     * its prior without it, BNN_env.py:374).  NULL / 0: fixed slopes, as npbnn_eval takes them. */
+     * its prior without it, BNN_env.py:374).  slope_idx NULL: FIXED slopes (ActFun("genReLU", prm=...), BNN_lib.py:84-85) - the
+     * n_slopes values of cur_slopes are the slopes of the hidden layers for every proposal of the batch (n_slopes = 0: none, slope 0). */
     const int32_t* slope_idx;
     const double* slope_delta;
     double cur_slopes[NPBNN_MAX_LAYERS];

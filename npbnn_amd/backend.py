@@ -274,14 +274,16 @@ class HipContext:
         return ms.value, used.value
 
     def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
-                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None, slopes=None):
+                        cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None, slopes=None,
+                        fixed_slopes=None):
         # the settings of a plain batch rarely change between dispatches: when they are the ones this struct already holds, only the
         # chain's state goes in
         plain = (slopes is None and sigma_mult is None and type(prior_scale) is np.ndarray and prior_scale.ndim == 1
                  and prior_scale.dtype == np.float64)
         key = None
         if plain:
-            key = (prior_kind, prior_scale.tobytes(), w_bound, temperature, lik_temp, n_candidates, schedule, sigma is None, cur_sigma is None)
+            key = (prior_kind, prior_scale.tobytes(), w_bound, temperature, lik_temp, n_candidates, schedule, sigma is None, cur_sigma is None,
+                   None if fixed_slopes is None else np.asarray(fixed_slopes, dtype=np.float64).tobytes())
             if cfg.__dict__.get("_plain_key") == key:
                 cfg.cur_loglik, cfg.cur_logprior = cur_loglik, cur_logprior
                 cfg.force_f32 = 0
@@ -298,6 +300,11 @@ class HipContext:
         cfg.slope_idx = cfg.slope_delta = None
         cfg.n_slopes = cfg.slope_term_in_prior = 0
         cfg._keep_slopes = None
+        if fixed_slopes is not None and slopes is None:      # ActFun("genReLU", prm=...): the hidden layers' slopes, the same for every proposal
+            fixed = np.asarray(fixed_slopes, dtype=np.float64).ravel()
+            cfg.n_slopes = len(fixed)
+            for i, v in enumerate(fixed):
+                cfg.cur_slopes[i] = float(v)
         if slopes is not None:        # (slope_idx [K] int32, slope_delta [K], accepted slopes, does cur_logprior hold their term?)
             s_idx = np.ascontiguousarray(slopes[0], dtype=np.int32)
             s_delta = capi.as_f64(slopes[1])
@@ -354,7 +361,7 @@ class HipContext:
 
     def chain_run(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
                   cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0, sigma_mult=None,
-                  hastings=None, slopes=None):
+                  hastings=None, slopes=None, fixed_slopes=None):
         """K device-resident Metropolis-Hastings iterations (npbnn_chain_run).  Returns
         (new packed weights, accepted flags, proposed logLik, proposed logPrior, result dict)."""
         w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights).copy()
@@ -364,7 +371,7 @@ class HipContext:
             cfg = self._chain_cfg = capi.ChainCfg()
             self._chain_res = capi.ChainResult()
         self._fill_chain_cfg(cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
-                             cur_sigma, sigma, n_candidates, schedule, sigma_mult, hastings, slopes)
+                             cur_sigma, sigma, n_candidates, schedule, sigma_mult, hastings, slopes, fixed_slopes)
         m = None if mask is None else (pack_weights(mask) if isinstance(mask, (list, tuple)) else capi.as_f64(mask))
         if idx.dtype != np.int32 or not idx.flags.c_contiguous:
             idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -317,7 +317,10 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_res, ctx->h_res, RL.acc, hipMemcpyHostToDevice, st));
     }
     stage_mark(ctx, "copy of state + weights", &t_stage);
-    for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
+    // activation slopes of the batch: fixed ones (ActFun("genReLU", prm=...): cfg->cur_slopes with no slope draws) go into the network
+    // description every candidate reads; trainable ones travel per candidate in the weight image (slope_idx below)
+    for (int l = 0; l < kMaxLayers; ++l)
+        ctx->net.act_prm[l] = (!cfg->slope_idx && l < cfg->n_slopes && l < NPBNN_MAX_LAYERS) ? (float)cfg->cur_slopes[l] : 0.f;
     ChainParams c{};
     c.st = ctx->d_chain;
     c.pass = reinterpret_cast<PassDesc*>(reinterpret_cast<char*>(ctx->d_eparams) + offsetof(EvalParams, pass_desc));   // inside the evaluation's block

@@ -367,7 +367,8 @@ extern "C" int npbnn_chain_run_general(npbnn_ctx* ctx, const npbnn_chain_cfg* cf
         for (int l = 0; l < kMaxLayers; ++l) g.prior_scale[l] = cfg->prior_scale[l];
         for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) g.sigma_fixed[j] = cfg->sigma[j];
         g.n_rows = d.n_rows;
-        for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
+        for (int l = 0; l < kMaxLayers; ++l)      // (fixed activation slopes: cfg->cur_slopes, as in npbnn_chain_run)
+            ctx->net.act_prm[l] = (!cfg->slope_idx && l < cfg->n_slopes && l < NPBNN_MAX_LAYERS) ? (float)cfg->cur_slopes[l] : 0.f;
         g.net = ctx->net;
         HIP_TRY(ctx, hipMalloc(&b_params.p, sizeof(GenParams)));
         HIP_TRY(ctx, hipMemcpyAsync(b_params.p, &g, sizeof g, hipMemcpyHostToDevice, st));      // (pageable source: staged before the call returns)

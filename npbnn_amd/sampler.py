@@ -146,7 +146,7 @@ class _FastDispatch:
     boundary ahead, an error code from the library - sends the call down :meth:`MCMC.run_steps`'s general path, which builds a
     new one when it applies.  The general path and this one leave the sampler in the same state, draws made ahead included."""
     __slots__ = ("k", "objects", "scalars", "n_bytes", "freq_bytes", "scale_bytes", "ws_src", "ws_copies", "plan", "key_tail", "batch",
-                 "layers", "regression", "fixed_sigma", "n_out", "adapt_possible", "empty", "empty_group")
+                 "layers", "regression", "fixed_sigma", "n_out", "adapt_possible", "empty", "empty_group", "fixed_slopes")
 
     @staticmethod
     def _objects(mcmc, bnn):
@@ -190,6 +190,7 @@ class _FastDispatch:
         self.n_bytes = mcmc._update_n.tobytes()
         self.freq_bytes = mcmc._freq_layer_update.tobytes()
         self.scale_bytes = bnn._prior_scale.tobytes()
+        self.fixed_slopes = mcmc._accepted_slopes(bnn)            # (None unless the activation is genReLU)
         self.ws_src, self.ws_copies, self.plan = cache[0], cache[1], cache[2]
         if len(self.ws_src) != len(mcmc._update_ws) or not all(map(_is, self.ws_src, mcmc._update_ws)):
             return None
@@ -216,6 +217,8 @@ class _FastDispatch:
         # arrays that may be edited in place
         if (mcmc._update_n.tobytes() != self.n_bytes or mcmc._freq_layer_update.tobytes() != self.freq_bytes
                 or bnn._prior_scale.tobytes() != self.scale_bytes):
+            return False
+        if self.fixed_slopes is not None and not np.array_equal(mcmc._accepted_slopes(bnn), self.fixed_slopes):
             return False
         live = mcmc._update_ws
         for src, copy, now in zip(self.ws_src, self.ws_copies, live):
@@ -1029,6 +1032,8 @@ class MCMC():
         extra = {}
         if slope_draws is not None:
             extra["slopes"] = (slope_draws[0], slope_draws[1], np.array(bnn_obj._act_fun._acc_prm, dtype=float), self._slope_term_in_prior)
+        elif bnn_obj._act_fun._function == "genReLU":
+            extra["fixed_slopes"] = self._accepted_slopes(bnn_obj)       # ActFun("genReLU", prm=...) with trainable=False
         return dict(extra, sigma_mult=sigma_mult, hastings=hastings, prior_kind=bnn_obj._prior_kind() if bnn_obj._prior else 0, prior_scale=bnn_obj._prior_scale,
                     w_bound=bnn_obj._w_bound, temperature=self._temperature, lik_temp=self._lik_temp,
                     cur_loglik=self._logLik, cur_logprior=self._logPrior, cur_sigma=cur_sigma, sigma=sigma,

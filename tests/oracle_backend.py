@@ -91,7 +91,7 @@ class OracleChainBackend(OracleBackend):
 
     def run_chain(self, weights, idx, delta, cnt, log_u, prior_kind, prior_scale, w_bound, temperature, lik_temp,
                   cur_loglik, cur_logprior, cur_sigma=None, sigma=None, mask=None, n_candidates=0, schedule=0, sigma_mult=None,
-                  hastings=None):
+                  hastings=None, fixed_slopes=None):
         shapes = [w.shape for w in weights]
         cur = np.concatenate([np.asarray(w, dtype=float).ravel() for w in weights])
         m = None if mask is None else np.concatenate([np.asarray(x, dtype=float).ravel() for x in mask])
@@ -123,10 +123,10 @@ class OracleChainBackend(OracleBackend):
             wl = unpack(prop)
             h = 0.0
             if sigma_mult is not None:             # sigma' = current sigma * pre-drawn factors (BNN_env.py:435-442)
-                r = self._chain_evaluate(wl, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
+                r = self._chain_evaluate(wl, slopes=fixed_slopes, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
                 h = hastings[t]
             else:
-                r = self._chain_evaluate(wl, lik_temp=lik_temp, sigma=sigma)
+                r = self._chain_evaluate(wl, slopes=fixed_slopes, lik_temp=lik_temp, sigma=sigma)
             p = orc.log_prior(wl, prior_kind, prior_scale)
             llp[t], lpp[t] = r["loglik"], p
             if ((r["loglik"] + p) - (ll + lp)) * temperature + h >= log_u[t]:
@@ -140,7 +140,7 @@ class OracleChainBackend(OracleBackend):
     def run_chain_general(self, weights, draws, log_u, mask=None, indicators=None, feature_indicators=None, feature_means=None,
                           prior_ind1=0.5, has_indicator_prior=False, prior_kind=1, prior_scale=None, w_bound=np.inf, temperature=1.0,
                           lik_temp=1.0, cur_loglik=0.0, cur_logprior=0.0, cur_sigma=None, sigma=None, n_candidates=0, schedule=0,
-                          sigma_mult=None, hastings=None):
+                          sigma_mult=None, hastings=None, fixed_slopes=None):
         """numpy stand-in for npbnn_chain_run_general: every iteration builds the full candidate from the pre-drawn numbers."""
         import scipy.stats
         shapes = [w.shape for w in weights]
@@ -196,10 +196,10 @@ class OracleChainBackend(OracleBackend):
                 dd = np.sqrt(0.5 / hf)
                 h = np.sum(scipy.stats.norm.logpdf(cur[hi], 0, dd) - scipy.stats.norm.logpdf(hv, 0, dd))
             if sigma_mult is not None:
-                r = self.evaluate(fw, col_override=override, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
+                r = self.evaluate(fw, slopes=fixed_slopes, col_override=override, lik_temp=lik_temp, sigma=np.asarray(sig, dtype=float) * sigma_mult[t])
                 h += hastings[t]
             else:
-                r = self.evaluate(fw, col_override=override, lik_temp=lik_temp, sigma=sigma)
+                r = self.evaluate(fw, slopes=fixed_slopes, col_override=override, lik_temp=lik_temp, sigma=sigma)
             p = orc.log_prior(wl, prior_kind, prior_scale)
             if has_indicator_prior and ind is not None:
                 n_on = np.sum(ind_p)

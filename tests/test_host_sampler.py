@@ -378,3 +378,49 @@ def test_repeated_dispatches_take_the_short_way_on_cpu(name, randomize_seed, mon
     assert mcmc_b._fast is not None and mcmc_b._fast is not fast       # ... before it keeps a dispatch again)
     if cfg["kind"] == "regression":
         np.testing.assert_allclose(bnn_a._error_prm, bnn_b._error_prm, rtol=1e-12)
+
+
+@pytest.mark.parametrize("short_way", [False, True])
+def test_fixed_genrelu_slopes_reach_the_device_chain(short_way, monkeypatch):
+    """ActFun("genReLU", prm=...) with the slopes NOT trainable: the batches of run_steps carry them (``fixed_slopes`` of the chain's
+    settings) - the device chains used to run such a network with every slope 0 -, and slopes edited in place between calls are
+    noticed by the kept dispatch."""
+    import npbnn_amd.backend as backend_mod
+    monkeypatch.setattr(backend_mod, "FastBatch", _FakeFastBatch)
+    dat = cases.classification_data(11, 300, 7, 3, 20)
+    chains = []
+    for _ in range(2):
+        np.random.seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            bnn = bn.npBNN(dat, n_nodes=[6, 4], actFun=bn.ActFun(fun="genReLU", prm=np.array([0.3, 0.7])), use_bias_node=1,
+                           prior_f=1, p_scale=1, seed=1234, init_std=0.3)
+        backend_cls = _ShortWayBackend if short_way else OracleChainBackend
+        serve_from_oracle(lambda b: backend_cls(b, 0))
+        chains.append((bnn, bn.MCMC(bnn, update_f=[0.1, 0.1, 0.2], update_ws=[0.1, 0.1, 0.1], n_iteration=2000, sampling_f=50,
+                                    print_f=10 ** 6, n_post_samples=5, adapt_f=0, mcmc_id=5)))
+    (bnn_a, mcmc_a), (bnn_b, mcmc_b) = chains
+    k = 30
+    seen = []
+    run_chain = mcmc_b._backend.run_chain
+    mcmc_b._backend.run_chain = lambda *a, **kw: (seen.append(np.array(kw["fixed_slopes"])), run_chain(*a, **kw))[1]
+
+    def advance(n_calls):
+        for _ in range(n_calls * k):
+            mcmc_a.mh_step(bnn_a)
+        for _ in range(n_calls):
+            mcmc_b.run_steps(bnn_b, k)
+        assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+        np.testing.assert_allclose([mcmc_b._logLik, mcmc_b._logPrior], [mcmc_a._logLik, mcmc_a._logPrior], rtol=1e-12)
+
+    advance(6)
+    assert sum(mcmc_a._last_accepted_mem) > 5
+    np.testing.assert_array_equal(seen[-1], [0.3, 0.7])
+    assert (mcmc_b._fast is not None) == short_way
+    for b in (bnn_a, bnn_b):
+        b._act_fun._prm[0] = 0.05                       # in place: the objects the kept dispatch compares are the same ones
+        b._act_fun._acc_prm = b._act_fun._prm + 0
+    for m, b in ((mcmc_a, bnn_a), (mcmc_b, bnn_b)):     # (the current likelihood under the new slopes, for both alike)
+        m._logLik = m._backend.evaluate(b._w_layers, slopes=np.array([0.05, 0.7]))["loglik"]
+        m._logPost = m._logLik + m._logPrior
+    advance(4)
+    np.testing.assert_array_equal(seen[-1], [0.05, 0.7])

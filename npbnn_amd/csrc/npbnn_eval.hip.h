@@ -53,6 +53,16 @@ __device__ __forceinline__ T* uni(T* ptr) { return reinterpret_cast<T*>(uni((lon
 // Launch-invariant scalars of the parameter block, copied once so that they stay in SGPRs: the counted s_waitcnt
 // statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
 // after each of them.
+// Builds that form what they derive from the thread index where it is used (eval_kernel: top of a pass, run_tail, epilogue) instead
+// of letting the compiler hoist it out of the pass and tile loops: the three-candidate Gaussian and block-structured fast builds, whose
+// registers are full - they spilled 6-10 such constants per lane around every pass (config 5: 5 MB of scratch writes per launch).  The
+// others have room and would only pay the handful of extra vector instructions per tile (config 2: +0.3 us per pass, measured).
+#ifndef NPBNN_LAUNDER_TID
+#define NPBNN_LAUNDER_TID (FAST && !SPEC && (BLK || LK == kLikGauss))
+#endif
+#ifndef NPBNN_LAUNDER_TAIL
+#define NPBNN_LAUNDER_TAIL (FAST && !SPEC && (BLK || LK == kLikGauss))
+#endif
 #ifndef NPBNN_FAST3_WAVES
 #define NPBNN_FAST3_WAVES 12
 #endif
@@ -574,7 +584,12 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // through the generic pointer it was a vector load whose readfirstlane waited for every image and X piece requested before it)
     typedef const __attribute__((address_space(4))) ChainParams ConstChainParams;
     ChainDev* const st_dev = chain ? uni(((ConstChainParams*)chain)->st) : nullptr;
-    const int tid = threadIdx.x;
+    // (the thread index through a copy the compiler cannot trace, once at the top of a pass and once behind its tiles: what the prologue
+    // and the epilogue derive from it - patch-list addresses, lane tests - is then formed where it is used, every pass, instead of being
+    // hoisted out of the pass loop of a persistent launch and kept in registers across the tile loop)
+    int tid_pass = threadIdx.x;
+    if constexpr (NPBNN_LAUNDER_TID) asm volatile("" : "+v"(tid_pass));
+    const int tid = tid_pass;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -1017,6 +1032,12 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         return;
 #endif
         const char* a_slot = aux + (tseq & aux_mask) * aux_sz;
+        // (the lane's coordinates through a copy the compiler cannot trace: every address and constant the tail derives from them is then
+        // formed inside the tail - hoisted out of the tile loop, as loop invariants, they are registers alive across layer 0)
+        int lane_t = lane;
+        if constexpr (NPBNN_LAUNDER_TAIL) asm volatile("" : "+v"(lane_t));
+        const int n = lane_t & 15, kq = lane_t >> 4;
+        const int lane = lane_t;
         const long long row = (long long)tile * 16 + n;
         // the candidates go through the tail together (their independent chains interleave) while the registers allow
         constexpr int HT = MT0 > MTI ? MT0 : MTI;
@@ -1264,6 +1285,16 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // sees, on every path: a load whose value is looked at on some paths only - the void flag of the last tile - stays "pending" for it,
     // and the next write to that register, a pass later and behind freshly requested copies, is made to wait for everything in flight)
     __builtin_amdgcn_s_waitcnt(0x0f70);       // s_waitcnt vmcnt(0)
+    const int tid_tiles = tid;
+    {
+    int tid_epi = tid_tiles;
+    if constexpr (NPBNN_LAUNDER_TID) {          // (see the top of the pass)
+        tid_epi = threadIdx.x;
+        asm volatile("" : "+v"(tid_epi));
+    }
+    const int tid = tid_epi;
+    const int lane = tid & 63;
+    const int n = lane & 15, kq = lane >> 4;
 
     NPBNN_ESTAMP(4);
     if (stamps && lane == 0) stamps[(size_t)gridDim.x * 8 + (size_t)bid * 16 + wave] = wall_clock64();   // every wave: tiles done
@@ -1348,6 +1379,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                                                 //  not touch the global image before every workgroup - this one too - has reported done)
             }
         }
+    }
     }
     NPBNN_ESTAMPX(4);
     }       // (next pass of the persistent form)

@@ -407,6 +407,8 @@ def moving_chain(wl):
            "us_per_dispatch_of_100": 1e6 * el4 / 20, "us_fixed_per_dispatch": 1e6 * (el4 / 20 - ITERATIONS_PER_STEP * el5 / 4000),
            "auto_turn_us": {"overlapped": ctx.info(capi.INFO_TURN_NS_OVERLAPPED) / 1e3,
                             "decision_between_passes": ctx.info(capi.INFO_TURN_NS_BETWEEN) / 1e3},
+           "auto_us_per_iteration": {"overlapped": ctx.info(capi.INFO_IT_NS_OVERLAPPED) / 1e3,
+                                     "decision_between_passes": ctx.info(capi.INFO_IT_NS_BETWEEN) / 1e3},
            "accept_rate_last_100": float(mcmc_q._acceptance_rate),
            "accept_rate": float(mcmc_q._device_accepted) / max(1, mcmc_q._device_iterations),
            "schedule": int(mcmc_q._device_schedule_used),

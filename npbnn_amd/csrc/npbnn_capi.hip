@@ -972,6 +972,10 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
         *out = (int)(1000.0 * ctx->turn_us[what == NPBNN_INFO_TURN_NS_BETWEEN ? 1 : 0]);
         return NPBNN_OK;
     }
+    if (what == NPBNN_INFO_IT_NS_OVERLAPPED || what == NPBNN_INFO_IT_NS_BETWEEN) {
+        *out = (int)(1000.0 * ctx->it_us[what == NPBNN_INFO_IT_NS_BETWEEN ? 1 : 0]);
+        return NPBNN_OK;
+    }
     if (what == NPBNN_INFO_MAX_CANDIDATES) {        // what plan_launch would give a chain pass that asks for as many as fit
         *out = 1;
         if (!ctx->arch_set || !ctx->ds[0].X) return NPBNN_OK;

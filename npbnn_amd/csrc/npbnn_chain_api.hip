@@ -158,23 +158,29 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         if (alone_on_device && seg_len == 0 && !ctx->sync_failed && ctx->persist_option && p_acc > 0.0 && group_blocks == 0 &&
             !cfg->slope_idx && M <= kPersistSerialMaxWidth && lp.fn_spec != nullptr &&
             (cfg->prior_kind == NPBNN_PRIOR_UNIFORM || (cfg->prior_kind == NPBNN_PRIOR_NORMAL && !cfg->prior_scale_w))) {
+            // What decides is what a form was MEASURED to cost per iteration on this chain (npbnn_ctx.it_us: a batch's time over its
+            // iterations); the model - a decided pass costs (1 + a) turns overlapped, a turn + `extra` with the decision between the
+            // passes - only prices the form that has not run yet from the one that has.
             const double a = 1.0 - std::pow(1.0 - p_acc, D);                 // share of the passes that accept something
+            const double ipp = a / p_acc;                                    // iterations a decided pass settles: 1 + (1-p) + ... + (1-p)^(D-1)
             const double extra = kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M;
-            double t_over = ctx->turn_us[0], t_serial = ctx->turn_us[1];
-            if (t_over <= 0.0 && t_serial <= 0.0) t_over = kTurnUsGuess;
-            if (t_over <= 0.0) t_over = t_serial - extra > 5.0 ? t_serial - extra : 5.0;
-            if (t_serial <= 0.0) t_serial = t_over + extra;
+            double c_over = ctx->it_us[0], c_ser = ctx->it_us[1];            // us per iteration
+            if (c_over <= 0.0 && c_ser <= 0.0) c_over = kTurnUsGuess * (1.0 + a) / ipp;
+            if (c_over <= 0.0) {
+                const double t_over = c_ser * ipp - extra > 5.0 ? c_ser * ipp - extra : 5.0;
+                c_over = t_over * (1.0 + a) / ipp;
+            }
+            if (c_ser <= 0.0) c_ser = (c_over * ipp / (1.0 + a) + extra) / ipp;
             // (3 % in favour of the form the chain is on: no flipping on noise)
             const bool on_serial = ctx->last_schedule == NPBNN_SCHED_PERSIST_SERIAL;
-            if (t_serial * (on_serial ? 0.97 : 1.03) < t_over * (1.0 + a)) schedule = NPBNN_SCHED_PERSIST_SERIAL;
-            // an estimate that was measured goes stale while the other form runs (the chain's acceptance rate moves, the box's clocks
-            // do): after kTurnReprobeBatches batches on one form, one batch on the other - if it is within reach (a factor 1.25)
+            if (c_ser * (on_serial ? 0.97 : 1.03) < c_over) schedule = NPBNN_SCHED_PERSIST_SERIAL;
+            // a measured cost goes stale while the other form runs (the chain's acceptance rate moves, the box's clocks do): after
+            // kTurnReprobeBatches batches on one form, one batch on the other - if it is within reach (a factor 1.25) or was never run
             const int other = schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1;
-            if (ctx->turn_us[other] > 0.0 && ctx->turn_batches[other] >= kTurnReprobeBatches) {
-                const double c_ser = t_serial, c_over = t_over * (1.0 + a);
+            if (ctx->turn_batches[other] >= kTurnReprobeBatches) {
                 const double ratio = other == 1 ? c_ser / c_over : c_over / c_ser;
                 ctx->turn_batches[other] = 0;
-                if (ratio < 1.25) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
+                if (ratio < 1.25 || ctx->it_us[other] <= 0.0) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
             }
         }
     }
@@ -721,6 +727,10 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         // that lost is not run again, so nothing would ever correct its estimate: a sample counts for at most 1.25 x the estimate
         if (t > 0.0 && now_us > 1.25 * t) now_us = 1.25 * t;
         t = t > 0.0 ? 0.75 * t + 0.25 * now_us : now_us;
+        double& c = ctx->it_us[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0];      // ... and what an iteration cost on it
+        double it_now = (tw2 - B.tw1) / K;
+        if (c > 0.0 && it_now > 1.25 * c) it_now = 1.25 * c;
+        c = c > 0.0 ? 0.75 * c + 0.25 * it_now : it_now;
         ctx->turn_batches[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0] = 0;
         ctx->turn_batches[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1] += 1;
     }

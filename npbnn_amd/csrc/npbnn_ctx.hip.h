@@ -150,6 +150,7 @@ struct npbnn_ctx {
     int last_schedule = 0;         // schedule of the previous batch
     int turn_batches[2] = {0, 0};   // batches run since that form's turn time was last measured (kTurnReprobeBatches)
     double turn_us[2] = {0.0, 0.0}; // measured time of a launch turn (pass, decided or void) of the persistent forms: overlapped, decision between passes
+    double it_us[2] = {0.0, 0.0};   // measured time per ITERATION of a batch on each of them (what NPBNN_SCHED_AUTO compares)
     double its_per_pass = 0.0;     // iterations a launch decided on average in the previous batch (0: unknown)
     double accept_rate = -1.0;     // acceptance rate of the previous batch (< 0: unknown)
     double* d_wcur = nullptr;
@@ -213,9 +214,10 @@ namespace npbnn_api {
 // NPBNN_SCHED_AUTO between the two persistent forms.  Overlapped (PERSIST): a pass that accepts voids the pass in flight behind it - a
 // decided pass costs (1 + a) turns, a = 1 - (1 - p)^D the share of passes that accept something.  Decision between the passes
 // (PERSIST_SERIAL): no pass in vain, but every turn is longer by the decision and by what the step workgroup cannot hide of preparing
-// the next pass for every outcome - more, the wider the proposals.  The context keeps the turn times it measured (npbnn_ctx.turn_us) and
-// picks the form with the lower predicted cost per decided pass; a form not measured yet is predicted from the other one with
-// kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M (measured on config-2 shapes: 33.2 against 28.5 us per turn at M = 33, 40 at M = 428).
+// the next pass for every outcome - more, the wider the proposals.  The context keeps what an iteration cost on each form
+// (npbnn_ctx.it_us: a batch's time over its iterations) and picks the cheaper one; a form that has not run yet is priced from the other
+// one with that model and kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M (measured on config-2 shapes: 33.2 against 28.5 us per turn
+// at M = 33, 40 at M = 428), and is given one batch after kTurnReprobeBatches batches on the other whatever the model says.
 constexpr double kSpecTurnExtraUs = 4.5, kSpecTurnExtraUsPerWeight = 0.0175;
 constexpr double kTurnUsGuess = 30.0;           // before anything has been measured
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed

@@ -106,6 +106,25 @@ def test_no_spills_inside_the_tile_loop():
     assert not problems, "\n".join(problems)
 
 
+@pytest.mark.skipif(not os.path.exists(LLVM + "/llvm-objdump"), reason="no ROCm LLVM tools")
+def test_three_candidate_fast_builds_spill_nothing_anywhere():
+    """The chain kernels of the BASELINE configurations (fast builds, three candidates per pass) keep every value of the evaluating
+    workgroups in registers - prologue and epilogue of a pass included, not only the tile loop: config 5's block-structured Gaussian
+    build used to park seven lane-derived constants in scratch around every pass (5 MB of scratch writes per launch, round 3; gone
+    with NPBNN_LAUNDER_TID / _TAIL, csrc/npbnn_eval.hip.h).  What is left in the Gaussian builds is the step workgroup's sigma array
+    (loglik_from_totals: 6 scratch instructions, once per decided candidate, one thread)."""
+    allowed_by_likelihood = {0: 0, 1: 6}
+    seen = 0
+    for obj in _objects():
+        unit = os.path.splitext(os.path.basename(obj))[0]
+        if not (unit.startswith("npbnn_eval_inst_d3_") and unit.endswith("_fast")):
+            continue
+        for args, (hot, total) in sorted(_kernels(obj).items()):
+            seen += 1
+            assert hot == 0 and total <= allowed_by_likelihood[args[4]], "%s<%s>: %d scratch instructions (%d in the tile loop)" % (unit, args, total, hot)
+    assert seen >= 10
+
+
 def test_three_candidate_builds_stop_at_two_output_tiles():
     """max_cand_for (csrc/npbnn_eval.hip.h): no D = 3 build of a first layer with three or more output tiles is shipped."""
     for obj in _objects():

@@ -1,13 +1,14 @@
 #!/bin/bash
 # The rocprofv3 evidence of a round, collected on the GPU box from the repository root:
-#   gpurun -- 'bash tools/collect_profiles.sh r02'
+#   gpurun -- 'bash tools/collect_profiles.sh r02'            (a second argument names the configs: "5", "2 4" ... default all)
 # kernel-trace statistics of the default bench run per config, and FETCH_SIZE / WRITE_SIZE of the pass kernel (separate --pmc
 # passes, nothing else traced with them).  Everything lands under gpurun_out/prof_<tag>/; copy what is to be kept into profiles/.
 tag=${1:-r04}
+configs=${2:-"2 4 5 0"}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for c in 2 4 5 0; do      # (0: config 2's data under the reference's default network [50,5]: one candidate per pass fits)
+for c in $configs; do      # (0: config 2's data under the reference's default network [50,5]: one candidate per pass fits)
   # one launch per pass (schedule 2): a launch's duration in the trace is the pass kernel's own, comparable with roofline.kernel_ms
   NPBNN_BENCH_SCHEDULE=2 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c$c -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_under_rocprof.json 2> $out/bench_c$c.err || echo "bench profile of config $c failed"
   # the default command (persistent launch: one kernel per run_steps call loops over the passes)
@@ -27,7 +28,7 @@ find $out -name "*.csv" | head -50
 keep=$out/keep
 mkdir -p $keep
 first() { find "$1" -name "$2" 2>/dev/null | head -1; }
-for c in 2 4 5 0; do
+for c in $configs; do
   f=$(first $out/bench_c$c "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_bench_cfg${c}_kernel_stats.csv
   f=$(first $out/bench_c${c}_persistent "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_bench_cfg${c}_persistent_kernel_stats.csv
   cp $out/bench_c${c}_under_rocprof.json $keep/${tag}_bench_cfg${c}_under_rocprof.json 2>/dev/null

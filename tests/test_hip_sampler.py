@@ -764,3 +764,44 @@ def test_device_chain_is_the_mh_step_loop_on_random_shapes(seed):
     np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
     if model_kw.get("estimation_mode") == "regression":
         np.testing.assert_allclose(np.ones(bnn_a._size_output) * bnn_a._error_prm, np.ones(bnn_b._size_output) * bnn_b._error_prm, rtol=1e-12)
+
+
+def test_automatic_schedule_goes_by_the_cost_it_measured():
+    """NPBNN_SCHED_AUTO between the two persistent forms on a chain that moves (config-2 shapes, a quarter of the proposals
+    accepted): the library times every batch over its iterations, per form, and runs the cheaper one; a form that has not
+    run yet gets a batch of its own sooner or later.  Whatever it picks, the chain is the one a fixed schedule runs."""
+    from npbnn_amd import _capi as capi
+    rs = np.random.default_rng(0)
+    n, f, c = 100_000, 256, 10
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    proj = rs.standard_normal((f, c)) / np.sqrt(f)
+    y = np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)
+    dat = dict(data=x, labels=y, test_data=np.zeros((0, f)), test_labels=np.zeros(0))
+
+    def chain(sched, calls):
+        np.random.seed(1234)
+        bnn = quiet(bn.npBNN, dat, n_nodes=[32, 8], actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+        m = bn.MCMC(bnn, update_f=[0.004] * 3)
+        m.device_schedule = sched
+        used = []
+        for _ in range(calls):
+            m.run_steps(bnn, 100)
+            used.append(m._device_schedule_used)
+        return bnn, m, used
+
+    calls = 70                                        # (past the 48 batches after which the other form is given one)
+    ba, ma, used = chain(0, calls)
+    ctx = ma._backend.ctx
+    cost = [ctx.info(capi.INFO_IT_NS_OVERLAPPED) / 1e3, ctx.info(capi.INFO_IT_NS_BETWEEN) / 1e3]      # us per iteration
+    assert set(used) <= {4, 5} and set(used) == {4, 5}, "both persistent forms get to run: %s" % sorted(set(used))
+    assert all(2.0 < v < 200.0 for v in cost), cost
+    late = used[-10:]
+    cheaper = 4 if cost[0] < cost[1] else 5
+    if abs(cost[0] - cost[1]) > 0.1 * min(cost):      # (a clear difference: the last batches are on the cheaper form, re-probes aside)
+        assert late.count(cheaper) >= 8, (late, cost)
+    assert 0.1 < ma._device_accepted / ma._device_iterations < 0.5
+    bb, mb, _ = chain(4, calls)
+    assert ma._last_accepted_mem == mb._last_accepted_mem
+    assert (ma._logLik, ma._logPrior) == (mb._logLik, mb._logPrior)
+    for wa, wb in zip(ba._w_layers, bb._w_layers):
+        np.testing.assert_array_equal(wa, wb)

@@ -408,8 +408,17 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
             for (int item = wave; item < n_pend * nvals; item += nw) {
                 const int j = item / nvals, v = partial_value_index(item % nvals, c.net.k_targets);
                 const double* src = part + ((size_t)j * kPartialStride + v) * c.n_blocks;
+                double x[4];           // (requested together, added in order: see spec_rounds)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = lane + 64 * u;
+                    x[u] = b < c.n_blocks ? src[b] : 0.0;
+                }
                 double s = 0.0;
-                for (int b = lane; b < c.n_blocks; b += 64) s += src[b];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lane + 64 * u < c.n_blocks) s += x[u];
+                for (int b = lane + 256; b < c.n_blocks; b += 64) s += src[b];
                 s = butterfly_sum_f64(s);
                 if (lane == 0) sh.tot[j][v] = s;
             }
@@ -1054,8 +1063,19 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
             for (int item = wave; item < n_pend * nvals; item += nwv) {
                 const int j = item / nvals, v = partial_value_index(item % nvals, k_targets);
                 const double* src = part + ((size_t)j * kPartialStride + v) * n_blocks;
+                // (a lane's values - workgroups lane, lane + 64, ... - requested TOGETHER, then added in that order: one round trip past the
+                // caches instead of one per value; this sits between two passes, on the chain's critical path)
+                double x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = lane + 64 * u;
+                    x[u] = b < n_blocks ? __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                }
                 double s = 0.0;
-                for (int b = lane; b < n_blocks; b += 64) s += __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lane + 64 * u < n_blocks) s += x[u];
+                for (int b = lane + 256; b < n_blocks; b += 64) s += __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s = butterfly_sum_f64(s);
                 if (lane == 0) sh.tot[j][v] = s;
             }

@@ -159,7 +159,8 @@ enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTEN
 enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
 /* NPBNN_INFO_TURN_NS_OVERLAPPED / _BETWEEN: what NPBNN_SCHED_AUTO last measured for one launch turn (a pass, decided or void) of the
  * two persistent forms, in nanoseconds (0: never run on this context); NPBNN_INFO_IT_NS_OVERLAPPED / _BETWEEN: what an ITERATION of a
- * batch cost on each of them - the figure NPBNN_SCHED_AUTO compares.  NPBNN_INFO_MAX_CANDIDATES: weight sets one pass over the
+ * batch cost on each of them - the figure NPBNN_SCHED_AUTO compares, kept apart for batches of fewer than 256 iterations (reported
+ * here when measured) and longer ones.  NPBNN_INFO_MAX_CANDIDATES: weight sets one pass over the
  * data can carry for this network (1-3: what fits a compute unit's LDS, and two from three layer-0 output tiles on) - the
  * candidates of a speculative chain pass, the chains of a group pass (npbnn_chains_run_batched), the sets of npbnn_predict_sets. */
 enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3, NPBNN_INFO_FAST_TAILS = 4,

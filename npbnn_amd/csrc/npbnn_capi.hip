@@ -973,7 +973,8 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
         return NPBNN_OK;
     }
     if (what == NPBNN_INFO_IT_NS_OVERLAPPED || what == NPBNN_INFO_IT_NS_BETWEEN) {
-        *out = (int)(1000.0 * ctx->it_us[what == NPBNN_INFO_IT_NS_BETWEEN ? 1 : 0]);
+        const double* c = ctx->it_us[what == NPBNN_INFO_IT_NS_BETWEEN ? 1 : 0];      // (short batches - dispatches of 100 - when measured, else long ones)
+        *out = (int)(1000.0 * (c[0] > 0.0 ? c[0] : c[1]));
         return NPBNN_OK;
     }
     if (what == NPBNN_INFO_MAX_CANDIDATES) {        // what plan_launch would give a chain pass that asks for as many as fit

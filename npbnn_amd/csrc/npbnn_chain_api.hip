@@ -164,7 +164,8 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
             const double a = 1.0 - std::pow(1.0 - p_acc, D);                 // share of the passes that accept something
             const double ipp = a / p_acc;                                    // iterations a decided pass settles: 1 + (1-p) + ... + (1-p)^(D-1)
             const double extra = kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M;
-            double c_over = ctx->it_us[0], c_ser = ctx->it_us[1];            // us per iteration
+            const int kc = K < kShortBatch ? 0 : 1;                          // (a form's fixed cost per batch differs: short and long batches apart)
+            double c_over = ctx->it_us[0][kc], c_ser = ctx->it_us[1][kc];    // us per iteration
             if (c_over <= 0.0 && c_ser <= 0.0) c_over = kTurnUsGuess * (1.0 + a) / ipp;
             if (c_over <= 0.0) {
                 const double t_over = c_ser * ipp - extra > 5.0 ? c_ser * ipp - extra : 5.0;
@@ -175,12 +176,20 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
             const bool on_serial = ctx->last_schedule == NPBNN_SCHED_PERSIST_SERIAL;
             if (c_ser * (on_serial ? 0.97 : 1.03) < c_over) schedule = NPBNN_SCHED_PERSIST_SERIAL;
             // a measured cost goes stale while the other form runs (the chain's acceptance rate moves, the box's clocks do): after
-            // kTurnReprobeBatches batches on one form, one batch on the other - if it is within reach (a factor 1.25) or was never run
+            // kTurnReprobeBatches batches on one form, one batch on the other - if it is within reach or was never run
+            // (a form's first batch in a size class pays for the switch - other builds of the kernel, cold tables: it runs a second one
+            // before its figure is held against the other's)
+            if (ctx->it_n[0][kc] == 1) schedule = NPBNN_SCHED_PERSIST;
+            else if (ctx->it_n[1][kc] == 1) schedule = NPBNN_SCHED_PERSIST_SERIAL;
             const int other = schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1;
-            if (ctx->turn_batches[other] >= kTurnReprobeBatches) {
+            // (a form never measured in this size class gets its batch after a handful on the other: the model is a prior, not a verdict -
+            // it prices every accept of the overlapped form at a whole pass in vain, and such a pass is cut short)
+            if (ctx->turn_batches[other][kc] >= (ctx->it_us[other][kc] <= 0.0 ? kTurnFirstProbeBatches : kTurnReprobeBatches)) {
                 const double ratio = other == 1 ? c_ser / c_over : c_over / c_ser;
-                ctx->turn_batches[other] = 0;
-                if (ratio < 1.25 || ctx->it_us[other] <= 0.0) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
+                ctx->turn_batches[other][kc] = 0;
+                // (within a factor two, that is: the other form's figure dates from when it last ran - the chain's acceptance rate has
+                // moved since, and with it both forms' costs; one batch in kTurnReprobeBatches costs a per cent at worst)
+                if (ratio < 2.0 || ctx->it_us[other][kc] <= 0.0) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
             }
         }
     }
@@ -727,12 +736,18 @@ int npbnn_chain_run(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, double* W_inout,
         // that lost is not run again, so nothing would ever correct its estimate: a sample counts for at most 1.25 x the estimate
         if (t > 0.0 && now_us > 1.25 * t) now_us = 1.25 * t;
         t = t > 0.0 ? 0.75 * t + 0.25 * now_us : now_us;
-        double& c = ctx->it_us[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0];      // ... and what an iteration cost on it
+        const int form = B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0, kc = K < kShortBatch ? 0 : 1;
+        double& c = ctx->it_us[form][kc];                  // ... and what an iteration cost on it, in batches of this size class
         double it_now = (tw2 - B.tw1) / K;
-        if (c > 0.0 && it_now > 1.25 * c) it_now = 1.25 * c;
-        c = c > 0.0 ? 0.75 * c + 0.25 * it_now : it_now;
-        ctx->turn_batches[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 1 : 0] = 0;
-        ctx->turn_batches[B.schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1] += 1;
+        int& n_seen = ctx->it_n[form][kc];
+        if (n_seen == 1) c = it_now < c ? it_now : c;      // (the better of a form's first two batches)
+        else {
+            if (c > 0.0 && it_now > 1.25 * c) it_now = 1.25 * c;
+            c = c > 0.0 ? 0.75 * c + 0.25 * it_now : it_now;
+        }
+        if (n_seen < 1000) ++n_seen;
+        ctx->turn_batches[form][kc] = 0;
+        ctx->turn_batches[1 - form][kc] += 1;
     }
     if (timing && ctx->d_spec && B.schedule == NPBNN_SCHED_PERSIST_SERIAL) {
         SpecState hs;

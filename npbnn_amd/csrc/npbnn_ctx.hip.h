@@ -148,9 +148,12 @@ struct npbnn_ctx {
     size_t res_cap = 0, res_k = 0, res_nw = 0;
     int* d_chain_ovf = nullptr;
     int last_schedule = 0;         // schedule of the previous batch
-    int turn_batches[2] = {0, 0};   // batches run since that form's turn time was last measured (kTurnReprobeBatches)
+    int turn_batches[2][2] = {{0, 0}, {0, 0}};   // [form][batch-size class] batches run since that form was last measured in that class (kTurnReprobeBatches)
     double turn_us[2] = {0.0, 0.0}; // measured time of a launch turn (pass, decided or void) of the persistent forms: overlapped, decision between passes
-    double it_us[2] = {0.0, 0.0};   // measured time per ITERATION of a batch on each of them (what NPBNN_SCHED_AUTO compares)
+    int it_n[2][2] = {{0, 0}, {0, 0}};           // [form][batch-size class] batches that went into it_us (the first one of a form is slow: a second follows it)
+    double it_us[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [form][batch-size class] measured time per ITERATION of a batch (what NPBNN_SCHED_AUTO
+                                    // compares); classes: batches of fewer than kShortBatch iterations, and the others - a form's fixed
+                                    // cost per batch differs, so what wins in dispatches of 100 need not win in sub-batches of 512
     double its_per_pass = 0.0;     // iterations a launch decided on average in the previous batch (0: unknown)
     double accept_rate = -1.0;     // acceptance rate of the previous batch (< 0: unknown)
     double* d_wcur = nullptr;
@@ -217,9 +220,13 @@ namespace npbnn_api {
 // the next pass for every outcome - more, the wider the proposals.  The context keeps what an iteration cost on each form
 // (npbnn_ctx.it_us: a batch's time over its iterations) and picks the cheaper one; a form that has not run yet is priced from the other
 // one with that model and kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M (measured on config-2 shapes: 33.2 against 28.5 us per turn
-// at M = 33, 40 at M = 428), and is given one batch after kTurnReprobeBatches batches on the other whatever the model says.
+// at M = 33, 40 at M = 428), and is given one batch after kTurnFirstProbeBatches batches on the other whatever the model says (then
+// one every kTurnReprobeBatches while within a factor two: measurements go stale).  Short batches (dispatches of 100) and long ones (the
+// sub-batches of a long call) are measured and decided apart.
 constexpr double kSpecTurnExtraUs = 4.5, kSpecTurnExtraUsPerWeight = 0.0175;
 constexpr double kTurnUsGuess = 30.0;           // before anything has been measured
+constexpr int kShortBatch = 256;                // batches below / from this many iterations are measured (and decided) apart
+constexpr int kTurnFirstProbeBatches = 4;       // batches on one persistent form before the other, never measured, is given one
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)

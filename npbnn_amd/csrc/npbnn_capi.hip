@@ -157,7 +157,11 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
                 net.l0_begin[mt] = b; net.l0_end[mt] = e; net.l0_base[mt] = slots;
                 slots += e - b;
             }
-            off += slots * (f16 ? 512 : 256);
+            // rows per tile in the image (NetMeta::l0_rows): a dense fp16-split first layer of three or more tiles whose width is not a
+            // multiple of 16 is stored without its padding rows (the builds for one and two tiles - every BASELINE shape - keep 16)
+            net.l0_rows = 16;
+            if (f16 && ctx->l0_blocks.empty() && L.mt >= 3 && out % 16 != 0 && !getenv("NPBNN_NO_COMPACT_ROWS")) net.l0_rows = (out + L.mt - 1) / L.mt;
+            off += slots * (f16 ? 32 * net.l0_rows : 256);
         } else if (l == 1 && net.l1_f16) {
             off += ((net.L[0].mt + 1) / 2) * 512;      // a high and a low block of 256 floats per K-step
         } else {
@@ -613,17 +617,20 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
                 const size_t wi = (size_t)L.w_off + (size_t)o * ld + j;
                 int pos;
                 const bool in_perm = l >= 1 && ctx->net.L[l - 1].out_perm;      // (a permuted layer has a single tile: o, c < 16)
-                if (L.has_bias && j == 0) pos = L.bias_off + (L.out_perm ? tile_pos(o) : o);
+                const int rows = f16 ? ctx->net.l0_rows : 16;         // (NetMeta::l0_rows: layer 0's units per tile in this image)
+                if (L.has_bias && j == 0) pos = L.bias_off + (L.out_perm ? tile_pos(o) : (l == 0 && rows < 16) ? l0_pos_of_unit(o, rows) : o);
                 else {
-                    const int c = in_perm ? tile_pos(j - L.has_bias) : j - L.has_bias;
-                    const int mt = o / 16, u = L.out_perm ? tile_pos(o) : o % 16;
+                    int c = in_perm ? tile_pos(j - L.has_bias) : j - L.has_bias;
+                    if (l == 1 && rows < 16) c = l0_pos_of_unit(c, rows);       // (the position layer 0 leaves that unit at)
+                    int mt = o / 16, u = L.out_perm ? tile_pos(o) : o % 16;
                     if (l == 0 && f16) {
+                        mt = o / rows; u = o % rows;
                         const int ks = c / 32, kg = (c % 32) / 8, jj = c % 8;
                         if (ks < ctx->net.l0_begin[mt] || ks >= ctx->net.l0_end[mt]) pos = kSkipPos;     // outside the block structure: always 0
                         else {
                             const int slot = ctx->net.l0_base[mt] + ks - ctx->net.l0_begin[mt];
-                            const int half_index = 2 * L.frag_off + (((slot * 2) * 64) + kg * 16 + u) * 8 + jj;
-                            pos = (int)(0x80000000u | (unsigned)half_index);
+                            const int half_index = 2 * L.frag_off + ((slot * 2) * (4 * rows) + kg * rows + u) * 8 + jj;
+                            pos = (int)(0x80000000u | (rows < 16 ? (unsigned)kPosCompact : 0u) | (unsigned)half_index);
                         }
                         scale[wi] = wscale[(size_t)c];
                     } else if (l == 0) {

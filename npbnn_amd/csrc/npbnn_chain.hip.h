@@ -219,21 +219,24 @@ __global__ void __launch_bounds__(256) gather_pos_kernel(int* __restrict__ idx, 
 }
 #endif  // NPBNN_KERNELS_CHAIN
 
-__device__ __forceinline__ void patch_image(float* image, int pos, float scale, double v) {
+// l0_rows: NetMeta::l0_rows of the image (where the low part of a layer-0 entry marked kPosCompact sits)
+__device__ __forceinline__ void patch_image(float* image, int pos, float scale, double v, int l0_rows) {
     if (pos == 0x7fffffff) return;                   // an entry the image does not hold (outside the layer-0 block structure: it is 0)
-    if (pos < 0) {                                   // fp16-split layer-0 entry
+    if (pos < 0) {                                   // fp16-split entry (layer 0, or layer 1 of NetMeta::l1_f16)
         const float wv = (float)(v * (double)scale);
         _Float16 hi, lo;
         split_f16(wv, hi, lo);
         _Float16* img16 = reinterpret_cast<_Float16*>(image);
-        const int h = pos & 0x7fffffff;
+        const int h = pos & 0x3fffffff;
         img16[h] = hi;
-        img16[h + 512] = lo;
+        img16[h + ((pos & kPosCompact) ? 32 * l0_rows : 512)] = lo;
     } else {
         image[pos] = (float)v;
     }
 }
-__device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) { patch_image(c.image, pos, scale, v); }
+__device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) {
+    patch_image(c.image, pos, scale, v, c.net.l0_rows);
+}
 
 // block-wide sum of one double per thread, fixed order; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double* red /*LDS, >= 16 doubles*/) {
@@ -815,6 +818,7 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
     double* const g_spec_pv = sgp(c.spec_pv);
     double* const Wc = sgp(c.w_cur);
     float* const g_image = sgp(c.image);
+    const int l0_rows_img = sg(c.net.l0_rows);
     const double* const g_smult = sgp(c.sigma_mult);
     unsigned char* const g_out_acc = sgp(c.out_acc);
     double* const g_out_ll = sgp(c.out_ll);
@@ -1151,7 +1155,7 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
                 const float sc = pscale_p[row + e];
                 if (i >= 0) {
                     Wc[i] = v;
-                    patch_image(g_image, pos, has_sc ? sc : 1.0f, v);
+                    patch_image(g_image, pos, has_sc ? sc : 1.0f, v, l0_rows_img);
                 }
             }
         }

@@ -83,8 +83,21 @@ struct NetMeta {
                         // of each, which are positions 8 kq + 0..7 of the step.  3 MFMAs of 16 cycles per step instead of 8 of 32.
     int slope_off;      // >= 0: float offset of kMaxLayers slots for per-candidate activation slopes (NPBNN_OPT_TRAINABLE_SLOPES; a chain
                         // pass writes each candidate's slopes into its LDS image copy), else -1
-    int pad_slope_;
+    int l0_rows;        // output units per layer-0 tile IN THE IMAGE of the fp16-split path: 16, or - a dense first layer of three or more
+                        // tiles whose width is not a multiple of 16 - ceil(width / tiles): unit o then sits at position 16 (o / rows) + o % rows
+                        // instead of o, a fragment slot holds rows instead of 16 rows (2 parts x 4 feature groups x rows x 16 bytes), and the
+                        // lanes of the padding rows read the tile's last real row (finite values that meet zero weights in layer 1).
+                        // The reference's default [50, 5] on 256 features: 57 KB instead of 70 KB per candidate - two fit the LDS
 };
+// the layer-0 unit at output position `pos` of such an image (-1: a padding position), and the other way round
+__host__ __device__ inline int l0_unit_at(int pos, int rows, int out_dim) {
+    const int t = pos >> 4, u = pos & 15;
+    if (u >= rows) return -1;
+    const int o = t * rows + u;
+    return o < out_dim ? o : -1;
+}
+__host__ __device__ inline int l0_pos_of_unit(int o, int rows) { return (o / rows) * 16 + o % rows; }
+constexpr int kPosCompact = 0x40000000;      // (image positions of fp16-split entries, bit 30: the low part sits 32 * l0_rows halves behind the high part, not 512)
 
 constexpr float kPadLogit = -3.0e38f;     // finite: (pad - max) stays finite, exp of it is exactly 0
 constexpr int kMaxCand = 3;    // candidates evaluated per pass over X by a speculative chain

@@ -54,14 +54,14 @@ __device__ __forceinline__ T* uni(T* ptr) { return reinterpret_cast<T*>(uni((lon
 // statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
 // after each of them.
 // Builds that form what they derive from the thread index where it is used (eval_kernel: top of a pass, run_tail, epilogue) instead
-// of letting the compiler hoist it out of the pass and tile loops: the three-candidate Gaussian and block-structured fast builds, whose
-// registers are full - they spilled 6-10 such constants per lane around every pass (config 5: 5 MB of scratch writes per launch).  The
+// of letting the compiler hoist it out of the pass and tile loops: the three-candidate Gaussian and block-structured fast builds and
+// the builds for three or more layer-0 tiles, whose registers are full - they spilled 6-10 such constants per lane around every pass (config 5: 5 MB of scratch writes per launch).  The
 // others have room and would only pay the handful of extra vector instructions per tile (config 2: +0.3 us per pass, measured).
 #ifndef NPBNN_LAUNDER_TID
-#define NPBNN_LAUNDER_TID (FAST && !SPEC && (BLK || LK == kLikGauss))
+#define NPBNN_LAUNDER_TID (FAST && !SPEC && (BLK || LK == kLikGauss || MT0 >= 3))
 #endif
 #ifndef NPBNN_LAUNDER_TAIL
-#define NPBNN_LAUNDER_TAIL (FAST && !SPEC && (BLK || LK == kLikGauss))
+#define NPBNN_LAUNDER_TAIL (FAST && !SPEC && (BLK || LK == kLikGauss || MT0 >= 3))
 #endif
 #ifndef NPBNN_FAST3_WAVES
 #define NPBNN_FAST3_WAVES 12
@@ -919,6 +919,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     NPBNN_ESTAMP(2);
 #pragma unroll
     for (int j = 0; j < D; ++j) asm volatile("" : "+v"(ppos[j]), "+v"(pval[j]), "+v"(psc[j]));      // (nothing computed from them in front of the barrier)
+    // where the low part of a patched fp16-split entry goes (NetMeta::l0_rows: only first layers of three or more tiles are ever stored
+    // with fewer than 16 rows per tile - the builds for one and two tiles keep the constant)
+    const int l0_rows_img = MT0 >= 3 ? uni(net.l0_rows) : 16;
+    auto lo_halves = [&](int pos) { return (MT0 >= 3 && (pos & kPosCompact)) ? 32 * l0_rows_img : 512; };
     if (acc_cnt > 0) {                        // every candidate starts from the accepted state
         auto put = [&](int pos, double v, float sc) {
             if (pos == kSkipPos) return;
@@ -929,9 +933,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     _Float16 hi, lo;
                     split_f16((float)(v * (double)sc), hi, lo);
                     _Float16* i16 = reinterpret_cast<_Float16*>(imgj);
-                    const int hpos = pos & 0x7fffffff;
+                    const int hpos = pos & 0x3fffffff;
                     i16[hpos] = hi;
-                    i16[hpos + 512] = lo;
+                    i16[hpos + lo_halves(pos)] = lo;
                 } else {
                     imgj[pos] = (float)v;
                 }
@@ -954,9 +958,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 _Float16 hi, lo;
                 split_f16((float)(v * (double)sc), hi, lo);
                 _Float16* i16 = reinterpret_cast<_Float16*>(imgj);
-                const int hpos = pos & 0x7fffffff;
+                const int hpos = pos & 0x3fffffff;
                 i16[hpos] = hi;
-                i16[hpos + 512] = lo;
+                i16[hpos + lo_halves(pos)] = lo;
             } else {
                 imgj[pos] = (float)v;
             }
@@ -997,7 +1001,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     }
 
     const float* const imgs = reinterpret_cast<const float*>(smem);
-    const int frag0_off = uni(net.L[0].frag_off) + lane * 4;       // float offsets inside an image
+    // float offsets inside an image.  Builds for three or more layer-0 tiles read fragment slots of NetMeta::l0_rows rows (16, or fewer
+    // when the layer's width is not a multiple of 16: the lanes of the padding rows read the tile's last real row)
+    const int l0_rows = (F16 && MT0 >= 3) ? uni(net.l0_rows) : 16;
+    const int slot_f = (F16 && MT0 >= 3) ? 32 * l0_rows : 512, lo_f = (F16 && MT0 >= 3) ? 16 * l0_rows : 256;      // floats per slot; low part behind the high part
+    const int frag0_off = uni(net.L[0].frag_off) + ((F16 && MT0 >= 3) ? (kq * l0_rows + (n < l0_rows ? n : l0_rows - 1)) * 4 : lane * 4);
     const int bias0_off = uni(net.L[0].bias_off) + 4 * kq;
     // block structure of layer 0 (NetMeta::l0_begin ...): output tile mt has fragments for the K-units ub[mt] .. ue[mt]-1 only, the
     // one of unit u at (uo[mt] + u) fragment slots into the layer-0 block (a slot = 512 floats on the fp16-split path: high and low
@@ -1213,8 +1221,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 #pragma unroll
                     for (int mt = 0; mt < MT0; ++mt)
                         if (live & (1 << mt)) {
-                            wh[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512);
-                            wl[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * 512 + 256);
+                            wh[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * slot_f);
+                            wl[mt] = *reinterpret_cast<const f16x8*>(fr + uo[mt] * slot_f + lo_f);
                         }
 #pragma unroll
                     for (int mt = 0; mt < MT0; ++mt)
@@ -1226,7 +1234,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                     for (int mt = 0; mt < MT0; ++mt)
                         if (live & (1 << mt)) acc0[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], xl, acc0[j][mt], 0, 0, 0);
                 }
-                fr_off += 512;
+                fr_off += slot_f;
                 ++unit;
             } else {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(ring + cs_slot + lane * 16);

@@ -33,7 +33,7 @@ constexpr int kFlagBadIndex = 4;       // a pre-drawn weight index of a chain ba
 // layer-0 tiles; its output is one tile)
 __host__ __device__ inline int layer_frag_items(const NetMeta& net, int l) {
     if (l == 1 && net.l1_f16) return ((net.L[0].mt + 1) / 2) * 2 * 64;
-    return net.L[l].kt * net.L[l].mt * 64;
+    return net.L[l].kt * net.L[l].mt * 64;      // (layer 0 with fewer than 16 rows per tile in the image: the items of the padding rows write nothing)
 }
 // One item of the weight image.  Layer-l fragment layouts (16-byte entries, one per lane):
 //   float32 : entry ((kt*MT + mt)*64 + lane) = W_l[o = 16mt + (lane&15)][c = 16kt + 4(lane>>4) + 0..3]
@@ -59,9 +59,10 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                 const int o = L.out_perm ? tile_pos(lane & 15) : (lane & 15);
                 f16x8 v;
                 for (int e = 0; e < 8; ++e) {
-                    const int c = 16 * (2 * q + (e >> 2)) + 4 * kq + (e & 3);      // input unit at position 8 kq + e of step q
+                    const int cp = 16 * (2 * q + (e >> 2)) + 4 * kq + (e & 3);     // layer-0 output position 8 kq + e of step q ...
+                    const int c = net.l0_rows < 16 ? l0_unit_at(cp, net.l0_rows, L.in_dim) : cp;      // ... and the unit that sits there
                     float wv = 0.f;
-                    if (o < L.out_dim && c < L.in_dim) wv = (float)w[L.w_off + (long long)o * ld + L.has_bias + c];
+                    if (o < L.out_dim && c >= 0 && c < L.in_dim) wv = (float)w[L.w_off + (long long)o * ld + L.has_bias + c];
                     if (overflow && !(fabsf(wv) <= kF16Safe)) atomicOr(overflow, kFlagF16Range);
                     _Float16 hi, lo;
                     split_f16(wv, hi, lo);
@@ -73,9 +74,10 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
             if (l == 0 && net.l0_f16) {
                 const int part = tile & 1, rest = tile >> 1;
                 const int mt = rest % L.mt, ks = rest / L.mt;
-                const int o = 16 * mt + (lane & 15);
+                const int rows = net.l0_rows, u = lane & 15;
+                const int o = u < rows ? rows * mt + u : 0x40000000;                      // (rows < 16: see NetMeta::l0_rows)
                 const int c0 = 32 * ks + 8 * (lane >> 4);
-                const bool stored = ks >= net.l0_begin[mt] && ks < net.l0_end[mt];       // (block structure: see NetMeta)
+                const bool stored = ks >= net.l0_begin[mt] && ks < net.l0_end[mt] && u < rows;       // (block structure: see NetMeta)
                 f16x8 v;
                 for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
                 if (o < L.out_dim) {
@@ -93,8 +95,9 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
                         }
                     }
                 }
-                if (stored)
-                    *reinterpret_cast<f16x8*>(image + L.frag_off + ((long long)((net.l0_base[mt] + ks - net.l0_begin[mt]) * 2 + part) * 64 + lane) * 4) = v;
+                if (stored)      // (slot, part, feature group, row): 4 * rows entries per part - 64, entry = lane, with all 16 rows
+                    *reinterpret_cast<f16x8*>(image + L.frag_off +
+                                              ((long long)((net.l0_base[mt] + ks - net.l0_begin[mt]) * 2 + part) * (4 * rows) + (lane >> 4) * rows + u) * 4) = v;
                 return;
             }
             const int mt = tile % L.mt, kt = tile / L.mt;
@@ -106,8 +109,9 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
             if (o < L.out_dim) {
                 const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
                 for (int s = 0; s < 4; ++s) {
-                    const int c = in_perm ? tile_pos(c0 + s) : c0 + s;                         // (input unit at this position)
-                    if (c < L.in_dim) {
+                    int c = in_perm ? tile_pos(c0 + s) : c0 + s;                               // (input unit at this position)
+                    if (l == 1 && net.l0_f16 && net.l0_rows < 16) c = l0_unit_at(c0 + s, net.l0_rows, L.in_dim);
+                    if (c >= 0 && c < L.in_dim) {
                         bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
                         v[s] = overridden ? 0.f : (float)row[c];
                         if (overflow && !stored && row[c] != 0.0) atomicOr(overflow, kFlagStructure);
@@ -124,9 +128,10 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
         const LayerMeta& L = net.L[l];
         const int nb = 16 * L.mt;
         if (piece < nb) {
-            const int o = L.out_perm ? tile_pos(piece) : piece;
+            int o = L.out_perm ? tile_pos(piece) : piece;
+            if (l == 0 && net.l0_f16 && net.l0_rows < 16) o = l0_unit_at(piece, net.l0_rows, L.out_dim);
             double b = (net.pad_masked && l == net.n_layers - 1) ? (double)kPadLogit : 0.0;
-            if (o < L.out_dim) {
+            if (o >= 0 && o < L.out_dim) {
                 b = 0.0;
                 const int ld = L.in_dim + L.has_bias;
                 const double* row = w + L.w_off + (long long)o * ld;

@@ -8,12 +8,12 @@ configs=${2:-"2 4 5 0"}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for c in $configs; do      # (0: config 2's data under the reference's default network [50,5]: one candidate per pass fits)
+for c in $configs; do      # (0: config 2's data under the reference's default network [50,5])
   # one launch per pass (schedule 2): a launch's duration in the trace is the pass kernel's own, comparable with roofline.kernel_ms
   NPBNN_BENCH_SCHEDULE=2 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c$c -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_under_rocprof.json 2> $out/bench_c$c.err || echo "bench profile of config $c failed"
   # the default command (persistent launch: one kernel per run_steps call loops over the passes)
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_c${c}_persistent -o b -- python3 bench.py --config $c --no-cpu-baseline > $out/bench_c${c}_persistent_under_rocprof.json 2> $out/bench_c${c}_persistent.err || echo "persistent bench profile of config $c failed"
-  cands="3 1"; [ $c = 0 ] && cands="1"
+  cands="3 1"; [ $c = 0 ] && cands="2 1"      # (the default network: two candidates per pass fit since its image holds 13 rows per tile)
   for cand in $cands; do
     # full passes only (a quarter second of spin-up, then 2000 launches of the pass kernel, nothing idle or void among them): the mean to
     # hold against roofline.kernel_ms
@@ -33,7 +33,7 @@ for c in $configs; do
   f=$(first $out/bench_c${c}_persistent "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_bench_cfg${c}_persistent_kernel_stats.csv
   cp $out/bench_c${c}_under_rocprof.json $keep/${tag}_bench_cfg${c}_under_rocprof.json 2>/dev/null
   cp $out/bench_c${c}_persistent_under_rocprof.json $keep/${tag}_bench_cfg${c}_persistent_under_rocprof.json 2>/dev/null
-  for cand in 3 1; do
+  for cand in 3 2 1; do
     f=$(first $out/pass_c${c}_d${cand} "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_cfg${c}_pass${cand}_kernel_stats.csv
     for ctr in FETCH_SIZE WRITE_SIZE; do
       f=$(first $out/pmc_c${c}_d${cand}_$ctr "*counter_collection.csv"); [ -n "$f" ] && cp "$f" $keep/${tag}_cfg${c}_pass${cand}_pmc_$ctr.csv

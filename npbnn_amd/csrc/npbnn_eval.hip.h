@@ -427,8 +427,10 @@ __device__ __forceinline__ void tile_tail(const NetMeta& net, const HotParams& h
 
 // software-pipelined layer 0 (the fragments of K-step s+1 are read from LDS while the MFMAs of step s run): builds whose two
 // fragment sets fit the register budget of their launch bounds
-__host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int d) {
-    return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && mt0 <= 1) || (d == 1 && mt0 <= 2));
+__host__ __device__ constexpr bool pipelined_l0(int mt0, int mti, bool f16, int d, bool fast_dense = false) {
+    // (two candidates: one tile - or, in the fast builds of dense first layers, three and four: 158 registers, nothing spilled, the
+    // reference's default [50, 5] +3-5 %; with two tiles the second fragment set does not fit, nor in the other builds of three and more)
+    return f16 && mti == 1 && ((d == 3 && mt0 <= 2) || (d == 2 && (mt0 <= 1 || (fast_dense && (mt0 == 3 || mt0 == 4)))) || (d == 1 && mt0 <= 2));
 }
 // candidates per pass a layer-0 width is built for: three sets of accumulators and tails side by side spill INSIDE the tile loop from
 // three output tiles on (tools/check_hot_loop_spills.sh; measured on 100k x 64, hidden [50, 5]: 30.3 us for three candidates
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 #define NPBNN_ESTAMPX(k) do { } while (0)
 #endif
     constexpr int DEPTH = F16 ? ((kRing - 1) & ~1) : kRing - 1;   // pieces in flight; whole pairs in fp16-split mode
-    constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D) && kRing == 4;
+    constexpr bool PIPE = pipelined_l0(MT0, MTI, F16, D, FAST && !BLK && !SPEC) && kRing == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // overlapped chain schedule: the last workgroup decides the previous pass and prepares the next one while the others
     // evaluate this one (chain_step above); passes alternate between two sets of descriptors / patch values / partial sums
@@ -1115,14 +1117,15 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
                 ld_slot ^= 2048;
             };
             auto load_w = [&](WFrag& w, int kstep, int j) {
-                const unsigned fr = w_lane[j] + (unsigned)kstep * 2048u;
+                const unsigned slot_b = (unsigned)slot_f * 4u, lo_b = (unsigned)lo_f * 4u;      // (2048 / 1024 bytes but for NetMeta::l0_rows < 16)
+                const unsigned fr = w_lane[j] + (unsigned)kstep * slot_b;
                 const int live = unit_tiles(kstep);
 #pragma unroll
                 for (int mt = 0; mt < MT0; ++mt)
                     if (live & (1 << mt)) {
-                        const char* pw = smem + (fr + (unsigned)uo[mt] * 2048u);
+                        const char* pw = smem + (fr + (unsigned)uo[mt] * slot_b);
                         w.wh[mt] = *reinterpret_cast<const f16x8*>(pw);
-                        w.wl[mt] = *reinterpret_cast<const f16x8*>(pw + 1024);
+                        w.wl[mt] = *reinterpret_cast<const f16x8*>(pw + lo_b);
                     }
             };
             NPBNN_WAIT_VMCNT(0);                          // (the barriers above already drained this wave's loads)

@@ -476,6 +476,8 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     p.M = M;
     p.chain = overlap ? ctx->d_cparams : nullptr;
     p.sync_mode = spec ? 3 : sync ? 1 : 0;
+    // (the persistent overlapped launch: workgroups run up to a pass ahead of each other, so the heavier shares taking turns evens out)
+    p.share_rot = (persist && !spec && group_blocks == 0 && lp.grid > 1 && !getenv("NPBNN_NO_SHARE_ROTATION")) ? d.n_tiles % lp.grid : 0;
     p.cand_slopes = c.slopes ? &ctx->d_slopes->cand[0][0][0] : nullptr;
     c.class_w = ctx->n_classw ? ctx->d_classw : nullptr;
     c.w_scale = f16 ? ctx->d_wscale : nullptr;

@@ -160,7 +160,11 @@ struct EvalParams {
     int pad_lay_;
     const ChainParams* chain;  // overlapped chain schedule: the last workgroup of the launch runs chain_step (else nullptr)
     int sync_mode;             // overlapped schedule with the launches alternating between two streams: no kernel boundary orders a
-    int pad_sync_;             // launch after the one before it - device-side flags do (ChainDev.prepared / .done, npbnn_chain.hip.h)
+    int share_rot;             // launch after the one before it - device-side flags do (ChainDev.prepared / .done, npbnn_chain.hip.h)
+                               // share_rot (persistent overlapped launch): n_tiles % evaluating workgroups - in pass L workgroup b takes the
+                               // tiles (and the partial-sum slot) of share (b + L * share_rot) % workgroups, so that the shares with one tile
+                               // more - a second round for one wave, which then runs alone - go round instead of holding up the same
+                               // workgroups in every pass (the sums are the same, slot for slot)
                                // 1: the step of launch L decides pass L - 1 while pass L is evaluated (NPBNN_SCHED_OVERLAP2 / _PERSIST);
                                // 3: the same with the next pass prepared ahead for every outcome (spec_round; NPBNN_SCHED_PERSIST_SERIAL):
                                //    the descriptor names the patch values the pass reads (pad[2]) and, after an accept, the accepted entries (pad[1])

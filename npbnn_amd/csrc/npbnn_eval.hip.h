@@ -524,6 +524,10 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // the step workgroup is the last one of the launch - or, when launches overlap, the FIRST: it must be resident before any
     // workgroup of the NEXT launch (which waits for it) can take a compute unit
     const int ebid = sync ? bid - 1 : bid;               // index among the evaluating workgroups
+    // the share of tiles this workgroup takes in the pass at hand (EvalParams::share_rot: the heavier shares go round in a persistent launch)
+    const int share_rot = (CHAIN && sync && !GN) ? uni(p.share_rot) : 0;
+    int lbid = ebid;
+    for (int i = 0; i < launch0 && share_rot > 0; ++i) { lbid += share_rot; if (lbid >= G) lbid -= G; }
     if (chain && bid == (sync ? 0 : G)) {
         StepShared& sh = *reinterpret_cast<StepShared*>(smem);
         int* const lds_flag = reinterpret_cast<int*>(smem + sizeof(StepShared));
@@ -563,7 +567,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int ahead_cnt[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) ahead_cnt[j] = 0;
-    for (int launch = launch0; launch < launch_end; ++launch) {         // (one pass, but for the persistent form: see n_loop)
+    for (int launch = launch0; launch < launch_end; ++launch, lbid = (lbid + share_rot >= G ? lbid + share_rot - G : lbid + share_rot)) {         // (one pass, but for the persistent form: see n_loop)
     // Every pass reads its parameters afresh, through a pointer the compiler cannot see through: otherwise it hoists the dozens of
     // launch-invariant scalars of the pass out of this loop and keeps them alive across it - far more than the scalar register file
     // holds (70 spilled scalars against 33).
@@ -682,7 +686,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     //      waves of that SIMD in turn (wave w sits on SIMD w % 4): the SIMDs of a CU - whose issue ports are what the tile
     //      loop saturates - get the same number of tiles to within one even when the waves do not divide by four ----
     const int KT0 = uni(net.L[0].kt);
-    const int first_tile = ebid + G * wave;
+    const int first_tile = lbid + G * wave;
     const int simd_waves = (wpb - (wave & 3) + 3) >> 2;      // waves of this workgroup on this wave's SIMD
     const int stride = G * 4 * simd_waves;
     // (counted, not divided, when it is a handful: an integer division runs on the vector unit, and the first vector instruction at
@@ -1368,8 +1372,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
             // (group pass: candidate j is slot 0 of chain j's own partial block)
-            double* const dst = GN ? p.group[j].partials + (((size_t)par * kMaxCand) * kPartialStride + v) * G + ebid
-                                   : g_partials + (((size_t)par * kMaxCand + j) * kPartialStride + v) * G + ebid;
+            double* const dst = GN ? p.group[j].partials + (((size_t)par * kMaxCand) * kPartialStride + v) * G + lbid
+                                   : g_partials + (((size_t)par * kMaxCand + j) * kPartialStride + v) * G + lbid;
             if (sync) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (write-through: no fence at the end)
             else *dst = s;
         }

@@ -54,14 +54,15 @@ __device__ __forceinline__ T* uni(T* ptr) { return reinterpret_cast<T*>(uni((lon
 // statements of the main loop are memory clobbers, and anything read through the block pointer would be fetched again
 // after each of them.
 // Builds that form what they derive from the thread index where it is used (eval_kernel: top of a pass, run_tail, epilogue) instead
-// of letting the compiler hoist it out of the pass and tile loops: the three-candidate Gaussian and block-structured fast builds and
-// the builds for three or more layer-0 tiles, whose registers are full - they spilled 6-10 such constants per lane around every pass (config 5: 5 MB of scratch writes per launch).  The
-// others have room and would only pay the handful of extra vector instructions per tile (config 2: +0.3 us per pass, measured).
+// of letting the compiler hoist it out of the pass and tile loops: the block-structured fast builds, the Gaussian ones for two layer-0
+// tiles and the builds for three or more tiles, whose registers are full - they spilled 6-10 such constants per lane around every pass
+// (config 5: 5 MB of scratch writes per launch).  The others have room (the one-tile Gaussian builds spill nothing either way) and would
+// only pay the extra vector instructions per tile (config 2: +0.3 us per pass; config 4, 21 tiles per wave: 60.2 -> 65.5 us, measured).
 #ifndef NPBNN_LAUNDER_TID
-#define NPBNN_LAUNDER_TID (FAST && !SPEC && (BLK || LK == kLikGauss || MT0 >= 3))
+#define NPBNN_LAUNDER_TID (FAST && !SPEC && (BLK || (LK == kLikGauss && MT0 >= 2) || MT0 >= 3))
 #endif
 #ifndef NPBNN_LAUNDER_TAIL
-#define NPBNN_LAUNDER_TAIL (FAST && !SPEC && (BLK || LK == kLikGauss || MT0 >= 3))
+#define NPBNN_LAUNDER_TAIL (FAST && !SPEC && (BLK || (LK == kLikGauss && MT0 >= 2) || MT0 >= 3))
 #endif
 #ifndef NPBNN_FAST3_WAVES
 #define NPBNN_FAST3_WAVES 12

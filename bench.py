@@ -146,7 +146,7 @@ def main():
         import ctypes
         n_dev = ctypes.c_int(0)
         capi.load_library().npbnn_device_count(ctypes.byref(n_dev))
-        if dist_backend in ("rccl", "nccl"):
+        if dist_backend in ("rccl", "nccl") and not os.environ.get("NPBNN_BENCH_RCCL_FAULT"):
             if n_dev.value < world:
                 sys.exit("[rank %d] --gpus %d over RCCL needs %d GPUs, %d visible (NPBNN_BENCH_DIST_BACKEND=socket rehearses the "
                          "rank flow on fewer)" % (rank, world, world, n_dev.value))
@@ -212,12 +212,20 @@ def main():
     if world > 1 and not os.environ.get("NPBNN_BENCH_NO_ROW_SHARD"):
         # after the timed region: the other way several GPUs serve this path - ONE chain, its rows split over the ranks.  Nothing in
         # here may cost the headline line: every failure is caught and reported inside it, on every rank
-        try:
-            leg = row_sharded_chain(comm, rank, world, device_index)
-        except Exception as e:      # noqa: BLE001
-            leg = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        leg, why = _with_deadline(lambda: row_sharded_chain(comm, rank, world, device_index),
+                                  float(os.environ.get("NPBNN_BENCH_LEG_DEADLINE", "240")))
+        if leg is None:
+            leg = {"error": why}
         if line is not None:
             line["row_sharded_chain"] = leg
+        if why is not None and why.startswith("not back"):
+            # a rank is still inside the leg (a collective that never completed): the line goes out, and the process ends without
+            # the closing barrier that would wait for that rank
+            if line is not None:
+                print(json.dumps(line), flush=True)
+            sys.stderr.write("[bench rank %d] row-sharded leg: %s; ending without the closing barrier\n" % (rank, why))
+            sys.stderr.flush()
+            os._exit(0)
     if line is not None:
         print(json.dumps(line), flush=True)
     if comm is not None:
@@ -269,12 +277,55 @@ def row_sharded_chain(comm, rank, world, device_index, config=4, n_steps=10):
     return out
 
 
+def _with_deadline(fn, seconds):
+    """``fn()`` on a helper thread: (result, None), or (None, reason) when it raised or is not back within ``seconds`` (a collective
+    that never completes must not take the line with it; the thread is left behind, the caller ends the process by ``os._exit``)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except BaseException as e:      # noqa: BLE001
+            box["err"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, "not back within %.0f s" % seconds
+    if "err" in box:
+        return None, box["err"]
+    return box["out"], None
+
+
 def make_comm(dist_backend, rank, world, local_rank, device_index):
     """The communicator of the swap exchange (see main).  A rank that cannot build it fails loudly; the launcher ends the others."""
     from npbnn_amd.comm import RcclComm, SocketComm
     if dist_backend == "rccl":
-        comm = RcclComm(rank=rank, world_size=world, device=device_index)
-        return comm, comm.describe()
+        # The RCCL communicator has to come up on EVERY rank or on none: the ranks tell each other over a TCP channel how theirs
+        # went (built and one all-gather through, within the deadline) and, if any of them failed, all carry the swap exchange
+        # over that channel instead - a few dozen bytes per swap interval, not a data path - and the line says so.
+        import numpy as np
+        ctl = SocketComm(rank=rank, world_size=world, timeout=400.0)
+
+        def bring_up():
+            if os.environ.get("NPBNN_BENCH_RCCL_FAULT"):          # (rehearsal of the fallback on a box with fewer GPUs than ranks)
+                raise RuntimeError("NPBNN_BENCH_RCCL_FAULT is set")
+            c = RcclComm(rank=rank, world_size=world, device=device_index)
+            c.barrier()
+            return c
+        comm, why = _with_deadline(bring_up, float(os.environ.get("NPBNN_BENCH_RCCL_DEADLINE", "150")))
+        ok = ctl.allgather_f64(np.array([0.0 if comm is None else 1.0]))[:, 0]
+        if bool(np.all(ok == 1.0)):
+            ctl.close()
+            return comm, comm.describe()
+        if comm is None:
+            print("[bench rank %d] RCCL communicator: %s" % (rank, why), file=sys.stderr)
+        else:
+            comm._comm = None          # (left as it is: tearing down a communicator whose peers never joined may not return)
+        failed = [int(r) for r in np.nonzero(ok != 1.0)[0]]
+        return ctl, ("tcp sockets through rank 0, %d ranks - the RCCL communicator did not come up on rank(s) %s%s"
+                     % (world, failed, (": " + why) if comm is None else ""))
     if dist_backend == "socket":
         return SocketComm(rank=rank, world_size=world), "tcp sockets through rank 0 (rehearsal; no RCCL), %d ranks" % world
     import torch

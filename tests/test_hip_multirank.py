@@ -122,6 +122,21 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     assert leg["ranks"] == 4 and sum(leg["rows_per_rank"]) == 1_000_000 and leg["ranks_hold_the_same_chain"]
 
 
+def test_bench_carries_on_over_tcp_when_rccl_does_not_come_up(tmp_path):
+    """`bench.py --gpus 2` whose RCCL communicator fails to come up (NPBNN_BENCH_RCCL_FAULT: every rank raises where it would build
+    it): the ranks agree on it over the TCP channel, carry the swap exchange over that channel and the line says what happened -
+    a node whose RCCL set-up is broken still yields its per-N line."""
+    env = dict(os.environ, NPBNN_BENCH_RCCL_FAULT="1", NPBNN_BENCH_NO_ROW_SHARD="1")
+    env.pop("NPBNN_BENCH_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["swap_exchange_nranks"] == 2 and line["value"] > 0
+    assert "did not come up on rank(s) [0, 1]" in line["config"]["swap_exchange"]
+    assert line["config"]["swap_exchange_path"].startswith("host")
+
+
 def test_bench_under_the_drivers_launcher(tmp_path):
     """The driver's command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...` - the ranks take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's

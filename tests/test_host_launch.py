@@ -80,3 +80,16 @@ def test_socket_comm_collectives():
         np.testing.assert_array_equal(a, [[0, 0], [1, 10], [2, 20]])
         np.testing.assert_array_equal(b, [7, 7])
         assert o == {"from": 1}
+
+
+def test_bench_deadline_helper_returns_results_errors_and_gives_up_on_time():
+    """bench.py's guard around its multi-rank set-up and the leg after the line: a result comes back as it is, an exception as its
+    text, and a call that never returns is left behind when the deadline passes."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench._with_deadline(lambda: 7, 5.0) == (7, None)
+    out, why = bench._with_deadline(lambda: 1 / 0, 5.0)
+    assert out is None and why.startswith("ZeroDivisionError")
+    t0 = time.time()
+    out, why = bench._with_deadline(lambda: time.sleep(30), 0.3)
+    assert out is None and why.startswith("not back within") and time.time() - t0 < 5

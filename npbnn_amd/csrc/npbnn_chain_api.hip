@@ -616,6 +616,9 @@ int chain_finish(npbnn_ctx* ctx, ChainBatch& B, const npbnn_chain_cfg* cfg, doub
         for (int r = 1; r < 1024; ++r) {
             const unsigned long long* q = &hs[(size_t)r * 8];
             if (!q[0] || !q[6]) continue;
+            bool whole = true;          // (a step that skipped a phase - a void pass has nothing to reduce - left an older stamp there)
+            for (int k = 1; k <= 6; ++k) whole = whole && q[k] >= q[k - 1];
+            if (!whole) continue;
             for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;   // 100 MHz wall clock -> us
             ++n;
         }

@@ -25,8 +25,6 @@ import glob
 import json
 import os
 import re
-import socket
-import subprocess
 import sys
 import time
 

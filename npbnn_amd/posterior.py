@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _capi as capi
 from .files import load_obj
-from .layers import ActFun, SoftMax, output_kind
+from .layers import ActFun, output_kind
 from .likelihoods import CalcAccuracy
 
 

@@ -19,7 +19,6 @@ What a sharded sampler does not run on the device: the general chain (indicators
 exchange run - those fall back to ``mh_step``, which is sharded through ``evaluate``.  Predictions (``_y``, ``predict``) are
 the LOCAL rows' predictions.
 """
-import ctypes as C
 
 import numpy as np
 

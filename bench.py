@@ -583,6 +583,14 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                              "us_fixed_per_dispatch": 1e6 * el2 / n_more - ITERATIONS_PER_STEP * 1e2 * el3,
                              "us_of_python_per_dispatch": 1e6 * (el2b - inside) / n_more,
                              "note": "upload of state and draws, first step kernel (full prior re-sum), result copy, synchronisation, host Python"}
+        # a pass INSIDE the persistent launch (the form the chain runs): wall time of the long call's 512-iteration batches over their
+        # turns - tiles, sums, the hand-over to the step and back; no launch of its own, so no ramp-up or ramp-down
+        turn_us = ctx.info(capi.INFO_TURN_NS_OVERLAPPED) / 1e3
+        if turn_us > 0 and roof.get("traffic") and int(mcmc._device_schedule_used) == 4:
+            roof["pass_inside_the_persistent_launch"] = {
+                "us": turn_us, "frac": roof["traffic"] / (turn_us * 1e-6) / 1e9 / roof["peak"],
+                "note": "a batch's wall time over its turns (decided and void passes), running mean of the library (NPBNN_INFO_TURN_NS_OVERLAPPED) "
+                        "after the long call; the same HBM bytes per pass as a launch of the pass kernel alone, which is what frac is on"}
         if "f32_path" in roof:          # the same chain with layer 0 on float32 matrix cores: a rate, not only kernel times
             try:
                 ctx.set_l0_precision("f32")

@@ -752,15 +752,62 @@ __device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch, b
 // ------------------------------------------------------------------------------------------------
 constexpr int kSpecOutcomes = kMaxCand + 1;
 constexpr int kSpecRows = 2 * kMaxCand;            // rows (iterations t0 .. t0+2D-1) a round looks at: the candidates in flight and those of every outcome
+struct SpecDesc {               // a prepared pass as the evaluating workgroups read it: sixteen words, so that ONE wave-wide load fetches
+    PassDesc d;                 // the four outcomes' (pad[0] terminal, pad[1] accepted entries to apply first, pad[2] = own patch-value
+    int tag;                    // slot | (slot of the accepted candidate's values + 1) << 8).  tag: the pass it describes (P + 1 >= 1),
+    int pad_[7];                // stored after the other words have arrived: a record whose tag matches is whole
+};
 struct SpecState {
     double cand_lp[2][kSpecOutcomes][kMaxCand];   // log priors of the prepared candidates, by parity of their pass and outcome
-    PassDesc desc[2][kSpecOutcomes];              // their descriptors (pad[0] terminal, pad[1] accepted entries to apply first,
-                                                  // pad[2] = own patch-value slot | (slot of the accepted candidate's values + 1) << 8)
+    SpecDesc desc[2][kSpecOutcomes];              // their descriptors, written while the pass before is still being evaluated: after the
+                                                  // decision the flag alone (ChainDev.prepared = (P + 1) << 2 | outcome) names one of them
     int ovf[2][kSpecOutcomes];                    // some candidate of that outcome leaves the fp16 range
     int o_cur;                                    // outcome slot the candidates of the pass in flight came from
     int rounds;                                   // diagnostics: rounds run, and wall-clock ticks (100 MHz) spent per phase:
     unsigned long long ticks[6];                  // touch tables | candidates | descriptors | wait for the pass | decide + publish | commit
 };
+
+// Evaluating workgroup of pass `launch` under the decision-between-passes schedule: wait for the flag, which names the outcome, and hand
+// the workgroup that outcome's descriptor (lds_words[0..7]; lds_words[8]: the wait ended well).  Wave 0 waits, and every look of it asks
+// for the flag AND for the four prepared descriptors (one wave-wide load): the look that sees the flag has the descriptor with it - no
+// second round trip between the flag and the pass.  (A record read before the step had written it shows in its tag and is fetched again.)
+__device__ __forceinline__ bool sync_eval_enter_spec(ChainDev* st, const SpecState* S, const PassDesc* pass, int launch, int par, int* lds_words) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int ok = 1, w = 0;
+        if (launch == 0) {
+            // the batch's first pass was prepared by the first step kernel, which was through before this launch began: its plain block
+            w = __hip_atomic_load(reinterpret_cast<const int*>(pass + par) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const int* const rec = reinterpret_cast<const int*>(&S->desc[par][0]);       // four records of sixteen words
+            const unsigned long long t_begin = wall_clock64();
+            int flag;
+            for (;;) {
+                flag = __hip_atomic_load(&st->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flag = __builtin_amdgcn_readfirstlane(flag);
+                if ((flag >> 2) >= launch) break;
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = 0; break; }
+                if (wall_clock64() - t_begin > kSyncTimeoutTicks) {
+                    if (lane == 0) __hip_atomic_store(&st->aborted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (ok) {
+                const int o = flag & 3;
+                if (__builtin_amdgcn_readlane(w, o * 16 + 8) != launch)      // (asked for before the record was there: now it is)
+                    w = __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = __builtin_amdgcn_ds_bpermute((o * 16 + (lane & 15)) << 2, w);
+            }
+        }
+        if (lane < 8) lds_words[lane] = w;
+        if (lane == 0) lds_words[8] = ok;
+    }
+    __syncthreads();
+    return lds_words[8] != 0;
+}
 
 #ifndef NPBNN_SPEC_INLINE
 #define NPBNN_SPEC_INLINE __attribute__((noinline))
@@ -1049,6 +1096,16 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
             d.pad[1] = o == 0 ? 0 : d_acc_cnt;                                 // accepted entries the evaluation applies first
             d.pad[2] = (slotN + o) | (o == 0 ? 0 : ((slotP * kMaxCand + (o - 1) + 1) << 8));
             sp.desc[o] = d;
+            // ... and in memory already, for the evaluating workgroups to pick from when the flag names the outcome: nothing but the flag is
+            // stored between the decision and the next pass.  (Two round trips here, while the pass is still being evaluated.)
+            SpecDesc* const pub = &S->desc[qn][o];
+            int* const dst = reinterpret_cast<int*>(&pub->d);
+            const int* const src = reinterpret_cast<const int*>(&d);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(&pub->tag, P + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
         }
 
         // ---- C. pass P has been evaluated: decide it ----
@@ -1116,10 +1173,13 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
                 }
             }
             const int o = accepted + 1;
-            // ---- D. publish the pass that outcome selects: its descriptor, then the flag; the book-keeping follows behind ----
+            // ---- D. publish the pass that outcome selects: the flag names it; the book-keeping follows behind ----
+            // (everything pass P + 1 reads was stored past the caches and has arrived - the patch values and the four descriptors during
+            // the preparation, each thread waiting for its own stores ahead of a barrier: the flag needs no release fence, which would
+            // write this XCD's whole L2 back, and nothing to wait for)
+            __hip_atomic_store(&st->prepared, ((P + 1) << 2) | o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const PassDesc nx = sp.desc[o];
-            {   // everything pass P + 1 reads was stored past the caches (the patch values above, the descriptor here): the flag needs
-                // no release fence - which would write this XCD's whole L2 back - only those stores to have completed
+            {   // the plain descriptor block as well (a later launch of the batch starts from it)
                 int* const dst = reinterpret_cast<int*>(pass + qn);
                 const int* const src = reinterpret_cast<const int*>(&nx);
 #pragma unroll
@@ -1129,8 +1189,6 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
             sp.accepted = accepted;
             sp.n_done = n_done;
             sp.go = nx.n_cand == 0 ? 0 : 1;
-            __builtin_amdgcn_s_waitcnt(0);             // (thread 0's stores are out; the other threads' were before the barrier below the candidates)
-            __hip_atomic_store(&st->prepared, P + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         NPBNN_SPEC_TICK(4);

@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     // through the generic pointer it was a vector load whose readfirstlane waited for every image and X piece requested before it)
     typedef const __attribute__((address_space(4))) ChainParams ConstChainParams;
     ChainDev* const st_dev = chain ? uni(((ConstChainParams*)chain)->st) : nullptr;
+    const SpecState* const spec_dev = (SPEC && chain) ? uni(((ConstChainParams*)chain)->spec) : nullptr;
     // (the thread index through a copy the compiler cannot trace, once at the top of a pass and once behind its tiles: what the prologue
     // and the epilogue derive from it - patch-list addresses, lane tests - is then formed where it is used, every pass, instead of being
     // hoisted out of the pass loop of a persistent launch and kept in registers across the tile loop)
@@ -775,7 +776,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
 
     const bool ahead = LOOK && ahead_t0 >= 0;      // (wave-uniform, the same in every wave: it came out of LDS behind a barrier)
     int early_prepared = 0x7fffffff;
-    if (sync && !ahead && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
+    if (sync && !ahead && !early_copy && threadIdx.x == 0)        // asked for now, looked at where the pass descriptor is needed (below)
         early_prepared = __hip_atomic_load(&st_dev->prepared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int par = (chain || GN) ? (launch & 1) : 0;
     // ---- which candidates does this pass evaluate?  A chain pass always computes all D weight sets (the step kernel
@@ -788,7 +789,15 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     const PassDesc* const pass = (CHAIN && uni(p.has_pass)) ? &p_generic.pass_desc[par] : nullptr;
     int pv_slot = par, acc_cnt = 0, acc_slot = -1;    // (sync_mode 3: named by the descriptor, below)
     // (the flag word of the wait: behind everything else in LDS - the image copies may be landing at the front)
-    if (sync && !ahead && !sync_eval_enter(st_dev, launch, reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds)), early_prepared)) {
+    int* const wait_words = reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds));
+    bool entered = true;
+    if constexpr (SPEC) {
+        if (early_copy) entered = sync_eval_enter_spec(st_dev, spec_dev, p_generic.pass_desc, launch, par, wait_words);
+        else if (sync && !ahead) entered = sync_eval_enter(st_dev, launch, wait_words, early_prepared);
+    } else {
+        if (sync && !ahead) entered = sync_eval_enter(st_dev, launch, wait_words, early_prepared);
+    }
+    if (!entered) {
         if constexpr (SPEC) NPBNN_WAIT_VMCNT(0);     // (copies requested ahead of the flag must not land in LDS that is no longer ours)
         return;
     }
@@ -810,7 +819,9 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         for (int j = 0; j < D; ++j) cnt[j] = ahead_cnt[j];
     } else if (pass) {
         if (sync) {     // the descriptor was written by a kernel that may still be running: no scalar (cached) loads of it
-            const int w = __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (decision between the passes: the wait brought the descriptor of the outcome the flag named with it)
+            const int w = (SPEC && early_copy) ? wait_words[lane & 7]
+                                               : __hip_atomic_load(reinterpret_cast<const int*>(pass) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__builtin_amdgcn_readlane(w, 1) == 0) {              // n_cand: an empty pass
                 if (threadIdx.x == 0) sync_eval_leave(st_dev, launch);
                 // one pass per launch: this launch is over.  Persistent form: over only at the terminal pass (PassDesc.pad[0]); an

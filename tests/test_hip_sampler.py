@@ -335,6 +335,36 @@ def test_two_stream_schedule_times_out_cleanly(monkeypatch):
         np.testing.assert_array_equal(wa, wb)
 
 
+@pytest.mark.parametrize("schedule", [4, 5])
+def test_persistent_schedules_time_out_cleanly(schedule):
+    """The same for the two persistent forms: a step workgroup that stops reporting in the middle of a launch (test hook) leaves the
+    evaluating workgroups in their bounded waits - the overlapped form's, and the decision-between-passes form's, whose wait also
+    fetches the descriptor the flag names - the batch ends with NPBNN_E_SYNC, runs again on kernel boundaries, and the chain is the
+    one it would have been."""
+    cfg = cases.TRACES["cfg1"]
+    bnn_a, mcmc_a = build(cfg, adapt_f=0, adapt_fM=1)
+    bnn_b, mcmc_b = build(cfg, adapt_f=0, adapt_fM=1)
+    bnn_c, mcmc_c = build(cfg, adapt_f=0, adapt_fM=1)
+    mcmc_c.device_schedule = schedule
+    mcmc_c.run_steps(bnn_c, 200)
+    if mcmc_c._device_schedule_used != schedule:
+        pytest.skip("schedule %d does not run on this chain here (ran %d)" % (schedule, mcmc_c._device_schedule_used))
+    mcmc_a.device_schedule = 2
+    mcmc_a.run_steps(bnn_a, 400)
+    ctx_b = mcmc_b._backend.ctx
+    assert ctx_b._lib.npbnn_debug_sync_skip_(ctx_b._ctx, 7) == 0        # (diagnostic entry point, not part of the ABI)
+    mcmc_b.device_schedule = schedule
+    with pytest.warns(UserWarning, match="flag-ordered"):
+        mcmc_b.run_steps(bnn_b, 200)
+    assert ctx_b.sync_fallbacks == 1
+    assert mcmc_b._device_schedule_used == 2          # the batch was repeated on kernel boundaries
+    mcmc_b.run_steps(bnn_b, 200)
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+    assert (mcmc_a._logLik, mcmc_a._logPrior) == (mcmc_b._logLik, mcmc_b._logPrior)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("hyper_p", [1, 2, 3])
 def test_run_steps_with_hyper_priors_is_the_mh_step_loop(hyper_p):
     """Hyper-priors (npBNN.sample_prior_scale, BNN_env.py:196-221): one scale per layer, per input node or per weight, re-drawn by

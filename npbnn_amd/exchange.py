@@ -247,7 +247,8 @@ def advance_intervals(chains, chain_ids, n_chains, n_intervals, seg_len, swaps, 
             grouped = len(chains) >= 2 and float(np.mean([m._acceptance_rate for _, m in chains])) > GROUP_PASS_ACCEPTANCE
         ok = (bool(device) and not (group_passes == "auto" and grouped) and n >= 2 and n_chains == world * len(chains) and exchange_ready(chains, n * seg_len)
               and (world == 1 or getattr(comm, "_comm", None) is not None))        # (several ranks: the native RCCL handle)
-        if world > 1:                  # every rank must take the same path
+        if world > 1 and bool(device):      # every rank must take the same path (without `device` - the same argument on every rank - it is
+            # the interval-by-interval one everywhere: nothing to agree on, and no collective of its own per interval for it)
             ok = bool(np.all(comm.allgather_f64(np.array([1.0 if ok else 0.0]))[:, 0] == 1.0))
         if not ok:
             if grouped:                         # the local chains share their passes over the data (run_steps_batched)

@@ -189,7 +189,10 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
                 ctx->turn_batches[other][kc] = 0;
                 // (within a factor two, that is: the other form's figure dates from when it last ran - the chain's acceptance rate has
                 // moved since, and with it both forms' costs; one batch in kTurnReprobeBatches costs a per cent at worst)
-                if (ratio < 2.0 || ctx->it_us[other][kc] <= 0.0) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
+                // (a form never run: when the model puts it within kFirstProbeWithin of the running one - at 2 % acceptance the decision
+                // between the passes is predicted a third dearer and is: two batches on it would be two batches lost)
+                if (ctx->it_us[other][kc] <= 0.0 ? ratio < kFirstProbeWithin : ratio < 2.0)
+                    schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
             }
         }
     }

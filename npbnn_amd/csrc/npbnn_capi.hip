@@ -705,7 +705,7 @@ void destroy_ctx(npbnn_ctx* c) {
     if (c->h_w) (void)hipHostFree(c->h_w);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_conf) (void)hipHostFree(c->h_conf);
-    void* chain_bufs[] = {c->d_spec, c->d_spec_pv, c->d_spec_touch, c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta, c->d_shard_recv, c->d_shard_part};
+    void* chain_bufs[] = {c->d_spec, c->d_spec_pv, c->d_spec_touch, c->d_spec_part, c->d_res, c->d_pv, c->d_mask, c->d_idx, c->d_pos, c->d_pscale, c->d_smult, c->d_hast, c->d_pscale_w, c->d_slopes, c->d_sidx, c->d_sdelta, c->d_shard_recv, c->d_shard_part};
     for (void* b : chain_bufs)
         if (b) (void)hipFree(b);
     if (c->h_res) (void)hipHostFree(c->h_res);

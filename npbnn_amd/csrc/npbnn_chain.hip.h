@@ -153,6 +153,7 @@ struct ChainParams {
     SpecState* spec;           // NPBNN_SCHED_PERSIST_SERIAL: outcome-speculative preparation (spec_round below), else nullptr
     double* spec_pv;           // [3][kSpecOutcomes][kMaxCand][M] candidate patch values per pass (mod 3) and outcome
     unsigned* spec_touch;             // [kMaxCand][n_weights][4] pass tag of the last candidate j that touched the weight, -, and the value it gave it
+    unsigned long long* spec_part;    // the evaluating workgroups' sums under that schedule: two tagged words per value (spec_part_*, below)
     int n_weights_spec, spec_gen;     // spec_gen: pass tags of this batch start above it (never reused: the host clears the tables first)
     const double* class_w;     // class weights for the weight image (pack_item), or nullptr
     const float* w_scale;      // fp16-split column scales of layer 0, or nullptr
@@ -751,6 +752,20 @@ __device__ __forceinline__ void sync_step_leave(ChainDev* st, int next_launch, b
 // Every decision is made in iteration order on sums computed from the true current state: the sequential chain.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSpecOutcomes = kMaxCand + 1;
+// The sums of a pass under this schedule travel as PAIRS OF 64-BIT WORDS that carry the pass tag: {high half of the double, tag},
+// {low half, tag}.  A 64-bit store arrives whole, so a pair whose two tags match is the value of that pass - and the evaluating workgroups
+// need not wait for their stores to be acknowledged before they report, nor report at all: the step looks at the words themselves, in the
+// loads it adds up anyway (two round trips through memory less between two passes).  Tags are the touch tables' pass tags
+// (ChainParams.spec_gen + P + 1: never repeated, the host clears the words with the tables).
+constexpr int kSpecPartSlots = 256;       // workgroups a record block is laid out for (one per compute unit at most)
+__device__ __forceinline__ size_t spec_part_index(int par, int j, int v, int b) {
+    return ((((size_t)par * kMaxCand + j) * kPartialStride + v) * kSpecPartSlots + b) * 2;
+}
+__device__ __forceinline__ void spec_part_store(unsigned long long* rec, double s, unsigned tag) {
+    const unsigned long long hi = (unsigned long long)(unsigned)__double2hiint(s), lo = (unsigned long long)(unsigned)__double2loint(s);
+    __hip_atomic_store(rec, (hi << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 1, (lo << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int kSpecRows = 2 * kMaxCand;            // rows (iterations t0 .. t0+2D-1) a round looks at: the candidates in flight and those of every outcome
 struct SpecDesc {               // a prepared pass as the evaluating workgroups read it: sixteen words, so that ONE wave-wide load fetches
     PassDesc d;                 // the four outcomes' (pad[0] terminal, pad[1] accepted entries to apply first, pad[2] = own patch-value
@@ -858,7 +873,7 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
     const int* const g_cnt = sgp(c.cnt);
     const double* const g_logu = sgp(c.log_u);
     const double* const g_hast = sgp(c.hastings);
-    const double* const g_partials = sgp(c.partials);
+    const unsigned long long* const g_spec_part = sgp(c.spec_part);
     // touch tables: one 16-byte record per weight and candidate - {pass tag, -, value} - so that a look-up is ONE gather
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4* const g_touch = reinterpret_cast<u32x4*>(sgp(c.spec_touch));
@@ -1111,36 +1126,52 @@ __device__ NPBNN_SPEC_INLINE void spec_rounds(const ChainParams& c, int P0, int 
         // ---- C. pass P has been evaluated: decide it ----
         NPBNN_SPEC_TICK(2);
         if (skip_round == P + 1) return;
-        if (tid == 0) {
-            const int slot = P & 3;
-            *lds_flag = sync_wait_ge(st, &st->done[slot], (P / 4 + 1) * n_eval_wgs) ? 1 : 0;
+        {   // every wave waits for the sums it adds: it asks for a value's words of all workgroups (lanes: workgroups lane, lane + 64, ...)
+            // and looks at their tags; complete, they are added in workgroup order - else asked for again.  Bounded like every wait here.
+            const int lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
+            const unsigned long long* const part = g_spec_part;
+            const unsigned long long t_begin = wall_clock64();
+            bool ok = true;
+            for (int item = wave; item < n_pend * nvals && ok; item += nwv) {
+                const int j = item / nvals, v = partial_value_index(item % nvals, k_targets);
+                const unsigned long long* src = part + spec_part_index(q, j, v, 0);
+                for (;;) {
+                    unsigned long long w0[4], w1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int b = lane + 64 * u < n_blocks ? lane + 64 * u : 0;
+                        w0[u] = __hip_atomic_load(src + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w1[u] = __hip_atomic_load(src + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    bool whole = true;
+                    double s = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (lane + 64 * u < n_blocks) {
+                            whole = whole && (unsigned)w0[u] == gen && (unsigned)w1[u] == gen;
+                            s += __hiloint2double((int)(w0[u] >> 32), (int)(w1[u] >> 32));
+                        }
+                    if (__builtin_amdgcn_ballot_w64(!whole) == 0ull) {
+                        s = butterfly_sum_f64(s);
+                        if (lane == 0) sh.tot[j][v] = s;
+                        break;
+                    }
+                    if (__hip_atomic_load(&st->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; break; }
+                    if (wall_clock64() - t_begin > kSyncTimeoutTicks) {
+                        __hip_atomic_store(&st->aborted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (tid == 0) *lds_flag = 1;
+            __syncthreads();
+            if (!ok) *lds_flag = 0;
         }
         __syncthreads();
         if (*lds_flag == 0) return;
         NPBNN_SPEC_TICK(3);
-        {   // (the sums were stored past the caches by the evaluating workgroups: read them the same way, no acquire fence needed)
-            const int lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
-            const double* part = g_partials + (size_t)q * kMaxCand * kPartialStride * n_blocks;
-            for (int item = wave; item < n_pend * nvals; item += nwv) {
-                const int j = item / nvals, v = partial_value_index(item % nvals, k_targets);
-                const double* src = part + ((size_t)j * kPartialStride + v) * n_blocks;
-                // (a lane's values - workgroups lane, lane + 64, ... - requested TOGETHER, then added in that order: one round trip past the
-                // caches instead of one per value; this sits between two passes, on the chain's critical path)
-                double x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int b = lane + 64 * u;
-                    x[u] = b < n_blocks ? __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                }
-                double s = 0.0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (lane + 64 * u < n_blocks) s += x[u];
-                for (int b = lane + 256; b < n_blocks; b += 64) s += __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s = butterfly_sum_f64(s);
-                if (lane == 0) sh.tot[j][v] = s;
-            }
-        }
         __syncthreads();
         if (tid == 0) {
             int accepted = -1, n_done = n_pend;

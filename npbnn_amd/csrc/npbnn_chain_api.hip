@@ -274,8 +274,14 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
             ctx->spec_touch_cap = (size_t)ctx->n_weights;
             ctx->spec_gen = 0xf0000000u;         // (forces the clearing below)
         }
+        const size_t part_bytes = (size_t)2 * kMaxCand * kPartialStride * kSpecPartSlots * 2 * sizeof(unsigned long long);
+        if (!ctx->d_spec_part) {
+            HIP_TRY(ctx, hipMalloc(&ctx->d_spec_part, part_bytes));
+            ctx->spec_gen = 0xf0000000u;         // (cleared below)
+        }
         if (ctx->spec_gen + (unsigned)K + 8u >= 0xf0000000u) {   // the batch's pass tags (one per pass, at most K + 1 passes) could repeat
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_spec_touch, 0, (size_t)kMaxCand * ctx->spec_touch_cap * 4 * sizeof(unsigned), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_spec_part, 0, part_bytes, ctx->stream));
             ctx->spec_gen = 0;
         }
     }
@@ -381,12 +387,14 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.spec = nullptr;
     c.spec_pv = nullptr;
     c.spec_touch = nullptr;
+    c.spec_part = nullptr;
     c.n_weights_spec = ctx->n_weights;
     c.spec_gen = 0;
     if (spec) {
         c.spec = ctx->d_spec;
         c.spec_pv = ctx->d_spec_pv;
         c.spec_touch = ctx->d_spec_touch;
+        c.spec_part = ctx->d_spec_part;
         c.spec_gen = (int)ctx->spec_gen;
         ctx->spec_gen += (unsigned)K + 8u;             // (a pass decides at least one iteration)
     }

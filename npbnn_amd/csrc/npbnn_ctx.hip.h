@@ -165,6 +165,7 @@ struct npbnn_ctx {
     size_t spec_pv_cap = 0;        // M capacity
     unsigned* d_spec_touch = nullptr;   // [kMaxCand][n_weights][4] touch tables: pass tag (cleared before it could repeat), -, value
     size_t spec_touch_cap = 0;     // weights capacity
+    unsigned long long* d_spec_part = nullptr;   // [2][kMaxCand][kPartialStride][256][2] the workgroups' sums of a pass as tagged word pairs (npbnn_chain.hip.h, SpecPart)
     unsigned spec_gen = 0;         // pass tags handed out so far
     // rows split over the ranks of a communicator (npbnn_set_row_shard): the records of partial sums are gathered before every step
     int shard_n = 0, shard_rank = 0;

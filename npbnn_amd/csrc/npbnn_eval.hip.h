@@ -592,6 +592,8 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     typedef const __attribute__((address_space(4))) ChainParams ConstChainParams;
     ChainDev* const st_dev = chain ? uni(((ConstChainParams*)chain)->st) : nullptr;
     const SpecState* const spec_dev = (SPEC && chain) ? uni(((ConstChainParams*)chain)->spec) : nullptr;
+    unsigned long long* const spec_part = (SPEC && chain) ? uni(((ConstChainParams*)chain)->spec_part) : nullptr;
+    const unsigned spec_gen0 = (SPEC && chain) ? (unsigned)uni(((ConstChainParams*)chain)->spec_gen) : 0u;
     // (the thread index through a copy the compiler cannot trace, once at the top of a pass and once behind its tiles: what the prologue
     // and the epilogue derive from it - patch-list addresses, lane tests - is then formed where it is used, every pass, instead of being
     // hoisted out of the pass loop of a persistent launch and kept in registers across the tile loop)
@@ -1386,6 +1388,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
             // (group pass: candidate j is slot 0 of chain j's own partial block)
             double* const dst = GN ? p.group[j].partials + (((size_t)par * kMaxCand) * kPartialStride + v) * G + lbid
                                    : g_partials + (((size_t)par * kMaxCand + j) * kPartialStride + v) * G + lbid;
+            if constexpr (SPEC) {
+                // (decision between the passes: the sums travel as tagged word pairs - nothing to wait for, nothing to report, the step
+                // reads the tags with the values: spec_part_store)
+                if (early_copy) { spec_part_store(spec_part + spec_part_index(par, j, v, lbid), s, spec_gen0 + (unsigned)launch + 1u); continue; }
+            }
             if (sync) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (write-through: no fence at the end)
             else *dst = s;
         }
@@ -1395,7 +1402,7 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         __syncthreads();
         // (by the LAST wave: it waits for the stores to be acknowledged, a round trip that wave 0 - which reads the next pass's flag
         // and descriptor for everybody - does not have to sit through)
-        if (threadIdx.x == blockDim.x - 64) sync_eval_leave(st_dev, launch);
+        if (threadIdx.x == blockDim.x - 64 && !(SPEC && early_copy)) sync_eval_leave(st_dev, launch);
         if constexpr (LOOK) {
             // (look_words were written before the barrier two above: every wave reads the same descriptor)
             if (look && look_words[1] > 0) {     // word 1: n_cand

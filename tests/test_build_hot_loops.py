@@ -30,7 +30,7 @@ KNOWN = {
     "npbnn_eval_inst_d1_cat": {(7, 1, 1, 1, 0): 12, (8, 1, 1, 1, 0): 16},
     "npbnn_eval_inst_d1_gauss": {(2, 1, 1, 1, 1): 8, (6, 1, 1, 1, 1): 2, (7, 1, 1, 1, 1): 14, (8, 1, 1, 1, 1): 18, (7, 1, 0, 1, 1): 7, (8, 1, 0, 1, 1): 23},
     "npbnn_eval_inst_d1_cat_spec": {(3, 1, 0, 1, 0): 1, (4, 1, 0, 1, 0): 1},
-    "npbnn_eval_inst_d1_gauss_spec": {(1, 1, 0, 1, 1): 4, (2, 1, 1, 1, 1): 18, (2, 1, 0, 1, 1): 5},
+    "npbnn_eval_inst_d1_gauss_spec": {(1, 1, 0, 1, 1): 12, (2, 1, 1, 1, 1): 18, (2, 1, 0, 1, 1): 5},
     "npbnn_eval_inst_d2_cat": {(4, 1, 1, 2, 0): 27, (5, 1, 1, 2, 0): 52, (6, 1, 1, 2, 0): 79, (7, 1, 1, 2, 0): 135, (8, 1, 1, 2, 0): 180,
                                (4, 1, 0, 2, 0): 10, (5, 1, 0, 2, 0): 22, (6, 1, 0, 2, 0): 48, (7, 1, 0, 2, 0): 83, (8, 1, 0, 2, 0): 196},
     "npbnn_eval_inst_d2_gauss": {(2, 1, 1, 2, 1): 16, (3, 1, 1, 2, 1): 3, (4, 1, 1, 2, 1): 32, (5, 1, 1, 2, 1): 53, (6, 1, 1, 2, 1): 94, (7, 1, 1, 2, 1): 122,

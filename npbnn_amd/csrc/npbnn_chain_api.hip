@@ -184,15 +184,19 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
             const int other = schedule == NPBNN_SCHED_PERSIST_SERIAL ? 0 : 1;
             // (a form never measured in this size class gets its batch after a handful on the other: the model is a prior, not a verdict -
             // it prices every accept of the overlapped form at a whole pass in vain, and such a pass is cut short)
-            if (ctx->turn_batches[other][kc] >= (ctx->it_us[other][kc] <= 0.0 ? kTurnFirstProbeBatches : kTurnReprobeBatches)) {
+            const int since = ctx->turn_batches[other][kc];
+            const bool never = ctx->it_us[other][kc] <= 0.0;
+            if (since >= (never ? kTurnFirstProbeBatches : kTurnReprobeBatches)) {
                 const double ratio = other == 1 ? c_ser / c_over : c_over / c_ser;
-                ctx->turn_batches[other][kc] = 0;
-                // (within a factor two, that is: the other form's figure dates from when it last ran - the chain's acceptance rate has
-                // moved since, and with it both forms' costs; one batch in kTurnReprobeBatches costs a per cent at worst)
-                // (a form never run: when the model puts it within kFirstProbeWithin of the running one - at 2 % acceptance the decision
-                // between the passes is predicted a third dearer and is: two batches on it would be two batches lost)
-                if (ctx->it_us[other][kc] <= 0.0 ? ratio < kFirstProbeWithin : ratio < 2.0)
-                    schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
+                // A form that has run: within a factor two, that is - its figure dates from when it last ran, the chain's acceptance rate has
+                // moved since, and with it both forms' costs; one batch in kTurnReprobeBatches costs a per cent at worst.  A form never
+                // run: when the model puts it within kFirstProbeWithin of the running one (at a few per cent acceptance the decision between
+                // the passes is predicted a fifth to a third dearer, and is: two batches on it would be two batches lost - a chain's first
+                // dispatches are where short runs are timed) - and whatever the model says after kTurnForcedProbeBatches, so that a wrong
+                // model cannot park a chain for good.
+                const bool probe = never ? (ratio < kFirstProbeWithin || since >= kTurnForcedProbeBatches) : ratio < 2.0;
+                if (probe || !never) ctx->turn_batches[other][kc] = 0;
+                if (probe) schedule = other == 1 ? NPBNN_SCHED_PERSIST_SERIAL : NPBNN_SCHED_PERSIST;
             }
         }
     }

@@ -221,13 +221,14 @@ namespace npbnn_api {
 // the next pass for every outcome - more, the wider the proposals.  The context keeps what an iteration cost on each form
 // (npbnn_ctx.it_us: a batch's time over its iterations) and picks the cheaper one; a form that has not run yet is priced from the other
 // one with that model and kSpecTurnExtraUs + kSpecTurnExtraUsPerWeight * M (measured on config-2 shapes: 33.2 against 28.5 us per turn
-// at M = 33, 40 at M = 428), and is given its first batches after kTurnFirstProbeBatches batches on the other when the model puts it within kFirstProbeWithin of it (then
+// at M = 33, 40 at M = 428), and is given its first batches after kTurnFirstProbeBatches batches on the other when the model puts it within kFirstProbeWithin of it, or after kTurnForcedProbeBatches regardless (then
 // one every kTurnReprobeBatches while within a factor two: measurements go stale).  Short batches (dispatches of 100) and long ones (the
 // sub-batches of a long call) are measured and decided apart.
 constexpr double kSpecTurnExtraUs = 4.5, kSpecTurnExtraUsPerWeight = 0.0175;
 constexpr double kTurnUsGuess = 30.0;           // before anything has been measured
 constexpr int kShortBatch = 256;                // batches below / from this many iterations are measured (and decided) apart
-constexpr double kFirstProbeWithin = 1.3;       // ... if the model prices it within this factor of the measured one (asked again every kTurnFirstProbeBatches batches: the acceptance rate moves)
+constexpr double kFirstProbeWithin = 1.15;      // ... if the model prices it within this factor of the measured one (asked again at every batch: the acceptance rate moves)
+constexpr int kTurnForcedProbeBatches = 200;    // ... or whatever the model says after this many batches without it (a wrong model must not park a chain for good)
 constexpr int kTurnFirstProbeBatches = 4;       // batches on one persistent form before the other, never measured, is given one
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for

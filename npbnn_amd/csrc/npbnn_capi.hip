@@ -494,11 +494,12 @@ void report_eval_stamps(unsigned long long* d_stamps, int grid, int wpb, int fir
     if (getenv("NPBNN_EVAL_STAMPS") && atoi(getenv("NPBNN_EVAL_STAMPS")) >= 2) {
         // per workgroup: pass start -> end of the pass (prologue stamp 4), the tile phase of wave 0, by (b - first_wg) % 8 (its place in the
         // round-robin over the 8 XCDs)
+        auto start_of_wg = [&](int b) { const unsigned long long* q = &hs[(size_t)b * 8]; return q[0] <= q[1] ? q[0] : q[1]; };
         double by_xcd[8] = {0}, tiles_xcd[8] = {0};
         int n_xcd[8] = {0};
         std::vector<std::pair<double, int>> dur;
         for (int b = first_wg; b < grid; ++b) {
-            const double d = (double)(hs[(size_t)grid * 24 + (size_t)b * 8 + 4] - hs[(size_t)b * 8]) * 0.01;
+            const double d = (double)(hs[(size_t)b * 8 + 6] - start_of_wg(b)) * 0.01;      // (start: see below)
             const double t = (double)(hs[(size_t)b * 8 + 4] - hs[(size_t)b * 8 + 3]) * 0.01;
             dur.push_back({d, b});
             by_xcd[b % 8] += d; tiles_xcd[b % 8] += t; ++n_xcd[b % 8];
@@ -526,14 +527,18 @@ void report_eval_stamps(unsigned long long* d_stamps, int grid, int wpb, int fir
         for (int w = 0; w < wpb && w < 16; ++w) fprintf(stderr, " %.1f", done[w] / nwg);
         fprintf(stderr, "\n");
     }
+    // (a pass in the middle of a persistent launch: stamp 0 is then the start of the turn AFTER it - the launch's last, empty one - and
+    // the pass is taken to start where its first barrier is reached, stamp 1; "issue" is not known for it)
+    auto start_of = [&](const unsigned long long* q) { return q[0] <= q[1] ? q[0] : q[1]; };
     unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
     double acc[8] = {0};
     for (int b = first_wg; b < grid; ++b) {
         const unsigned long long* q = &hs[(size_t)b * 8];
-        if (q[0] < first) first = q[0];
+        if (start_of(q) < first) first = start_of(q);
         if (q[6] > last) last = q[6];
         if (q[6] < first_end) first_end = q[6];
-        for (int k = 1; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;      // 100 MHz wall clock -> us
+        if (q[0] <= q[1]) acc[1] += (double)(q[1] - q[0]) * 0.01;                     // 100 MHz wall clock -> us
+        for (int k = 2; k <= 6; ++k) acc[k] += (double)(q[k] - q[k - 1]) * 0.01;
         acc[7] += (double)q[7] * 0.01;
     }
     if (hs[(size_t)grid * 24 + (size_t)first_wg * 8] || hs[(size_t)grid * 24 + (size_t)first_wg * 8 + 3]) {      // (a build with NPBNN_EXP_PROLOGUE_STAMPS)
@@ -551,7 +556,7 @@ void report_eval_stamps(unsigned long long* d_stamps, int grid, int wpb, int fir
                         "first X pieces requested %.2f; end of the pass (sums out, workgroup reported done) %.2f\n", px[0] / nwg, px[1] / nwg, px[2] / nwg, px[3] / nwg, px[4] / nwg);
     }
     double late = 0;
-    for (int b = first_wg; b < grid; ++b) late += (double)(hs[(size_t)b * 8] - first) * 0.01;
+    for (int b = first_wg; b < grid; ++b) late += (double)(start_of(&hs[(size_t)b * 8]) - first) * 0.01;
     fprintf(stderr, "[npbnn eval stamps] wave 0 of a workgroup, mean us: start skew %.2f | issue %.2f  barrier1 %.2f  patch %.2f  tiles %.2f  "
                     "barrier2 %.2f  partials %.2f | tails within tiles %.2f | first start -> first end %.2f, -> last end %.2f\n",
             late / nwg, acc[1] / nwg, acc[2] / nwg, acc[3] / nwg, acc[4] / nwg, acc[5] / nwg, acc[6] / nwg, acc[7] / nwg,

@@ -32,7 +32,8 @@ extern "C" {
 
 #define NPBNN_ABI_VERSION 1
 #define NPBNN_MAX_LAYERS 8      /* weight matrices per network                    */
-#define NPBNN_MAX_WIDTH 128     /* max nodes of any hidden/output layer           */
+#define NPBNN_MAX_WIDTH 4096    /* max nodes of any hidden/output layer (layers of more than 128 nodes, and networks whose
+                                   weights do not fit a compute unit's LDS, run on the weight-streamed path) */
 #define NPBNN_MAX_TARGETS 16    /* max target columns for the Gaussian/count liks */
 #define NPBNN_XSTATE_DOUBLES (4 + NPBNN_MAX_TARGETS)   /* doubles per exchange in npbnn_chain_job.out_state */
 
@@ -155,7 +156,12 @@ int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
  * that has its GPU to itself; 0 keeps the automatic choice on kernel boundaries (NPBNN_SCHED_OVERLAP / _SERIAL). */
 /* NPBNN_OPT_TRAINABLE_SLOPES (default 0): 1 reserves a slot per hidden layer in the weight image for the activation slope, so that the
  * candidates of a chain pass can each carry their own (npbnn_chain_cfg.slope_idx ...); such a network runs on the general builds. */
-enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTENT = 3, NPBNN_OPT_TRAINABLE_SLOPES = 4 };
+/* NPBNN_OPT_WIDE (default 0): the weight-streamed path.  A network runs on it BY ITSELF when a layer has more than 128 nodes or when its
+ * weights would leave a compute unit's LDS fewer than 8 waves beside them (the reference's default n_nodes = [50, 5], np_bnn/BNN_env.py:20,
+ * from ~550 features on; MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape): every layer is then a tiled matrix product
+ * whose operands both stream through LDS, weights from a resident image in HBM, one weight set per pass.  1 = every network runs on it
+ * (A/B timing, tests).  NPBNN_INFO_WIDE: 1 when the architecture set last runs on it. */
+enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTENT = 3, NPBNN_OPT_TRAINABLE_SLOPES = 4, NPBNN_OPT_WIDE = 5 };
 enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
 /* NPBNN_INFO_TURN_NS_OVERLAPPED / _BETWEEN: what NPBNN_SCHED_AUTO last measured for one launch turn (a pass, decided or void) of the
  * two persistent forms, in nanoseconds (0: never run on this context); NPBNN_INFO_IT_NS_OVERLAPPED / _BETWEEN: what an ITERATION of a
@@ -165,7 +171,7 @@ enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
  * candidates of a speculative chain pass, the chains of a group pass (npbnn_chains_run_batched), the sets of npbnn_predict_sets. */
 enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3, NPBNN_INFO_FAST_TAILS = 4,
        NPBNN_INFO_TURN_NS_OVERLAPPED = 5, NPBNN_INFO_TURN_NS_BETWEEN = 6, NPBNN_INFO_MAX_CANDIDATES = 7,
-       NPBNN_INFO_IT_NS_OVERLAPPED = 8, NPBNN_INFO_IT_NS_BETWEEN = 9 };
+       NPBNN_INFO_IT_NS_OVERLAPPED = 8, NPBNN_INFO_IT_NS_BETWEEN = 9, NPBNN_INFO_WIDE = 10 };
 int npbnn_set_option(npbnn_ctx* ctx, int option, int value);
 int npbnn_get_info(npbnn_ctx* ctx, int what, int* out);
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 MAX_LAYERS = 8
-MAX_WIDTH = 128
+MAX_WIDTH = 4096
 MAX_TARGETS = 16
 XSTATE_DOUBLES = 4 + MAX_TARGETS      # doubles per exchange in ChainJob.out_state: logLik, logPrior, temperature, iterations, sigma[...]
 
@@ -24,9 +24,11 @@ OPT_L0_PRECISION = 1
 OPT_FAST_TAILS = 2
 OPT_PERSISTENT = 3
 OPT_TRAINABLE_SLOPES = 4
+OPT_WIDE = 5
 L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
 INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU, INFO_FAST_TAILS, INFO_TURN_NS_OVERLAPPED, INFO_TURN_NS_BETWEEN, INFO_MAX_CANDIDATES = 1, 2, 3, 4, 5, 6, 7
 INFO_IT_NS_OVERLAPPED, INFO_IT_NS_BETWEEN = 8, 9
+INFO_WIDE = 10
 E_RANGE = -6
 E_SYNC = -7
 

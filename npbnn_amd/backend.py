@@ -129,6 +129,16 @@ class HipContext:
         cb = C.cast(gather_cb, C.c_void_p) if gather_cb is not None else None
         self._chk(self._lib.npbnn_set_row_shard(self._ctx, comm_handle, cb, None, int(rank), int(n_ranks), int(n_rows_total)))
 
+    def set_wide(self, on):
+        """Run every network of this context on the weight-streamed path (layers as tiled matrix products, weights streamed from
+        HBM), not only those the LDS-resident path cannot hold (layers of more than 128 nodes, weight images that crowd out the
+        waves): for A/B timing and tests.  Results agree to rounding, not bit for bit."""
+        self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_WIDE, 1 if on else 0))
+
+    def is_wide(self):
+        """Does the architecture set last run on the weight-streamed path?"""
+        return bool(self.info(capi.INFO_WIDE))
+
     def set_persistent(self, on):
         """May the library pick the persistent form of the overlapped chain schedule by itself (default on)?"""
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_PERSISTENT, 1 if on else 0))

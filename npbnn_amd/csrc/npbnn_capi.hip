@@ -126,11 +126,46 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         net.l1_f16 = (f16 && narrow_later && a->act_kind == NPBNN_ACT_TANH && a->out_dim[0] > 16 && !a->final_act && !getenv("NPBNN_NO_L1_F16")) ? 1 : 0;
     }
     int in = a->in_dim, off = 0, woff = 0;
-    for (int l = 0; l < a->n_layers; ++l) {
-        const int out = a->out_dim[l];
-        if (out < 1 || out > NPBNN_MAX_WIDTH)
-            return fail(ctx, NPBNN_E_ARG, "set_arch: layer %d has %d nodes; this backend supports 1..%d per layer", l, out,
+    for (int l = 0; l < a->n_layers; ++l)
+        if (a->out_dim[l] < 1 || a->out_dim[l] > NPBNN_MAX_WIDTH)
+            return fail(ctx, NPBNN_E_ARG, "set_arch: layer %d has %d nodes; this backend supports 1..%d per layer", l, a->out_dim[l],
                         NPBNN_MAX_WIDTH);
+    {
+        long long nw = 0;
+        int in_l = a->in_dim;
+        for (int l = 0; l < a->n_layers; ++l) { nw += (long long)a->out_dim[l] * (in_l + (a->has_bias[l] ? 1 : 0)); in_l = a->out_dim[l]; }
+        if (nw >= (1ll << 31)) return fail(ctx, NPBNN_E_ARG, "set_arch: %lld weights; this backend indexes up to 2^31", nw);
+    }
+    // Networks the LDS of a compute unit cannot hold (or a layer wider than the resident builds' tiles) run on the weight-streamed
+    // path (npbnn_wide.hip): the description below then carries what the chain step and the likelihood need - shapes, offsets into
+    // the packed weights, kinds - and none of the resident image's layout.
+    ctx->wide = wide_needed(ctx, a);
+    if (ctx->wide) {
+        net.pad_masked = 0;
+        net.l1_f16 = 0;
+        net.l0_rows = 16;
+        for (int mt = 0; mt < kMaxMT; ++mt) { net.l0_begin[mt] = 0; net.l0_end[mt] = 0; net.l0_base[mt] = 0; }
+        for (int l = 0; l < a->n_layers; ++l) {
+            LayerMeta& L = net.L[l];
+            L.in_dim = in;
+            L.out_dim = a->out_dim[l];
+            L.has_bias = a->has_bias[l] ? 1 : 0;
+            L.kt = (in + 15) / 16;
+            L.mt = (L.out_dim + 15) / 16;
+            L.frag_off = 0;
+            L.bias_off = 0;
+            L.out_perm = 0;
+            L.in_live = 4;
+            L.w_off = woff;
+            woff += L.out_dim * (in + L.has_bias);
+            in = L.out_dim;
+        }
+        net.classw_off = -1;
+        net.slope_off = ctx->slopes_option ? 0 : -1;     // (>= 0 says "candidates carry their own slopes": the streamed kernels read them from the chain)
+        net.image_floats = 0;
+    }
+    for (int l = 0; l < a->n_layers && !ctx->wide; ++l) {
+        const int out = a->out_dim[l];
         LayerMeta& L = net.L[l];
         L.in_dim = in;
         L.out_dim = out;
@@ -171,13 +206,14 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         woff += out * (in + L.has_bias);
         in = out;
     }
+    if (!ctx->wide) {
     for (int l = 0; l < a->n_layers; ++l) {
         net.L[l].bias_off = off;
         off += 16 * net.L[l].mt;
     }
     if (ctx->n_classw > 0) {            // class weights ride in the image only when there are any
         net.classw_off = off;
-        off += NPBNN_MAX_WIDTH;
+        off += kResidentMaxWidth;
     } else {
         net.classw_off = -1;
     }
@@ -187,6 +223,7 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
         off += kMaxLayers;
     }
     net.image_floats = round_up(off, 64);   // a multiple of 256 B (the LDS copies of several candidates sit back to back)
+    }
     net.n_out = a->out_dim[a->n_layers - 1];
     if (a->lik_kind == NPBNN_LIK_GAUSS) {
         if (a->n_targets < 1 || a->n_targets > NPBNN_MAX_TARGETS || a->n_targets > net.n_out)
@@ -370,6 +407,8 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
         int rc0 = rebuild_net(ctx, want_f16);
         if (rc0) return rc0;
     }
+    if (ctx->wide) return wide_plan(ctx, which, lp);
+    lp->wide = false;
     size_t lds = 0;
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
     int n_cand = (max_inner_tiles(ctx->net) == 1 && (predict_only || !lik_needs_row_scratch(ctx->net.lik_kind))) ? want_cand : 1;
@@ -453,11 +492,8 @@ int stage_weights(npbnn_ctx* ctx, const double* W, const double* act_prm, const 
     for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
     if (act_prm)
         for (int l = 0; l + 1 < ctx->net.n_layers; ++l) ctx->net.act_prm[l] = (float)act_prm[l];
-    const int total = pack_item_count(ctx->net, true);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wraw, d_co,
-                       ctx->n_classw ? ctx->d_classw : nullptr, ctx->d_image, ctx->net,
-                       ctx->net.l0_f16 ? ctx->d_wscale : nullptr, ctx->d_overflow);
+    launch_pack_weights(ctx, ctx->d_wraw, d_co, ctx->d_image, ctx->d_overflow);
     HIP_TRY(ctx, hipGetLastError());
     return NPBNN_OK;
 }
@@ -598,6 +634,8 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
     if (ctx->d_image) { (void)hipFree(ctx->d_image); ctx->d_image = nullptr; }
     if (ctx->d_w2img) { (void)hipFree(ctx->d_w2img); ctx->d_w2img = nullptr; }
     if (ctx->d_w2scale) { (void)hipFree(ctx->d_w2scale); ctx->d_w2scale = nullptr; }
+    if (ctx->wide) return wide_build(ctx, f16);
+    wide_free(ctx);
     size_t lds = 0;
     if (pick_waves_per_block(ctx, &lds, 1, make_wave_layout(true, false, ctx->net.k_targets, ctx->net.L[0].kt, ctx->net.lik_kind)) == 0)
         return fail(ctx, NPBNN_E_ARG, "network too large: weight image of %d KiB does not fit the %zu KiB LDS of a CU",
@@ -666,9 +704,29 @@ int rebuild_net(npbnn_ctx* ctx, bool f16) {
 double wall_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void launch_pack_weights(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, float* image, int* flags) {
+    if (ctx->wide) { wide_pack(ctx, d_w, d_col_override, image, flags); return; }
     const int total = pack_item_count(ctx->net, true);
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, d_w, d_col_override,
                        ctx->n_classw ? ctx->d_classw : nullptr, image, ctx->net, ctx->net.l0_f16 ? ctx->d_wscale : nullptr, flags);
+}
+
+int launch_plain_eval(npbnn_ctx* ctx, const LaunchPlan& lp, int which) {
+    if (lp.wide) return wide_forward(ctx, which, ctx->d_image, false);
+    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+    return NPBNN_OK;
+}
+
+// confusion counts: device and pinned host buffers for n_classes x n_classes
+int ensure_conf(npbnn_ctx* ctx, int n_classes) {
+    unsigned need = (unsigned)(n_classes < kResidentMaxWidth ? kResidentMaxWidth : n_classes);
+    if (need <= ctx->conf_cap) return NPBNN_OK;
+    if (ctx->d_conf) { (void)hipFree(ctx->d_conf); ctx->d_conf = nullptr; }
+    if (ctx->h_conf) { (void)hipHostFree(ctx->h_conf); ctx->h_conf = nullptr; }
+    ctx->conf_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_conf, (size_t)need * need * sizeof(unsigned)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_conf, (size_t)need * need * sizeof(unsigned)));
+    ctx->conf_cap = need;
+    return NPBNN_OK;
 }
 
 void launch_finalize(npbnn_ctx* ctx) {
@@ -682,6 +740,7 @@ extern "C" void npbnn_set_global_error_(const char* msg) { g_last_error = msg ? 
 namespace npbnn_api {
 void destroy_ctx(npbnn_ctx* c) {
     (void)hipSetDevice(c->device);
+    wide_free(c);
     free_dataset(c->ds[0]);
     free_dataset(c->ds[1]);
     if (c->d_classw) (void)hipFree(c->d_classw);
@@ -756,7 +815,7 @@ int npbnn_create(int device_id, npbnn_ctx** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_limit = 160 * 1024;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&c->d_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&c->d_conf, (size_t)kResidentMaxWidth * kResidentMaxWidth * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&c->d_out, sizeof(npbnn_eval_out));
     if (e == hipSuccess) e = hipMalloc(&c->d_overflow, sizeof(int));
     // the kernels' parameter blocks: ONE device allocation laid out like its page-locked staging twin, so that a chain batch sends
@@ -768,7 +827,8 @@ int npbnn_create(int device_id, npbnn_ctx** out) {
     }
     if (e == hipSuccess) e = hipHostMalloc(&c->h_params, sizeof(EvalParams) + sizeof(FinalizeParams) + sizeof(ChainParams));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_out, sizeof(npbnn_eval_out));
-    if (e == hipSuccess) e = hipHostMalloc(&c->h_conf, (size_t)NPBNN_MAX_WIDTH * NPBNN_MAX_WIDTH * sizeof(unsigned));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_conf, (size_t)kResidentMaxWidth * kResidentMaxWidth * sizeof(unsigned));
+    if (e == hipSuccess) c->conf_cap = kResidentMaxWidth;
     if (e == hipSuccess) e = hipEventCreate(&c->ev[0]);
     if (e == hipSuccess) e = hipEventCreate(&c->ev[1]);
     if (e != hipSuccess) {
@@ -964,6 +1024,17 @@ int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
         ctx->persist_option = value ? 1 : 0;
         return NPBNN_OK;
     }
+    if (option == NPBNN_OPT_WIDE) {
+        const int on = value ? 1 : 0;
+        if (on != ctx->wide_option) {
+            ctx->wide_option = on;
+            if (ctx->arch_set) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                return rebuild_net(ctx, ctx->net.l0_f16 != 0);
+            }
+        }
+        return NPBNN_OK;
+    }
     if (option == NPBNN_OPT_TRAINABLE_SLOPES) {
         const int on = value ? 1 : 0;
         if (on != ctx->slopes_option) {
@@ -978,6 +1049,11 @@ int npbnn_set_option(npbnn_ctx* ctx, int option, int value) {
 int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (!ctx || !out) return fail(ctx, NPBNN_E_ARG, "get_info: bad arguments");
     if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
+    if (what == NPBNN_INFO_WIDE) { *out = (ctx->arch_set && ctx->wide) ? 1 : 0; return NPBNN_OK; }
+    if (ctx->arch_set && ctx->wide && (what == NPBNN_INFO_WAVES_PER_BLOCK || what == NPBNN_INFO_MAX_CANDIDATES || what == NPBNN_INFO_FAST_TAILS)) {
+        *out = what == NPBNN_INFO_WAVES_PER_BLOCK ? 4 : what == NPBNN_INFO_MAX_CANDIDATES ? 1 : 0;      // (one weight set per pass; no shape-specialised tails)
+        return NPBNN_OK;
+    }
     if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds, 1, layout_for(ctx, ctx->ds[0])); return NPBNN_OK; }
     if (what == NPBNN_INFO_N_CU) { *out = ctx->n_cu; return NPBNN_OK; }
     if (what == NPBNN_INFO_TURN_NS_OVERLAPPED || what == NPBNN_INFO_TURN_NS_BETWEEN) {
@@ -1022,12 +1098,15 @@ static int eval_once(npbnn_ctx* ctx, const double* W_packed, const double* act_p
     p.use_classw = (which == 0 && ctx->n_classw > 0) ? 1 : 0;
     const int C = ctx->net.n_out;
     if (confusion) {
+        rc = ensure_conf(ctx, C);
+        if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_conf, 0, (size_t)C * C * sizeof(unsigned), ctx->stream));
         p.confusion = ctx->d_conf;
     }
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+    rc = launch_plain_eval(ctx, lp, which);
+    if (rc) return rc;
     HIP_TRY(ctx, hipGetLastError());
     FinalizeParams f{};
     f.partials = ctx->d_partials;
@@ -1115,7 +1194,8 @@ int npbnn_predict(npbnn_ctx* ctx, const double* W_packed, const double* act_prm,
     p.predict_mode = apply_out_fn ? 2 : 1;
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
-    hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+    rc = launch_plain_eval(ctx, lp, which);
+    if (rc) return rc;
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, n_el * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     int ovf = 0;
@@ -1170,13 +1250,9 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
             for (int l = 0; l < kMaxLayers; ++l) ctx->net.act_prm[l] = 0.f;
             if (act_prm_sets)
                 for (int l = 0; l < n_act; ++l) ctx->net.act_prm[l] = (float)act_prm_sets[(size_t)s0 * n_act + l];
-            const int total = pack_item_count(ctx->net, true);
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), ctx->stream));
-            for (int j = 0; j < g; ++j)
-                hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wraw + (size_t)j * wn,
-                                   (const double*)nullptr, ctx->n_classw ? ctx->d_classw : nullptr,
-                                   ctx->d_image + (size_t)j * ctx->net.image_floats, ctx->net, ctx->net.l0_f16 ? ctx->d_wscale : nullptr,
-                                   ctx->d_overflow);
+            for (int j = 0; j < g; ++j)         // (the weight-streamed path carries one set per pass: g = 1)
+                launch_pack_weights(ctx, ctx->d_wraw + (size_t)j * wn, nullptr, ctx->d_image + (size_t)j * ctx->net.image_floats, ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
             EvalParams p = make_params(ctx, d);
             p.labels = nullptr;
@@ -1188,7 +1264,8 @@ int npbnn_predict_sets(npbnn_ctx* ctx, const double* W_sets, const double* act_p
             p.lay = layout_for(ctx, d, true);
             rc = push_eval_params(ctx, p);
             if (rc) return rc;
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+            rc = launch_plain_eval(ctx, lp, which);
+            if (rc) return rc;
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_y, (size_t)g * per_set * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
             int ovf = 0;
@@ -1263,6 +1340,19 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     }
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
+    if (lp.wide) {      // the pass of the weight-streamed path: its layers' products + the likelihood kernel, timed together
+        for (int i = 0; i < 3 && !rc; ++i) rc = wide_forward(ctx, 0, ctx->d_image, false);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        for (int i = 0; i < iters && !rc; ++i) rc = wide_forward(ctx, 0, ctx->d_image, false);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (rc) return rc;
+        float msw = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&msw, ctx->ev[0], ctx->ev[1]));
+        *ms_kernel = (double)msw / iters;
+        if (used_candidates) *used_candidates = 1;
+        return NPBNN_OK;
+    }
     for (int i = 0; i < 3; ++i)
         hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -1343,22 +1433,22 @@ int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* m
     // (1) the dominant kernel alone: `iters` back-to-back launches between one pair of events (per-launch event pairs
     //     would add ~4 us of command-processor overhead to each 20 us kernel); includes the ~1.5 us launch boundary
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+    for (int i = 0; i < 3 && !rc; ++i) rc = launch_plain_eval(ctx, lp, 0);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_plain_eval(ctx, lp, 0);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (rc) return rc;
     float burst = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&burst, ctx->ev[0], ctx->ev[1]));
     const double sum = (double)burst;
     // (2) evaluation = eval kernel + finalize
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    for (int i = 0; i < iters; ++i) {
-        hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, ctx->stream, (const EvalParams*)ctx->d_eparams, 0, 1);
+    for (int i = 0; i < iters && !rc; ++i) {
+        rc = launch_plain_eval(ctx, lp, 0);
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, (const FinalizeParams*)ctx->d_fparams);
     }
+    if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());

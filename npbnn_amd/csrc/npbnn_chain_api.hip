@@ -135,7 +135,10 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     if (sharded && (group_blocks > 0 || seg_len > 0))
         return fail(ctx, NPBNN_E_STATE, "chain_run: a context whose rows are split over ranks runs plain batches only (no group pass, no exchange run)");
     // schedule: overlapping the decision of a pass with the evaluation of the next pays as long as most passes reject everything
-    int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : sharded ? NPBNN_SCHED_SERIAL : cfg->schedule;      // (row shards: a gather between pass and step)
+    if (lp.wide && group_blocks > 0)
+        return fail(ctx, NPBNN_E_STATE, "chain_run: a network on the weight-streamed path carries one weight set per pass (no group pass)");
+    // (row shards: a gather between pass and step; weight-streamed path: the candidate image is patched between step and pass)
+    int schedule = group_blocks > 0 ? NPBNN_SCHED_OVERLAP : (sharded || lp.wide) ? NPBNN_SCHED_SERIAL : cfg->schedule;
     if (schedule != NPBNN_SCHED_SERIAL && schedule != NPBNN_SCHED_OVERLAP && schedule != NPBNN_SCHED_OVERLAP2 && schedule != NPBNN_SCHED_PERSIST &&
         schedule != NPBNN_SCHED_PERSIST_SERIAL) {
         const double p_acc = ctx->accept_rate < 0 ? 0.0 : ctx->accept_rate;
@@ -508,9 +511,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     {   // one launch: image position (and fp16-split scale) of every drawn entry, so that no kernel needs a dependent lookup - indices
         // outside the network are neutralised there and reported when the batch comes back (kFlagBadIndex) - and, in the blocks
         // behind those, the weight image of the state the batch starts from (accepted candidates are committed to it entry by entry)
-        const int gather_blocks = (int)((need + 255) / 256), pack_blocks = (pack_item_count(ctx->net, true) + 255) / 256;
+        const int gather_blocks = (int)((need + 255) / 256), pack_blocks = lp.wide ? 0 : (pack_item_count(ctx->net, true) + 255) / 256;
         PackJob pk;
-        pk.w = ctx->d_wcur;
+        pk.w = lp.wide ? nullptr : ctx->d_wcur;      // (weight-streamed path: its own packing kernel, below)
         pk.class_w = ctx->n_classw ? ctx->d_classw : nullptr;
         pk.image = ctx->d_image;
         pk.net = reinterpret_cast<const NetMeta*>(reinterpret_cast<const char*>(ctx->d_cparams) + offsetof(ChainParams, net));
@@ -518,6 +521,11 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
         hipLaunchKernelGGL(gather_pos_kernel, dim3((unsigned)(gather_blocks + pack_blocks)), dim3(256), 0, st, ctx->d_idx, (long long)need, ctx->n_weights,
                            (const int*)ctx->d_w2img, (const float*)(f16 ? ctx->d_w2scale : nullptr), ctx->d_pos,
                            f16 ? ctx->d_pscale : (float*)nullptr, ctx->d_chain_ovf, gather_blocks, pk);
+    }
+    if (lp.wide) {       // the committed image of the state the batch starts from, and the candidate image as a copy of it
+        wide_pack(ctx, ctx->d_wcur, nullptr, ctx->d_image, ctx->d_chain_ovf);
+        rc = wide_cand_begin(ctx);
+        if (rc) return rc;
     }
     stage_mark(ctx, "gather + pack kernel", &t_stage);
     hipLaunchKernelGGL(chain_step_kernel, dim3(1), dim3(1024), 0, st, (const ChainParams*)ctx->d_cparams, 1);
@@ -603,7 +611,13 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch, 1);
     } else {
         for (int i = 0; i < n; ++i, ++B.launch) {
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0, 1);
+            if (lp.wide) {      // candidate image <- committed image + the pending proposal, then the layers' products and the likelihood
+                wide_cand_sync(ctx);
+                const int rcw = wide_forward(ctx, 0, ctx->d_wide_cand, true);
+                if (rcw) return rcw;
+            } else {
+                hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0, 1);
+            }
             if (ctx->shard_n > 0) {
                 const int rc = shard_exchange(ctx, lp, B.D);
                 if (rc) return rc;

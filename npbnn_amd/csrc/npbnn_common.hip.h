@@ -9,7 +9,10 @@
 namespace npbnn {
 
 constexpr int kMaxLayers = NPBNN_MAX_LAYERS;
-constexpr int kMaxMT = NPBNN_MAX_WIDTH / 16;   // 16-unit tiles per layer
+// The LDS-resident path (eval_kernel) holds layers of up to kResidentMaxWidth nodes; wider ones - up to NPBNN_MAX_WIDTH - run on the
+// weight-streamed path (npbnn_wide.hip.h), as does any network whose image does not fit a compute unit's LDS.
+constexpr int kResidentMaxWidth = 128;
+constexpr int kMaxMT = kResidentMaxWidth / 16;   // 16-unit tiles per layer of the resident path
 #ifndef NPBNN_RING
 #define NPBNN_RING 4
 #endif
@@ -62,7 +65,7 @@ __host__ __device__ inline int tile_pos(int u) { return 4 * (u & 3) + (u >> 2); 
 struct NetMeta {
     int n_layers;
     int image_floats;   // total floats of the image (multiple of 256)
-    int classw_off;     // float offset of class weights (NPBNN_MAX_WIDTH floats; only present when class weights are set, else -1)
+    int classw_off;     // float offset of class weights (kResidentMaxWidth floats; only present when class weights are set, else -1)
     int act_kind, out_kind, lik_kind, n_out, k_targets;
     int final_act;      // apply the activation to the last layer's output too (RunHiddenLayer on its own)
     int l0_f16;         // layer 0 runs on the fp16-split path (x = xh + xl, w = wh + wl; 3 f16 MFMAs, f32 accumulate)

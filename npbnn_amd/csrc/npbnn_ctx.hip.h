@@ -209,6 +209,15 @@ struct npbnn_ctx {
     npbnn_ctx* data_owner = nullptr;
     int n_borrowers = 0;
     bool zombie = false;
+    // weight-streamed path (npbnn_wide.hip): the network does not fit a compute unit's LDS (or NPBNN_OPT_WIDE asks for it)
+    bool wide = false;
+    int wide_option = 0;           // NPBNN_OPT_WIDE: 0 when the resident path cannot hold the network, 1 always
+    WideMeta wmeta{};
+    float* d_wide_cand = nullptr;  // candidate image of a device chain (the committed image with the pending proposal patched in)
+    float* d_wide_act[2] = {nullptr, nullptr};   // hidden activations [rows][16 * tiles], ping-pong between layers
+    size_t wide_act_cap = 0;       // floats each
+    WideCandState* d_wide_cs = nullptr;
+    unsigned conf_cap = 0;         // classes d_conf / h_conf are sized for
 };
 
 static_assert(sizeof(EvalParams) % 8 == 0 && sizeof(FinalizeParams) % 8 == 0, "parameter blocks are laid out back to back");
@@ -254,7 +263,23 @@ struct LaunchPlan {
     size_t lds;
     int n_waves;
     bool fast;
+    bool wide = false;       // weight-streamed path: no single kernel - wide_forward launches the layers' products and the likelihood
 };
+
+// ---- weight-streamed path (npbnn_wide.hip) ----
+bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a);
+int wide_build(npbnn_ctx* ctx, bool f16);
+void wide_free(npbnn_ctx* ctx);
+int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp);
+void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, float* image, int* flags);
+// the forward pass + likelihood of the weights in `image` on the ctx stream; the launch's EvalParams must be in ctx->d_eparams.
+// chain_pass: a pass of a device chain (the kernels leave at once when the chain's batch is through; candidate slopes from the chain)
+int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass);
+int wide_cand_begin(npbnn_ctx* ctx);     // start of a chain batch: candidate image = committed image, nothing patched
+void wide_cand_sync(npbnn_ctx* ctx);     // before a chain pass: candidate image = committed image + the pending proposal
+int ensure_conf(npbnn_ctx* ctx, int n_classes);
+// one evaluation launch of a plan on the ctx stream (resident: the plan's kernel; weight-streamed: wide_forward on the committed image)
+int launch_plain_eval(npbnn_ctx* ctx, const LaunchPlan& lp, int which);
 
 int max_inner_tiles(const NetMeta& net);
 WaveLayout layout_for(const npbnn_ctx* ctx, const Dataset& d, bool predict_only = false);

@@ -382,7 +382,8 @@ extern "C" int npbnn_chain_run_general(npbnn_ctx* ctx, const npbnn_chain_cfg* cf
         for (int t = 0; t < K; ++t) {
             hipLaunchKernelGGL(gen_propose_kernel, dim3(1), dim3(1024), 0, st, dgp, t);
             launch_pack_weights(ctx, g.Weff, g.colov, ctx->d_image, reinterpret_cast<int*>(b_flags.p));
-            hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0, 1);
+            rc = launch_plain_eval(ctx, lp, 0);
+            if (rc) return rc;
             hipLaunchKernelGGL(gen_decide_kernel, dim3(1), dim3(1024), 0, st, dgp, t);
         }
         HIP_TRY(ctx, hipGetLastError());

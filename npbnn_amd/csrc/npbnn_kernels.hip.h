@@ -5,6 +5,8 @@
 //                       layer 0) + padded biases; col_absmax / col_scale / split_x kernels: one-off fp16-split copy of X
 //   npbnn_chain.hip.h   finalize_kernel (fixed-order float64 reduction of the partial sums -> log-likelihood, sigma, moments);
 //                       chain_step: decide the candidates of a pass in iteration order, commit, prepare the next pass
+//   npbnn_wide.hip.h    the weight-streamed path for networks that do not fit the LDS: wide_gemm_kernel (a layer as a tiled matrix
+//                       product, both operands through an LDS ring), wide_lik_kernel, wide_pack_kernel, wide_cand_kernel
 //   npbnn_eval.hip.h    eval_kernel<MT0, MTI, F16, D, LK>: fused forward pass of the whole MLP + likelihood terms for D weight
 //                       sets against one streaming read of X (+ confusion counts, + prediction output); in the overlapped chain
 //                       schedule its last workgroup runs chain_step
@@ -33,3 +35,4 @@
 #include "npbnn_pack.hip.h"
 #include "npbnn_chain.hip.h"
 #include "npbnn_eval.hip.h"
+#include "npbnn_wide.hip.h"

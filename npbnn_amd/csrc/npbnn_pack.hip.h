@@ -148,13 +148,13 @@ __device__ __forceinline__ void pack_item(int item, const double* __restrict__ w
         }
         piece -= nb;
     }
-    if (with_classw && net.classw_off >= 0 && piece < NPBNN_MAX_WIDTH) {
+    if (with_classw && net.classw_off >= 0 && piece < kResidentMaxWidth) {
         image[net.classw_off + piece] = (class_w != nullptr && piece < net.n_out) ? (float)class_w[piece] : 1.0f;
     }
 }
 
 __host__ __device__ inline int pack_item_count(const NetMeta& net, bool with_classw) {
-    int total = with_classw ? NPBNN_MAX_WIDTH : 0;
+    int total = with_classw ? kResidentMaxWidth : 0;
     for (int l = 0; l < net.n_layers; ++l) total += layer_frag_items(net, l) + 16 * net.L[l].mt;
     return total;
 }

@@ -1,0 +1,268 @@
+// Host side of the weight-streamed path (device code and design: npbnn_wide.hip.h).  Not part of the ABI: the entry points of
+// include/npbnn_hip.h pick this path by themselves (npbnn_set_arch: a layer of more than 128 nodes, or a weight image the LDS of a
+// compute unit cannot hold with a useful number of waves beside it; NPBNN_OPT_WIDE) - the reference takes any shape
+// (MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162; default n_nodes = [50, 5] on any number of features, np_bnn/BNN_env.py:20).
+#define NPBNN_KERNELS_WIDE
+#include "npbnn_ctx.hip.h"
+
+namespace npbnn_api {
+
+namespace {
+
+// tilings of wide_gemm_kernel: rows x outputs of a workgroup = 16 RT WR x 16 CT WC
+struct GemmCfg {
+    wide_gemm_fn_t f16, f32;
+    int xt, wt;            // row tiles / output tiles of a workgroup
+    int threads, ppw;      // LDS-DMA pieces a wave requests per K-unit
+    int n_stage;           // stages of the ring
+    bool attr16 = false, attr32 = false;
+};
+GemmCfg g_cfg[3] = {
+    {wide_gemm_kernel<4, 4, 2, 2, true>, wide_gemm_kernel<4, 4, 2, 2, false>, 8, 8, 256, 8, 4},     // 128 x 128: 32 KiB per stage
+    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 4},     // 128 x 64 : 24 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 4},     // 128 x 32 : 20 KiB
+};
+GemmCfg& cfg_for(int mt) { return g_cfg[mt > 4 ? 0 : mt > 2 ? 1 : 2]; }
+
+int stages_env() {
+    static const int v = getenv("NPBNN_WIDE_STAGES") ? atoi(getenv("NPBNN_WIDE_STAGES")) : 0;
+    return v;
+}
+
+// bytes of LDS the resident path would need for this network with one candidate and `waves` waves (build_net's layout arithmetic)
+size_t resident_lds_bytes(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16, int waves) {
+    long long off = 0;
+    int in = a->in_dim;
+    bool narrow_later = a->n_layers >= 2;
+    for (int l = 1; l < a->n_layers; ++l) narrow_later = narrow_later && a->out_dim[l] <= 16;
+    const bool l1_f16 = f16 && narrow_later && a->act_kind == NPBNN_ACT_TANH && a->out_dim[0] > 16 && !a->final_act;
+    for (int l = 0; l < a->n_layers; ++l) {
+        const int out = a->out_dim[l], mt = (out + 15) / 16;
+        if (l == 0) {
+            const int units = f16 ? (in + 31) / 32 : (in + 15) / 16;
+            int rows = 16;
+            if (f16 && mt >= 3 && out % 16 != 0) rows = (out + mt - 1) / mt;
+            off += (long long)mt * units * (f16 ? 32 * rows : 256);
+        } else if (l == 1 && l1_f16) {
+            off += ((a->out_dim[0] + 15) / 16 + 1) / 2 * 512;
+        } else {
+            off += (long long)((in + 15) / 16) * mt * 256;
+        }
+        off += 16 * mt;
+        in = out;
+    }
+    if (ctx->n_classw > 0) off += kResidentMaxWidth;
+    off += kMaxLayers + 64;
+    const int kt0 = f16 ? 2 * ((a->in_dim + 31) / 32) : (a->in_dim + 15) / 16;
+    const WaveLayout lay = make_wave_layout(true, true, a->n_targets, kt0, a->lik_kind);
+    return (size_t)off * 4 + (size_t)waves * lay.wave_lds + 64;
+}
+
+}  // namespace
+
+// Does this network run on the weight-streamed path?  A layer the resident builds have no tiles for, or an image that leaves the
+// resident kernel fewer than kMinResidentWaves waves per compute unit on either layer-0 layout (below that the resident kernel no
+// longer hides the latency of its own stream; NPBNN_WIDE_MIN_WAVES: A/B switch).
+bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a) {
+    if (ctx->wide_option == 1) return true;
+    if (const char* e = getenv("NPBNN_FORCE_WIDE")) { if (atoi(e) != 0) return true; }
+    for (int l = 0; l < a->n_layers; ++l)
+        if (a->out_dim[l] > kResidentMaxWidth) return true;
+    static const int min_waves = getenv("NPBNN_WIDE_MIN_WAVES") ? atoi(getenv("NPBNN_WIDE_MIN_WAVES")) : 8;
+    const int w = min_waves < 1 ? 1 : min_waves;
+    return resident_lds_bytes(ctx, a, true, w) > ctx->lds_limit || resident_lds_bytes(ctx, a, false, w) > ctx->lds_limit;
+}
+
+void wide_free(npbnn_ctx* ctx) {
+    if (ctx->d_wide_cand) { (void)hipFree(ctx->d_wide_cand); ctx->d_wide_cand = nullptr; }
+    for (int i = 0; i < 2; ++i)
+        if (ctx->d_wide_act[i]) { (void)hipFree(ctx->d_wide_act[i]); ctx->d_wide_act[i] = nullptr; }
+    ctx->wide_act_cap = 0;
+    if (ctx->d_wide_cs) { (void)hipFree(ctx->d_wide_cs); ctx->d_wide_cs = nullptr; }
+}
+
+// image layout, device images, packed weight -> image position map (called by rebuild_net after build_net has filled ctx->net)
+int wide_build(npbnn_ctx* ctx, bool f16) {
+    const npbnn_arch& a = ctx->arch;
+    WideMeta m{};
+    m.n_layers = a.n_layers;
+    m.n_out = a.out_dim[a.n_layers - 1];
+    long long off = 0;
+    int in = a.in_dim, woff = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        WideLayer& L = m.L[l];
+        L.in_dim = in;
+        L.out_dim = a.out_dim[l];
+        L.has_bias = a.has_bias[l] ? 1 : 0;
+        L.w_off = woff;
+        L.mt = (L.out_dim + 15) / 16;
+        L.units = (in + 31) / 32;
+        L.f16 = (l == 0 && f16) ? 1 : 0;
+        L.frag_off = off;
+        off += wide_frag_items(L) * 4;
+        woff += L.out_dim * (in + L.has_bias);
+        in = L.out_dim;
+    }
+    for (int l = 0; l < a.n_layers; ++l) {
+        m.L[l].bias_off = off;
+        off += 16 * m.L[l].mt;
+    }
+    m.classw_off = -1;
+    if (ctx->n_classw > 0) {
+        m.classw_off = off;
+        off += 16 * m.L[a.n_layers - 1].mt;
+    }
+    m.image_floats = (off + 63) / 64 * 64;
+    // positions of fp16-split entries are 30-bit indices of 2-byte halves (ChainParams::pos): images of up to 2 GiB
+    if (m.image_floats >= (1ll << 29))
+        return fail(ctx, NPBNN_E_ARG, "network too large: a weight image of %.1f GiB (this backend holds up to 2 GiB)", (double)m.image_floats * 4 / (1 << 30) / 1.0);
+    ctx->wmeta = m;
+    wide_free(ctx);
+    HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)m.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)m.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_wide_cand, (size_t)m.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMemset(ctx->d_wide_cand, 0, (size_t)m.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_wide_cs, sizeof(WideCandState)));
+    HIP_TRY(ctx, hipMemset(ctx->d_wide_cs, 0, sizeof(WideCandState)));
+    std::vector<int> map((size_t)ctx->n_weights);
+    std::vector<float> scale, wscale;
+    if (f16) {
+        scale.assign((size_t)ctx->n_weights, 1.0f);
+        wscale.resize((size_t)round_up(a.in_dim, 32));
+        HIP_TRY(ctx, hipMemcpy(wscale.data(), ctx->d_wscale, wscale.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    for (int l = 0; l < m.n_layers; ++l) {
+        const WideLayer& L = m.L[l];
+        const int ld = L.in_dim + L.has_bias;
+        for (int o = 0; o < L.out_dim; ++o) {
+            const int mt = o / 16, u16 = o % 16;
+            for (int j = 0; j < ld; ++j) {
+                const size_t wi = (size_t)L.w_off + (size_t)o * ld + j;
+                if (L.has_bias && j == 0) { map[wi] = (int)(L.bias_off + o); continue; }
+                const int c = j - L.has_bias;
+                if (L.f16) {
+                    const int u = c / 32, kg = (c % 32) / 8, jj = c % 8;
+                    const long long half_index = 2 * L.frag_off + ((((long long)u * L.mt + mt) * 2) * 64 + kg * 16 + u16) * 8 + jj;
+                    map[wi] = (int)(0x80000000u | (unsigned)half_index);
+                    scale[wi] = wscale[(size_t)c];
+                } else {
+                    const int kt = c / 16, kq = (c % 16) / 4, s = c % 4;
+                    map[wi] = (int)(L.frag_off + (((long long)kt * L.mt + mt) * 64 + kq * 16 + u16) * 4 + s);
+                }
+            }
+        }
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_w2img, map.size() * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_w2img, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (f16) {
+        HIP_TRY(ctx, hipMalloc(&ctx->d_w2scale, scale.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_w2scale, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return NPBNN_OK;
+}
+
+int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp) {
+    Dataset& d = ctx->ds[which];
+    const WideMeta& m = ctx->wmeta;
+    int max_ld = 16;
+    for (int l = 0; l < m.n_layers; ++l)
+        if (16 * m.L[l].mt > max_ld) max_ld = 16 * m.L[l].mt;
+    const size_t need = (size_t)d.n_tiles * 16 * (size_t)max_ld;
+    if (need > ctx->wide_act_cap) {
+        for (int i = 0; i < 2; ++i)
+            if (ctx->d_wide_act[i]) { (void)hipFree(ctx->d_wide_act[i]); ctx->d_wide_act[i] = nullptr; }
+        ctx->wide_act_cap = 0;
+        for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipMalloc(&ctx->d_wide_act[i], need * sizeof(float)));
+        ctx->wide_act_cap = need;
+    }
+    lp->fn = nullptr;
+    lp->fn_spec = nullptr;
+    lp->n_cand = 1;
+    lp->wpb = 4;
+    lp->lds = 0;
+    lp->fast = false;
+    lp->wide = true;
+    int grid = (int)((d.n_rows + 255) / 256);
+    if (grid < 1) grid = 1;
+    lp->grid = grid;             // workgroups of wide_lik_kernel: one partial record each
+    lp->n_waves = grid;
+    return NPBNN_OK;
+}
+
+void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, float* image, int* flags) {
+    const long long total = wide_item_count(ctx->wmeta);
+    hipLaunchKernelGGL(wide_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_w, d_col_override,
+                       ctx->n_classw ? ctx->d_classw : nullptr, image, ctx->wmeta, ctx->wmeta.L[0].f16 ? ctx->d_wscale : nullptr, flags);
+}
+
+int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass) {
+    Dataset& d = ctx->ds[which];
+    const WideMeta& m = ctx->wmeta;
+    hipStream_t st = ctx->stream;
+    const bool f16 = m.L[0].f16 != 0;
+    const float* A = f16 ? d.X16 : d.X;
+    long long lda = f16 ? d.Fp16 : d.Fp;
+    const PassDesc* pass = chain_pass ? reinterpret_cast<const PassDesc*>(reinterpret_cast<const char*>(ctx->d_eparams) + offsetof(EvalParams, pass_desc)) : nullptr;
+    const bool dev_slopes = chain_pass && ctx->batch_slopes && ctx->d_slopes;
+    for (int l = 0; l < m.n_layers; ++l) {
+        const WideLayer& L = m.L[l];
+        GemmCfg& cf = cfg_for(L.mt);
+        WideGemmArgs g{};
+        g.A = A;
+        g.lda = lda;
+        g.n_row_tiles = d.n_tiles;
+        g.n_units = L.units;
+        g.a_half_last = lda < 32ll * L.units ? 1 : 0;
+        g.mt_total = L.mt;
+        g.W = image + L.frag_off;
+        g.bias = image + L.bias_off;
+        g.out = ctx->d_wide_act[l & 1];
+        g.ldo = 16 * L.mt;
+        g.act_kind = l + 1 < m.n_layers ? ctx->net.act_kind : -1;
+        g.act_prm = ctx->net.act_prm[l];
+        g.act_prm_dev = (dev_slopes && l + 1 < m.n_layers) ? &ctx->d_slopes->cand[0][0][l] : nullptr;
+        g.pass = pass;
+        int n_stage = stages_env() >= 2 ? stages_env() : cf.n_stage;
+        const int stage_bytes = (cf.xt + cf.wt) * 2048;
+        while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * cf.ppw > kWideMaxYounger)) --n_stage;
+        if (n_stage > L.units + 1) n_stage = L.units + 1 < 2 ? 2 : L.units + 1;
+        g.n_stage = n_stage;
+        const size_t lds = (size_t)n_stage * stage_bytes;
+        const bool use16 = L.f16 != 0;
+        wide_gemm_fn_t fn = use16 ? cf.f16 : cf.f32;
+        bool& attr = use16 ? cf.attr16 : cf.attr32;
+        if (!attr) {         // (the largest ring any launch asks for: once per kernel)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_limit));
+            attr = true;
+        }
+        const int n_rb = (d.n_tiles + cf.xt - 1) / cf.xt, n_cb = (L.mt + cf.wt - 1) / cf.wt;
+        const int grid = (n_rb + 7) / 8 * 8 * n_cb;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(cf.threads), lds, st, g);
+        A = g.out;
+        lda = g.ldo;
+    }
+    WideLikArgs la{};
+    la.p = ctx->d_eparams;
+    la.z = A;
+    la.ldz = lda;
+    la.image = image;
+    la.classw_off = m.classw_off;
+    la.final_prm_dev = nullptr;
+    const int grid = (int)((d.n_rows + 255) / 256) < 1 ? 1 : (int)((d.n_rows + 255) / 256);
+    hipLaunchKernelGGL(wide_lik_kernel, dim3(grid), dim3(256), 0, st, la);
+    HIP_TRY(ctx, hipGetLastError());
+    return NPBNN_OK;
+}
+
+int wide_cand_begin(npbnn_ctx* ctx) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wide_cand, ctx->d_image, (size_t)ctx->wmeta.image_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_wide_cs, 0, sizeof(WideCandState), ctx->stream));
+    return NPBNN_OK;
+}
+
+void wide_cand_sync(npbnn_ctx* ctx) {
+    hipLaunchKernelGGL(wide_cand_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand,
+                       (const float*)ctx->d_image);
+}
+
+}  // namespace npbnn_api

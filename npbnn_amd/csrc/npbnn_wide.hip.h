@@ -1,0 +1,508 @@
+// The weight-streamed path: networks whose weight image does not fit a compute unit's LDS (wide layers, many features)
+// (part of the device code of the npBNN hot path, see npbnn_kernels.hip.h)
+//
+// The resident path (npbnn_eval.hip.h) keeps the whole network in LDS and chains the layers through the accumulators of one
+// wavefront.  That stops where the image stops fitting: the reference's own default [50, 5] (np_bnn/BNN_env.py:20) above ~650
+// features, any layer wider than 128 nodes.  np.dot (MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162) has no such limit, so this
+// path has none either: every layer is a tiled matrix product whose operands BOTH stream through LDS -
+//
+//   wide_gemm_kernel   out[N x H] = act(in[N x K] . W^T + b): a workgroup owns a (16 RT WR) x (16 CT WC) block of the output; per
+//                      K-unit of 32 columns the rows' pieces of `in` and the fragments of W arrive by LDS-DMA
+//                      (global_load_lds_dwordx4) into a ring of stages, a counted s_waitcnt + one barrier per unit hands a stage
+//                      over, every wave multiplies its RT x CT tiles out of LDS.  Layer 0 contracts the feature matrix: fp16-split
+//                      operands (3 x v_mfma_f32_16x16x32_f16 per tile and unit, float32 accumulate - the resident path's
+//                      arithmetic) or exact float32 (v_mfma_f32_16x16x4_f32); later layers are float32.  Hidden activations go to a
+//                      float32 buffer in HBM (written once, read once by the next layer's launch - a few per cent of X's bytes for
+//                      the shapes this path exists for).
+//   wide_lik_kernel    the last layer's values -> per-row likelihood terms (the resident epilogue's arithmetic: float32 per row,
+//                      float64 sums, fixed order), confusion counts, predictions; one partial record per workgroup, summed by
+//                      finalize_kernel / chain_step exactly like the resident path's.
+//   wide_pack_kernel   float64 packed weights -> the streamed image (layer blocks in K-unit-major fragment order).
+//   wide_cand_kernel   a device chain's candidate image: the committed image with the pending proposal's entries patched in -
+//                      what the resident path does to its LDS copy, done here to a second image in HBM (entries of the previous
+//                      pass restored from the committed image first).
+#pragma once
+#include "npbnn_common.hip.h"
+#include "npbnn_pack.hip.h"
+#include "npbnn_chain.hip.h"
+
+namespace npbnn {
+
+struct WideLayer {
+    long long frag_off;   // float offset of the fragment block in the image
+    long long bias_off;   // float offset of the 16 * mt bias floats
+    int in_dim, out_dim, has_bias, w_off;
+    int mt;               // 16-unit output tiles
+    int units;            // K-units of 32 input columns
+    int f16;              // fp16-split fragments (layer 0 only)
+    int pad_;
+};
+struct WideMeta {
+    int n_layers, n_out;
+    long long image_floats;
+    long long classw_off;     // class weights (16 * mt of the last layer floats), or -1
+    WideLayer L[kMaxLayers];
+};
+
+// Fragment blocks (16-byte entries, one per lane; o = 16 mt + (lane & 15)):
+//   fp16-split layer 0 : entry (((u * MT + mt) * 2 + part) * 64 + lane) = part (0 high, 1 low) of W[o][32 u + 8 (lane >> 4) + 0..7] * w_scale
+//   float32            : entry (((2 u + h) * MT + mt) * 64 + lane) = W[o][32 u + 16 h + 4 (lane >> 4) + 0..3]
+// - per K-unit u the 2 KiB of every output tile lie side by side: a stage of the ring is one contiguous run per tile.
+__host__ __device__ inline long long wide_frag_items(const WideLayer& L) { return (long long)L.units * L.mt * 128; }
+__host__ __device__ inline long long wide_item_count(const WideMeta& m) {
+    long long total = m.classw_off >= 0 ? 16 * m.L[m.n_layers - 1].mt : 0;
+    for (int l = 0; l < m.n_layers; ++l) total += wide_frag_items(m.L[l]) + 16 * m.L[l].mt;
+    return total;
+}
+
+#ifdef NPBNN_KERNELS_WIDE
+__global__ void __launch_bounds__(256) wide_pack_kernel(const double* __restrict__ w, const double* __restrict__ col_override,
+                                                        const double* __restrict__ class_w, float* __restrict__ image, const WideMeta m,
+                                                        const float* __restrict__ w_scale, int* overflow) {
+    long long piece = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (int l = 0; l < m.n_layers; ++l) {
+        const WideLayer& L = m.L[l];
+        const long long n_items = wide_frag_items(L);
+        if (piece < n_items) {
+            const int lane = (int)(piece & 63);
+            const long long tile = piece >> 6;
+            const int ld = L.in_dim + L.has_bias;
+            if (L.f16) {
+                const int part = (int)(tile & 1);
+                const long long rest = tile >> 1;
+                const int mt = (int)(rest % L.mt), u = (int)(rest / L.mt);
+                const int o = 16 * mt + (lane & 15), c0 = 32 * u + 8 * (lane >> 4);
+                f16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+                if (o < L.out_dim) {
+                    const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = c0 + j;
+                        if (c < L.in_dim) {
+                            const bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
+                            const float wv = overridden ? 0.f : (float)(row[c] * (double)w_scale[c]);
+                            if (overflow && !(fabsf(wv) <= kF16Safe)) atomicOr(overflow, kFlagF16Range);
+                            _Float16 hi, lo;
+                            split_f16(wv, hi, lo);
+                            v[j] = part ? lo : hi;
+                        }
+                    }
+                }
+                *reinterpret_cast<f16x8*>(image + L.frag_off + piece * 4) = v;
+            } else {
+                const int mt = (int)(tile % L.mt);
+                const int kt = (int)(tile / L.mt);          // 16-column step: 2 u + h
+                const int o = 16 * mt + (lane & 15), c0 = 16 * kt + 4 * (lane >> 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (o < L.out_dim) {
+                    const double* row = w + L.w_off + (long long)o * ld + L.has_bias;
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = c0 + s;
+                        if (c < L.in_dim) {
+                            const bool overridden = (l == 0 && col_override != nullptr && !isnan(col_override[c]));
+                            v[s] = overridden ? 0.f : (float)row[c];
+                        }
+                    }
+                }
+                *reinterpret_cast<f32x4*>(image + L.frag_off + piece * 4) = v;
+            }
+            return;
+        }
+        piece -= n_items;
+    }
+    for (int l = 0; l < m.n_layers; ++l) {
+        const WideLayer& L = m.L[l];
+        const int nb = 16 * L.mt;
+        if (piece < nb) {
+            const int o = (int)piece;
+            double b = 0.0;
+            if (o < L.out_dim) {
+                const int ld = L.in_dim + L.has_bias;
+                const double* row = w + L.w_off + (long long)o * ld;
+                if (L.has_bias) b = row[0];
+                if (l == 0 && col_override != nullptr) {         // (data_transform_obj, np_bnn/BNN_env.py:14-17: a constant column moves into the bias)
+                    for (int c = 0; c < L.in_dim; ++c) {
+                        const double ov = col_override[c];
+                        if (!isnan(ov)) b += ov * row[L.has_bias + c];
+                    }
+                }
+            }
+            image[L.bias_off + piece] = (float)b;
+            return;
+        }
+        piece -= nb;
+    }
+    if (m.classw_off >= 0 && piece < 16 * m.L[m.n_layers - 1].mt)
+        image[m.classw_off + piece] = (class_w != nullptr && piece < m.n_out) ? (float)class_w[piece] : 1.0f;
+}
+#endif  // NPBNN_KERNELS_WIDE
+
+// ------------------------------------------------------------------------------------------------
+// the tiled matrix product of one layer
+// ------------------------------------------------------------------------------------------------
+struct WideGemmArgs {
+    const float* A;           // [rows][lda] float32, or the fp16-split copy of X (same bytes per element: per 8 columns, 8 fp16 high
+                              // parts then 8 fp16 low parts)
+    long long lda;            // floats per row
+    int n_row_tiles;          // 16-row tiles of A (A is zero padded to whole tiles)
+    int n_units;              // K-units of 32 columns
+    int a_half_last;          // 1: A's rows end 16 columns into the last unit - its second piece does not exist and the first is read
+                              // in its place (the fragments of those columns are zero)
+    int mt_total;             // 16-unit output tiles of the layer
+    const float* W;           // the layer's fragment block
+    const float* bias;        // [16 * mt_total]
+    float* out;               // [rows][ldo]
+    long long ldo;
+    int act_kind;             // activation applied to the result (hidden layers), -1: none (last layer)
+    float act_prm;
+    const double* act_prm_dev;   // device chain with trainable slopes: the candidate's slope for this layer, else nullptr
+    const PassDesc* pass;     // chain pass: nothing to do when its descriptor says the batch is through (n_cand == 0); else nullptr
+    int n_stage;              // stages of the LDS ring (>= 2)
+    int pad_;
+};
+
+#define NPBNN_WVM_(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wide_wait_vm(int younger) {     // wave-uniform: all but the `younger` youngest vector-memory operations are done
+    switch (younger) {
+        NPBNN_WVM_(0) NPBNN_WVM_(1) NPBNN_WVM_(2) NPBNN_WVM_(3) NPBNN_WVM_(4) NPBNN_WVM_(5) NPBNN_WVM_(6) NPBNN_WVM_(7) NPBNN_WVM_(8) NPBNN_WVM_(9)
+        NPBNN_WVM_(10) NPBNN_WVM_(11) NPBNN_WVM_(12) NPBNN_WVM_(13) NPBNN_WVM_(14) NPBNN_WVM_(15) NPBNN_WVM_(16) NPBNN_WVM_(17) NPBNN_WVM_(18)
+        NPBNN_WVM_(19) NPBNN_WVM_(20) NPBNN_WVM_(21) NPBNN_WVM_(22) NPBNN_WVM_(23) NPBNN_WVM_(24) NPBNN_WVM_(25) NPBNN_WVM_(26) NPBNN_WVM_(27)
+        NPBNN_WVM_(28) NPBNN_WVM_(29) NPBNN_WVM_(30) NPBNN_WVM_(31) NPBNN_WVM_(32) NPBNN_WVM_(33) NPBNN_WVM_(34) NPBNN_WVM_(35) NPBNN_WVM_(36)
+        NPBNN_WVM_(37) NPBNN_WVM_(38) NPBNN_WVM_(39) NPBNN_WVM_(40) NPBNN_WVM_(41) NPBNN_WVM_(42) NPBNN_WVM_(43) NPBNN_WVM_(44) NPBNN_WVM_(45)
+        NPBNN_WVM_(46) NPBNN_WVM_(47) NPBNN_WVM_(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // (more than the counter holds in flight never happens: kWideMaxYounger)
+    }
+}
+#undef NPBNN_WVM_
+constexpr int kWideMaxYounger = 48;
+
+// RT x CT: 16 x 16 tiles a wave computes (rows x outputs); WR x WC: waves of the workgroup (rows x outputs); F16: fp16-split operands
+template <int RT, int CT, int WR, int WC, bool F16>
+__global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmArgs a) {
+    constexpr int NW = WR * WC;
+    constexpr int XT = WR * RT, WT = WC * CT;            // row tiles / output tiles of the workgroup
+    constexpr int PIECES = 2 * (XT + WT);                // 1-KiB LDS-DMA pieces per stage
+    static_assert(PIECES % NW == 0, "every wave requests the same number of pieces per unit");
+    constexpr int PPW = PIECES / NW;
+    constexpr int STAGE = (XT + WT) * 2048;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.pass != nullptr) {
+        const int n_cand = __builtin_amdgcn_readfirstlane(a.pass->n_cand);
+        if (n_cand == 0) return;
+    }
+    // workgroup -> (row block, output block): the output blocks of one row block sit 8 workgroup indices apart - the same XCD (workgroups
+    // go round the 8 XCDs), dispatched close together: the second reads the rows' pieces out of the L2 the first filled
+    const int n_cb = (a.mt_total + WT - 1) / WT;
+    const int bid = (int)blockIdx.x;
+    const int grp = bid / (8 * n_cb), rem = bid % (8 * n_cb);
+    const int cb = rem / 8, rb = grp * 8 + rem % 8;
+    if (rb * XT >= a.n_row_tiles) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int wr = wave / WC, wc = wave % WC;
+    const int n_units = a.n_units, n_stage = a.n_stage;
+
+    // ---- this wave's pieces of a stage: piece p = wave + i * NW; p < 2 XT: rows (tile p >> 1, half p & 1), else fragments ----
+    const float* src[PPW];        // this lane's source address for unit 0
+    long long ustride[PPW];       // floats per unit (wave-uniform)
+    int lds_off[PPW];             // byte offset inside a stage (wave-uniform)
+    int half_x[PPW];              // 1: the second piece of a row tile (a_half_last)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * NW;
+        if (p < 2 * XT) {
+            const int t = p >> 1, h = p & 1;
+            int T = rb * XT + t;
+            if (T > a.n_row_tiles - 1) T = a.n_row_tiles - 1;        // (past the matrix: the last tile again; its results are not stored)
+            src[i] = a.A + ((long long)T * 16 + n) * a.lda + 16 * h + 4 * kq;
+            ustride[i] = 32;
+            lds_off[i] = t * 2048 + h * 1024;
+            half_x[i] = h;
+        } else {
+            const int q = p - 2 * XT;
+            const int c = q >> 1, h = q & 1;
+            int mt = cb * WT + c;
+            if (mt > a.mt_total - 1) mt = a.mt_total - 1;
+            if constexpr (F16) {
+                src[i] = a.W + ((long long)mt * 2 + h) * 256 + lane * 4;
+                ustride[i] = (long long)a.mt_total * 512;
+            } else {
+                src[i] = a.W + ((long long)h * a.mt_total + mt) * 256 + lane * 4;
+                ustride[i] = (long long)a.mt_total * 512;
+            }
+            lds_off[i] = XT * 2048 + c * 2048 + h * 1024;
+            half_x[i] = 0;
+        }
+    }
+    int st_in = 0, st_out = 0;                // stage the next request goes to / the next unit is read from
+    auto issue = [&](int u) {                 // request unit u into its stage of the ring
+        char* const sb = smem + (size_t)st_in * STAGE;
+        st_in = st_in + 1 == n_stage ? 0 : st_in + 1;
+        const bool last_half = a.a_half_last && u == n_units - 1;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const float* g = src[i] + (long long)u * ustride[i];
+            if (half_x[i] && last_half) g -= 16;
+            dma16(g, sb + lds_off[i]);
+        }
+    };
+
+    // ---- accumulators start from the bias ----
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        int mt = cb * WT + wc * CT + ct;
+        if (mt > a.mt_total - 1) mt = a.mt_total - 1;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = b;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the bias loads: not counted with the pieces below)
+
+    for (int u = 0; u < n_stage - 1 && u < n_units; ++u) issue(u);
+    for (int u = 0; u < n_units; ++u) {
+        int ahead = n_units - 1 - u;                      // units requested behind unit u
+        if (ahead > n_stage - 2) ahead = n_stage - 2;
+        wide_wait_vm(ahead * PPW);
+        __syncthreads();                                  // unit u has landed for every wave; every wave is through with unit u - 1
+        if (u + n_stage - 1 < n_units) issue(u + n_stage - 1);      // (into the stage unit u - 1 was read from)
+        const char* const sb = smem + (size_t)st_out * STAGE;
+        st_out = st_out + 1 == n_stage ? 0 : st_out + 1;
+        if constexpr (F16) {
+            // lane (n, kq) takes feature group kq of the unit: piece kq >> 1, entries 2 (kq & 1) (high parts) and 2 (kq & 1) + 1 (low parts)
+            f16x8 xh[RT], xl[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const char* px = sb + (wr * RT + rt) * 2048 + (kq >> 1) * 1024 + ((2 * (kq & 1)) * 16 + n) * 16;
+                xh[rt] = *reinterpret_cast<const f16x8*>(px);
+                xl[rt] = *reinterpret_cast<const f16x8*>(px + 256);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const char* pw = sb + XT * 2048 + (wc * CT + ct) * 2048 + lane * 16;
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(pw);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(pw + 1024);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[rt], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[rt], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[rt], acc[rt][ct], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 x[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const f32x4*>(sb + (wr * RT + rt) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sb + XT * 2048 + (wc * CT + ct) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], x[rt][s], acc[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- activation, store: lane (n, kq) holds the units 4 kq .. 4 kq + 3 of a tile for row n ----
+    float prm = a.act_prm;
+    if (a.act_prm_dev != nullptr) prm = (float)*a.act_prm_dev;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int T = rb * XT + wr * RT + rt;
+        if (T >= a.n_row_tiles) continue;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int mt = cb * WT + wc * CT + ct;
+            if (mt >= a.mt_total) continue;
+            f32x4 v = acc[rt][ct];
+            if (a.act_kind >= 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], a.act_kind, prm);
+            }
+            *reinterpret_cast<f32x4*>(a.out + ((long long)T * 16 + n) * a.ldo + 16 * mt + 4 * kq) = v;
+        }
+    }
+}
+
+typedef void (*wide_gemm_fn_t)(const WideGemmArgs);
+struct WideCandState { int prev_t0, prev_cnt; };      // what wide_cand_kernel patched last (entries of iteration prev_t0's proposal)
+
+// ------------------------------------------------------------------------------------------------
+// likelihood terms / statistics / predictions from the last layer's values (one thread per data row)
+// ------------------------------------------------------------------------------------------------
+struct WideLikArgs {
+    const EvalParams* p;      // the launch's parameter block (labels, targets, row weights, partial sums, confusion counts, predictions ...)
+    const float* z;           // [rows][ldz] last layer's values (no activation applied)
+    long long ldz;
+    const float* image;       // weight image the values came from (class weights)
+    long long classw_off;     // or -1
+    const double* final_prm_dev;   // slope of the activation behind the last layer (final_act) of a chain candidate, or nullptr
+};
+
+#ifdef NPBNN_KERNELS_WIDE
+__global__ void __launch_bounds__(256) wide_lik_kernel(const WideLikArgs a) {
+    const EvalParams& p = *a.p;
+    if (p.has_pass && p.pass_desc[0].n_cand == 0) return;
+    const NetMeta& net = p.net;
+    const int C = net.n_out, lik_kind = net.lik_kind, k = net.k_targets;
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool row_ok = row < p.n_rows;
+    const float* z = a.z + row * a.ldz;
+    const int act_kind = net.act_kind;
+    float fprm = net.act_prm[net.n_layers - 1];
+    if (a.final_prm_dev != nullptr) fprm = (float)*a.final_prm_dev;
+    auto val = [&](int o) -> float {
+        const float v = z[o];
+        return net.final_act ? act_apply(v, act_kind, fprm) : v;
+    };
+    double ll = 0.0;
+    double s1[NPBNN_MAX_TARGETS], s2[NPBNN_MAX_TARGETS];
+#pragma unroll
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
+    const bool need_softmax = lik_kind == NPBNN_LIK_CATEGORICAL || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
+    float lse = 0.f;
+    int best = 0;
+    if (row_ok && need_softmax) {
+        float m = -INFINITY;
+        for (int o = 0; o < C; ++o) {
+            const float v = val(o);
+            if (v > m) { m = v; best = o; }          // np.argmax: the first maximum (BNN_lib.py:207)
+        }
+        float se = 0.f;
+        for (int o = 0; o < C; ++o) se += __expf(val(o) - m);
+        lse = m + log_1_to_n(se);
+    }
+    if (row_ok && lik_kind == NPBNN_LIK_CATEGORICAL && p.labels != nullptr) {
+        const int lab = p.labels[row];
+        if (lab >= 0) {
+            float wgt = 1.f;
+            if (p.inst_w) wgt *= p.inst_w[row];
+            if (p.use_classw && a.classw_off >= 0) wgt *= a.image[a.classw_off + lab];
+            float term = (lab < C ? val(lab) : 0.f) - lse;
+            term *= wgt;
+            ll += (double)term;
+            if (p.confusion) atomicAdd(p.confusion + (size_t)lab * C + best, 1u);
+        }
+    } else if (row_ok && lik_kind == NPBNN_LIK_GAUSS && p.targets != nullptr) {
+        for (int j = 0; j < k; ++j) {
+            const float r = p.targets[row * k + j] - val(j);
+            s1[j] += (double)r;
+            s2[j] += (double)r * (double)r;
+        }
+    } else if (row_ok && lik_needs_row_scratch(lik_kind) && p.targets != nullptr) {
+        // float64 row-wise likelihoods (BNN_lib.py:134-143, BNN_lik.py:5-66), as the resident path's generic epilogue has them
+        double term = 0.0;
+        for (int j = 0; j < k; ++j) {
+            const double y = (double)p.targets[row * k + j];
+            if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
+                const double mu = (double)val(j);
+                const double zs = (double)val(k + j);
+                const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));
+                const double r = (y - mu) / sg;
+                term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
+            } else if (lik_kind == NPBNN_LIK_POISSON) {
+                if (j == 0) {
+                    const double eta = (double)val(0);
+                    term += y * eta - exp(eta) - lgamma(y + 1.0);
+                }
+            } else {
+                const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
+                if (one_col && j > 0) continue;
+                const int jp = one_col ? 1 : k + j;
+                const double e0 = (double)val(j), e1 = (double)val(jp);
+                double mean, pr;
+                if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
+                    mean = exp(2.302585092994046 * e0);
+                    pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+                } else {
+                    mean = exp(e0);
+                    pr = 1.0 / (1.0 + exp(-e1));
+                }
+                const double nn = pr * mean / (1.0 - pr);
+                term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
+            }
+        }
+        ll += term;
+    }
+    if (row_ok && p.predict_mode && p.y_out != nullptr) {
+        float* yo = p.y_out + row * C;
+        for (int o = 0; o < C; ++o) {
+            float v = val(o);
+            if (p.predict_mode == 2) {
+                if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
+                else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+            }
+            yo[o] = v;
+        }
+    }
+    // ---- one partial record per workgroup: lanes -> wave (fixed butterfly) -> workgroup (waves in order) ----
+    if (p.partials == nullptr) return;
+    __shared__ double red[4][kPartialStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = (int)gridDim.x;
+    if (lik_kind == NPBNN_LIK_GAUSS) {
+        for (int j = 0; j < k; ++j) {
+            const double a1 = butterfly_sum_f64(s1[j]), a2 = butterfly_sum_f64(s2[j]);
+            if (lane == 0) { red[wave][1 + j] = a1; red[wave][1 + NPBNN_MAX_TARGETS + j] = a2; }
+        }
+        if (lane == 0) red[wave][0] = 0.0;
+    } else {
+        const double s = butterfly_sum_f64(ll);
+        if (lane == 0) red[wave][0] = s;
+    }
+    __syncthreads();
+    const int nvals = lik_kind == NPBNN_LIK_GAUSS ? 1 + 2 * k : 1;
+    for (int it = threadIdx.x; it < nvals; it += 256) {
+        const int v = it <= k ? it : 1 + NPBNN_MAX_TARGETS + (it - k - 1);
+        const double s = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
+        p.partials[(size_t)v * G + blockIdx.x] = s;          // (candidate 0 of pass parity 0: [value][workgroup])
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidate image of a device chain (serial schedule, one candidate per pass)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wide_restore_entry(float* cand, const float* image, int pos) {
+    if (pos == kSkipPos) return;
+    if (pos < 0) {
+        const _Float16* s = reinterpret_cast<const _Float16*>(image);
+        _Float16* d = reinterpret_cast<_Float16*>(cand);
+        const int h = pos & 0x3fffffff;
+        d[h] = s[h];
+        d[h + 512] = s[h + 512];
+    } else {
+        cand[pos] = image[pos];
+    }
+}
+__global__ void __launch_bounds__(1024) wide_cand_kernel(const ChainParams* __restrict__ cp, WideCandState* st, float* __restrict__ cand,
+                                                         const float* __restrict__ image) {
+    const ChainParams& c = *cp;
+    const int tid = threadIdx.x;
+    const int M = c.M;
+    const int pt = st->prev_t0, pn = st->prev_cnt;
+    const PassDesc d = c.pass[0];
+    __syncthreads();                                 // (everybody has read the record before thread 0 rewrites it)
+    // the entries the pass before this one had patched: back to what the committed image holds (the accepted values, if it was accepted)
+    if (pn > 0) {
+        const size_t row = (size_t)pt * M;
+        for (int e = tid; e < pn; e += blockDim.x) wide_restore_entry(cand, image, c.pos[row + e]);
+    }
+    __threadfence_block();
+    __syncthreads();
+    int cnt = 0;
+    if (d.n_cand > 0) {
+        cnt = d.cnt[0];
+        const size_t row = (size_t)d.t0 * M;
+        for (int e = tid; e < cnt; e += blockDim.x)
+            patch_image(cand, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, c.pv[e], 16);
+    }
+    if (tid == 0) { st->prev_t0 = d.t0; st->prev_cnt = cnt; }
+}
+#endif  // NPBNN_KERNELS_WIDE
+
+}  // namespace npbnn

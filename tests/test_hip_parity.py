@@ -206,10 +206,11 @@ def test_error_paths(hip):
     with pytest.raises(NpbnnError):
         ctx.set_labels(np.zeros(11, dtype=int))             # wrong length
     with pytest.raises(NpbnnError):
-        ctx.set_arch(4, [200, 3], [1, 1], 0, 0, 0)           # layer wider than NPBNN_MAX_WIDTH
-    with pytest.raises(NpbnnError, match="too large"):
-        ctx.set_arch(4000, [128, 3], [1, 1], 0, 0, 0)        # weight image cannot live in LDS
+        ctx.set_arch(4, [5000, 3], [1, 1], 0, 0, 0)          # layer wider than NPBNN_MAX_WIDTH
+    ctx.set_arch(4, [200, 3], [1, 1], 0, 0, 0)               # wider than the LDS-resident builds' tiles: the weight-streamed path
+    assert ctx.is_wide()
     ctx.set_arch(4, [3, 2], [1, 0], 3, 0, 0)
+    assert not ctx.is_wide()
     with pytest.raises(NpbnnError):
         ctx.eval([np.zeros((3, 5)), np.zeros((2, 3))])      # categorical likelihood without labels
     ctx.close()

@@ -1,0 +1,287 @@
+"""GPU tests of the weight-streamed path (npbnn_amd/csrc/npbnn_wide.hip.h): networks the LDS of a compute unit cannot hold -
+layers of more than 128 nodes, the reference's default [50, 5] (np_bnn/BNN_env.py:20) on thousands of features - run layer by
+layer as tiled matrix products (MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape).
+
+Held to the same fixtures and tolerances as the resident path (tests/test_hip_parity.py): the reference's golden grid with the
+path forced on small networks (NPBNN_OPT_WIDE), the oracle at the sizes that need it, and the device chain against the mh_step
+loop (same accept / reject sequence, same weights to the bit)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as orc
+import npbnn_amd as bn
+from npbnn_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 2e-6
+Z_TOL = 2e-5
+ACT_KIND = {"relu": 0, "leaky": 1, "swish": 2, "tanh": 3}
+
+
+def make_ctx(x, weights, act, out_kind, lik_kind, labels=None, targets=None, n_targets=0, wide=True, precision="auto", test=None):
+    ctx = bn.HipContext(0)
+    ctx.set_l0_precision(precision)
+    if wide:
+        ctx.set_wide(True)
+    ctx.set_data(x)
+    if test is not None:
+        ctx.set_data(test, capi.TEST)
+    if labels is not None:
+        ctx.set_labels(labels)
+    if targets is not None:
+        ctx.set_targets(targets)
+    ctx.set_arch_from_weights(weights, x.shape[1], ACT_KIND[act.kind], out_kind, lik_kind, n_targets)
+    return ctx
+
+
+def act_prm(act, n_hidden):
+    if act.kind != "leaky":
+        return None
+    return np.array([act.slope(i) for i in range(n_hidden)], dtype=float)
+
+
+def assert_close(got, want, tol=Z_TOL):
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= tol, "max scaled error %.3e" % err.max()
+
+
+def check_confusion(conf, y64, labels):
+    want = orc.confusion_counts(y64, labels)
+    if np.array_equal(conf, want):
+        return
+    top2 = np.sort(y64, axis=1)[:, -2:]
+    near_ties = int(np.sum(top2[:, 1] - top2[:, 0] < 1e-5))
+    assert np.abs(conf - want).sum() <= 2 * near_ties, "confusion counts differ beyond fp32 ties"
+    assert conf.sum() == want.sum()
+
+
+@pytest.fixture(scope="module")
+def grid(golden_dir):
+    return np.load(os.path.join(golden_dir, "grid.npz"))
+
+
+@pytest.mark.parametrize("case", cases.grid_cases(), ids=lambda c: c["name"])
+def test_forced_on_the_reference_grid(case, grid):
+    """G1 (every activation x bias mode x shape of the reference's golden grid) with the small networks forced onto the streamed path."""
+    inp = cases.grid_inputs(case)
+    act = orc.Act(case["fun"], inp["prm"]) if inp["prm"] is not None else orc.Act(case["fun"])
+    x, w, lab = inp["x"], inp["weights"], inp["labels"]
+    k = case["name"]
+    ctx = make_ctx(x, w, act, 0, 0, labels=lab)
+    assert ctx.is_wide()
+    ap = act_prm(act, len(w) - 1)
+    z = ctx.predict(w, act_prm=ap, apply_out_fn=False)
+    y = ctx.predict(w, act_prm=ap, apply_out_fn=True)
+    assert_close(z[:16], grid[k + "/z_head"])
+    assert_close(y[:16], grid[k + "/y_head"])
+    np.testing.assert_allclose(z.sum(axis=0), grid[k + "/z_colsum"], rtol=1e-4, atol=1e-3)
+    lik = grid[k + "/lik"]
+    r = ctx.eval(w, act_prm=ap, want_confusion=True)
+    if np.isfinite(lik[0]):
+        np.testing.assert_allclose(r["loglik"], lik[0], rtol=LL_RTOL)
+        np.testing.assert_allclose(ctx.eval(w, act_prm=ap, lik_temp=0.5)["loglik"], lik[3], rtol=LL_RTOL)
+        ctx.set_row_weights(instance_w=inp["inst_w"])
+        np.testing.assert_allclose(ctx.eval(w, act_prm=ap)["loglik"], lik[1], rtol=LL_RTOL)
+        ctx.set_row_weights(class_w=inp["class_w"])
+        np.testing.assert_allclose(ctx.eval(w, act_prm=ap)["loglik"], lik[2], rtol=LL_RTOL)
+    check_confusion(r["confusion"], orc.forward(x, w, act, orc.out_softmax), lab)
+    ctx.close()
+
+
+@pytest.mark.parametrize("precision", ["auto", "f32"])
+def test_forced_on_the_regression_and_count_fixtures(golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, "regression.npz"))
+    act = orc.Act("tanh")
+    inp = cases.regression_inputs()
+    x, w, t = inp["x"], inp["weights"], inp["targets"]
+    ctx = make_ctx(x, w, act, 1, 1, targets=t, n_targets=t.shape[1], precision=precision)
+    assert ctx.is_wide() and ctx.l0_mode() == ("f32" if precision == "f32" else ctx.l0_mode())
+    assert_close(ctx.predict(w), g["y"])
+    np.testing.assert_allclose(ctx.eval(w, sigma=1.0)["loglik"], g["lik_sig1"], rtol=LL_RTOL)
+    np.testing.assert_allclose(ctx.eval(w, sigma=inp["sig_vec"])["loglik"], g["lik_sigvec"], rtol=LL_RTOL)
+    r = ctx.eval(w)
+    np.testing.assert_allclose(r["loglik"], g["lik_emp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sigma"], g["emp_sigma"], rtol=1e-5)
+    np.testing.assert_allclose(ctx.eval(w, lik_temp=0.7)["loglik"], g["lik_emp_temp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sum_r2"] / len(x), g["mse_col"], rtol=1e-5)
+    ctx.close()
+    inp2 = cases.regression_inputs(seed=12, double_out=True)
+    ctx = make_ctx(inp2["x"], inp2["weights"], act, 2, 7, precision=precision)
+    assert_close(ctx.predict(inp2["weights"]), g["y_err"])
+    ctx.close()
+    # predicted-sigma Gaussian and the count plug-ins: float64 row-wise terms
+    ctx = make_ctx(inp2["x"], inp2["weights"], act, 2, 2, targets=inp2["targets"], n_targets=2, precision=precision)
+    np.testing.assert_allclose(ctx.eval(inp2["weights"])["loglik"], g["lik_err"], rtol=LL_RTOL)
+    np.testing.assert_allclose(ctx.eval(inp2["weights"], lik_temp=0.5)["loglik"], 0.5 * g["lik_err"], rtol=LL_RTOL)
+    ctx.close()
+    gc = np.load(os.path.join(golden_dir, "counts.npz"))
+    sw = orc.Act("swish")
+    a = cases.count_inputs(seed=23, n_out=1, k=1)
+    ctx = make_ctx(a["x"], a["weights"], sw, 1, 3, targets=a["counts"], n_targets=1, precision=precision)
+    np.testing.assert_allclose(ctx.eval(a["weights"])["loglik"], gc["poi"], rtol=LL_RTOL)
+    ctx.close()
+    b = cases.count_inputs(seed=24, n_out=2, k=1)
+    for kind, key in ((4, "nb"), (6, "nb10")):
+        ctx = make_ctx(b["x"], b["weights"], sw, 1, kind, targets=b["counts"], n_targets=1, precision=precision)
+        np.testing.assert_allclose(ctx.eval(b["weights"])["loglik"], gc[key], rtol=5e-6)
+        ctx.close()
+    c = cases.count_inputs(seed=25, n_out=4, k=2)
+    ctx = make_ctx(c["x"], c["weights"], sw, 1, 5, targets=c["counts"], n_targets=2, precision=precision)
+    np.testing.assert_allclose(ctx.eval(c["weights"])["loglik"], gc["nb2d"], rtol=5e-6)
+    ctx.close()
+
+
+def _classification_problem(seed, n, f, c, hidden, bias=2, scale=1.0):
+    rs = np.random.default_rng(seed)
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    lab = rs.integers(0, c, n)
+    np.random.seed(1234)
+    if hidden:
+        w = orc.init_weights(hidden, f, c, bias_node=bias)
+    else:           # (the reference's initialiser wants a hidden layer; RunPredict itself takes a single matrix)
+        w = [np.random.normal(0, 0.1, (c, f + 1))]
+    return x, lab, [wi * scale for wi in w]
+
+
+SHAPES = {
+    # (rows, features, hidden, classes): the shapes VERDICT r04 names, and two that exercise the tilings' edges
+    "default_net_2000x2000": (2000, 2000, [50, 5], 10),
+    "f4096_h256_64": (20000, 4096, [256, 64], 10),
+    "f1000_h200_50_10": (5000, 1000, [200, 50, 10], 7),
+    "h300_odd_tiles": (777, 100, [300, 33], 150),
+    "single_layer_wide_out": (1000, 72, [], 200),
+}
+
+
+@pytest.mark.parametrize("precision", ["auto", "f32"])
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_shapes_the_lds_cannot_hold_against_the_oracle(name, precision):
+    n, f, hidden, c = SHAPES[name]
+    x, lab, w = _classification_problem(3, n, f, c, hidden, scale=2.0)
+    act = orc.Act("tanh")
+    ctx = make_ctx(x, w, act, 0, 0, labels=lab, wide=False, precision=precision)
+    assert ctx.is_wide(), "this shape must pick the weight-streamed path by itself"
+    r = ctx.eval(w, want_confusion=True)
+    assert ctx.l0_mode() == ("f16-split" if precision == "auto" else "f32")
+    assert r["loglik"] == ctx.eval(w)["loglik"], "not run-to-run deterministic"
+    x64 = x.astype(np.float64)
+    y64 = orc.forward(x64, w, act, orc.out_softmax)
+    want = orc.lik_categorical(y64, lab, np.arange(n))
+    assert abs(r["loglik"] - want) / abs(want) < LL_RTOL
+    check_confusion(r["confusion"], y64, lab)
+    z = ctx.predict(w, apply_out_fn=False)
+    assert_close(z, orc.forward_logits(x64, w, act))
+    assert_close(ctx.predict(w), y64)
+    ctx.close()
+
+
+def test_wide_regression_with_a_test_set_and_column_override():
+    rs = np.random.default_rng(5)
+    n, f, k = 3000, 1500, 3
+    x = rs.standard_normal((n, f))
+    xt = rs.standard_normal((500, f))
+    np.random.seed(7)
+    w = orc.init_weights([64, 8], f, k, bias_node=1)
+    act = orc.Act("swish")
+    t = rs.standard_normal((n, k))
+    ctx = make_ctx(x, w, act, 1, 1, targets=t, n_targets=k, wide=False, test=xt)
+    assert ctx.is_wide()
+    y64 = orc.forward(x, w, act, orc.out_identity)
+    r = ctx.eval(w)
+    want = orc.closed_gaussian_empirical(y64, t)
+    np.testing.assert_allclose(r["loglik"], want, rtol=LL_RTOL)
+    assert_close(ctx.predict(w, which=capi.TEST), orc.forward(xt, w, act, orc.out_identity))
+    ov = np.full(f, np.nan)
+    ov[[3, 700, 1499]] = [0.25, -1.0, 2.0]
+    x2 = x.copy()
+    x2[:, [3, 700, 1499]] = [0.25, -1.0, 2.0]
+    assert_close(ctx.predict(w, col_override=ov), orc.forward(x2, w, act, orc.out_identity))
+    ctx.close()
+
+
+def _chains(dat, model_kw, act_kw, sampler_kw):
+    from test_hip_sampler import quiet
+    out = []
+    for _ in range(2):
+        np.random.seed(77)
+        bnn = quiet(bn.npBNN, dat, actFun=bn.ActFun(**act_kw), **model_kw)
+        out.append((bnn, bn.MCMC(bnn, **sampler_kw)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["default_net_2000x2000", "f1000_h200_50_10", "h300_odd_tiles"])
+def test_run_steps_is_the_mh_step_loop_on_streamed_networks(name):
+    n, f, hidden, c = SHAPES[name]
+    dat = cases.classification_data(11, n, f, c, n_test=200)
+    (bnn_a, mcmc_a), (bnn_b, mcmc_b) = _chains(dat, dict(n_nodes=hidden, use_bias_node=2, prior_f=1, p_scale=1), dict(fun="tanh"),
+                                               dict(update_f=[0.02] * (len(hidden) + 1), update_ws=[0.05] * (len(hidden) + 1), n_iteration=100000))
+    assert mcmc_a._backend.ctx.is_wide()
+    np.testing.assert_allclose(mcmc_a._logLik, mcmc_b._logLik, rtol=0)
+    for _ in range(90):
+        mcmc_a.mh_step(bnn_a)
+    for _ in range(3):
+        mcmc_b.run_steps(bnn_b, 30)
+    assert mcmc_b._device_iterations == 90
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem
+    assert 0 < sum(mcmc_a._last_accepted_mem) or mcmc_a._acceptance_rate >= 0
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
+    # the chain's state against the oracle
+    act = orc.Act("tanh")
+    y64 = orc.forward(dat["data"], bnn_b._w_layers, act, orc.out_softmax)
+    want = orc.lik_categorical(y64, dat["labels"], np.arange(n))
+    assert abs(mcmc_b._logLik - want) / abs(want) < LL_RTOL
+
+
+@pytest.mark.parametrize("name", list(cases.TRACES))
+def test_forced_chain_follows_the_reference_trace(name, golden_dir, monkeypatch):
+    """The reference's golden Metropolis-Hastings traces with the networks forced onto the streamed path: mh_step free-running
+    against the reference's decisions, run_steps against mh_step."""
+    from test_hip_sampler import build
+    monkeypatch.setenv("NPBNN_FORCE_WIDE", "1")
+    cfg = cases.TRACES[name]
+    g = np.load(os.path.join(golden_dir, "trace_%s.npz" % name))
+    bnn, mcmc = build(cfg)
+    assert mcmc._backend.ctx.is_wide()
+    np.testing.assert_allclose(mcmc._logLik, g["init"][0], rtol=2e-6)
+    np.testing.assert_allclose([mcmc._accuracy, mcmc._test_accuracy], g["init"][2:4], rtol=1e-4)
+    rows = g["rows"]
+    n_match = 0
+    for it in range(min(cfg["steps"], 200)):
+        mcmc.mh_step(bnn)
+        if mcmc._last_accepted != int(rows[it, 2]):
+            break
+        np.testing.assert_allclose(mcmc._logLik, rows[it, 3], rtol=2e-6)
+        n_match += 1
+    assert n_match >= min(150, cfg["steps"]), "chains diverged after %d iterations" % n_match
+    bnn_b, mcmc_b = build(cfg)
+    mcmc_b.run_steps(bnn_b, 100)
+    mcmc_b.run_steps(bnn_b, n_match - 100)
+    assert mcmc_b._last_accepted_mem[:n_match] == mcmc._last_accepted_mem[:n_match]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_forced_device_chain_is_the_mh_step_loop_on_random_shapes(seed, monkeypatch):
+    """tests/test_hip_sampler.py's random networks (depths, activations, bias modes, priors, both estimation modes, tempered and
+    heated chains) forced onto the streamed path: run_steps against the mh_step loop, to the bit."""
+    from test_hip_sampler import _random_case
+    monkeypatch.setenv("NPBNN_FORCE_WIDE", "1")
+    dat, model_kw, act_kw, sampler_kw = _random_case(1000 + seed)
+    (bnn_a, mcmc_a), (bnn_b, mcmc_b) = _chains(dat, model_kw, act_kw, sampler_kw)
+    assert mcmc_a._backend.ctx.is_wide()
+    for _ in range(90):
+        mcmc_a.mh_step(bnn_a)
+    for _ in range(3):
+        mcmc_b.run_steps(bnn_b, 30)
+    assert mcmc_b._device_iterations == 90, "the device chain did not take these iterations: %s %s" % (model_kw, sampler_kw)
+    assert mcmc_a._last_accepted_mem == mcmc_b._last_accepted_mem, (model_kw, act_kw, sampler_kw)
+    for wa, wb in zip(bnn_a._w_layers, bnn_b._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
+    np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)

@@ -26,6 +26,7 @@ void free_dataset(Dataset& d) {
     if (d.targets) (void)hipFree(d.targets);
     if (d.inst_w) (void)hipFree(d.inst_w);
     if (d.X16 && !d.borrowed) (void)hipFree(d.X16);
+    if (d.X16w && !d.x16w_borrowed) (void)hipFree(d.X16w);
     d = Dataset();
 }
 
@@ -36,7 +37,10 @@ void unshare_data(npbnn_ctx* ctx) {
     npbnn_ctx* owner = ctx->data_owner;
     if (!owner) return;
     for (int w = 0; w < 2; ++w)
-        if (ctx->ds[w].borrowed) { ctx->ds[w].X = nullptr; ctx->ds[w].X16 = nullptr; ctx->ds[w].borrowed = false; ctx->ds[w].f16_state = 0; }
+        if (ctx->ds[w].borrowed) {
+            ctx->ds[w].X = nullptr; ctx->ds[w].X16 = nullptr; ctx->ds[w].borrowed = false; ctx->ds[w].f16_state = 0;
+            if (ctx->ds[w].x16w_borrowed) { ctx->ds[w].X16w = nullptr; ctx->ds[w].x16w_borrowed = false; }
+        }
     ctx->d_xscale = nullptr;          // (the scales travel with the training matrix)
     ctx->d_wscale = nullptr;
     ctx->scale_F = 0;
@@ -65,6 +69,7 @@ int upload_matrix(npbnn_ctx* ctx, const T* X, int64_t n_rows, int32_t F, int whi
         if (ctx->d_wscale) { (void)hipFree(ctx->d_wscale); ctx->d_wscale = nullptr; }
         ctx->scale_F = 0;
         if (ctx->ds[1].X16) { (void)hipFree(ctx->ds[1].X16); ctx->ds[1].X16 = nullptr; }
+        if (ctx->ds[1].X16w) { (void)hipFree(ctx->ds[1].X16w); ctx->ds[1].X16w = nullptr; }
         ctx->ds[1].f16_state = 0;
     }
     d.n_rows = n_rows;

@@ -140,6 +140,9 @@ struct ChainParams {
     double* out_lp;            // [K] proposed logPrior
     const double* partials;    // [2][candidate][kPartialStride][n_blocks], by pass parity
     float* image;              // fragment image of the current weights, read by the evaluation kernel
+    float* cand_image;         // weight-streamed path (npbnn_wide.hip.h; serial schedule, one candidate per pass): the image its kernels read -
+                               // the committed image with the pending proposal's entries patched in by the step itself (prepare), and put
+                               // back when the proposal is rejected; nullptr on the resident path, whose kernels patch their LDS copies
     const int* pos;            // [K][M] image position of every pre-drawn entry; bit 31 set: fp16-split layer-0 entry (the
                                // low bits are the half index of the high part, low part 512 halfs later); kSkipPos: none
     const float* pscale;       // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
@@ -237,6 +240,19 @@ __device__ __forceinline__ void patch_image(float* image, int pos, float scale, 
 }
 __device__ __forceinline__ void patch_global_image(const ChainParams& c, int pos, float scale, double v) {
     patch_image(c.image, pos, scale, v, c.net.l0_rows);
+}
+// an entry of the candidate image back to what the committed image holds (weight-streamed path: images without compact rows)
+__device__ __forceinline__ void restore_image_entry(float* cand, const float* image, int pos) {
+    if (pos == 0x7fffffff) return;
+    if (pos < 0) {
+        const _Float16* src = reinterpret_cast<const _Float16*>(image);
+        _Float16* dst = reinterpret_cast<_Float16*>(cand);
+        const int h = pos & 0x3fffffff;
+        dst[h] = src[h];
+        dst[h + 512] = src[h + 512];
+    } else {
+        cand[pos] = image[pos];
+    }
 }
 
 // block-wide sum of one double per thread, fixed order; result valid in thread 0
@@ -487,17 +503,45 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
         __syncthreads();
         NPBNN_STAMP(3);
         const int a = sh.s_accepted;
+        constexpr int CU = 4;   // entries per thread requested together (wide proposals: each level of dependent loads is a round trip)
         if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
             const size_t row = (size_t)(t0 + a) * c.M;
             const int n = c.cnt[t0 + a];
             const double* pv = c.pv + (size_t)pl.dec * pv_stride;
-            for (int e = tid; e < n; e += blockDim.x) {
-                const int i = c.idx[row + e];
-                if (i >= 0) {
-                    const double v = pv[(size_t)a * c.M + e];
-                    c.w_cur[i] = v;
-                    patch_global_image(c_generic, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, v);
+            for (int e0 = tid; e0 < n; e0 += CU * (int)blockDim.x) {
+                int ci[CU], cp[CU];
+                double cv[CU];
+                float cs[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const int e = e0 + u * (int)blockDim.x;
+                    ci[u] = -1; cp[u] = 0; cv[u] = 0.0; cs[u] = 1.0f;
+                    if (e < n) {
+                        ci[u] = c.idx[row + e];
+                        cv[u] = pv[(size_t)a * c.M + e];
+                        cp[u] = c.pos[row + e];
+                        if (c.pscale) cs[u] = c.pscale[row + e];
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < CU; ++u)
+                    if (ci[u] >= 0) {
+                        c.w_cur[ci[u]] = cv[u];
+                        patch_global_image(c_generic, cp[u], cs[u], cv[u]);
+                    }
+            }
+        } else if (c.cand_image) {      // rejected (weight-streamed path): the candidate image's patched entries back to the committed values
+            const size_t row = (size_t)t0 * c.M;
+            const int n = c.cnt[t0];
+            for (int e0 = tid; e0 < n; e0 += CU * (int)blockDim.x) {
+                int cp[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const int e = e0 + u * (int)blockDim.x;
+                    cp[u] = e < n ? c.pos[row + e] : 0x7fffffff;
+                }
+#pragma unroll
+                for (int u = 0; u < CU; ++u) restore_image_entry(c.cand_image, c.image, cp[u]);
             }
         }
         __syncthreads();
@@ -598,6 +642,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
             const double v = spec_entry<false>(c.w_bound, c.prior_kind, c.prior_scale_w != nullptr, base, d, m, scale_w, his, lsc, dlp[j]);
             pv_out[(size_t)j * c.M + e] = v;
             if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
+            if (c.cand_image) patch_image(c.cand_image, pos, sc, v, 16);       // (weight-streamed path: the image its kernels read)
         };
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j) {
@@ -605,11 +650,35 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
             for (int u = 0; u < ES; ++u)
                 if (ii[j][u] >= 0) make(j, tid + u * (int)blockDim.x, ii[j][u], bb[j][u], dd[j][u], mm[j][u], pp[j][u], ss[j][u], sw[j][u]);
             if (cn[j] > ES * (int)blockDim.x) {
+                // (proposals wider than the staged entries: four entries per thread requested together, made in entry order - the
+                // order a thread adds its prior terms in is part of the sum's bits)
+                constexpr int PU = 4;
                 const size_t row = (size_t)(t_new + j) * c.M;
-                for (int e = tid + ES * blockDim.x; e < cn[j]; e += blockDim.x) {
-                    const int i = c.idx[row + e];
-                    if (i >= 0) make(j, e, i, wcur[i], c.delta[row + e], mask ? mask[i] : 1.0, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f,
-                                     c.prior_scale_w ? c.prior_scale_w[i] : 1.0);
+                for (int e0 = tid + ES * (int)blockDim.x; e0 < cn[j]; e0 += PU * (int)blockDim.x) {
+                    int qi[PU], qp[PU];
+                    double qd[PU], qb[PU], qm[PU], qw[PU];
+                    float qs[PU];
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        const int e = e0 + u * (int)blockDim.x;
+                        qi[u] = -1; qp[u] = 0; qd[u] = 0.0; qs[u] = 1.0f;
+                        if (e < cn[j]) {
+                            qi[u] = c.idx[row + e];
+                            qd[u] = c.delta[row + e];
+                            qp[u] = c.pos[row + e];
+                            if (c.pscale) qs[u] = c.pscale[row + e];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        const int i = qi[u];
+                        qb[u] = i >= 0 ? wcur[i] : 0.0;
+                        qm[u] = (i >= 0 && mask) ? mask[i] : 1.0;
+                        qw[u] = (i >= 0 && c.prior_scale_w) ? c.prior_scale_w[i] : 1.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < PU; ++u)
+                        if (qi[u] >= 0) make(j, e0 + u * (int)blockDim.x, qi[u], qb[u], qd[u], qm[u], qp[u], qs[u], qw[u]);
                 }
             }
         }

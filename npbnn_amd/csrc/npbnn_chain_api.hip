@@ -388,6 +388,9 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.out_lp = ctx->d_lpp;
     c.partials = sharded ? ctx->d_shard_part : ctx->d_partials;
     c.image = ctx->d_image;
+    // (weight-streamed path: the step keeps the candidate image itself while a proposal fits its staged entries; wider ones get two
+    // launches over all compute units between step and pass - wide_cand_sync)
+    c.cand_image = (lp.wide && M <= kWideStepPatchMax) ? ctx->d_wide_cand : nullptr;
     c.pos = ctx->d_pos;
     c.pscale = f16 ? ctx->d_pscale : nullptr;
     c.pv = spec ? ctx->d_spec_pv : ctx->d_pv;      // (spec: the first step writes pass 0 into slot (parity 0, outcome 0))
@@ -611,8 +614,8 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
             hipLaunchKernelGGL(lp.fn, dim3(lp.grid + 1), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, B.launch, 1);
     } else {
         for (int i = 0; i < n; ++i, ++B.launch) {
-            if (lp.wide) {      // candidate image <- committed image + the pending proposal, then the layers' products and the likelihood
-                wide_cand_sync(ctx);
+            if (lp.wide) {      // the layers' products and the likelihood of the candidate image (kept by the step, or by wide_cand_sync)
+                if (B.M > kWideStepPatchMax) wide_cand_sync(ctx, B.M);
                 const int rcw = wide_forward(ctx, 0, ctx->d_wide_cand, true);
                 if (rcw) return rcw;
             } else {

@@ -81,6 +81,8 @@ struct Dataset {
     int f16_worst_col = -1;    // column with the largest (max entry error / mean |entry|) of the fp16 pair, and that ratio
     double f16_worst_ratio = 0.0;
     bool borrowed = false;     // X / X16 belong to another ctx (npbnn_share_data)
+    float* X16w = nullptr;     // the fp16-split copy in the weight-streamed path's piece order (split_x_tiled_kernel), built when a
+    bool x16w_borrowed = false;   // network on that path first asks for it; a borrower of X uses (and, if need be, builds) its owner's
 };
 
 }  // namespace npbnn_api
@@ -214,9 +216,9 @@ struct npbnn_ctx {
     int wide_option = 0;           // NPBNN_OPT_WIDE: 0 when the resident path cannot hold the network, 1 always
     WideMeta wmeta{};
     float* d_wide_cand = nullptr;  // candidate image of a device chain (the committed image with the pending proposal patched in)
-    float* d_wide_act[2] = {nullptr, nullptr};   // hidden activations [rows][16 * tiles], ping-pong between layers
+    float* d_wide_act[3] = {nullptr, nullptr, nullptr};   // hidden activations [rows][16 * tiles], ping-pong between layers; [2]: the K-slices' sums
     size_t wide_act_cap = 0;       // floats each
-    WideCandState* d_wide_cs = nullptr;
+    WideCandState* d_wide_cs = nullptr;   // what the candidate image's last patch covered (wide proposals: wide_cand_sync)
     unsigned conf_cap = 0;         // classes d_conf / h_conf are sized for
 };
 
@@ -241,6 +243,7 @@ constexpr int kTurnForcedProbeBatches = 200;    // ... or whatever the model say
 constexpr int kTurnFirstProbeBatches = 4;       // batches on one persistent form before the other, never measured, is given one
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
+constexpr int kWideStepPatchMax = 2048;      // widest proposal whose candidate image the step workgroup keeps by itself (weight-streamed path)
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 
 int fail(npbnn_ctx* ctx, int code, const char* fmt, ...);
@@ -276,7 +279,7 @@ void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, 
 // chain_pass: a pass of a device chain (the kernels leave at once when the chain's batch is through; candidate slopes from the chain)
 int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass);
 int wide_cand_begin(npbnn_ctx* ctx);     // start of a chain batch: candidate image = committed image, nothing patched
-void wide_cand_sync(npbnn_ctx* ctx);     // before a chain pass: candidate image = committed image + the pending proposal
+void wide_cand_sync(npbnn_ctx* ctx, int M);   // before a pass of a chain with wide proposals: candidate image = committed image + the pending proposal
 int ensure_conf(npbnn_ctx* ctx, int n_classes);
 // one evaluation launch of a plan on the ctx stream (resident: the plan's kernel; weight-streamed: wide_forward on the committed image)
 int launch_plain_eval(npbnn_ctx* ctx, const LaunchPlan& lp, int which);

@@ -9,7 +9,10 @@ namespace npbnn_api {
 
 namespace {
 
-// tilings of wide_gemm_kernel: rows x outputs of a workgroup = 16 RT WR x 16 CT WC
+// tilings of wide_gemm_kernel: rows x outputs of a workgroup = 16 RT WR x 16 CT WC.  What a compute unit takes in by LDS-DMA grows
+// with the number of waves that request it (tools/microbench_ingest.hip: 7 / 12 / 17 B per clock from the L2 with 4 / 8 / 16 waves,
+// whatever each has in flight), and both operands come in that way: eight waves, and blocks as large as LDS and registers allow - the
+// bytes a block reads per product fall with its size.
 struct GemmCfg {
     wide_gemm_fn_t f16, f32;
     int xt, wt;            // row tiles / output tiles of a workgroup
@@ -17,12 +20,34 @@ struct GemmCfg {
     int n_stage;           // stages of the ring
     bool attr16 = false, attr32 = false;
 };
-GemmCfg g_cfg[3] = {
-    {wide_gemm_kernel<4, 4, 2, 2, true>, wide_gemm_kernel<4, 4, 2, 2, false>, 8, 8, 256, 8, 4},     // 128 x 128: 32 KiB per stage
-    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 4},     // 128 x 64 : 24 KiB
-    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 4},     // 128 x 32 : 20 KiB
+GemmCfg g_cfg[5] = {
+    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, 16, 16, 512, 8, 2},    // 256 x 256: 64 KiB per stage
+    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, 16, 8, 512, 6, 3},     // 256 x 128: 48 KiB
+    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, 16, 4, 512, 5, 3},     // 256 x 64 : 40 KiB
+    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 3},      // 128 x 64 : 24 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 3},      // 128 x 32 : 20 KiB
 };
-GemmCfg& cfg_for(int mt) { return g_cfg[mt > 4 ? 0 : mt > 2 ? 1 : 2]; }
+// the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)
+GemmCfg& cfg_for(int mt, int n_row_tiles, int n_cu) {
+    if (const char* e = getenv("NPBNN_WIDE_CFG")) { const int v = atoi(e); if (v >= 0 && v < 5) return g_cfg[v]; }
+    if (mt > 8) return g_cfg[0];
+    if (mt > 4) return g_cfg[1];
+    const bool few_rows = (n_row_tiles + 15) / 16 < n_cu / 2;
+    if (mt > 2) return few_rows ? g_cfg[3] : g_cfg[2];
+    return g_cfg[4];
+}
+
+// K-slices of a layer's product: while the blocks of the output do not fill the chip and a slice keeps a contraction worth its prologue
+int slices_for(const GemmCfg& cf, int n_row_tiles, int mt, int units, int n_cu) {
+    const int n_rb = (n_row_tiles + cf.xt - 1) / cf.xt, n_cb = (mt + cf.wt - 1) / cf.wt;
+    int n_sl = 1;
+    if (const char* e = getenv("NPBNN_WIDE_SLICES")) n_sl = atoi(e);
+    else while (n_sl < kWideMaxSlices && n_rb * n_cb * (n_sl + 1) <= n_cu && units / (n_sl + 1) >= 8) ++n_sl;
+    if (n_sl > kWideMaxSlices) n_sl = kWideMaxSlices;
+    if (n_sl > units) n_sl = units;
+    if (n_sl < 1) n_sl = 1;
+    return n_sl;
+}
 
 int stages_env() {
     static const int v = getenv("NPBNN_WIDE_STAGES") ? atoi(getenv("NPBNN_WIDE_STAGES")) : 0;
@@ -75,7 +100,7 @@ bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a) {
 
 void wide_free(npbnn_ctx* ctx) {
     if (ctx->d_wide_cand) { (void)hipFree(ctx->d_wide_cand); ctx->d_wide_cand = nullptr; }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         if (ctx->d_wide_act[i]) { (void)hipFree(ctx->d_wide_act[i]); ctx->d_wide_act[i] = nullptr; }
     ctx->wide_act_cap = 0;
     if (ctx->d_wide_cs) { (void)hipFree(ctx->d_wide_cs); ctx->d_wide_cs = nullptr; }
@@ -169,11 +194,35 @@ int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp) {
         if (16 * m.L[l].mt > max_ld) max_ld = 16 * m.L[l].mt;
     const size_t need = (size_t)d.n_tiles * 16 * (size_t)max_ld;
     if (need > ctx->wide_act_cap) {
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 3; ++i)
             if (ctx->d_wide_act[i]) { (void)hipFree(ctx->d_wide_act[i]); ctx->d_wide_act[i] = nullptr; }
         ctx->wide_act_cap = 0;
         for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipMalloc(&ctx->d_wide_act[i], need * sizeof(float)));
+        int max_sl = 1;           // the K-slices' sums of a layer: room for the most any layer of this network is cut into on this table
+        for (int l = 0; l < m.n_layers; ++l) {
+            const int sl = slices_for(cfg_for(m.L[l].mt, d.n_tiles, ctx->n_cu), d.n_tiles, m.L[l].mt, m.L[l].units, ctx->n_cu);
+            if (sl > max_sl) max_sl = sl;
+        }
+        if (max_sl > 1) HIP_TRY(ctx, hipMalloc(&ctx->d_wide_act[2], need * sizeof(float) * max_sl));
         ctx->wide_act_cap = need;
+    }
+    if (m.L[0].f16 && !d.X16w) {        // the fp16-split copy in piece order
+        Dataset* home = &d;
+        if (d.borrowed && ctx->data_owner) {
+            npbnn_ctx* root = ctx->data_owner;
+            while (root->data_owner) root = root->data_owner;
+            home = &root->ds[which];
+        }
+        if (!home->X16w) {
+            const int n_units = (d.F + 31) / 32;
+            const size_t n_pad = (size_t)d.n_tiles * 16;
+            HIP_TRY(ctx, hipMalloc(&home->X16w, n_pad * (size_t)n_units * 32 * sizeof(float)));
+            const long long items = (long long)n_pad * n_units * 4;
+            hipLaunchKernelGGL(split_x_tiled_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d.X, (long long)n_pad, d.Fp,
+                               n_units, (const float*)ctx->d_xscale, home->X16w);
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (home != &d) { d.X16w = home->X16w; d.x16w_borrowed = true; }
     }
     lp->fn = nullptr;
     lp->fn_spec = nullptr;
@@ -200,13 +249,64 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass)
     const WideMeta& m = ctx->wmeta;
     hipStream_t st = ctx->stream;
     const bool f16 = m.L[0].f16 != 0;
-    const float* A = f16 ? d.X16 : d.X;
-    long long lda = f16 ? d.Fp16 : d.Fp;
+    const float* A = f16 ? d.X16w : d.X;
+    long long lda = f16 ? 32ll * m.L[0].units : d.Fp;
+    if (f16 && !d.X16w) return fail(ctx, NPBNN_E_STATE, "the weight-streamed path has no fp16-split copy of this matrix (internal error)");
     const PassDesc* pass = chain_pass ? reinterpret_cast<const PassDesc*>(reinterpret_cast<const char*>(ctx->d_eparams) + offsetof(EvalParams, pass_desc)) : nullptr;
     const bool dev_slopes = chain_pass && ctx->batch_slopes && ctx->d_slopes;
+    static const bool no_tail = getenv("NPBNN_WIDE_NO_TAIL") != nullptr;
+    static bool tail_attr = false;
     for (int l = 0; l < m.n_layers; ++l) {
         const WideLayer& L = m.L[l];
-        GemmCfg& cf = cfg_for(L.mt);
+        // the narrow end of the network in one launch (wide_tail_kernel): every remaining layer of <= 128 nodes, behind <= 256 inputs,
+        // their weights within 96 KiB of LDS
+        if (l >= 1 && !no_tail && lda <= 16 * kTailIn) {
+            bool ok = true;
+            long long lds_floats = 0;
+            for (int q = l; q < m.n_layers; ++q) {
+                ok = ok && m.L[q].mt <= kTailOut;
+                lds_floats += (long long)m.L[q].units * 2 * m.L[q].mt * 256 + 16 * m.L[q].mt;
+            }
+            if (ok && lds_floats * 4 <= 96 * 1024) {
+                WideTailArgs t{};
+                t.A = A;
+                t.lda = lda;
+                t.n_row_tiles = d.n_tiles;
+                t.n_layers = m.n_layers - l;
+                t.kt0 = (int)(lda / 16);
+                t.last_is_output = 1;
+                t.image = image;
+                int off = 0;
+                for (int q = l; q < m.n_layers; ++q) {
+                    const int i = q - l;
+                    t.frag_off[i] = m.L[q].frag_off;
+                    t.bias_off[i] = m.L[q].bias_off;
+                    t.mt[i] = m.L[q].mt;
+                    t.frag_floats[i] = m.L[q].units * 2 * m.L[q].mt * 256;
+                    t.lds_frag[i] = off;
+                    off += t.frag_floats[i];
+                    t.lds_bias[i] = off;
+                    off += 16 * m.L[q].mt;
+                    t.act_prm[i] = ctx->net.act_prm[q];
+                }
+                t.act_kind = ctx->net.act_kind;
+                t.act_prm_dev = dev_slopes ? &ctx->d_slopes->cand[0][0][l] : nullptr;
+                t.out = ctx->d_wide_act[l & 1];
+                t.ldo = 16 * m.L[m.n_layers - 1].mt;
+                t.pass = pass;
+                if (!tail_attr) {
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + 1024));
+                    tail_attr = true;
+                }
+                int grid = (d.n_tiles + 7) / 8;
+                if (grid > 2 * ctx->n_cu) grid = 2 * ctx->n_cu;
+                hipLaunchKernelGGL(wide_tail_kernel, dim3(grid), dim3(512), (size_t)off * 4, st, t);
+                A = t.out;
+                lda = t.ldo;
+                break;
+            }
+        }
+        GemmCfg& cf = cfg_for(L.mt, d.n_tiles, ctx->n_cu);
         WideGemmArgs g{};
         g.A = A;
         g.lda = lda;
@@ -222,6 +322,7 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass)
         g.act_prm = ctx->net.act_prm[l];
         g.act_prm_dev = (dev_slopes && l + 1 < m.n_layers) ? &ctx->d_slopes->cand[0][0][l] : nullptr;
         g.pass = pass;
+        g.a_tiled = (l == 0 && f16) ? 1 : 0;
         int n_stage = stages_env() >= 2 ? stages_env() : cf.n_stage;
         const int stage_bytes = (cf.xt + cf.wt) * 2048;
         while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * cf.ppw > kWideMaxYounger)) --n_stage;
@@ -236,9 +337,20 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass)
             attr = true;
         }
         const int n_rb = (d.n_tiles + cf.xt - 1) / cf.xt, n_cb = (L.mt + cf.wt - 1) / cf.wt;
-        const int grid = (n_rb + 7) / 8 * 8 * n_cb;
+        int n_sl = slices_for(cf, d.n_tiles, L.mt, L.units, ctx->n_cu);
+        if (n_sl > 1 && !ctx->d_wide_act[2]) n_sl = 1;
+        float* const layer_out = ctx->d_wide_act[l & 1];
+        g.k_slices = n_sl;
+        g.slice_stride = (long long)d.n_tiles * 16 * g.ldo;
+        if (n_sl > 1) g.out = ctx->d_wide_act[2];
+        const int grid = (n_rb + 7) / 8 * 8 * n_cb * n_sl;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(cf.threads), lds, st, g);
-        A = g.out;
+        if (n_sl > 1) {
+            const long long n_vec4 = g.slice_stride / 4;
+            hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)((n_vec4 + 255) / 256)), dim3(256), 0, st, (const float*)ctx->d_wide_act[2], g.slice_stride, n_sl,
+                               layer_out, n_vec4, g.act_kind, g.act_prm, g.act_prm_dev, pass);
+        }
+        A = layer_out;
         lda = g.ldo;
     }
     WideLikArgs la{};
@@ -260,9 +372,12 @@ int wide_cand_begin(npbnn_ctx* ctx) {
     return NPBNN_OK;
 }
 
-void wide_cand_sync(npbnn_ctx* ctx) {
-    hipLaunchKernelGGL(wide_cand_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand,
-                       (const float*)ctx->d_image);
+// before a chain pass whose proposals are too wide for the step to keep the candidate image itself (chain_prepare: ChainParams::cand_image unset)
+void wide_cand_sync(npbnn_ctx* ctx, int M) {
+    const unsigned grid = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(wide_cand_restore_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, (const WideCandState*)ctx->d_wide_cs,
+                       ctx->d_wide_cand, (const float*)ctx->d_image);
+    hipLaunchKernelGGL(wide_cand_apply_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand);
 }
 
 }  // namespace npbnn_api

@@ -18,9 +18,9 @@
 //                      float64 sums, fixed order), confusion counts, predictions; one partial record per workgroup, summed by
 //                      finalize_kernel / chain_step exactly like the resident path's.
 //   wide_pack_kernel   float64 packed weights -> the streamed image (layer blocks in K-unit-major fragment order).
-//   wide_cand_kernel   a device chain's candidate image: the committed image with the pending proposal's entries patched in -
-//                      what the resident path does to its LDS copy, done here to a second image in HBM (entries of the previous
-//                      pass restored from the committed image first).
+//   A device chain's candidate = the committed image with the pending proposal's entries patched in - what the resident path does
+//   to its LDS copy is done here to a second image in HBM, by the chain step itself (ChainParams::cand_image: patched when a
+//   proposal is prepared, put back when it is rejected).
 #pragma once
 #include "npbnn_common.hip.h"
 #include "npbnn_pack.hip.h"
@@ -158,7 +158,10 @@ struct WideGemmArgs {
     const double* act_prm_dev;   // device chain with trainable slopes: the candidate's slope for this layer, else nullptr
     const PassDesc* pass;     // chain pass: nothing to do when its descriptor says the batch is through (n_cand == 0); else nullptr
     int n_stage;              // stages of the LDS ring (>= 2)
-    int pad_;
+    int a_tiled;              // A is the tile-major fp16-split copy of X (split_x_tiled_kernel): every 1-KiB piece is contiguous
+    int k_slices;             // > 1: the contraction is cut into that many slices of K-units, one workgroup each; slice s writes its raw
+    int pad_;                 // sums (the bias in slice 0, no activation) to out + s * slice_stride; wide_reduce_kernel adds them up
+    long long slice_stride;   // floats
 };
 
 #define NPBNN_WVM_(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -175,6 +178,8 @@ __device__ __forceinline__ void wide_wait_vm(int younger) {     // wave-uniform:
 }
 #undef NPBNN_WVM_
 constexpr int kWideMaxYounger = 48;
+constexpr int kWideMaxSlices = 8;    // K-slices a layer's contraction is cut into at most
+constexpr int kWideFlush = 8;        // K-units (256 columns) added up by the matrix cores before the sum joins the running total
 
 // RT x CT: 16 x 16 tiles a wave computes (rows x outputs); WR x WC: waves of the workgroup (rows x outputs); F16: fp16-split operands
 template <int RT, int CT, int WR, int WC, bool F16>
@@ -193,15 +198,20 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
     // workgroup -> (row block, output block): the output blocks of one row block sit 8 workgroup indices apart - the same XCD (workgroups
     // go round the 8 XCDs), dispatched close together: the second reads the rows' pieces out of the L2 the first filled
     const int n_cb = (a.mt_total + WT - 1) / WT;
+    const int n_sl = a.k_slices > 1 ? a.k_slices : 1;
+    const int per_grp = 8 * n_cb * n_sl;               // (the slices of a block of the output sit 8 apart as well)
     const int bid = (int)blockIdx.x;
-    const int grp = bid / (8 * n_cb), rem = bid % (8 * n_cb);
-    const int cb = rem / 8, rb = grp * 8 + rem % 8;
+    const int grp = bid / per_grp, rem = bid % per_grp;
+    const int cb = (rem / 8) % n_cb, slice = rem / (8 * n_cb), rb = grp * 8 + rem % 8;
     if (rb * XT >= a.n_row_tiles) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const int wr = wave / WC, wc = wave % WC;
-    const int n_units = a.n_units, n_stage = a.n_stage;
+    const int n_stage = a.n_stage;
+    // this workgroup's K-units: [u_begin, u_begin + n_units)
+    const int u_begin = (int)((long long)a.n_units * slice / n_sl);
+    const int n_units = (int)((long long)a.n_units * (slice + 1) / n_sl) - u_begin;
 
     // ---- this wave's pieces of a stage: piece p = wave + i * NW; p < 2 XT: rows (tile p >> 1, half p & 1), else fragments ----
     const float* src[PPW];        // this lane's source address for unit 0
@@ -215,8 +225,13 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
             const int t = p >> 1, h = p & 1;
             int T = rb * XT + t;
             if (T > a.n_row_tiles - 1) T = a.n_row_tiles - 1;        // (past the matrix: the last tile again; its results are not stored)
-            src[i] = a.A + ((long long)T * 16 + n) * a.lda + 16 * h + 4 * kq;
-            ustride[i] = 32;
+            if (a.a_tiled) {      // tile-major copy: piece (T, u, h) is the 1 KiB at ((T * units + u) * 2 + h) * 256 floats
+                src[i] = a.A + (((long long)T * a.n_units) * 2 + h) * 256 + lane * 4;
+                ustride[i] = 512;
+            } else {
+                src[i] = a.A + ((long long)T * 16 + n) * a.lda + 16 * h + 4 * kq;
+                ustride[i] = 32;
+            }
             lds_off[i] = t * 2048 + h * 1024;
             half_x[i] = h;
         } else {
@@ -239,25 +254,34 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
     auto issue = [&](int u) {                 // request unit u into its stage of the ring
         char* const sb = smem + (size_t)st_in * STAGE;
         st_in = st_in + 1 == n_stage ? 0 : st_in + 1;
-        const bool last_half = a.a_half_last && u == n_units - 1;
+        const bool last_half = a.a_half_last && u_begin + u == a.n_units - 1;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const float* g = src[i] + (long long)u * ustride[i];
+            const float* g = src[i] + (long long)(u_begin + u) * ustride[i];
             if (half_x[i] && last_half) g -= 16;
             dma16(g, sb + lds_off[i]);
         }
     };
 
-    // ---- accumulators start from the bias ----
-    f32x4 acc[RT][CT];
+    // ---- two levels of float32 accumulation: the matrix cores add into `acc`, which is emptied into `tot` every kWideFlush units
+    //      (a long contraction's rounding error grows with the length of ONE chain of additions: thousands of columns would
+    //      otherwise cost the last layer's values a digit); `tot` starts from the bias ----
+    constexpr bool TWO = RT * CT <= 16;       // (the tilings of 32 tiles per wave have no registers for a second set: their long
+                                              // contractions are cut into K-slices, whose sums meet in wide_reduce_kernel)
+    f32x4 acc[RT][CT], tot[TWO ? RT : 1][TWO ? CT : 1];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         int mt = cb * WT + wc * CT + ct;
         if (mt > a.mt_total - 1) mt = a.mt_total - 1;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + 16 * mt + 4 * kq);
+        f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + 16 * mt + 4 * kq);
+        if (slice > 0) b = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = b;
+        for (int rt = 0; rt < RT; ++rt) {
+            if constexpr (TWO) { tot[rt][ct] = b; acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            else acc[rt][ct] = b;
+        }
     }
+    int since_flush = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the bias loads: not counted with the pieces below)
 
     for (int u = 0; u < n_stage - 1 && u < n_units; ++u) issue(u);
@@ -306,8 +330,23 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
                 }
             }
         }
+        if constexpr (TWO) {
+            if (++since_flush == kWideFlush) {
+                since_flush = 0;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) { tot[rt][ct] += acc[rt][ct]; acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+        }
     }
 
+    if constexpr (TWO) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += tot[rt][ct];
+    }
     // ---- activation, store: lane (n, kq) holds the units 4 kq .. 4 kq + 3 of a tile for row n ----
     float prm = a.act_prm;
     if (a.act_prm_dev != nullptr) prm = (float)*a.act_prm_dev;
@@ -320,17 +359,158 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
             const int mt = cb * WT + wc * CT + ct;
             if (mt >= a.mt_total) continue;
             f32x4 v = acc[rt][ct];
-            if (a.act_kind >= 0) {
+            if (a.act_kind >= 0 && n_sl == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], a.act_kind, prm);
             }
-            *reinterpret_cast<f32x4*>(a.out + ((long long)T * 16 + n) * a.ldo + 16 * mt + 4 * kq) = v;
+            *reinterpret_cast<f32x4*>(a.out + (long long)slice * a.slice_stride + ((long long)T * 16 + n) * a.ldo + 16 * mt + 4 * kq) = v;
         }
     }
 }
 
 typedef void (*wide_gemm_fn_t)(const WideGemmArgs);
-struct WideCandState { int prev_t0, prev_cnt; };      // what wide_cand_kernel patched last (entries of iteration prev_t0's proposal)
+struct WideCandState { int prev_t0, prev_cnt; };      // entries the candidate image's last patch covered (wide_cand_*_kernel)
+
+#ifdef NPBNN_KERNELS_WIDE
+// the K-slices' sums of a layer, added in slice order (fixed: the same bits every run), then the activation
+__global__ void __launch_bounds__(256) wide_reduce_kernel(const float* __restrict__ part, long long slice_stride, int n_slices, float* __restrict__ out,
+                                                          long long n_vec4, int act_kind, float act_prm, const double* act_prm_dev, const PassDesc* pass) {
+    if (pass != nullptr && pass->n_cand == 0) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_vec4) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * i);
+    for (int s = 1; s < n_slices; ++s) v += *reinterpret_cast<const f32x4*>(part + (long long)s * slice_stride + 4 * i);
+    if (act_kind >= 0) {
+        const float prm = act_prm_dev != nullptr ? (float)*act_prm_dev : act_prm;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], act_kind, prm);
+    }
+    *reinterpret_cast<f32x4*>(out + 4 * i) = v;
+}
+
+// The fp16-split copy of X in the order the products read it: per 16-row tile T and K-unit u the two 1-KiB pieces a workgroup's
+// LDS-DMA fetches, each contiguous - piece h holds, for lane (row n, entry kq), 16 bytes: entries 0 / 2 the high parts of feature
+// groups 2 h / 2 h + 1 of the unit, entries 1 / 3 their low parts (what the 16-rows-x-64-bytes piece of the row-major copy puts into
+// LDS).  A tile's whole K-stream is one contiguous run: 1-KiB requests instead of 16 x 64 bytes 4 * F bytes apart (measured,
+// tools/microbench_ingest.hip: 1.3-1.5 x the LDS-DMA rate per compute unit).
+__global__ void __launch_bounds__(256) split_x_tiled_kernel(const float* __restrict__ X, long long n_rows_pad, int Fp, int n_units,
+                                                            const float* __restrict__ x_scale, float* __restrict__ X16w) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per (row, group of 8 features)
+    const int groups = n_units * 4;
+    if (g >= n_rows_pad * groups) return;
+    const long long r = g / groups;
+    const int grp = (int)(g % groups), c0 = grp * 8;
+    f16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const float v = c < Fp ? X[r * Fp + c] * x_scale[c] : 0.f;
+        _Float16 h, l;
+        split_f16(v, h, l);
+        hi[j] = h;
+        lo[j] = l;
+    }
+    const long long T = r >> 4;
+    const int n = (int)(r & 15), u = grp >> 2, kg = grp & 3;
+    float* piece = X16w + (((T * n_units + u) * 2) + (kg >> 1)) * 256;
+    *reinterpret_cast<f16x8*>(piece + ((2 * (kg & 1)) * 16 + n) * 4) = hi;
+    *reinterpret_cast<f16x8*>(piece + ((2 * (kg & 1) + 1) * 16 + n) * 4) = lo;
+}
+#endif  // NPBNN_KERNELS_WIDE
+
+// ------------------------------------------------------------------------------------------------
+// the narrow end of a network in one launch: layers of <= 128 nodes behind an input of <= 256 (the [64] of [256, 64], the [5] of
+// [50, 5], every output layer of a few classes).  As tiled products of their own each would cost a launch, a pass over the activations
+// and a prologue per workgroup for a few MFMAs; here their weights (a few tens of KiB) sit in LDS, a wave takes a 16-row tile of the
+// activations and chains the layers through its accumulators - the resident path's scheme: the accumulator of one layer is the B
+// operand of the next (v_mfma_f32_16x16x4_f32, exact float32), bias = initial accumulator, activation elementwise.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTailIn = 16;       // 16-unit tiles of the activations it reads at most
+constexpr int kTailOut = 8;       // ... and of any layer it computes
+struct WideTailArgs {
+    const float* A;           // [rows][lda] activations behind the last tiled product (activation applied)
+    long long lda;
+    int n_row_tiles;
+    int n_layers;             // layers computed here
+    int kt0;                  // 16-column steps of the first one's input
+    int last_is_output;       // the last of them is the network's last layer: no activation behind it
+    const float* image;       // weight image (global)
+    long long frag_off[kMaxLayers], bias_off[kMaxLayers];     // of each layer, in the image
+    int mt[kMaxLayers];
+    int lds_frag[kMaxLayers], lds_bias[kMaxLayers];           // float offsets of their copies in LDS
+    int frag_floats[kMaxLayers];
+    int act_kind;
+    float act_prm[kMaxLayers];
+    const double* act_prm_dev;    // device chain with trainable slopes: the candidate's slopes of these layers, or nullptr
+    float* out;               // [rows][ldo] values of the last layer computed
+    long long ldo;
+    const PassDesc* pass;
+};
+
+#ifdef NPBNN_KERNELS_WIDE
+__global__ void __launch_bounds__(512) wide_tail_kernel(const WideTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.pass != nullptr) {
+        const int n_cand = __builtin_amdgcn_readfirstlane(a.pass->n_cand);
+        if (n_cand == 0) return;
+    }
+    float* const lds = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    for (int l = 0; l < a.n_layers; ++l) {      // the layers' fragments and biases into LDS, once per workgroup
+        const f32x4* gf = reinterpret_cast<const f32x4*>(a.image + a.frag_off[l]);
+        f32x4* lf = reinterpret_cast<f32x4*>(lds + a.lds_frag[l]);
+        for (int i = tid; i < a.frag_floats[l] / 4; i += blockDim.x) lf[i] = gf[i];
+        const f32x4* gb = reinterpret_cast<const f32x4*>(a.image + a.bias_off[l]);
+        f32x4* lb = reinterpret_cast<f32x4*>(lds + a.lds_bias[l]);
+        for (int i = tid; i < 4 * a.mt[l]; i += blockDim.x) lb[i] = gb[i];
+    }
+    __syncthreads();
+    constexpr int HT = kTailIn;
+    for (int T = (int)blockIdx.x * nw + wave; T < a.n_row_tiles; T += (int)gridDim.x * nw) {
+        f32x4 h[HT];
+        const float* row = a.A + ((long long)T * 16 + n) * a.lda + 4 * kq;
+#pragma unroll
+        for (int ct = 0; ct < HT; ++ct) h[ct] = ct < a.kt0 ? *reinterpret_cast<const f32x4*>(row + 16 * ct) : f32x4{0.f, 0.f, 0.f, 0.f};
+        int kt = a.kt0;
+        for (int l = 0; l < a.n_layers; ++l) {
+            const int mt_l = __builtin_amdgcn_readfirstlane(a.mt[l]);
+            const float* frag = lds + a.lds_frag[l] + lane * 4;
+            const float* bias = lds + a.lds_bias[l] + 4 * kq;
+            f32x4 acc[kTailOut];
+#pragma unroll
+            for (int mt = 0; mt < kTailOut; ++mt) {
+                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (mt < mt_l) {
+                    acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
+#pragma unroll
+                    for (int ct = 0; ct < HT; ++ct)
+                        if (ct < kt) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * mt_l + mt) * 256);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], h[ct][s], acc[mt], 0, 0, 0);
+                        }
+                }
+            }
+            const bool last = l + 1 == a.n_layers;
+            if (!(last && a.last_is_output)) {
+                const float prm = a.act_prm_dev != nullptr ? (float)a.act_prm_dev[l] : a.act_prm[l];
+#pragma unroll
+                for (int mt = 0; mt < kTailOut; ++mt)
+                    if (mt < mt_l)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[mt][i] = act_apply(acc[mt][i], a.act_kind, prm);
+            }
+#pragma unroll
+            for (int ct = 0; ct < HT; ++ct) h[ct] = ct < kTailOut ? acc[ct < kTailOut ? ct : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = mt_l;
+        }
+        float* orow = a.out + ((long long)T * 16 + n) * a.ldo + 4 * kq;
+#pragma unroll
+        for (int mt = 0; mt < kTailOut; ++mt)
+            if (mt < kt) *reinterpret_cast<f32x4*>(orow + 16 * mt) = h[mt];
+    }
+}
+#endif  // NPBNN_KERNELS_WIDE
 
 // ------------------------------------------------------------------------------------------------
 // likelihood terms / statistics / predictions from the last layer's values (one thread per data row)
@@ -465,43 +645,27 @@ __global__ void __launch_bounds__(256) wide_lik_kernel(const WideLikArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// candidate image of a device chain (serial schedule, one candidate per pass)
+// candidate image of a device chain with WIDE proposals (more entries than the step's workgroup holds at once: the reference's default
+// perturbs 5 % of every layer, np_bnn/BNN_env.py:285 - tens of thousands of entries of a network this path exists for).  The step
+// keeps the image itself for narrow proposals (ChainParams::cand_image); for wide ones two launches over all compute units do it
+// between the step and the pass: the entries the pass before had patched go back to the committed image's values (which hold the
+// accepted proposal, if it was accepted), then the pending proposal's entries are patched in.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wide_restore_entry(float* cand, const float* image, int pos) {
-    if (pos == kSkipPos) return;
-    if (pos < 0) {
-        const _Float16* s = reinterpret_cast<const _Float16*>(image);
-        _Float16* d = reinterpret_cast<_Float16*>(cand);
-        const int h = pos & 0x3fffffff;
-        d[h] = s[h];
-        d[h + 512] = s[h + 512];
-    } else {
-        cand[pos] = image[pos];
-    }
+__global__ void __launch_bounds__(256) wide_cand_restore_kernel(const ChainParams* __restrict__ cp, const WideCandState* __restrict__ st, float* __restrict__ cand,
+                                                                const float* __restrict__ image) {
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e >= st->prev_cnt) return;
+    restore_image_entry(cand, image, cp->pos[(size_t)st->prev_t0 * cp->M + e]);
 }
-__global__ void __launch_bounds__(1024) wide_cand_kernel(const ChainParams* __restrict__ cp, WideCandState* st, float* __restrict__ cand,
-                                                         const float* __restrict__ image) {
+__global__ void __launch_bounds__(256) wide_cand_apply_kernel(const ChainParams* __restrict__ cp, WideCandState* __restrict__ st, float* __restrict__ cand) {
     const ChainParams& c = *cp;
-    const int tid = threadIdx.x;
-    const int M = c.M;
-    const int pt = st->prev_t0, pn = st->prev_cnt;
     const PassDesc d = c.pass[0];
-    __syncthreads();                                 // (everybody has read the record before thread 0 rewrites it)
-    // the entries the pass before this one had patched: back to what the committed image holds (the accepted values, if it was accepted)
-    if (pn > 0) {
-        const size_t row = (size_t)pt * M;
-        for (int e = tid; e < pn; e += blockDim.x) wide_restore_entry(cand, image, c.pos[row + e]);
-    }
-    __threadfence_block();
-    __syncthreads();
-    int cnt = 0;
-    if (d.n_cand > 0) {
-        cnt = d.cnt[0];
-        const size_t row = (size_t)d.t0 * M;
-        for (int e = tid; e < cnt; e += blockDim.x)
-            patch_image(cand, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, c.pv[e], 16);
-    }
-    if (tid == 0) { st->prev_t0 = d.t0; st->prev_cnt = cnt; }
+    const int cnt = d.n_cand > 0 ? d.cnt[0] : 0;
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e == 0) { st->prev_t0 = d.t0; st->prev_cnt = cnt; }      // (read by the NEXT restore launch only)
+    if (e >= cnt) return;
+    const size_t k = (size_t)d.t0 * c.M + e;
+    patch_image(cand, c.pos[k], c.pscale ? c.pscale[k] : 1.0f, c.pv[e], 16);
 }
 #endif  // NPBNN_KERNELS_WIDE
 

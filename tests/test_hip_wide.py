@@ -173,9 +173,12 @@ def test_shapes_the_lds_cannot_hold_against_the_oracle(name, precision):
     want = orc.lik_categorical(y64, lab, np.arange(n))
     assert abs(r["loglik"] - want) / abs(want) < LL_RTOL
     check_confusion(r["confusion"], y64, lab)
+    # (float32 accumulation: the rounding error of a contraction grows with the square root of its length - the budget of the short
+    # contractions, 2e-5, times sqrt(features / 1024) from there on; the log-likelihood keeps its 2e-6)
+    tol = Z_TOL * max(1.0, np.sqrt(f / 1024.0))
     z = ctx.predict(w, apply_out_fn=False)
-    assert_close(z, orc.forward_logits(x64, w, act))
-    assert_close(ctx.predict(w), y64)
+    assert_close(z, orc.forward_logits(x64, w, act), tol)
+    assert_close(ctx.predict(w), y64, tol)
     ctx.close()
 
 
@@ -192,8 +195,9 @@ def test_wide_regression_with_a_test_set_and_column_override():
     assert ctx.is_wide()
     y64 = orc.forward(x, w, act, orc.out_identity)
     r = ctx.eval(w)
-    want = orc.closed_gaussian_empirical(y64, t)
+    want, sig = orc.closed_gaussian_empirical(y64, t)
     np.testing.assert_allclose(r["loglik"], want, rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sigma"][:k], sig, rtol=1e-6)
     assert_close(ctx.predict(w, which=capi.TEST), orc.forward(xt, w, act, orc.out_identity))
     ov = np.full(f, np.nan)
     ov[[3, 700, 1499]] = [0.25, -1.0, 2.0]

@@ -826,7 +826,10 @@ constexpr int kSpecOutcomes = kMaxCand + 1;
 // need not wait for their stores to be acknowledged before they report, nor report at all: the step looks at the words themselves, in the
 // loads it adds up anyway (two round trips through memory less between two passes).  Tags are the touch tables' pass tags
 // (ChainParams.spec_gen + P + 1: never repeated, the host clears the words with the tables).
-constexpr int kSpecPartSlots = 256;       // workgroups a record block is laid out for (one per compute unit at most)
+constexpr int kSpecPartSlots = 256;       // workgroups a record block is laid out for (one per compute unit at most); spec_rounds reads
+                                          // them as 4 x 64 lanes with no remainder loop: chain_prepare keeps launches with more evaluating
+                                          // workgroups off this schedule
+static_assert(kSpecPartSlots == 4 * 64, "spec_rounds adds the workgroups' sums up as four loads per lane of one wave");
 __device__ __forceinline__ size_t spec_part_index(int par, int j, int v, int b) {
     return ((((size_t)par * kMaxCand + j) * kPartialStride + v) * kSpecPartSlots + b) * 2;
 }

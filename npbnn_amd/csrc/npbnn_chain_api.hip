@@ -206,8 +206,11 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     if ((schedule == NPBNN_SCHED_OVERLAP2 || schedule == NPBNN_SCHED_PERSIST) && ctx->sync_failed) schedule = NPBNN_SCHED_OVERLAP;
     // (asked for by name where it cannot run - no build with the speculative step for this launch, another prior, trainable slopes, a
     // shared GPU: the persistent overlapped form where that can, else kernel boundaries)
+    // (the evaluating workgroups' tagged sums of that schedule sit in kSpecPartSlots slots per value, and the step reads exactly that
+    // many: a part with more compute units than slots - none today: 256 of each on gfx950 - stays on the overlapped form)
+    const int eval_wgs = lp.grid > ctx->n_cu - 1 ? ctx->n_cu - 1 : lp.grid;
     if (schedule == NPBNN_SCHED_PERSIST_SERIAL &&
-        (ctx->sync_failed || !alone_on_device || seg_len > 0 || group_blocks > 0 || lp.fn_spec == nullptr || cfg->slope_idx || getenv("NPBNN_NO_SPEC_STEP") ||
+        (eval_wgs > kSpecPartSlots || ctx->sync_failed || !alone_on_device || seg_len > 0 || group_blocks > 0 || lp.fn_spec == nullptr || cfg->slope_idx || getenv("NPBNN_NO_SPEC_STEP") ||
          !(cfg->prior_kind == NPBNN_PRIOR_UNIFORM || (cfg->prior_kind == NPBNN_PRIOR_NORMAL && !cfg->prior_scale_w))))
         schedule = (alone_on_device && seg_len == 0 && !ctx->sync_failed && group_blocks == 0) ? NPBNN_SCHED_PERSIST : NPBNN_SCHED_OVERLAP;
     // the persistent form needs every workgroup of its launch resident at once: one per compute unit at most, the GPU to itself, and

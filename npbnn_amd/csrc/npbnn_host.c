@@ -16,6 +16,7 @@
  *   random()  (accept test)
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -228,15 +229,24 @@ static inline double fast_standard_normal(pcg64_t* r, bitgen_t* own_bg) {
     return random_standard_normal(own_bg);
 }
 
+static int fast_build_and_verify(void);
+/* Runs ONCE per process (pthread_once: ctypes releases the interpreter lock, so the helper thread's pre-draw and a pre-draw on the
+ * main thread - or two samplers - can arrive together); fast_state says "verified" only after the last comparison has passed, so
+ * nobody draws from tables that verification is about to reject. */
+static void fast_init_once(void) {
+    if (getenv("NPBNN_NO_FAST_PREDRAW")) { __atomic_store_n(&fast_state, -1, __ATOMIC_RELEASE); return; }
+    __atomic_store_n(&fast_state, fast_build_and_verify() ? 1 : -1, __ATOMIC_RELEASE);
+}
 static void fast_init(void) {
-    if (fast_state != 0) return;
-    fast_state = -1;
-    if (getenv("NPBNN_NO_FAST_PREDRAW")) return;
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, fast_init_once);
+}
+static int fast_build_and_verify(void) {
     for (int layer = 0; layer < 256; ++layer) {
         double w = 0.0;
         if (!probe_fast(layer, 1, &w) || !(w > 0.0)) {       /* magnitude 1 leaves the fast branch: not the table we think it is */
             if (!probe_fast(layer, 0, NULL)) { zig_ki[layer] = 0; zig_wi[layer] = 0.0; continue; }
-            return;
+            return 0;
         }
         zig_wi[layer] = w;
         uint64_t lo = 1, hi = (uint64_t)1 << 52;             /* fast at lo; ki in (lo, hi] */
@@ -255,22 +265,22 @@ static void fast_init(void) {
     b = a;
     pcg64_bitgen(&a, &bga);
     pcg64_bitgen(&b, &bgb);
-    fast_state = 1;                                           /* (fast_standard_normal reads the tables unconditionally) */
     for (int i = 0; i < (1 << 18); ++i) {
         const double x = fast_standard_normal(&a, &bga), y = random_standard_normal(&bgb);
-        if (memcmp(&x, &y, sizeof x) != 0 || a.state != b.state) { fast_state = -1; return; }
+        if (memcmp(&x, &y, sizeof x) != 0 || a.state != b.state) return 0;
     }
     static const uint32_t ranges[] = {1, 2, 4, 7, 9, 31, 32, 63, 255, 256, 511, 1000, 8191, 65535, 65536, 1000003, 0x7fffffffu, 0xfffffffeu};
     for (size_t q = 0; q < sizeof ranges / sizeof ranges[0]; ++q) {
         uint64_t want[257];
         random_bounded_uint64_fill(&bgb, 0, ranges[q], 257, 0, want);
         for (int i = 0; i < 257; ++i)
-            if ((uint64_t)fast_bounded32(&a, ranges[q]) != want[i]) { fast_state = -1; return; }
+            if ((uint64_t)fast_bounded32(&a, ranges[q]) != want[i]) return 0;
         /* an odd number of 32-bit draws leaves a buffered half behind: the two generators must agree on it too */
-        if (a.state != b.state || a.has_uint32 != b.has_uint32 || a.uinteger != b.uinteger) { fast_state = -1; return; }
+        if (a.state != b.state || a.has_uint32 != b.has_uint32 || a.uinteger != b.uinteger) return 0;
         const double x = fast_double(&a), y = random_standard_uniform(&bgb);
-        if (x != y) { fast_state = -1; return; }
+        if (x != y) return 0;
     }
+    return 1;
 }
 
 /* 1 when the inlined draws are in use (verified against numpy's routines in this process), else 0 */

@@ -20,16 +20,17 @@ struct GemmCfg {
     int n_stage;           // stages of the ring
     bool attr16 = false, attr32 = false;
 };
-GemmCfg g_cfg[5] = {
+GemmCfg g_cfg[6] = {
     {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, 16, 16, 512, 8, 2},    // 256 x 256: 64 KiB per stage
     {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, 16, 8, 512, 6, 3},     // 256 x 128: 48 KiB
     {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, 16, 4, 512, 5, 3},     // 256 x 64 : 40 KiB
     {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 3},      // 128 x 64 : 24 KiB
     {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 3},      // 128 x 32 : 20 KiB
+    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, 16, 16, 1024, 4, 2},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
 };
 // the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)
 GemmCfg& cfg_for(int mt, int n_row_tiles, int n_cu) {
-    if (const char* e = getenv("NPBNN_WIDE_CFG")) { const int v = atoi(e); if (v >= 0 && v < 5) return g_cfg[v]; }
+    if (const char* e = getenv("NPBNN_WIDE_CFG")) { const int v = atoi(e); if (v >= 0 && v < 6) return g_cfg[v]; }
     if (mt > 8) return g_cfg[0];
     if (mt > 4) return g_cfg[1];
     const bool few_rows = (n_row_tiles + 15) / 16 < n_cu / 2;

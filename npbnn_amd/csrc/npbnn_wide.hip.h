@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
     // ---- two levels of float32 accumulation: the matrix cores add into `acc`, which is emptied into `tot` every kWideFlush units
     //      (a long contraction's rounding error grows with the length of ONE chain of additions: thousands of columns would
     //      otherwise cost the last layer's values a digit); `tot` starts from the bias ----
-    constexpr bool TWO = RT * CT <= 16;       // (the tilings of 32 tiles per wave have no registers for a second set: their long
+    constexpr bool TWO = RT * CT <= 16 && NW <= 8;      // (the tilings of 32 tiles per wave have no registers for a second set: their long
                                               // contractions are cut into K-slices, whose sums meet in wide_reduce_kernel)
     f32x4 acc[RT][CT], tot[TWO ? RT : 1][TWO ? CT : 1];
 #pragma unroll

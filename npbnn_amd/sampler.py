@@ -207,6 +207,7 @@ class _FastDispatch:
         return self
 
     def matches(self, mcmc, bnn, k):
+        self.missed_on_boundary = False
         if k != self.k or bnn._w_layers is not self.layers:
             return False
         for now, then in zip(self._objects(mcmc, bnn), self.objects):
@@ -227,8 +228,11 @@ class _FastDispatch:
         if self.fixed_sigma and mcmc._current_iteration + k - 1 > mcmc._estimate_error:
             return False
         if self.adapt_possible:
+            # (what MCMC._adapt itself tests: nothing adapts from adapt_stop on, whatever the iteration count divides by)
             boundary = mcmc._next_adapt_boundary()
-            if mcmc._current_iteration % mcmc._adapt_freq == 0 or (boundary is not None and boundary < mcmc._current_iteration + k):
+            at_one = mcmc._current_iteration % mcmc._adapt_freq == 0 and mcmc._current_iteration < mcmc._adapt_stop
+            if at_one or (boundary is not None and boundary < mcmc._current_iteration + k):
+                self.missed_on_boundary = True      # this dispatch goes the general way; the kept one stays for the next
                 return False
         return True
 
@@ -540,6 +544,9 @@ class MCMC():
     def _light_view(self, bnn_view):
         """This sampler as a light checkpoint stores it (see postLogger): same state, bound to ``bnn_view``, pickled without the
         prediction matrices - after loading they are computed on demand from the weights, like every other statistic."""
+        # draws made ahead of the chain's position go back first (the view shares the generator: a checkpoint taken with them in flight
+        # would store a generator one or two batches past the iteration it claims to be at, and a run resumed from it would skip those draws)
+        self._cancel_speculation()
         view = self.__class__.__new__(self.__class__)
         view.__dict__.update(self.__dict__)
         view._speculation = view._speculation2 = None
@@ -838,8 +845,9 @@ class MCMC():
         if fast is not None:
             if fast.matches(self, bnn_obj, remaining) and fast.run(self, bnn_obj):
                 return
-            self._fast = None
-            self._fast_hold = 16        # (what made it fail may last: a few dispatches the general way before another is built)
+            if not getattr(fast, "missed_on_boundary", False):
+                self._fast = None
+                self._fast_hold = 16        # (what made it fail may last: a few dispatches the general way before another is built)
         while remaining > 0:
             seg = remaining                       # iterations over which the proposal settings stay constant
             boundary = self._next_adapt_boundary()

@@ -5,7 +5,8 @@
 ``np_bnn`` is made to resolve to ``npbnn_amd`` before the script is executed from where it lies (nothing of it is copied); the
 device is absent here, so the package's device seams are served by the float64 oracle: the sampler's backend
 (npbnn_amd.sampler._make_backend), the posterior predictor (npbnn_amd.posterior._SamplePredictor) and the two reductions behind
-the stand-alone accuracy helpers (npbnn_amd.device_ops._confusion / _sse).  Everything else the
+the stand-alone accuracy helpers (npbnn_amd.device_ops._confusion / _sse) and the stand-alone forward pass on host arrays
+(npbnn_amd.layers._forward: RunPredict called directly, as bnn_regress.py does).  Everything else the
 script touches - get_data, npBNN, ActFun, MCMC, postLogger, run_mcmc, predictBNN, feature_importance, npBNN(pickle_file=...) -
 is the product's host code."""
 import os
@@ -65,13 +66,29 @@ def _sse(y, lab, link, first_col_only):
     return np.sum((pred - t) ** 2, axis=0), y.shape[0]
 
 
+def _forward(data, weights, actFun, out_fn, final_activation=False, layer_offset=0):
+    """Stand-in for layers._forward (the stand-alone RunPredict / RunHiddenLayer / MatrixMultiplication on host arrays, one temporary
+    device context per call): the oracle's layer loop."""
+    z = np.asarray(data, dtype=float)
+    n = len(weights)
+    act = None
+    if actFun:
+        act = orc.Act(actFun._function, prm=np.asarray(actFun._prm, dtype=float) if np.ndim(actFun._prm) else None, trainable=actFun._trainable)
+    for i, w in enumerate(weights):
+        z = orc.dense(z, np.asarray(w, dtype=float))
+        if act is not None and (i + 1 < n or final_activation):
+            z = orc.activate(z, act, i + layer_offset)
+    return z if out_fn is None else out_fn(z)
+
+
 def _backend(bnn, likelihood_f):
     kind = output_kind(bnn._output_act_fun)
     return OracleChainBackend(bnn, 0 if kind is None else kind)
 
 
 if __name__ == "__main__":
-    from npbnn_amd import device_ops
+    from npbnn_amd import device_ops, layers
+    layers._forward = _forward
     sampler._make_backend = _backend
     posterior._SamplePredictor = OraclePredictor
     device_ops._confusion, device_ops._sse = _confusion, _sse

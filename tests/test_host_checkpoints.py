@@ -119,3 +119,28 @@ def test_gibbs_step_takes_the_slope_term_out_of_the_prior():
     mcmc.gibbs_step(bnn)
     assert mcmc._slope_term_in_prior is False
     assert mcmc._logPrior == bnn.calc_prior()
+
+
+def test_light_checkpoint_stores_the_generator_where_the_chain_is():
+    """run_steps leaves the draws of the probable next call in flight (one batch ahead, two on the kept dispatch); a light
+    checkpoint taken then must hold the generator at the chain's position, not behind those draws - a run resumed from it makes the
+    draws of the iterations that follow, as the reference's would."""
+    import pickle
+    dat, bnn = small_model()
+    serve_from_oracle(lambda b: OracleChainBackend(b, 0))
+    mcmc = bn.MCMC(bnn, n_iteration=1000, sampling_f=1000, print_f=1000)
+    for _ in range(4):                                   # (the third identical call runs on the kept dispatch: two batches ahead)
+        mcmc.run_steps(bnn, 25)
+        view = mcmc._light_view(bnn)
+        stored = pickle.loads(pickle.dumps(view))._gen.bit_generator.state
+        assert stored == mcmc._rs.bit_generator.state
+    # and the chain goes on as one that was never looked at
+    dat2, bnn2 = small_model()
+    mcmc2 = bn.MCMC(bnn2, n_iteration=1000, sampling_f=1000, print_f=1000)
+    for _ in range(4):
+        mcmc2.run_steps(bnn2, 25)
+    mcmc.run_steps(bnn, 25)
+    mcmc2.run_steps(bnn2, 25)
+    assert mcmc._last_accepted_mem == mcmc2._last_accepted_mem
+    for u, v in zip(bnn._w_layers, bnn2._w_layers):
+        np.testing.assert_array_equal(u, v)

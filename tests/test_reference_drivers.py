@@ -29,12 +29,20 @@ def _scratch(tmp_path, name):
     return d
 
 
-def _run_both(tmp_path, script, threads="2"):
+# bnn_regress.py plots with seaborn, which this image does not have: both runs get a module of that name whose regplot returns the
+# current axes (test infrastructure only - nothing of the script or of either package is touched), and matplotlib's Agg backend
+_SEABORN_STUB = ("import types; _sb = types.ModuleType('seaborn'); "
+                 "_sb.regplot = lambda *a, **k: __import__('matplotlib.pyplot').pyplot.gca(); sys.modules['seaborn'] = _sb; ")
+
+
+def _run_both(tmp_path, script, threads="2", stub_seaborn=False):
     """The script under np_bnn and under npbnn_amd, side by side; returns their scratch directories."""
-    env = dict(os.environ, OMP_NUM_THREADS=threads, OPENBLAS_NUM_THREADS=threads, MKL_NUM_THREADS=threads)
+    env = dict(os.environ, OMP_NUM_THREADS=threads, OPENBLAS_NUM_THREADS=threads, MKL_NUM_THREADS=threads, MPLBACKEND="Agg")
     env.pop("PYTHONPATH", None)
     ref_dir, our_dir = _scratch(tmp_path, "reference"), _scratch(tmp_path, "ours")
     seeded = "import sys, runpy, numpy as np; np.random.seed(%d); " % SEED
+    if stub_seaborn:
+        seeded += _SEABORN_STUB
     ref = subprocess.Popen([sys.executable, "-c", seeded + "sys.path.insert(0, %r); runpy.run_path(%r, run_name='__main__')"
                             % (REF, os.path.join(REF, script))], cwd=str(ref_dir), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     ours = subprocess.Popen([sys.executable, "-c", seeded + "sys.argv = ['run_reference_driver.py', %r]; runpy.run_path(%r, run_name='__main__')"
@@ -75,6 +83,36 @@ def test_bnn_classify_runs_unchanged_and_writes_the_references_files(tmp_path):
 def test_block_bnns_runs_unchanged(tmp_path):
     """block_bnns.py (the layouts of BASELINE.json config 5): get_data in regression mode, three masked models."""
     _run_both(tmp_path, "block_bnns.py")
+
+
+@needs_reference
+def test_bnn_regress_runs_unchanged_and_writes_the_references_files(tmp_path):
+    """bnn_regress.py (BASELINE.json config 4's driver: regression with the empirical error, 20 000 iterations, then every posterior
+    sample through RunPredict): the 200-row log file and the stored posterior samples of both runs."""
+    import pickle
+    ref_dir, our_dir = _run_both(tmp_path, "bnn_regress.py", stub_seaborn=True)
+    stem = "testM_l6_4"
+    log_ref, log_ours = str(ref_dir / (stem + ".log")), str(our_dir / (stem + ".log"))
+    assert open(log_ref).readline() == open(log_ours).readline()
+    a, b = np.loadtxt(log_ref, skiprows=1), np.loadtxt(log_ours, skiprows=1)
+    assert a.shape == b.shape == (200, 18)
+    np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-12)
+    sys.path.insert(0, REF)
+    try:
+        with open(str(ref_dir / (stem + ".pkl")), "rb") as fh:
+            ref_samples = pickle.load(fh)[2]._post_weight_samples
+    finally:
+        sys.path.remove(REF)
+        for name in [k for k in sys.modules if k == "np_bnn" or k.startswith("np_bnn.")]:
+            del sys.modules[name]
+    import npbnn_amd as bn
+    ours = bn.load_obj(str(our_dir / (stem + ".pkl")))[2]._post_weight_samples
+    assert len(ours) == len(ref_samples) == 100
+    for so, sr in zip(ours, ref_samples):
+        assert so["mcmc_it"] == sr["mcmc_it"]
+        for wo, wr in zip(so["weights"], sr["weights"]):
+            np.testing.assert_allclose(wo, wr, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(np.ones(2) * so["error_prm"], np.ones(2) * sr["error_prm"], rtol=1e-10)
 
 
 @needs_reference

@@ -200,13 +200,22 @@ def main():
     advance(args.steps)
     sync()
     el = time.perf_counter() - t0
+    per_rank = None
     if comm is not None:
-        el = float(np.max(comm.allgather_f64(np.array([el]))))          # the slowest rank's clock
+        # the slowest rank's clock prices the job; every rank's own clock, rate and acceptance go into the line beside it, so that
+        # the first run on real multi-GPU hardware can be read rank by rank
+        mine = np.array([el, float(mcmc._device_accepted) / max(1, mcmc._device_iterations), float(mcmc._device_schedule_used)])
+        all_ranks = comm.allgather_f64(mine)
+        el = float(np.max(all_ranks[:, 0]))
+        per_rank = [{"rank": r, "seconds": float(all_ranks[r, 0]), "value": args.steps * ITERATIONS_PER_STEP / float(all_ranks[r, 0]),
+                     "accept_rate": float(all_ranks[r, 1]), "schedule": int(all_ranks[r, 2])} for r in range(all_ranks.shape[0])]
 
     line = None
     if rank == 0:
         its = args.steps * ITERATIONS_PER_STEP
         line = report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, device_swaps)
+        if per_rank is not None:
+            line["per_rank"] = per_rank
     if world > 1 and not os.environ.get("NPBNN_BENCH_NO_ROW_SHARD"):
         # after the timed region: the other way several GPUs serve this path - ONE chain, its rows split over the ranks.  Nothing in
         # here may cost the headline line: every failure is caught and reported inside it, on every rank
@@ -332,7 +341,8 @@ def make_comm(dist_backend, rank, world, local_rank, device_index):
         return SocketComm(rank=rank, world_size=world), "tcp sockets through rank 0 (rehearsal; no RCCL), %d ranks" % world
     import torch
     import torch.distributed as dist
-    from npbnn_amd.comm import TorchDistComm
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from torch_dist_comm import TorchDistComm
     if dist_backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -367,6 +377,35 @@ def profiled_kernel_ms(config, cand):
     return None, "no profiles/*_cfg%d_pass%d_kernel_stats.csv" % (config, cand)
 
 
+def served_from(config, cand):
+    """Where the pass kernel's bytes come from, from the newest profiles/r*_dram_vs_mall.csv: the same columns and
+    network timed at row counts below and above what the 256-MiB Infinity Cache holds (tools/dram_vs_mall.py).  No counter rocprofv3
+    exposes here separates the two - TCC_EA0_RDREQ_DRAM counts every request that leaves the L2 - so the clock is asked instead."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dram_vs_mall.csv")), reverse=True)
+    cols = {2: "256", 0: "256", 4: "64"}.get(config)
+    if not files or cols is None:
+        return None
+    rows = []
+    with open(files[0], newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r["columns"] == cols and int(r["candidates"]) == (1 if cand == 1 else 3):
+                rows.append(r)
+    if not rows:
+        return None
+    fits = [r for r in rows if r["fits_infinity_cache"] == "yes" and float(r["MB_of_X"]) >= 100.0]
+    beyond = [r for r in rows if r["fits_infinity_cache"] == "no"]
+    out = {"source": os.path.relpath(files[0], ROOT), "candidates": 1 if cand == 1 else 3,
+           "us_per_100MB_by_MB_of_X": {r["MB_of_X"]: float(r["us_per_100MB"]) for r in rows},
+           "TBps_beyond_the_infinity_cache": max(float(r["TB_per_s"]) for r in beyond) if beyond else None,
+           "infinity_cache_lds_dma_TBps_measured": 10.4, "infinity_cache_source": "profiles/r05_microbench_ingest.txt (16 waves per CU, 96 MB region)"}
+    if fits and beyond:
+        a, b = float(fits[0]["us_per_100MB"]), min(float(r["us_per_100MB"]) for r in beyond)
+        out["verdict"] = ("X of this configuration fits the Infinity Cache, so its bytes may be served from there (FETCH_SIZE counts those reads too); "
+                          "the same kernel takes %.1f us per 100 MB on it and %.1f us per 100 MB on matrices 2-8 x larger, which HBM must serve: "
+                          "it is not bound by where the bytes come from, and the HBM peak is the roof that applies in either case" % (a, b))
+    return out
+
+
 def kernel_roofline(config, wl, ctx, bnn, mcmc, useful=None):
     """The dominant kernel of a chain - the pass kernel: one launch streams X once and evaluates ``cand`` proposals against it -
     timed live with HIP events on the chain's stream (npbnn_time_pass), priced with the HBM bytes the PMC passes under profiles/
@@ -396,6 +435,9 @@ def kernel_roofline(config, wl, ctx, bnn, mcmc, useful=None):
                                       "x_hbm_peak": alg * cand / (ms_kernel * 1e-3) / HBM_PEAK},
            "single_candidate_kernel_ms": ms_single,
            "single_candidate_frac": alg / (ms_single * 1e-3) / HBM_PEAK}
+    sf = served_from(config, cand)
+    if sf is not None:
+        out["served_from"] = sf
     if useful is not None:
         out["useful_iterations_per_launch"] = useful
     if l0 == "f16-split":        # the same launches with layer 0 on float32 matrix cores (bit-exact float32 products)
@@ -410,6 +452,20 @@ def kernel_roofline(config, wl, ctx, bnn, mcmc, useful=None):
             ctx.set_l0_precision("auto")
             ctx.time_eval(bnn._w_layers, iters=1)      # (back on the default layout before the chain goes on)
     return out, cand
+
+
+def _moving_summary(mv, wl, roof, bytes_per_proposal=None):
+    if not mv:
+        return None
+    bpp = wl.bytes_per_proposal if wl is not None else bytes_per_proposal
+    out = {"value": mv["value"], "unit": "iterations/s", "one_call_of_4000": mv.get("one_call_of_4000"), "accept_rate": mv.get("accept_rate"),
+           "iterations_per_pass": mv.get("iterations_per_pass"), "schedule": mv.get("schedule")}
+    if bpp and roof:
+        kernel_ms = roof.get("kernel_ms")
+        out["roofline"] = {"bound": "hbm", "kernel": roof.get("kernel"), "kernel_ms": kernel_ms, "frac": roof.get("frac"),
+                           "one_read_per_iteration_it_per_s": HBM_PEAK / bpp,
+                           "value_over_one_read_per_iteration": mv["value"] / (HBM_PEAK / bpp)}
+    return out
 
 
 def _drop_the_last_leg():
@@ -498,7 +554,7 @@ def other_config(args, config):
     t0 = time.perf_counter()
     mcmc.run_steps(bnn, 4000)          # (before the parity check: the oracle's BLAS threads keep the host cores busy for a while after it,
     one_call = 4000 / (time.perf_counter() - t0)      #  and config 5's proposals cost the one pre-draw thread 10 us per iteration)
-    out = {"workload": wl.description, "value": args.steps * ITERATIONS_PER_STEP / el, "unit": "iterations/s",
+    out = {"workload": wl.description, "bytes_per_proposal": wl.bytes_per_proposal, "value": args.steps * ITERATIONS_PER_STEP / el, "unit": "iterations/s",
            "ms_per_step": 1e3 * el / args.steps, "roofline_it_per_s_one_read_per_proposal": HBM_PEAK / wl.bytes_per_proposal,
            "accept_rate": acc_rate, "iterations_per_pass": done / passes,
            "schedule": int(mcmc._device_schedule_used), "candidates_per_pass": cand, "layer0": mcmc._backend.ctx.l0_mode(),
@@ -509,6 +565,114 @@ def other_config(args, config):
     mv = moving_chain(wl)
     if mv is not None:
         out["moving_chain"] = mv
+    return out
+
+
+MFMA_F16_PEAK = 2.5e15      # dense fp16 matrix-core peak of an MI355X (MI355X_MICROARCH.md); the fp16-split path spends 3 products per term
+MFMA_F32_PEAK = 157.3e12
+
+
+def wide_config(args):
+    """The weight-streamed path (networks the LDS cannot hold): the chain the way the headline is timed, and the first layer's
+    product - a real contraction - against the matrix cores' roofline."""
+    from bench_support import workload
+    _drop_the_last_leg()
+    wl = workload(9)
+    bnn, mcmc = wl.build()
+    ctx = mcmc._backend.ctx
+    ms0, ms_pass, geo = ctx.time_wide(bnn._w_layers, iters=100)          # (also the spin-up)
+    ms0, ms_pass, geo = ctx.time_wide(bnn._w_layers, iters=200)
+    for _ in range(args.warmup):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    el = time.perf_counter() - t0
+    f16 = ctx.l0_mode() == "f16-split"
+    products = 3 if f16 else 1
+    peak = MFMA_F16_PEAK if f16 else MFMA_F32_PEAK
+    achieved = products * wl.flops_layer0 / (ms0 * 1e-3)
+    recorded = recorded_wide_counters()
+    out = {"workload": wl.description, "path": "weight-streamed" if ctx.is_wide() else "resident", "layer0": ctx.l0_mode(),
+           "value": args.steps * ITERATIONS_PER_STEP / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / args.steps,
+           "value_note": "the reference's default proposal perturbs 5 %% of every layer: %d of this network's %d weights per iteration - the "
+                         "chain is paced by the host's numpy-identical pre-draw of those entries and by the step's walk over them, not by "
+                         "the pass (pass_us)" % (int(sum(mcmc._update_n)), int(bnn._n_params)),
+           "pass_us": 1e3 * ms_pass, "layer0_product_us": 1e3 * ms0, "layer0_block": geo,
+           "roofline": {"bound": "mfma", "kernel": "wide_gemm_kernel<8,4,2,4,%s> (+ wide_reduce_kernel)" % ("fp16-split" if f16 else "f32"),
+                        "kernel_ms": ms0, "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                        "algorithmic_TFLOPs": wl.flops_layer0 / (ms0 * 1e-3) / 1e12,
+                        "note": "achieved = matrix-core flops of the first layer's product (2 N F H0, x 3 on the fp16-split path: "
+                                "wh.xh + wl.xh + wh.xl) / its duration (HIP events around back-to-back launches, npbnn_time_wide); peak = dense "
+                                "fp16 matrix-core rate.  The same kernel against HBM: hbm_frac (one read of X)",
+                        "hbm_frac": wl.bytes_per_proposal / (ms0 * 1e-3) / HBM_PEAK,
+                        "traffic": recorded.get("traffic"), "mfma_busy": recorded.get("mfma_busy"), "recorded_from": recorded.get("source")},
+           "accept_rate": float(mcmc._device_accepted) / max(1, mcmc._device_iterations),
+           "schedule": int(mcmc._device_schedule_used), "parity": wl.parity(bnn, mcmc)}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, budget_s=5.0)
+    mcmc._backend.close()
+    return out
+
+
+def recorded_wide_counters():
+    """What the rocprofv3 --pmc passes under profiles/ recorded for the first layer's product of the wide leg (a RECORDED measurement of
+    the round the file name carries): HBM bytes per launch and the share of its cycles the matrix cores were busy."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wide_layer0_counters.json")), reverse=True)
+    for path in files:
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            d["source"] = os.path.relpath(path, ROOT)
+            return d
+        except Exception:       # noqa: BLE001
+            continue
+    return {}
+
+
+def group_pass_leg():
+    """Three chains of config 2's model on ONE GPU sharing their passes over the data (group passes, npbnn_chains_run_batched: one
+    proposal per chain per streaming read of X), at the default proposal size and at one a quarter of whose
+    proposals is accepted; aggregate iterations/s over the three chains, beside one such chain alone."""
+    import numpy as np
+    import npbnn_amd as bn
+    from npbnn_amd import exchange as ex
+    from bench_support import _quiet
+    _drop_the_last_leg()
+    rs = np.random.default_rng(0)
+    n, f, c = 100_000, 256, 10
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    proj = rs.standard_normal((f, c)) / np.sqrt(f)
+    y = np.argmax(x @ proj + 0.5 * rs.standard_normal((n, c)), axis=1)          # learnable labels: the proposal size sets the rate
+    dat = dict(data=x, labels=y, test_data=np.zeros((0, f)), test_labels=np.zeros(0))
+    out = {"workload": "config-2 shapes (100k x 256, [32,8], tanh), learnable labels; chains of one model sharing the resident matrix",
+           "note": "20 rounds of %d iterations per chain after 1500 of warm-up; value = aggregate over the chains" % ITERATIONS_PER_STEP}
+    for uf in (0.05, 0.002):
+        row = {}
+        for n_chains in (1, 3):
+            chains = []
+            for i in range(n_chains):
+                np.random.seed(1234 + i)
+                bnn = _quiet(bn.npBNN, dat, n_nodes=[32, 8], actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+                chains.append((bnn, bn.MCMC(bnn, update_f=[uf] * 3, mcmc_id=i, randomize_seed=True)))
+            for bnn, m in chains:
+                m.run_steps(bnn, 1500)
+            for rep in range(2):
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    if n_chains == 1:
+                        chains[0][1].run_steps(chains[0][0], ITERATIONS_PER_STEP)
+                    else:
+                        ex.run_steps_batched(chains, ITERATIONS_PER_STEP)
+                el = time.perf_counter() - t0
+            row["one chain" if n_chains == 1 else "group pass of 3"] = {
+                "value": n_chains * 20 * ITERATIONS_PER_STEP / el, "unit": "iterations/s (aggregate)",
+                "accept_rate": float(np.mean([m._acceptance_rate for _, m in chains]))}
+            for bnn, m in chains:
+                m._backend.close()
+            del chains
+            _drop_the_last_leg()
+        out["update_f %.3f" % uf] = row
     return out
 
 
@@ -623,6 +787,25 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                     line["other_configs"][name] = other_config(args, cfg)
                 except Exception as e:        # noqa: BLE001 - the headline must not be lost to a side measurement
                     line["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            for name, leg in (("wide", lambda: wide_config(args)), ("group_pass", group_pass_leg)):
+                try:
+                    line["other_configs"][name] = leg()
+                except Exception as e:        # noqa: BLE001
+                    line["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # the chains that move, side by side at the top of the line: about a quarter of the proposals accepted
+            # - the regime the reference's drivers adapt to (bnn_classify.py:61-69, bnn_regress.py:44-51)
+            c4 = line["other_configs"].get("config 4") or {}
+            mv4 = c4.get("moving_chain")
+            if mv4 is None and "value" in c4:       # (config 4's chain moves by itself: its default proposals are accepted 4 times in 10)
+                mv4 = {"value": c4["value"], "one_call_of_4000": c4.get("one_call_of_4000"), "accept_rate": c4.get("accept_rate"),
+                       "iterations_per_pass": c4.get("iterations_per_pass"), "schedule": c4.get("schedule")}
+            roof4 = (line["other_configs"].get("config 4") or {}).get("roofline") or {}
+            line["moving_chains"] = {
+                "config 2": _moving_summary(line.get("moving_chain"), wl, roof),
+                "config 4": _moving_summary(mv4, None, roof4, bytes_per_proposal=(line["other_configs"].get("config 4") or {}).get("bytes_per_proposal")),
+                "note": "value: 20 dispatches of %d iterations; roofline: the pass kernel these chains run (same launch as the headline's: "
+                        "its candidates share one read of X) and what a DECIDED iteration costs in HBM time - bytes of one read of X over "
+                        "the iterations a pass decides on average" % ITERATIONS_PER_STEP}
     else:
         line["cpu_baseline"] = None
     return line

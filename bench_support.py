@@ -196,8 +196,46 @@ class DefaultNetwork(Config2):
                     chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)), tolerance="1e-4 relative (BASELINE.json)")
 
 
+class WideNetwork(Workload):
+    """A network the LDS of a compute unit cannot hold (the weight-streamed path, npbnn_amd/csrc/npbnn_wide.hip.h): 20 000 x 4 096
+    features, hidden [256, 64], 10 classes, tanh, bias 2 - layer 0 is a real contraction (42 GF per proposal against 328 MB of X)."""
+    config = 9
+    n, f, c, hidden = 20_000, 4096, 10, [256, 64]
+    short = "wide network (20k x 4096, [256,64])"
+    description = "weight-streamed path: 20k x 4096 features, 10 classes, hidden [256,64], tanh, bias 2"
+
+    def __init__(self):
+        rs = np.random.default_rng(0)
+        self.x = rs.standard_normal((self.n, self.f)).astype(np.float32)
+        self.y = rs.integers(0, self.c, self.n)
+        self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n
+        self.flops_layer0 = 2.0 * self.n * self.f * self.hidden[0]
+        self.flops = self.flops_layer0 + 2.0 * self.n * (self.hidden[0] * self.hidden[1] + self.hidden[1] * self.c)
+
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
+        dat = dict(data=self.x, labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
+        np.random.seed(1234)
+        bnn = _quiet(bn.npBNN, dat, n_nodes=self.hidden, actFun=bn.ActFun(fun="tanh"), use_bias_node=2, prior_f=1, p_scale=1)
+        return bnn, bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **sampler_kw)
+
+    def oracle_chain(self, orc):
+        np.random.seed(1234)
+        return orc.make_chain(self.x.astype(np.float64), self.y, self.hidden, act=orc.Act("tanh"), use_bias_node=2, prior_kind=1, p_scale=1)
+
+    def parity(self, bnn, mcmc):
+        import oracle as orc
+        w = [np.array(v, dtype=np.float64) for v in bnn._w_layers]
+        pred = orc.forward(self.x.astype(np.float64), w, orc.Act("tanh"), orc.out_softmax)
+        ll = orc.lik_categorical(pred, self.y, np.arange(self.n))
+        dev = mcmc._backend.evaluate(bnn._w_layers, None)["loglik"]
+        dev_pred = mcmc._backend.predict(bnn._w_layers)
+        return dict(loglik_oracle=float(ll), loglik_device=float(dev), loglik_rel_err=float(abs(dev - ll) / abs(ll)),
+                    chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)), pred_max_abs_err=float(np.max(np.abs(dev_pred - pred))),
+                    tolerance="1e-4 relative (BASELINE.json)")
+
+
 def workload(config):
-    return {2: Config2, 4: Config4, 5: Config5, 0: DefaultNetwork}[config]()
+    return {2: Config2, 4: Config4, 5: Config5, 0: DefaultNetwork, 9: WideNetwork}[config]()
 
 
 def build_config2(x, y, hidden, mcmc_id=0, temperature=1.0, randomize_seed=False):

@@ -478,6 +478,13 @@ int npbnn_chains_run_batched(npbnn_chain_job* jobs, int32_t n_jobs, int32_t K);
  * `iters` back-to-back launches between one pair of HIP events on the ctx stream; mean milliseconds per launch */
 int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, int iters, double* ms_kernel, int* used_candidates);
 
+/* timing hook for the weight-streamed path (NPBNN_INFO_WIDE): `iters` back-to-back passes between one pair of HIP events - ms_pass:
+ * all of a pass's launches (the layers' products, the likelihood kernel); ms_layer0: the first layer's product alone (with the
+ * reduction of its K-slices, when it is cut into any) - the contraction over the feature matrix, the kernel the matrix cores'
+ * roofline is quoted for.  info[0..3]: rows x outputs of a workgroup's block of that product, its K-slices, its workgroups.
+ * NPBNN_E_STATE when the architecture set last runs on the LDS-resident path. */
+int npbnn_time_wide(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_layer0, double* ms_pass, int* info);
+
 /* page-locked host memory for the per-batch inputs of npbnn_chain_run (idx / delta / cnt / log_u): arrays drawn straight into
  * such memory are uploaded asynchronously at link speed instead of through the driver's bounce buffer.  (The reference has no
  * counterpart: its draws never leave the host, np_bnn/BNN_mcmc.py:57-69.) */

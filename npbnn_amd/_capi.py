@@ -132,6 +132,7 @@ SIGNATURES = {
     "npbnn_predict_sets": (C.c_int, [_P, _DP, _DP, C.c_int32, C.c_int, C.c_int, _DP]),
     "npbnn_time_eval": (C.c_int, [_P, _DP, C.c_int, _DP, _DP]),
     "npbnn_time_pass": (C.c_int, [_P, _DP, C.c_int, C.c_int, _DP, C.POINTER(C.c_int)]),
+    "npbnn_time_wide": (C.c_int, [_P, _DP, C.c_int, _DP, _DP, C.POINTER(C.c_int)]),
     "npbnn_share_data": (C.c_int, [_P, _P]),
     "npbnn_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "npbnn_pinned_free": (None, [C.c_void_p]),

@@ -283,6 +283,15 @@ class HipContext:
         self._chk(self._lib.npbnn_time_pass(self._ctx, capi.dptr(w), int(n_candidates), int(iters), C.byref(ms), C.byref(used)))
         return ms.value, used.value
 
+    def time_wide(self, weights, iters=20):
+        """Weight-streamed path: mean duration (ms) of the first layer's product alone and of a whole pass, and the product's
+        geometry (rows, outputs of a workgroup's block, K-slices, workgroups)."""
+        w = pack_weights(weights) if isinstance(weights, (list, tuple)) else capi.as_f64(weights)
+        ms0, ms = C.c_double(0), C.c_double(0)
+        info = (C.c_int * 4)()
+        self._chk(self._lib.npbnn_time_wide(self._ctx, capi.dptr(w), int(iters), C.byref(ms0), C.byref(ms), info))
+        return ms0.value, ms.value, dict(block_rows=info[0], block_outputs=info[1], k_slices=info[2], workgroups=info[3])
+
     def _fill_chain_cfg(self, cfg, prior_kind, prior_scale, w_bound, temperature, lik_temp, cur_loglik, cur_logprior,
                         cur_sigma=None, sigma=None, n_candidates=0, schedule=0, sigma_mult=None, hastings=None, slopes=None,
                         fixed_slopes=None):

@@ -1403,6 +1403,44 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     return NPBNN_OK;
 }
 
+int npbnn_time_wide(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_layer0, double* ms_pass, int* info) {
+    if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
+    if (iters < 1 || !ms_layer0 || !ms_pass || !W_packed) return fail(ctx, NPBNN_E_ARG, "time_wide: bad arguments");
+    if (!ctx->arch_set) return fail(ctx, NPBNN_E_STATE, "time_wide: call npbnn_set_arch first");
+    Dataset& d = ctx->ds[0];
+    int rc = check_dataset_for_lik(ctx, d, ctx->net.lik_kind);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchPlan lp;
+    rc = plan_launch(ctx, 0, &lp, 0, 1, false, true);
+    if (rc) return rc;
+    if (!lp.wide) return fail(ctx, NPBNN_E_STATE, "time_wide: this network runs on the LDS-resident path");
+    rc = ensure_work_buffers(ctx, lp.n_waves);
+    if (rc) return rc;
+    rc = stage_weights(ctx, W_packed, nullptr, nullptr);
+    if (rc) return rc;
+    EvalParams p = make_params(ctx, d);
+    p.partials = ctx->d_partials;
+    p.inst_w = d.inst_w;
+    p.use_classw = ctx->n_classw > 0 ? 1 : 0;
+    rc = push_eval_params(ctx, p);
+    if (rc) return rc;
+    int geo[4] = {0, 0, 0, 0};
+    for (int only0 = 1; only0 >= 0; --only0) {
+        for (int i = 0; i < 3 && !rc; ++i) rc = wide_forward(ctx, 0, ctx->d_image, false, only0 != 0, geo);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        for (int i = 0; i < iters && !rc; ++i) rc = wide_forward(ctx, 0, ctx->d_image, false, only0 != 0, nullptr);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (rc) return rc;
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        *(only0 ? ms_layer0 : ms_pass) = (double)ms / iters;
+    }
+    if (info) for (int i = 0; i < 4; ++i) info[i] = geo[i];
+    return NPBNN_OK;
+}
+
 int npbnn_time_eval(npbnn_ctx* ctx, const double* W_packed, int iters, double* ms_main_kernel, double* ms_total) {
     if (!ctx) return fail(nullptr, NPBNN_E_ARG, "null ctx");
     if (iters < 1 || !ms_main_kernel || !ms_total) return fail(ctx, NPBNN_E_ARG, "time_eval: bad arguments");

@@ -277,7 +277,8 @@ int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp);
 void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, float* image, int* flags);
 // the forward pass + likelihood of the weights in `image` on the ctx stream; the launch's EvalParams must be in ctx->d_eparams.
 // chain_pass: a pass of a device chain (the kernels leave at once when the chain's batch is through; candidate slopes from the chain)
-int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass);
+// only_layer0: stop behind the first layer's product (timing hook); info: that product's geometry, or nullptr
+int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0 = false, int* info = nullptr);
 int wide_cand_begin(npbnn_ctx* ctx);     // start of a chain batch: candidate image = committed image, nothing patched
 void wide_cand_sync(npbnn_ctx* ctx, int M);   // before a pass of a chain with wide proposals: candidate image = committed image + the pending proposal
 int ensure_conf(npbnn_ctx* ctx, int n_classes);

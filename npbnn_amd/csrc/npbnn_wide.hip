@@ -245,7 +245,7 @@ void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, 
                        ctx->n_classw ? ctx->d_classw : nullptr, image, ctx->wmeta, ctx->wmeta.L[0].f16 ? ctx->d_wscale : nullptr, flags);
 }
 
-int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass) {
+int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0, int* info) {
     Dataset& d = ctx->ds[which];
     const WideMeta& m = ctx->wmeta;
     hipStream_t st = ctx->stream;
@@ -353,6 +353,8 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass)
         }
         A = layer_out;
         lda = g.ldo;
+        if (l == 0 && info) { info[0] = 16 * cf.xt; info[1] = 16 * cf.wt; info[2] = n_sl; info[3] = n_rb * n_cb * n_sl; }
+        if (l == 0 && only_layer0) return NPBNN_OK;
     }
     WideLikArgs la{};
     la.p = ctx->d_eparams;

@@ -145,7 +145,7 @@ class _FastDispatch:
     outcome.  Any difference - another ``k``, an attribute set from outside, new step-size or weight arrays, an adaptation
     boundary ahead, an error code from the library - sends the call down :meth:`MCMC.run_steps`'s general path, which builds a
     new one when it applies.  The general path and this one leave the sampler in the same state, draws made ahead included."""
-    __slots__ = ("k", "objects", "scalars", "n_bytes", "freq_bytes", "scale_bytes", "ws_src", "ws_copies", "plan", "key_tail", "batch",
+    __slots__ = ("missed_on_boundary", "k", "objects", "scalars", "n_bytes", "freq_bytes", "scale_bytes", "ws_src", "ws_copies", "plan", "key_tail", "batch",
                  "layers", "regression", "fixed_sigma", "n_out", "adapt_possible", "empty", "empty_group", "fixed_slopes")
 
     @staticmethod

@@ -117,7 +117,7 @@ def _worker(rank, world, port, tmpdir, q):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from npbnn_amd.comm import TorchDistComm
+        from torch_dist_comm import TorchDistComm
         out = {}
         for name, device in (("host", False), ("dev", True)):
             comm = TorchDistComm()

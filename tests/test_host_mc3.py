@@ -81,7 +81,7 @@ def _worker(rank, world, port, tmpdir, golden_dir, q):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from npbnn_amd.comm import TorchDistComm
+        from torch_dist_comm import TorchDistComm
         comm = TorchDistComm()
         g = np.load(os.path.join(golden_dir, "mc3.npz"))
         mc3, logger = build_mc3(tmpdir, comm)

@@ -1,2 +1,4 @@
-export NPBNN_CHAIN=0
-for cfg in 0 5; do for sl in 1 2 3 4; do echo "== cfg $cfg slices $sl"; NPBNN_WIDE_NO_TAIL=1 NPBNN_WIDE_CFG=$cfg NPBNN_WIDE_SLICES=$sl timeout -k 10 100 python tools/time_wide.py 20000,4096,256-64,10 2>&1 | grep pass; done; done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 60 rocprofv3 -L 2>/dev/null | grep -i "mall\|dram\|EA0_RDREQ\|TCC_EA\|HBM\|_MISS\b" | head -40 > gpurun_out/counters_list.txt
+timeout -k 10 500 python tools/dram_vs_mall.py > gpurun_out/dram_vs_mall.csv 2> gpurun_out/dram_vs_mall.err
+cat gpurun_out/dram_vs_mall.csv; tail -3 gpurun_out/dram_vs_mall.err; cat gpurun_out/counters_list.txt | cut -c1-200

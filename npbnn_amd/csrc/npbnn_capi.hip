@@ -144,7 +144,7 @@ int build_net(npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     // Networks the LDS of a compute unit cannot hold (or a layer wider than the resident builds' tiles) run on the weight-streamed
     // path (npbnn_wide.hip): the description below then carries what the chain step and the likelihood need - shapes, offsets into
     // the packed weights, kinds - and none of the resident image's layout.
-    ctx->wide = wide_needed(ctx, a);
+    ctx->wide = wide_needed(ctx, a, f16);
     if (ctx->wide) {
         net.pad_masked = 0;
         net.l1_f16 = 0;
@@ -454,6 +454,11 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
             lds = (size_t)n_cand * ctx->net.image_floats * 4 + (size_t)wpb * lay.wave_lds;
         }
     }
+    // (the tile schedule of eval_kernel needs a wave on every SIMD of the compute unit: networks that leave fewer run on the
+    // weight-streamed path - wide_needed - and a data set whose row-aux slots push a launch below that is refused rather than mis-summed)
+    if (wpb < 4)
+        return fail(ctx, NPBNN_E_ARG, "network too large for the LDS-resident path on this data set (%d waves beside a weight image of %d KiB); "
+                                      "NPBNN_OPT_WIDE = 1 runs it on the weight-streamed path", wpb, ctx->net.image_floats * 4 / 1024);
     lp->wpb = wpb;
     lp->lds = lds;
     int grid = (d.n_tiles + wpb - 1) / wpb;

@@ -243,6 +243,7 @@ constexpr int kTurnForcedProbeBatches = 200;    // ... or whatever the model say
 constexpr int kTurnFirstProbeBatches = 4;       // batches on one persistent form before the other, never measured, is given one
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
+constexpr int kMinResidentWaves = 4;           // fewer waves than this beside the weight image: the network runs on the weight-streamed path
 constexpr int kWideStepPatchMax = 2048;      // widest proposal whose candidate image the step workgroup keeps by itself (weight-streamed path)
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
 
@@ -270,7 +271,7 @@ struct LaunchPlan {
 };
 
 // ---- weight-streamed path (npbnn_wide.hip) ----
-bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a);
+bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16);
 int wide_build(npbnn_ctx* ctx, bool f16);
 void wide_free(npbnn_ctx* ctx);
 int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp);

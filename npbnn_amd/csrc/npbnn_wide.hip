@@ -67,8 +67,19 @@ size_t resident_lds_bytes(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16, i
         if (l == 0) {
             const int units = f16 ? (in + 31) / 32 : (in + 15) / 16;
             int rows = 16;
-            if (f16 && mt >= 3 && out % 16 != 0) rows = (out + mt - 1) / mt;
-            off += (long long)mt * units * (f16 ? 32 * rows : 256);
+            if (f16 && ctx->l0_blocks.empty() && mt >= 3 && out % 16 != 0) rows = (out + mt - 1) / mt;
+            long long slots = (long long)mt * units;
+            if (!ctx->l0_blocks.empty()) {       // block-structured first layer (npbnn_set_layer_mask): per output tile the hull of its K-units
+                const int g16 = (in + 15) / 16, per_unit = f16 ? 2 : 1;
+                slots = 0;
+                for (int t = 0; t < mt; ++t) {
+                    int b = units, e = 0;
+                    for (int g = 0; g < g16; ++g)
+                        if (ctx->l0_blocks[(size_t)t * g16 + g]) { const int u = g / per_unit; if (u < b) b = u; if (u + 1 > e) e = u + 1; }
+                    if (e > b) slots += e - b;
+                }
+            }
+            off += slots * (f16 ? 32 * rows : 256);
         } else if (l == 1 && l1_f16) {
             off += ((a->out_dim[0] + 15) / 16 + 1) / 2 * 512;
         } else {
@@ -86,17 +97,23 @@ size_t resident_lds_bytes(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16, i
 
 }  // namespace
 
-// Does this network run on the weight-streamed path?  A layer the resident builds have no tiles for, or an image that leaves the
-// resident kernel fewer than kMinResidentWaves waves per compute unit on either layer-0 layout (below that the resident kernel no
-// longer hides the latency of its own stream; NPBNN_WIDE_MIN_WAVES: A/B switch).
-bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a) {
+// Does this network run on the weight-streamed path on this layer-0 layout?  A layer the resident builds have no tiles for, or an
+// image that leaves the resident kernel fewer than kMinResidentWaves waves per compute unit (measured, tools/time_wide.py on
+// 100k rows: wherever the resident kernel keeps a handful of waves it beats the streamed path - one launch per pass, several
+// candidates per read of X, the persistent schedules - e.g. [32, 8] on 1024 features, 7 waves: 10.2 k against 6.6 k it/s;
+// NPBNN_WIDE_MIN_WAVES: A/B switch).  Asked per layout: the float32 image of a first layer is larger than its fp16-split one
+// (no compact rows), so a network may run resident on the fp16-split path and streamed on the float32 fallback.
+bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     if (ctx->wide_option == 1) return true;
     if (const char* e = getenv("NPBNN_FORCE_WIDE")) { if (atoi(e) != 0) return true; }
     for (int l = 0; l < a->n_layers; ++l)
         if (a->out_dim[l] > kResidentMaxWidth) return true;
-    static const int min_waves = getenv("NPBNN_WIDE_MIN_WAVES") ? atoi(getenv("NPBNN_WIDE_MIN_WAVES")) : 8;
-    const int w = min_waves < 1 ? 1 : min_waves;
-    return resident_lds_bytes(ctx, a, true, w) > ctx->lds_limit || resident_lds_bytes(ctx, a, false, w) > ctx->lds_limit;
+    static const int min_waves = getenv("NPBNN_WIDE_MIN_WAVES") ? atoi(getenv("NPBNN_WIDE_MIN_WAVES")) : kMinResidentWaves;
+    // (never fewer than four: the resident kernel deals a workgroup's tiles to the four SIMDs of its compute unit and, there, to the
+    // waves of that SIMD - with fewer than four waves the tiles of the SIMDs without one are never computed.  Until this round such
+    // launches were planned whenever the image left room for 1-3 waves: sums over 1/4 to 3/4 of the rows, silently)
+    const int w = min_waves < 4 ? 4 : min_waves;
+    return resident_lds_bytes(ctx, a, f16, w) > ctx->lds_limit;
 }
 
 void wide_free(npbnn_ctx* ctx) {

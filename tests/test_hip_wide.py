@@ -182,6 +182,33 @@ def test_shapes_the_lds_cannot_hold_against_the_oracle(name, precision):
     ctx.close()
 
 
+@pytest.mark.parametrize("f", [608, 672, 704, 736, 800])
+def test_either_side_of_the_switch_between_the_paths(f):
+    """The reference's default [50, 5] on 600-800 features: the weight image takes 127-166 KB of a compute unit's 160 KB of LDS.  While
+    four waves fit beside it the resident kernel runs (a wave per SIMD - its tile schedule needs that many; until round 5 such
+    networks were planned with one to three waves and summed a quarter to three quarters of the rows); from there on the
+    weight-streamed path.  Either way the log-likelihood is the oracle's."""
+    n, c = 30_000, 10
+    x, lab, w = _classification_problem(5, n, f, c, [50, 5], bias=1)
+    act = orc.Act("ReLU")
+    ctx = make_ctx(x, w, act, 0, 0, labels=lab, wide=False)
+    r = ctx.eval(w, want_confusion=True)
+    assert ctx.l0_mode() == "f16-split"
+    assert ctx.is_wide() == (f > 672), "F = %d: weight-streamed %s" % (f, ctx.is_wide())
+    if not ctx.is_wide():
+        assert ctx.info(capi.INFO_WAVES_PER_BLOCK) >= 4
+    x64 = x.astype(np.float64)
+    y64 = orc.forward(x64, w, act, orc.out_softmax)
+    want = orc.lik_categorical(y64, lab, np.arange(n))
+    assert abs(r["loglik"] - want) / abs(want) < LL_RTOL
+    check_confusion(r["confusion"], y64, lab)
+    ctx.set_l0_precision("f32")            # the float32 image of this layer keeps its padding rows: the switch comes earlier
+    r32 = ctx.eval(w)
+    assert abs(r32["loglik"] - want) / abs(want) < LL_RTOL
+    assert ctx.is_wide()                   # (64 rows x 600 features and more: past the LDS on that layout)
+    ctx.close()
+
+
 def test_wide_regression_with_a_test_set_and_column_override():
     rs = np.random.default_rng(5)
     n, f, k = 3000, 1500, 3

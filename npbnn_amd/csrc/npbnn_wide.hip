@@ -18,15 +18,16 @@ struct GemmCfg {
     int xt, wt;            // row tiles / output tiles of a workgroup
     int threads, ppw;      // LDS-DMA pieces a wave requests per K-unit
     int n_stage;           // stages of the ring
+    int wc;                // waves along the outputs (1: every wave holds whole rows of the block - the fused end applies)
     bool attr16 = false, attr32 = false;
 };
 GemmCfg g_cfg[6] = {
-    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, 16, 16, 512, 8, 2},    // 256 x 256: 64 KiB per stage
-    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, 16, 8, 512, 6, 3},     // 256 x 128: 48 KiB
-    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, 16, 4, 512, 5, 3},     // 256 x 64 : 40 KiB
-    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 3},      // 128 x 64 : 24 KiB
-    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 3},      // 128 x 32 : 20 KiB
-    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, 16, 16, 1024, 4, 2},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
+    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, 16, 16, 512, 8, 2, 4},    // 256 x 256: 64 KiB per stage
+    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
+    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
+    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
+    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
 };
 // the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)
 GemmCfg& cfg_for(int mt, int n_row_tiles, int n_cu) {
@@ -48,6 +49,57 @@ int slices_for(const GemmCfg& cf, int n_row_tiles, int mt, int units, int n_cu) 
     if (n_sl > units) n_sl = units;
     if (n_sl < 1) n_sl = 1;
     return n_sl;
+}
+
+// the narrow layers from layer `l` on as wide_tail_layers takes them, or false when they are not narrow (or too large for `lds_budget` bytes)
+bool tail_desc(const npbnn_ctx* ctx, int l, const float* image, bool dev_slopes, size_t lds_budget, WideTailDesc* t, int* lds_floats) {
+    const WideMeta& m = ctx->wmeta;
+    *t = WideTailDesc{};
+    int off = 0;
+    for (int q = l; q < m.n_layers; ++q) {
+        if (m.L[q].mt > kTailOut) return false;
+        const int i = q - l;
+        t->frag_off[i] = m.L[q].frag_off;
+        t->bias_off[i] = m.L[q].bias_off;
+        t->mt[i] = m.L[q].mt;
+        t->frag_floats[i] = m.L[q].units * 2 * m.L[q].mt * 256;
+        t->lds_frag[i] = off;
+        off += t->frag_floats[i];
+        t->lds_bias[i] = off;
+        off += 16 * m.L[q].mt;
+        t->act_prm[i] = ctx->net.act_prm[q];
+    }
+    if ((size_t)off * 4 > lds_budget) return false;
+    t->n_layers = m.n_layers - l;
+    t->last_is_output = 1;
+    t->act_kind = ctx->net.act_kind;
+    t->image = image;
+    t->act_prm_dev = (dev_slopes && t->n_layers > 0) ? &ctx->d_slopes->cand[0][0][l] : nullptr;
+    *lds_floats = off;
+    return true;
+}
+
+// Does the first layer's product take the rest of the pass along (WideGemmArgs::fuse)?  Its tiling must give every wave whole rows (one
+// output block, WC = 1), the contraction one K-slice, the remaining layers be narrow and fit the LDS beside the rows' scratch.
+bool fused_pass(const npbnn_ctx* ctx, const Dataset& d, int* n_row_blocks, size_t* lds_need) {
+    static const bool off = getenv("NPBNN_WIDE_NO_FUSE") != nullptr || getenv("NPBNN_WIDE_NO_TAIL") != nullptr;
+    if (off) return false;
+    const WideMeta& m = ctx->wmeta;
+    const GemmCfg& cf = cfg_for(m.L[0].mt, d.n_tiles, ctx->n_cu);
+    if (cf.wc != 1 || m.L[0].mt > cf.wt || m.L[0].mt > kTailIn) return false;
+    if (slices_for(cf, d.n_tiles, m.L[0].mt, m.L[0].units, ctx->n_cu) != 1) return false;
+    if (m.n_out > 128) return false;
+    const int lik = ctx->net.lik_kind;          // (the float64 row-wise likelihoods and wide Gaussian targets stay with wide_lik_kernel)
+    if (lik_needs_row_scratch(lik) || (lik == NPBNN_LIK_GAUSS && ctx->net.k_targets > kFuseTargets)) return false;
+    WideTailDesc t;
+    int tail_floats = 0;
+    if (!tail_desc(ctx, 1, nullptr, false, 64 * 1024, &t, &tail_floats)) return false;
+    const int ldz = ((m.n_out + 15) & ~15) + 1;
+    const size_t need = ((size_t)((tail_floats + 3) & ~3) + (size_t)(cf.threads / 64) * 16 * ldz) * 4;
+    if (need > 150 * 1024) return false;
+    *n_row_blocks = (d.n_tiles + cf.xt - 1) / cf.xt;
+    *lds_need = need;
+    return true;
 }
 
 int stages_env() {
@@ -251,7 +303,10 @@ int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp) {
     lp->wide = true;
     int grid = (int)((d.n_rows + 255) / 256);
     if (grid < 1) grid = 1;
-    lp->grid = grid;             // workgroups of wide_lik_kernel: one partial record each
+    int n_rb = 0;
+    size_t fuse_lds = 0;
+    if (fused_pass(ctx, d, &n_rb, &fuse_lds)) grid = n_rb;        // (one partial record per row block of the first layer's product)
+    lp->grid = grid;             // workgroups that write a partial record each (wide_lik_kernel's, or the fused product's row blocks)
     lp->n_waves = grid;
     return NPBNN_OK;
 }
@@ -279,36 +334,13 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
         // the narrow end of the network in one launch (wide_tail_kernel): every remaining layer of <= 128 nodes, behind <= 256 inputs,
         // their weights within 96 KiB of LDS
         if (l >= 1 && !no_tail && lda <= 16 * kTailIn) {
-            bool ok = true;
-            long long lds_floats = 0;
-            for (int q = l; q < m.n_layers; ++q) {
-                ok = ok && m.L[q].mt <= kTailOut;
-                lds_floats += (long long)m.L[q].units * 2 * m.L[q].mt * 256 + 16 * m.L[q].mt;
-            }
-            if (ok && lds_floats * 4 <= 96 * 1024) {
-                WideTailArgs t{};
+            WideTailArgs t{};
+            int tail_floats = 0;
+            if (tail_desc(ctx, l, image, dev_slopes, 96 * 1024, &t.t, &tail_floats)) {
                 t.A = A;
                 t.lda = lda;
                 t.n_row_tiles = d.n_tiles;
-                t.n_layers = m.n_layers - l;
                 t.kt0 = (int)(lda / 16);
-                t.last_is_output = 1;
-                t.image = image;
-                int off = 0;
-                for (int q = l; q < m.n_layers; ++q) {
-                    const int i = q - l;
-                    t.frag_off[i] = m.L[q].frag_off;
-                    t.bias_off[i] = m.L[q].bias_off;
-                    t.mt[i] = m.L[q].mt;
-                    t.frag_floats[i] = m.L[q].units * 2 * m.L[q].mt * 256;
-                    t.lds_frag[i] = off;
-                    off += t.frag_floats[i];
-                    t.lds_bias[i] = off;
-                    off += 16 * m.L[q].mt;
-                    t.act_prm[i] = ctx->net.act_prm[q];
-                }
-                t.act_kind = ctx->net.act_kind;
-                t.act_prm_dev = dev_slopes ? &ctx->d_slopes->cand[0][0][l] : nullptr;
                 t.out = ctx->d_wide_act[l & 1];
                 t.ldo = 16 * m.L[m.n_layers - 1].mt;
                 t.pass = pass;
@@ -318,7 +350,7 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
                 }
                 int grid = (d.n_tiles + 7) / 8;
                 if (grid > 2 * ctx->n_cu) grid = 2 * ctx->n_cu;
-                hipLaunchKernelGGL(wide_tail_kernel, dim3(grid), dim3(512), (size_t)off * 4, st, t);
+                hipLaunchKernelGGL(wide_tail_kernel, dim3(grid), dim3(512), (size_t)tail_floats * 4, st, t);
                 A = t.out;
                 lda = t.ldo;
                 break;
@@ -341,12 +373,26 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
         g.act_prm_dev = (dev_slopes && l + 1 < m.n_layers) ? &ctx->d_slopes->cand[0][0][l] : nullptr;
         g.pass = pass;
         g.a_tiled = (l == 0 && f16) ? 1 : 0;
+        int fuse_rb = 0;
+        size_t fuse_lds = 0;
+        const bool fuse = l == 0 && !only_layer0 && fused_pass(ctx, d, &fuse_rb, &fuse_lds);
+        if (fuse) {
+            int tail_floats = 0;
+            (void)tail_desc(ctx, 1, image, dev_slopes, 64 * 1024, &g.tail, &tail_floats);
+            g.fuse = 1;
+            g.n_row_blocks = fuse_rb;
+            g.p = ctx->d_eparams;
+            g.image = image;
+            g.classw_off = m.classw_off;
+            if (m.n_layers == 1) g.act_kind = -1;
+        }
         int n_stage = stages_env() >= 2 ? stages_env() : cf.n_stage;
         const int stage_bytes = (cf.xt + cf.wt) * 2048;
         while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * cf.ppw > kWideMaxYounger)) --n_stage;
         if (n_stage > L.units + 1) n_stage = L.units + 1 < 2 ? 2 : L.units + 1;
         g.n_stage = n_stage;
-        const size_t lds = (size_t)n_stage * stage_bytes;
+        size_t lds = (size_t)n_stage * stage_bytes;
+        if (fuse && fuse_lds > lds) lds = fuse_lds;
         const bool use16 = L.f16 != 0;
         wide_gemm_fn_t fn = use16 ? cf.f16 : cf.f32;
         bool& attr = use16 ? cf.attr16 : cf.attr32;
@@ -371,6 +417,7 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
         A = layer_out;
         lda = g.ldo;
         if (l == 0 && info) { info[0] = 16 * cf.xt; info[1] = 16 * cf.wt; info[2] = n_sl; info[3] = n_rb * n_cb * n_sl; }
+        if (fuse) { HIP_TRY(ctx, hipGetLastError()); return NPBNN_OK; }       // (the rest of the pass went with the product)
         if (l == 0 && only_layer0) return NPBNN_OK;
     }
     WideLikArgs la{};

@@ -138,6 +138,286 @@ __global__ void __launch_bounds__(256) wide_pack_kernel(const double* __restrict
 #endif  // NPBNN_KERNELS_WIDE
 
 // ------------------------------------------------------------------------------------------------
+// helpers shared by the kernels below
+// ------------------------------------------------------------------------------------------------
+// The narrow end of a network - layers of <= 128 nodes behind an input of <= 256 (the [64] of [256, 64], the [5] of [50, 5], every
+// output layer of a few classes): their weights (a few tens of KiB) sit in LDS, a wave takes a 16-row tile of the activations and
+// chains the layers through its accumulators - the resident path's scheme: the accumulator of one layer is the B operand of the next
+// (v_mfma_f32_16x16x4_f32, exact float32), bias = initial accumulator, activation elementwise.
+constexpr int kTailIn = 16;       // 16-unit tiles of the activations it reads at most
+constexpr int kTailOut = 8;       // ... and of any layer it computes
+struct WideTailDesc {
+    int n_layers;             // layers computed (0: none)
+    int last_is_output;       // the last of them is the network's last layer: no activation behind it
+    int act_kind;
+    int pad_;
+    const float* image;       // weight image (global)
+    long long frag_off[kMaxLayers], bias_off[kMaxLayers];     // of each layer, in the image
+    int mt[kMaxLayers];
+    int lds_frag[kMaxLayers], lds_bias[kMaxLayers];           // float offsets of their copies in LDS
+    int frag_floats[kMaxLayers];
+    float act_prm[kMaxLayers];
+    const double* act_prm_dev;    // device chain with trainable slopes: the candidate's slopes of these layers, or nullptr
+};
+// the layers' fragments and biases into LDS (every thread of the workgroup; a barrier follows at the caller)
+__device__ __forceinline__ void wide_tail_stage(const WideTailDesc& t, float* lds, int tid, int n_threads) {
+    for (int l = 0; l < t.n_layers; ++l) {
+        const f32x4* gf = reinterpret_cast<const f32x4*>(t.image + t.frag_off[l]);
+        f32x4* lf = reinterpret_cast<f32x4*>(lds + t.lds_frag[l]);
+        for (int i = tid; i < t.frag_floats[l] / 4; i += n_threads) lf[i] = gf[i];
+        const f32x4* gb = reinterpret_cast<const f32x4*>(t.image + t.bias_off[l]);
+        f32x4* lb = reinterpret_cast<f32x4*>(lds + t.lds_bias[l]);
+        for (int i = tid; i < 4 * t.mt[l]; i += n_threads) lb[i] = gb[i];
+    }
+}
+// h[0 .. kt-1]: a 16-row tile of activations (lane (n, kq) holds the units 4 kq .. 4 kq + 3 of every 16-unit tile for row n); on
+// return h[0 .. result-1] holds the last computed layer's values
+__device__ __forceinline__ int wide_tail_layers(const WideTailDesc& t, const float* lds, f32x4 (&h)[kTailIn], int kt, int lane, int kq) {
+    for (int l = 0; l < t.n_layers; ++l) {
+        const int mt_l = __builtin_amdgcn_readfirstlane(t.mt[l]);
+        const float* frag = lds + t.lds_frag[l] + lane * 4;
+        const float* bias = lds + t.lds_bias[l] + 4 * kq;
+        f32x4 acc[kTailOut];
+#pragma unroll
+        for (int mt = 0; mt < kTailOut; ++mt) {
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mt < mt_l) {
+                acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
+#pragma unroll
+                for (int ct = 0; ct < kTailIn; ++ct)
+                    if (ct < kt) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * mt_l + mt) * 256);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], h[ct][s], acc[mt], 0, 0, 0);
+                    }
+            }
+        }
+        const bool last = l + 1 == t.n_layers;
+        if (!(last && t.last_is_output)) {
+            const float prm = t.act_prm_dev != nullptr ? (float)t.act_prm_dev[l] : t.act_prm[l];
+#pragma unroll
+            for (int mt = 0; mt < kTailOut; ++mt)
+                if (mt < mt_l)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[mt][i] = act_apply(acc[mt][i], t.act_kind, prm);
+        }
+#pragma unroll
+        for (int ct = 0; ct < kTailIn; ++ct) h[ct] = ct < kTailOut ? acc[ct < kTailOut ? ct : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+        kt = mt_l;
+    }
+    return kt;
+}
+
+// Likelihood terms / statistics / predictions of ONE data row from the last layer's values z[0 .. C-1] (no activation applied): the
+// resident epilogue's arithmetic - float32 per row, float64 sums.
+struct WideRowAcc {
+    double ll;
+    double s1[NPBNN_MAX_TARGETS], s2[NPBNN_MAX_TARGETS];
+};
+__device__ __forceinline__ void wide_row_terms(const EvalParams& p, const float* z, long long row, const float* image, long long classw_off,
+                                               float final_prm, WideRowAcc& A) {
+    const NetMeta& net = p.net;
+    const int C = net.n_out, lik_kind = net.lik_kind, k = net.k_targets;
+    const int act_kind = net.act_kind;
+    auto val = [&](int o) -> float {
+        const float v = z[o];
+        return net.final_act ? act_apply(v, act_kind, final_prm) : v;
+    };
+    const bool need_softmax = lik_kind == NPBNN_LIK_CATEGORICAL || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
+    float lse = 0.f;
+    int best = 0;
+    if (need_softmax) {
+        float m = -INFINITY;
+        for (int o = 0; o < C; ++o) {
+            const float v = val(o);
+            if (v > m) { m = v; best = o; }          // np.argmax: the first maximum (BNN_lib.py:207)
+        }
+        float se = 0.f;
+        for (int o = 0; o < C; ++o) se += __expf(val(o) - m);
+        lse = m + log_1_to_n(se);
+    }
+    if (lik_kind == NPBNN_LIK_CATEGORICAL && p.labels != nullptr) {
+        const int lab = p.labels[row];
+        if (lab >= 0) {
+            float wgt = 1.f;
+            if (p.inst_w) wgt *= p.inst_w[row];
+            if (p.use_classw && classw_off >= 0) wgt *= image[classw_off + lab];
+            float term = (lab < C ? val(lab) : 0.f) - lse;
+            term *= wgt;
+            A.ll += (double)term;
+            if (p.confusion) atomicAdd(p.confusion + (size_t)lab * C + best, 1u);
+        }
+    } else if (lik_kind == NPBNN_LIK_GAUSS && p.targets != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NPBNN_MAX_TARGETS; ++j)          // (unrolled under a predicate: a run-time index would put the sums in scratch)
+            if (j < k) {
+                const float r = p.targets[row * k + j] - val(j);
+                A.s1[j] += (double)r;
+                A.s2[j] += (double)r * (double)r;
+            }
+    } else if (lik_needs_row_scratch(lik_kind) && p.targets != nullptr) {
+        // float64 row-wise likelihoods (BNN_lib.py:134-143, BNN_lik.py:5-66), as the resident path's generic epilogue has them
+        double term = 0.0;
+        for (int j = 0; j < k; ++j) {
+            const double y = (double)p.targets[row * k + j];
+            if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
+                const double mu = (double)val(j);
+                const double zs = (double)val(k + j);
+                const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));
+                const double r = (y - mu) / sg;
+                term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
+            } else if (lik_kind == NPBNN_LIK_POISSON) {
+                if (j == 0) {
+                    const double eta = (double)val(0);
+                    term += y * eta - exp(eta) - lgamma(y + 1.0);
+                }
+            } else {
+                const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
+                if (one_col && j > 0) continue;
+                const int jp = one_col ? 1 : k + j;
+                const double e0 = (double)val(j), e1 = (double)val(jp);
+                double mean, pr;
+                if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
+                    mean = exp(2.302585092994046 * e0);
+                    pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
+                } else {
+                    mean = exp(e0);
+                    pr = 1.0 / (1.0 + exp(-e1));
+                }
+                const double nn = pr * mean / (1.0 - pr);
+                term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
+            }
+        }
+        A.ll += term;
+    }
+    if (p.predict_mode && p.y_out != nullptr) {
+        float* yo = p.y_out + row * C;
+        for (int o = 0; o < C; ++o) {
+            float v = val(o);
+            if (p.predict_mode == 2) {
+                if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
+                else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+            }
+            yo[o] = v;
+        }
+    }
+}
+// The same for the product's fused end (WideGemmArgs::fuse), without what would cost that kernel its registers: the categorical and the
+// Gaussian likelihood (up to kFuseTargets target columns) and predictions; the float64 row-wise likelihoods stay with wide_lik_kernel.
+constexpr int kFuseTargets = 4;
+struct WideRowAccLean {
+    double ll;
+    double s1[kFuseTargets], s2[kFuseTargets];
+};
+struct WideRowAux {           // what a row's terms read beside its values, requested ahead of them (a dependent miss per tile otherwise)
+    int lab;
+    float inst_w;
+    float tg[kFuseTargets];
+};
+__device__ __forceinline__ WideRowAux wide_row_aux(const EvalParams& p, long long row, bool ok) {
+    WideRowAux x;
+    x.lab = -1;
+    x.inst_w = 1.f;
+#pragma unroll
+    for (int j = 0; j < kFuseTargets; ++j) x.tg[j] = 0.f;
+    if (ok) {
+        const int lik_kind = p.net.lik_kind, k = p.net.k_targets;
+        if (lik_kind == NPBNN_LIK_CATEGORICAL && p.labels != nullptr) {
+            x.lab = p.labels[row];
+            if (p.inst_w) x.inst_w = p.inst_w[row];
+        } else if (lik_kind == NPBNN_LIK_GAUSS && p.targets != nullptr) {
+#pragma unroll
+            for (int j = 0; j < kFuseTargets; ++j)
+                if (j < k) x.tg[j] = p.targets[row * k + j];
+        }
+    }
+    return x;
+}
+__device__ __forceinline__ void wide_row_terms_lean(const EvalParams& p, const float* z, long long row, const float* image, long long classw_off,
+                                                    float final_prm, const WideRowAux& aux, WideRowAccLean& A) {
+    const NetMeta& net = p.net;
+    const int C = net.n_out, lik_kind = net.lik_kind, k = net.k_targets;
+    const int act_kind = net.act_kind;
+    auto val = [&](int o) -> float {
+        const float v = z[o];
+        return net.final_act ? act_apply(v, act_kind, final_prm) : v;
+    };
+    const bool need_softmax = lik_kind == NPBNN_LIK_CATEGORICAL || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
+    float lse = 0.f;
+    int best = 0;
+    if (need_softmax) {
+        float m = -INFINITY;
+        for (int o = 0; o < C; ++o) {
+            const float v = val(o);
+            if (v > m) { m = v; best = o; }
+        }
+        float se = 0.f;
+        for (int o = 0; o < C; ++o) se += __expf(val(o) - m);
+        lse = m + log_1_to_n(se);
+    }
+    if (lik_kind == NPBNN_LIK_CATEGORICAL && p.labels != nullptr) {
+        const int lab = aux.lab;
+        if (lab >= 0) {
+            float wgt = aux.inst_w;
+            if (p.use_classw && classw_off >= 0) wgt *= image[classw_off + lab];
+            float term = (lab < C ? val(lab) : 0.f) - lse;
+            term *= wgt;
+            A.ll += (double)term;
+            if (p.confusion) atomicAdd(p.confusion + (size_t)lab * C + best, 1u);
+        }
+    } else if (lik_kind == NPBNN_LIK_GAUSS && p.targets != nullptr) {
+#pragma unroll
+        for (int j = 0; j < kFuseTargets; ++j)
+            if (j < k) {
+                const float r = aux.tg[j] - val(j);
+                A.s1[j] += (double)r;
+                A.s2[j] += (double)r * (double)r;
+            }
+    }
+    if (p.predict_mode && p.y_out != nullptr) {
+        float* yo = p.y_out + row * C;
+        for (int o = 0; o < C; ++o) {
+            float v = val(o);
+            if (p.predict_mode == 2) {
+                if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
+                else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
+            }
+            yo[o] = v;
+        }
+    }
+}
+template <typename ACC, int KT>
+__device__ __forceinline__ void wide_block_partials_t(const EvalParams& p, const ACC& A, double* red, int n_waves, int slot, int n_slots) {
+    const int lik_kind = p.net.lik_kind, k = p.net.k_targets;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lik_kind == NPBNN_LIK_GAUSS) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if (j < k) {
+                const double a1 = butterfly_sum_f64(A.s1[j]), a2 = butterfly_sum_f64(A.s2[j]);
+                if (lane == 0) { red[wave * kPartialStride + 1 + j] = a1; red[wave * kPartialStride + 1 + NPBNN_MAX_TARGETS + j] = a2; }
+            }
+        if (lane == 0) red[wave * kPartialStride] = 0.0;
+    } else {
+        const double s = butterfly_sum_f64(A.ll);
+        if (lane == 0) red[wave * kPartialStride] = s;
+    }
+    __syncthreads();
+    const int nvals = lik_kind == NPBNN_LIK_GAUSS ? 1 + 2 * k : 1;
+    for (int it = threadIdx.x; it < nvals; it += blockDim.x) {
+        const int v = it <= k ? it : 1 + NPBNN_MAX_TARGETS + (it - k - 1);
+        double s = 0.0;
+        for (int w = 0; w < n_waves; ++w) s += red[w * kPartialStride + v];
+        p.partials[(size_t)v * n_slots + slot] = s;          // (candidate 0 of pass parity 0: [value][workgroup])
+    }
+}
+// one partial record per workgroup: lanes -> wave (fixed butterfly) -> workgroup (waves in order) -> partials[value][slot of n_slots]
+// (every wave of the workgroup calls it; `red`: LDS, n_waves x kPartialStride doubles)
+__device__ __forceinline__ void wide_block_partials(const EvalParams& p, const WideRowAcc& A, double* red, int n_waves, int slot, int n_slots) {
+    wide_block_partials_t<WideRowAcc, NPBNN_MAX_TARGETS>(p, A, red, n_waves, slot, n_slots);
+}
+
+// ------------------------------------------------------------------------------------------------
 // the tiled matrix product of one layer
 // ------------------------------------------------------------------------------------------------
 struct WideGemmArgs {
@@ -162,6 +442,14 @@ struct WideGemmArgs {
     int k_slices;             // > 1: the contraction is cut into that many slices of K-units, one workgroup each; slice s writes its raw
     int pad_;                 // sums (the bias in slice 0, no activation) to out + s * slice_stride; wide_reduce_kernel adds them up
     long long slice_stride;   // floats
+    // fused end (tilings whose waves hold whole rows - one output block, WC = 1 - on one K-slice): behind the product the narrow layers
+    // that follow (tail) and the likelihood terms of the rows, in the same launch - no activations through HBM, no further launches
+    int fuse;                 // 0 none; 1 tail layers + likelihood (p, image, classw_off; one partial record per row block)
+    int n_row_blocks;         // slots of the partial records
+    WideTailDesc tail;
+    const EvalParams* p;
+    const float* image;
+    long long classw_off;
 };
 
 #define NPBNN_WVM_(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -350,6 +638,65 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
     // ---- activation, store: lane (n, kq) holds the units 4 kq .. 4 kq + 3 of a tile for row n ----
     float prm = a.act_prm;
     if (a.act_prm_dev != nullptr) prm = (float)*a.act_prm_dev;
+    if constexpr (WC == 1 && CT <= kTailIn) {
+        if (a.fuse) {
+            // every wave holds whole rows of this layer's values: the narrow layers behind it from LDS copies of their weights (the ring is
+            // free: every wave is through with the last unit after the barrier), the rows' values through a per-wave LDS scratch to one
+            // lane per row for the likelihood terms
+            const EvalParams& p = *a.p;
+            WideRowAux aux[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const long long row = ((long long)(rb * XT + wr * RT + rt)) * 16 + lane;
+                aux[rt] = wide_row_aux(p, row, lane < 16 && row < p.n_rows);
+            }
+            __syncthreads();
+            float* const lds = reinterpret_cast<float*>(smem);
+            wide_tail_stage(a.tail, lds, tid, NW * 64);
+            __syncthreads();
+            const int C = p.net.n_out;
+            const int ldz = ((C + 15) & ~15) + 1;            // (odd: the 16 lanes that each read one row of the scratch hit 16 banks)
+            int tail_floats = 0;
+            if (a.tail.n_layers > 0) tail_floats = a.tail.lds_bias[a.tail.n_layers - 1] + 16 * a.tail.mt[a.tail.n_layers - 1];
+            float* const zs = lds + ((tail_floats + 3) & ~3) + wave * 16 * ldz;
+            WideRowAccLean A;
+            A.ll = 0.0;
+#pragma unroll
+            for (int j = 0; j < kFuseTargets; ++j) { A.s1[j] = 0.0; A.s2[j] = 0.0; }
+            const float fprm = p.net.act_prm[p.net.n_layers - 1];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int T = rb * XT + wr * RT + rt;
+                if (T >= a.n_row_tiles) continue;
+                f32x4 h[kTailIn];
+#pragma unroll
+                for (int ct = 0; ct < kTailIn; ++ct) {
+                    h[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ct < CT && ct < a.mt_total) {
+                        h[ct] = acc[rt][ct < CT ? ct : 0];
+                        if (a.act_kind >= 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) h[ct][i] = act_apply(h[ct][i], a.act_kind, prm);
+                        }
+                    }
+                }
+                const int mt_last = wide_tail_layers(a.tail, lds, h, a.mt_total, lane, kq);
+#pragma unroll
+                for (int mt = 0; mt < kTailOut; ++mt)
+                    if (mt < mt_last) {                                  // (the odd row stride leaves no 16-byte alignment: dword stores)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) zs[n * ldz + 16 * mt + 4 * kq + i] = h[mt][i];
+                    }
+                const long long row = (long long)T * 16 + lane;
+                if (lane < 16 && row < p.n_rows) wide_row_terms_lean(p, zs + lane * ldz, row, a.image, a.classw_off, fprm, aux[rt], A);
+            }
+            if (p.partials != nullptr) {
+                __syncthreads();                                  // (every wave is through with the tail weights' neighbours: the sums go where they sat)
+                wide_block_partials_t<WideRowAccLean, kFuseTargets>(p, A, reinterpret_cast<double*>(smem), NW, rb, a.n_row_blocks);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int T = rb * XT + wr * RT + rt;
@@ -418,29 +765,16 @@ __global__ void __launch_bounds__(256) split_x_tiled_kernel(const float* __restr
 #endif  // NPBNN_KERNELS_WIDE
 
 // ------------------------------------------------------------------------------------------------
-// the narrow end of a network in one launch: layers of <= 128 nodes behind an input of <= 256 (the [64] of [256, 64], the [5] of
-// [50, 5], every output layer of a few classes).  As tiled products of their own each would cost a launch, a pass over the activations
-// and a prologue per workgroup for a few MFMAs; here their weights (a few tens of KiB) sit in LDS, a wave takes a 16-row tile of the
-// activations and chains the layers through its accumulators - the resident path's scheme: the accumulator of one layer is the B
-// operand of the next (v_mfma_f32_16x16x4_f32, exact float32), bias = initial accumulator, activation elementwise.
+// the narrow end of a network in one launch (where the product before it could not take it along: several output blocks or K-slices):
+// as tiled products of their own each narrow layer would cost a launch, a pass over the activations and a prologue per workgroup for
+// a few MFMAs
 // ------------------------------------------------------------------------------------------------
-constexpr int kTailIn = 16;       // 16-unit tiles of the activations it reads at most
-constexpr int kTailOut = 8;       // ... and of any layer it computes
 struct WideTailArgs {
     const float* A;           // [rows][lda] activations behind the last tiled product (activation applied)
     long long lda;
     int n_row_tiles;
-    int n_layers;             // layers computed here
-    int kt0;                  // 16-column steps of the first one's input
-    int last_is_output;       // the last of them is the network's last layer: no activation behind it
-    const float* image;       // weight image (global)
-    long long frag_off[kMaxLayers], bias_off[kMaxLayers];     // of each layer, in the image
-    int mt[kMaxLayers];
-    int lds_frag[kMaxLayers], lds_bias[kMaxLayers];           // float offsets of their copies in LDS
-    int frag_floats[kMaxLayers];
-    int act_kind;
-    float act_prm[kMaxLayers];
-    const double* act_prm_dev;    // device chain with trainable slopes: the candidate's slopes of these layers, or nullptr
+    int kt0;                  // 16-column steps of the first layer's input
+    WideTailDesc t;
     float* out;               // [rows][ldo] values of the last layer computed
     long long ldo;
     const PassDesc* pass;
@@ -456,54 +790,14 @@ __global__ void __launch_bounds__(512) wide_tail_kernel(const WideTailArgs a) {
     float* const lds = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
-    for (int l = 0; l < a.n_layers; ++l) {      // the layers' fragments and biases into LDS, once per workgroup
-        const f32x4* gf = reinterpret_cast<const f32x4*>(a.image + a.frag_off[l]);
-        f32x4* lf = reinterpret_cast<f32x4*>(lds + a.lds_frag[l]);
-        for (int i = tid; i < a.frag_floats[l] / 4; i += blockDim.x) lf[i] = gf[i];
-        const f32x4* gb = reinterpret_cast<const f32x4*>(a.image + a.bias_off[l]);
-        f32x4* lb = reinterpret_cast<f32x4*>(lds + a.lds_bias[l]);
-        for (int i = tid; i < 4 * a.mt[l]; i += blockDim.x) lb[i] = gb[i];
-    }
+    wide_tail_stage(a.t, lds, tid, blockDim.x);
     __syncthreads();
-    constexpr int HT = kTailIn;
     for (int T = (int)blockIdx.x * nw + wave; T < a.n_row_tiles; T += (int)gridDim.x * nw) {
-        f32x4 h[HT];
+        f32x4 h[kTailIn];
         const float* row = a.A + ((long long)T * 16 + n) * a.lda + 4 * kq;
 #pragma unroll
-        for (int ct = 0; ct < HT; ++ct) h[ct] = ct < a.kt0 ? *reinterpret_cast<const f32x4*>(row + 16 * ct) : f32x4{0.f, 0.f, 0.f, 0.f};
-        int kt = a.kt0;
-        for (int l = 0; l < a.n_layers; ++l) {
-            const int mt_l = __builtin_amdgcn_readfirstlane(a.mt[l]);
-            const float* frag = lds + a.lds_frag[l] + lane * 4;
-            const float* bias = lds + a.lds_bias[l] + 4 * kq;
-            f32x4 acc[kTailOut];
-#pragma unroll
-            for (int mt = 0; mt < kTailOut; ++mt) {
-                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (mt < mt_l) {
-                    acc[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt);
-#pragma unroll
-                    for (int ct = 0; ct < HT; ++ct)
-                        if (ct < kt) {
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(frag + (size_t)(ct * mt_l + mt) * 256);
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], h[ct][s], acc[mt], 0, 0, 0);
-                        }
-                }
-            }
-            const bool last = l + 1 == a.n_layers;
-            if (!(last && a.last_is_output)) {
-                const float prm = a.act_prm_dev != nullptr ? (float)a.act_prm_dev[l] : a.act_prm[l];
-#pragma unroll
-                for (int mt = 0; mt < kTailOut; ++mt)
-                    if (mt < mt_l)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[mt][i] = act_apply(acc[mt][i], a.act_kind, prm);
-            }
-#pragma unroll
-            for (int ct = 0; ct < HT; ++ct) h[ct] = ct < kTailOut ? acc[ct < kTailOut ? ct : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
-            kt = mt_l;
-        }
+        for (int ct = 0; ct < kTailIn; ++ct) h[ct] = ct < a.kt0 ? *reinterpret_cast<const f32x4*>(row + 16 * ct) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kt = wide_tail_layers(a.t, lds, h, a.kt0, lane, kq);
         float* orow = a.out + ((long long)T * 16 + n) * a.ldo + 4 * kq;
 #pragma unroll
         for (int mt = 0; mt < kTailOut; ++mt)
@@ -528,120 +822,17 @@ struct WideLikArgs {
 __global__ void __launch_bounds__(256) wide_lik_kernel(const WideLikArgs a) {
     const EvalParams& p = *a.p;
     if (p.has_pass && p.pass_desc[0].n_cand == 0) return;
-    const NetMeta& net = p.net;
-    const int C = net.n_out, lik_kind = net.lik_kind, k = net.k_targets;
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool row_ok = row < p.n_rows;
-    const float* z = a.z + row * a.ldz;
-    const int act_kind = net.act_kind;
-    float fprm = net.act_prm[net.n_layers - 1];
+    float fprm = p.net.act_prm[p.net.n_layers - 1];
     if (a.final_prm_dev != nullptr) fprm = (float)*a.final_prm_dev;
-    auto val = [&](int o) -> float {
-        const float v = z[o];
-        return net.final_act ? act_apply(v, act_kind, fprm) : v;
-    };
-    double ll = 0.0;
-    double s1[NPBNN_MAX_TARGETS], s2[NPBNN_MAX_TARGETS];
+    WideRowAcc A;
+    A.ll = 0.0;
 #pragma unroll
-    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
-    const bool need_softmax = lik_kind == NPBNN_LIK_CATEGORICAL || (p.predict_mode == 2 && net.out_kind == NPBNN_OUT_SOFTMAX);
-    float lse = 0.f;
-    int best = 0;
-    if (row_ok && need_softmax) {
-        float m = -INFINITY;
-        for (int o = 0; o < C; ++o) {
-            const float v = val(o);
-            if (v > m) { m = v; best = o; }          // np.argmax: the first maximum (BNN_lib.py:207)
-        }
-        float se = 0.f;
-        for (int o = 0; o < C; ++o) se += __expf(val(o) - m);
-        lse = m + log_1_to_n(se);
-    }
-    if (row_ok && lik_kind == NPBNN_LIK_CATEGORICAL && p.labels != nullptr) {
-        const int lab = p.labels[row];
-        if (lab >= 0) {
-            float wgt = 1.f;
-            if (p.inst_w) wgt *= p.inst_w[row];
-            if (p.use_classw && a.classw_off >= 0) wgt *= a.image[a.classw_off + lab];
-            float term = (lab < C ? val(lab) : 0.f) - lse;
-            term *= wgt;
-            ll += (double)term;
-            if (p.confusion) atomicAdd(p.confusion + (size_t)lab * C + best, 1u);
-        }
-    } else if (row_ok && lik_kind == NPBNN_LIK_GAUSS && p.targets != nullptr) {
-        for (int j = 0; j < k; ++j) {
-            const float r = p.targets[row * k + j] - val(j);
-            s1[j] += (double)r;
-            s2[j] += (double)r * (double)r;
-        }
-    } else if (row_ok && lik_needs_row_scratch(lik_kind) && p.targets != nullptr) {
-        // float64 row-wise likelihoods (BNN_lib.py:134-143, BNN_lik.py:5-66), as the resident path's generic epilogue has them
-        double term = 0.0;
-        for (int j = 0; j < k; ++j) {
-            const double y = (double)p.targets[row * k + j];
-            if (lik_kind == NPBNN_LIK_GAUSS_PRED_SIGMA) {
-                const double mu = (double)val(j);
-                const double zs = (double)val(k + j);
-                const double sg = fmax(zs, 0.0) + log1p(exp(-fabs(zs)));
-                const double r = (y - mu) / sg;
-                term += -0.9189385332046727418 - log(sg) - 0.5 * r * r;
-            } else if (lik_kind == NPBNN_LIK_POISSON) {
-                if (j == 0) {
-                    const double eta = (double)val(0);
-                    term += y * eta - exp(eta) - lgamma(y + 1.0);
-                }
-            } else {
-                const bool one_col = lik_kind != NPBNN_LIK_NEGBIN2D;
-                if (one_col && j > 0) continue;
-                const int jp = one_col ? 1 : k + j;
-                const double e0 = (double)val(j), e1 = (double)val(jp);
-                double mean, pr;
-                if (lik_kind == NPBNN_LIK_NEGBIN_BASE10) {
-                    mean = exp(2.302585092994046 * e0);
-                    pr = 1.0 / (1.0 + exp(-2.302585092994046 * e1));
-                } else {
-                    mean = exp(e0);
-                    pr = 1.0 / (1.0 + exp(-e1));
-                }
-                const double nn = pr * mean / (1.0 - pr);
-                term += lgamma(y + nn) - lgamma(y + 1.0) - lgamma(nn) + nn * log(pr) + y * log1p(-pr);
-            }
-        }
-        ll += term;
-    }
-    if (row_ok && p.predict_mode && p.y_out != nullptr) {
-        float* yo = p.y_out + row * C;
-        for (int o = 0; o < C; ++o) {
-            float v = val(o);
-            if (p.predict_mode == 2) {
-                if (net.out_kind == NPBNN_OUT_SOFTMAX) v = __expf(v - lse);
-                else if (net.out_kind == NPBNN_OUT_SOFTPLUS_HALF && o >= C / 2) v = softplus_f(v);
-            }
-            yo[o] = v;
-        }
-    }
-    // ---- one partial record per workgroup: lanes -> wave (fixed butterfly) -> workgroup (waves in order) ----
+    for (int j = 0; j < NPBNN_MAX_TARGETS; ++j) { A.s1[j] = 0.0; A.s2[j] = 0.0; }
+    if (row < p.n_rows) wide_row_terms(p, a.z + row * a.ldz, row, a.image, a.classw_off, fprm, A);
     if (p.partials == nullptr) return;
-    __shared__ double red[4][kPartialStride];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int G = (int)gridDim.x;
-    if (lik_kind == NPBNN_LIK_GAUSS) {
-        for (int j = 0; j < k; ++j) {
-            const double a1 = butterfly_sum_f64(s1[j]), a2 = butterfly_sum_f64(s2[j]);
-            if (lane == 0) { red[wave][1 + j] = a1; red[wave][1 + NPBNN_MAX_TARGETS + j] = a2; }
-        }
-        if (lane == 0) red[wave][0] = 0.0;
-    } else {
-        const double s = butterfly_sum_f64(ll);
-        if (lane == 0) red[wave][0] = s;
-    }
-    __syncthreads();
-    const int nvals = lik_kind == NPBNN_LIK_GAUSS ? 1 + 2 * k : 1;
-    for (int it = threadIdx.x; it < nvals; it += 256) {
-        const int v = it <= k ? it : 1 + NPBNN_MAX_TARGETS + (it - k - 1);
-        const double s = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
-        p.partials[(size_t)v * G + blockIdx.x] = s;          // (candidate 0 of pass parity 0: [value][workgroup])
-    }
+    __shared__ double red[4 * kPartialStride];
+    wide_block_partials(p, A, red, 4, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------

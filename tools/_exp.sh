@@ -1,8 +1,2 @@
-for f in 704; do
-NPBNN_WIDE_MIN_WAVES=1 python tools/_exp.py $f mh
-NPBNN_WIDE_MIN_WAVES=1 python tools/_exp.py $f run 0
-NPBNN_WIDE_MIN_WAVES=1 python tools/_exp.py $f run 1
-NPBNN_WIDE_MIN_WAVES=1 python tools/_exp.py $f run 2
-NPBNN_FORCE_WIDE=1 python tools/_exp.py $f mh
-NPBNN_FORCE_WIDE=1 python tools/_exp.py $f run 0
-done
+timeout -k 10 600 python -m pytest tests/test_hip_wide.py -q -m gpu --maxfail=8 2>&1 | tail -4
+NPBNN_CHAIN=0 timeout -k 10 300 python tools/time_wide.py 100000,1024,50-5,10 100000,704,50-5,10 2>&1 | grep pass | cut -c1-100

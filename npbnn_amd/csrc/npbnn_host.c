@@ -300,6 +300,9 @@ typedef struct {
     int32_t update_n[NPBNN_HOST_MAX_LAYERS];  /* MCMC._update_n */
     const double* update_ws[NPBNN_HOST_MAX_LAYERS]; /* MCMC._update_ws[i], rows*cols doubles */
     double freq_layer_update[NPBNN_HOST_MAX_LAYERS];
+    int32_t ws_uniform[NPBNN_HOST_MAX_LAYERS]; /* 1: every entry of update_ws[i] is the same number (the sampler's default: a scalar per layer,
+                                                  np_bnn/BNN_env.py:291) - the step size is then read once, not per drawn entry: on a layer of a
+                                                  million weights that read is a cache miss per entry */
 } npbnn_proposal_spec;
 
 int npbnn_host_abi_version(void) { return 1; }
@@ -440,9 +443,17 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
                 random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->cols[i] - 1), n, 0, iy);
             }
             const int base = used;
+            const int uniform = spec->ws_uniform[i];
+            const double scale0 = spec->update_ws[i][0];
+            const int cols_i = spec->cols[i], off_i = spec->w_off[i];
             for (int j = 0; j < n; ++j) {
+                if (j + 8 < n) {      /* (the entry's slot of the last-writer table, requested ahead: 4 bytes per weight, out of cache on wide layers) */
+                    const int ahead = off_i + (int)ix[j + 8] * cols_i + (int)iy[j + 8];
+                    __builtin_prefetch(&last[ahead], 1, 1);
+                    if (!uniform) __builtin_prefetch(&spec->update_ws[i][ahead - off_i], 0, 1);
+                }
                 const int local_pos = (int)ix[j] * spec->cols[i] + (int)iy[j];
-                const double scale = spec->update_ws[i][local_pos];
+                const double scale = uniform ? scale0 : spec->update_ws[i][local_pos];
                 const int flat = spec->w_off[i] + local_pos;
                 /* random_normal(loc, scale) = loc + scale * standard normal */
                 row_delta[base + j] = fr ? 0.0 + scale * fast_standard_normal(fr, bg) : random_normal(bg, 0.0, scale);

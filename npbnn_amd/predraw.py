@@ -16,7 +16,8 @@ _NO_STATE_HANDOVER = bool(os.environ.get("NPBNN_NO_STATE_HANDOVER"))     # A/B: 
 class ProposalSpec(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("rows", C.c_int32 * MAX_LAYERS), ("cols", C.c_int32 * MAX_LAYERS),
                 ("w_off", C.c_int32 * MAX_LAYERS), ("update_n", C.c_int32 * MAX_LAYERS),
-                ("update_ws", C.POINTER(C.c_double) * MAX_LAYERS), ("freq_layer_update", C.c_double * MAX_LAYERS)]
+                ("update_ws", C.POINTER(C.c_double) * MAX_LAYERS), ("freq_layer_update", C.c_double * MAX_LAYERS),
+                ("ws_uniform", C.c_int32 * MAX_LAYERS)]
 
 
 _lib = None
@@ -72,6 +73,7 @@ class PredrawPlan:
             ws = np.ascontiguousarray(np.broadcast_to(update_ws[i], w.shape), dtype=np.float64)
             self._keep.append(ws)
             spec.update_ws[i] = ws.ctypes.data_as(C.POINTER(C.c_double))
+            spec.ws_uniform[i] = 1 if ws.size and bool(np.all(ws == ws.flat[0])) else 0      # (kept unchanged for the life of the plan)
             spec.freq_layer_update[i] = float(freq_layer_update[i])
         self.spec = spec
         self.spec_ref = C.byref(spec)

@@ -40,6 +40,49 @@ class LocalComm:
         pass
 
 
+def _exchange_unique_id(rank, world, uid, addr, port, timeout=120.0):
+    """Rank 0 hands the 128-byte RCCL unique id to every other rank over a TCP socket."""
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            conn, _ = srv.accept()
+            conn.sendall(uid)
+            conn.close()
+        srv.close()
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < 128:
+        chunk = s.recv(128 - len(buf))
+        if not chunk:
+            raise ConnectionError("unique id exchange interrupted")
+        buf += chunk
+    s.close()
+    return buf
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
 class SocketComm:
     """The exchange over plain TCP: every rank keeps one connection to rank 0, which gathers and hands back.  For rehearsing
     the multi-rank flow where RCCL cannot run (several ranks on one GPU, CPU tests) - the payloads are a few dozen bytes per

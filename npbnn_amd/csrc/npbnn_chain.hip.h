@@ -343,6 +343,11 @@ struct StepShared {            // LDS scratch of chain_step
     int s_accepted, s_t, s_start, s_lim;
 };
 
+// WIDE (the stand-alone step kernel only - the serial schedule, the weight-streamed path): proposals of tens of thousands of entries are
+// walked four entries per thread at a time, and the step keeps the candidate image (ChainParams::cand_image).  The step INSIDE the
+// evaluation kernels is instantiated without it: that code beside the tile loop costs the tightest builds registers in the loop
+// (tests/test_build_hot_loops.py; the three-candidate pass kernel of config 2 went from 25.3 to 27.8 us with it).
+template <bool WIDE = false>
 __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const StepPlan pl, StepShared& sh) {
     // The step's parameter block does not change while a launch runs (what its pointers point at does): read through the CONSTANT
     // address space its fields are scalar loads the compiler may keep - through the generic reference every field was fetched again
@@ -503,45 +508,61 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
         __syncthreads();
         NPBNN_STAMP(3);
         const int a = sh.s_accepted;
-        constexpr int CU = 4;   // entries per thread requested together (wide proposals: each level of dependent loads is a round trip)
-        if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
-            const size_t row = (size_t)(t0 + a) * c.M;
-            const int n = c.cnt[t0 + a];
-            const double* pv = c.pv + (size_t)pl.dec * pv_stride;
-            for (int e0 = tid; e0 < n; e0 += CU * (int)blockDim.x) {
-                int ci[CU], cp[CU];
-                double cv[CU];
-                float cs[CU];
-#pragma unroll
-                for (int u = 0; u < CU; ++u) {
-                    const int e = e0 + u * (int)blockDim.x;
-                    ci[u] = -1; cp[u] = 0; cv[u] = 0.0; cs[u] = 1.0f;
-                    if (e < n) {
-                        ci[u] = c.idx[row + e];
-                        cv[u] = pv[(size_t)a * c.M + e];
-                        cp[u] = c.pos[row + e];
-                        if (c.pscale) cs[u] = c.pscale[row + e];
+        if constexpr (WIDE) {
+            constexpr int CU = 4;   // entries per thread requested together (wide proposals: each level of dependent loads is a round trip)
+            if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
+                const size_t row = (size_t)(t0 + a) * c.M;
+                const int n = c.cnt[t0 + a];
+                const double* pv = c.pv + (size_t)pl.dec * pv_stride;
+                for (int e0 = tid; e0 < n; e0 += CU * (int)blockDim.x) {
+                    int ci[CU], cp[CU];
+                    double cv[CU];
+                    float cs[CU];
+    #pragma unroll
+                    for (int u = 0; u < CU; ++u) {
+                        const int e = e0 + u * (int)blockDim.x;
+                        ci[u] = -1; cp[u] = 0; cv[u] = 0.0; cs[u] = 1.0f;
+                        if (e < n) {
+                            ci[u] = c.idx[row + e];
+                            cv[u] = pv[(size_t)a * c.M + e];
+                            cp[u] = c.pos[row + e];
+                            if (c.pscale) cs[u] = c.pscale[row + e];
+                        }
                     }
+    #pragma unroll
+                    for (int u = 0; u < CU; ++u)
+                        if (ci[u] >= 0) {
+                            c.w_cur[ci[u]] = cv[u];
+                            patch_global_image(c_generic, cp[u], cs[u], cv[u]);
+                        }
                 }
-#pragma unroll
-                for (int u = 0; u < CU; ++u)
-                    if (ci[u] >= 0) {
-                        c.w_cur[ci[u]] = cv[u];
-                        patch_global_image(c_generic, cp[u], cs[u], cv[u]);
+            } else if (c.cand_image) {      // rejected (weight-streamed path): the candidate image's patched entries back to the committed values
+                const size_t row = (size_t)t0 * c.M;
+                const int n = c.cnt[t0];
+                for (int e0 = tid; e0 < n; e0 += CU * (int)blockDim.x) {
+                    int cp[CU];
+    #pragma unroll
+                    for (int u = 0; u < CU; ++u) {
+                        const int e = e0 + u * (int)blockDim.x;
+                        cp[u] = e < n ? c.pos[row + e] : 0x7fffffff;
                     }
+    #pragma unroll
+                    for (int u = 0; u < CU; ++u) restore_image_entry(c.cand_image, c.image, cp[u]);
+                }
             }
-        } else if (c.cand_image) {      // rejected (weight-streamed path): the candidate image's patched entries back to the committed values
-            const size_t row = (size_t)t0 * c.M;
-            const int n = c.cnt[t0];
-            for (int e0 = tid; e0 < n; e0 += CU * (int)blockDim.x) {
-                int cp[CU];
-#pragma unroll
-                for (int u = 0; u < CU; ++u) {
-                    const int e = e0 + u * (int)blockDim.x;
-                    cp[u] = e < n ? c.pos[row + e] : 0x7fffffff;
+        } else {
+            if (a >= 0) {           // commit the accepted candidate: master weights and the global weight image
+                const size_t row = (size_t)(t0 + a) * c.M;
+                const int n = c.cnt[t0 + a];
+                const double* pv = c.pv + (size_t)pl.dec * pv_stride;
+                for (int e = tid; e < n; e += blockDim.x) {
+                    const int i = c.idx[row + e];
+                    if (i >= 0) {
+                        const double v = pv[(size_t)a * c.M + e];
+                        c.w_cur[i] = v;
+                        patch_global_image(c_generic, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f, v);
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < CU; ++u) restore_image_entry(c.cand_image, c.image, cp[u]);
             }
         }
         __syncthreads();
@@ -642,7 +663,7 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
             const double v = spec_entry<false>(c.w_bound, c.prior_kind, c.prior_scale_w != nullptr, base, d, m, scale_w, his, lsc, dlp[j]);
             pv_out[(size_t)j * c.M + e] = v;
             if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
-            if (c.cand_image) patch_image(c.cand_image, pos, sc, v, 16);       // (weight-streamed path: the image its kernels read)
+            if constexpr (WIDE) { if (c.cand_image) patch_image(c.cand_image, pos, sc, v, 16); }      // (weight-streamed path: the image its kernels read)
         };
 #pragma unroll
         for (int j = 0; j < kMaxCand; ++j) {
@@ -650,35 +671,44 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
             for (int u = 0; u < ES; ++u)
                 if (ii[j][u] >= 0) make(j, tid + u * (int)blockDim.x, ii[j][u], bb[j][u], dd[j][u], mm[j][u], pp[j][u], ss[j][u], sw[j][u]);
             if (cn[j] > ES * (int)blockDim.x) {
-                // (proposals wider than the staged entries: four entries per thread requested together, made in entry order - the
-                // order a thread adds its prior terms in is part of the sum's bits)
-                constexpr int PU = 4;
-                const size_t row = (size_t)(t_new + j) * c.M;
-                for (int e0 = tid + ES * (int)blockDim.x; e0 < cn[j]; e0 += PU * (int)blockDim.x) {
-                    int qi[PU], qp[PU];
-                    double qd[PU], qb[PU], qm[PU], qw[PU];
-                    float qs[PU];
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) {
-                        const int e = e0 + u * (int)blockDim.x;
-                        qi[u] = -1; qp[u] = 0; qd[u] = 0.0; qs[u] = 1.0f;
-                        if (e < cn[j]) {
-                            qi[u] = c.idx[row + e];
-                            qd[u] = c.delta[row + e];
-                            qp[u] = c.pos[row + e];
-                            if (c.pscale) qs[u] = c.pscale[row + e];
+                if constexpr (WIDE) {
+                    // (proposals wider than the staged entries: four entries per thread requested together, made in entry order - the
+                    // order a thread adds its prior terms in is part of the sum's bits)
+                    constexpr int PU = 4;
+                    const size_t row = (size_t)(t_new + j) * c.M;
+                    for (int e0 = tid + ES * (int)blockDim.x; e0 < cn[j]; e0 += PU * (int)blockDim.x) {
+                        int qi[PU], qp[PU];
+                        double qd[PU], qb[PU], qm[PU], qw[PU];
+                        float qs[PU];
+    #pragma unroll
+                        for (int u = 0; u < PU; ++u) {
+                            const int e = e0 + u * (int)blockDim.x;
+                            qi[u] = -1; qp[u] = 0; qd[u] = 0.0; qs[u] = 1.0f;
+                            if (e < cn[j]) {
+                                qi[u] = c.idx[row + e];
+                                qd[u] = c.delta[row + e];
+                                qp[u] = c.pos[row + e];
+                                if (c.pscale) qs[u] = c.pscale[row + e];
+                            }
                         }
+    #pragma unroll
+                        for (int u = 0; u < PU; ++u) {
+                            const int i = qi[u];
+                            qb[u] = i >= 0 ? wcur[i] : 0.0;
+                            qm[u] = (i >= 0 && mask) ? mask[i] : 1.0;
+                            qw[u] = (i >= 0 && c.prior_scale_w) ? c.prior_scale_w[i] : 1.0;
+                        }
+    #pragma unroll
+                        for (int u = 0; u < PU; ++u)
+                            if (qi[u] >= 0) make(j, e0 + u * (int)blockDim.x, qi[u], qb[u], qd[u], qm[u], qp[u], qs[u], qw[u]);
                     }
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) {
-                        const int i = qi[u];
-                        qb[u] = i >= 0 ? wcur[i] : 0.0;
-                        qm[u] = (i >= 0 && mask) ? mask[i] : 1.0;
-                        qw[u] = (i >= 0 && c.prior_scale_w) ? c.prior_scale_w[i] : 1.0;
+                } else {
+                    const size_t row = (size_t)(t_new + j) * c.M;
+                    for (int e = tid + ES * blockDim.x; e < cn[j]; e += blockDim.x) {
+                        const int i = c.idx[row + e];
+                        if (i >= 0) make(j, e, i, wcur[i], c.delta[row + e], mask ? mask[i] : 1.0, c.pos[row + e], c.pscale ? c.pscale[row + e] : 1.0f,
+                                         c.prior_scale_w ? c.prior_scale_w[i] : 1.0);
                     }
-#pragma unroll
-                    for (int u = 0; u < PU; ++u)
-                        if (qi[u] >= 0) make(j, e0 + u * (int)blockDim.x, qi[u], qb[u], qd[u], qm[u], qp[u], qs[u], qw[u]);
                 }
             }
         }
@@ -1383,7 +1413,7 @@ __global__ void __launch_bounds__(1024) chain_step_kernel(const ChainParams* __r
     pl.fly = -1;
     pl.out = 0;
     pl.launch = 0;
-    chain_step(c, pl, sh);
+    chain_step<true>(c, pl, sh);
     if (first_launch) sync_step_leave(c.st, 0);       // (flag-ordered schedule: pass 0 is ready)
 }
 #endif  // NPBNN_KERNELS_CHAIN
@@ -1472,7 +1502,7 @@ __global__ void __launch_bounds__(1024) exchange_apply_kernel(const ChainParams*
     pl.fly = -1;
     pl.out = overlapped ? (next_launch & 1) : 0;
     pl.launch = next_launch;
-    chain_step(c, pl, sh);
+    chain_step<true>(c, pl, sh);        // (a kernel of its own: the form that also keeps a weight-streamed chain's candidate image)
     sync_step_leave(c.st, next_launch);             // (flag-ordered schedule: the pass of launch next_launch is ready)
     if (threadIdx.x == 0) __hip_atomic_store(&st->exchanged, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }

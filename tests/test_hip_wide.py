@@ -316,3 +316,29 @@ def test_forced_device_chain_is_the_mh_step_loop_on_random_shapes(seed, monkeypa
         np.testing.assert_array_equal(wa, wb)
     np.testing.assert_allclose(mcmc_b._logLik, mcmc_a._logLik, rtol=1e-12)
     np.testing.assert_allclose(mcmc_b._logPrior, mcmc_a._logPrior, rtol=1e-11)
+
+
+# ---- the rest of the reference's fixtures with every network forced onto the streamed path (the existing tests' bodies, re-run) ----
+@pytest.mark.parametrize("advance", ["mh_step", "run_steps"])
+@pytest.mark.parametrize("name", list(cases.OPTION_TRACES))
+def test_forced_option_traces_follow_the_reference(name, advance, golden_dir, monkeypatch):
+    """G9 (one reference chain per sampler option: trainable slopes, indicators, hyper-priors, the other proposals, sigma proposals,
+    weights, priors, tempering, predicted sigma, a count likelihood) on the streamed path: tests/test_hip_options.py's check."""
+    import test_hip_options as t
+    monkeypatch.setenv("NPBNN_FORCE_WIDE", "1")
+    t.test_free_running_chain_follows_the_reference_under_every_option(name, advance, np.load(os.path.join(golden_dir, "options.npz")))
+
+
+def test_forced_mc3_follows_the_reference(golden_dir, tmp_path, monkeypatch):
+    """G5 (four chains, swaps every 100 iterations) on the streamed path: exchange runs on the serial schedule."""
+    import test_hip_sampler as t
+    monkeypatch.setenv("NPBNN_FORCE_WIDE", "1")
+    t.test_mc3_four_chains_on_one_gpu_follow_reference(golden_dir, tmp_path)
+
+
+@pytest.mark.parametrize("case", cases.POSTERIOR_CASES, ids=lambda c: c["name"])
+def test_forced_posterior_prediction_matches_the_reference(case, golden_dir, monkeypatch):
+    """G7 (posterior samples replayed: get_posterior_cat_prob) on the streamed path: one weight set per pass."""
+    import test_hip_posterior as t
+    monkeypatch.setenv("NPBNN_FORCE_WIDE", "1")
+    t.test_get_posterior_cat_prob_matches_reference(case, golden_dir)

@@ -412,7 +412,7 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
         int rc0 = rebuild_net(ctx, want_f16);
         if (rc0) return rc0;
     }
-    if (ctx->wide) return wide_plan(ctx, which, lp);
+    if (ctx->wide) return wide_plan(ctx, which, lp, (predict_only || !lik_only) ? 1 : want_cand);
     lp->wide = false;
     size_t lds = 0;
     // speculative passes: as many candidates as still leave >= 8 waves per workgroup (only the MTI = 1 builds have them)
@@ -1061,7 +1061,7 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
     if (what == NPBNN_INFO_WIDE) { *out = (ctx->arch_set && ctx->wide) ? 1 : 0; return NPBNN_OK; }
     if (ctx->arch_set && ctx->wide && (what == NPBNN_INFO_WAVES_PER_BLOCK || what == NPBNN_INFO_MAX_CANDIDATES || what == NPBNN_INFO_FAST_TAILS)) {
-        *out = what == NPBNN_INFO_WAVES_PER_BLOCK ? 4 : what == NPBNN_INFO_MAX_CANDIDATES ? 1 : 0;      // (one weight set per pass; no shape-specialised tails)
+        *out = what == NPBNN_INFO_WAVES_PER_BLOCK ? 4 : what == NPBNN_INFO_MAX_CANDIDATES ? 1 : 0;      // (group passes and prediction sets: one weight set per pass)
         return NPBNN_OK;
     }
     if (what == NPBNN_INFO_WAVES_PER_BLOCK) { size_t lds = 0; *out = pick_waves_per_block(ctx, &lds, 1, layout_for(ctx, ctx->ds[0])); return NPBNN_OK; }
@@ -1351,16 +1351,22 @@ int npbnn_time_pass(npbnn_ctx* ctx, const double* W_packed, int n_candidates, in
     rc = push_eval_params(ctx, p);
     if (rc) return rc;
     if (lp.wide) {      // the pass of the weight-streamed path: its layers' products + the likelihood kernel, timed together
-        for (int i = 0; i < 3 && !rc; ++i) rc = wide_forward(ctx, 0, ctx->d_image, false);
+        const float* img = ctx->d_image;
+        if (lp.n_cand > 1) {          // (every candidate = the staged weights, as on the resident path)
+            rc = wide_cand_begin(ctx);
+            if (rc) return rc;
+            img = ctx->d_wide_cand;
+        }
+        for (int i = 0; i < 3 && !rc; ++i) rc = wide_forward(ctx, 0, img, false, false, nullptr, lp.n_cand);
         HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        for (int i = 0; i < iters && !rc; ++i) rc = wide_forward(ctx, 0, ctx->d_image, false);
+        for (int i = 0; i < iters && !rc; ++i) rc = wide_forward(ctx, 0, img, false, false, nullptr, lp.n_cand);
         HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (rc) return rc;
         float msw = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&msw, ctx->ev[0], ctx->ev[1]));
         *ms_kernel = (double)msw / iters;
-        if (used_candidates) *used_candidates = 1;
+        if (used_candidates) *used_candidates = lp.n_cand;
         return NPBNN_OK;
     }
     for (int i = 0; i < 3; ++i)

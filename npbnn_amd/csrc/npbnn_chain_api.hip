@@ -128,6 +128,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     int want_cand = cfg->n_candidates;
     if (want_cand < 1) want_cand = kMaxCand;            // 0 = as many as fit
     if (group_blocks > 0) want_cand = 1;
+    if (cfg->slope_idx && ctx->wide) want_cand = 1;      // (weight-streamed path: candidates with slopes of their own travel one per pass)
     rc = plan_launch(ctx, 0, &lp, cfg->force_f32, want_cand, false, true);
     if (rc) return rc;
     const int D = lp.n_cand;
@@ -393,7 +394,7 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     c.image = ctx->d_image;
     // (weight-streamed path: the step keeps the candidate image itself while a proposal fits its staged entries; wider ones get two
     // launches over all compute units between step and pass - wide_cand_sync)
-    c.cand_image = (lp.wide && M <= kWideStepPatchMax) ? ctx->d_wide_cand : nullptr;
+    c.cand_image = (lp.wide && M <= kWideStepPatchMax && D == 1) ? ctx->d_wide_cand : nullptr;
     c.pos = ctx->d_pos;
     c.pscale = f16 ? ctx->d_pscale : nullptr;
     c.pv = spec ? ctx->d_spec_pv : ctx->d_pv;      // (spec: the first step writes pass 0 into slot (parity 0, outcome 0))
@@ -618,8 +619,8 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     } else {
         for (int i = 0; i < n; ++i, ++B.launch) {
             if (lp.wide) {      // the layers' products and the likelihood of the candidate image (kept by the step, or by wide_cand_sync)
-                if (B.M > kWideStepPatchMax) wide_cand_sync(ctx, B.M);
-                const int rcw = wide_forward(ctx, 0, ctx->d_wide_cand, true);
+                if (B.M > kWideStepPatchMax || B.D > 1) wide_cand_sync(ctx, B.M, B.D);
+                const int rcw = wide_forward(ctx, 0, ctx->d_wide_cand, true, false, nullptr, B.D);
                 if (rcw) return rcw;
             } else {
                 hipLaunchKernelGGL(lp.fn, dim3(lp.grid), dim3(lp.wpb * 64), lp.lds, st, (const EvalParams*)ctx->d_eparams, 0, 1);

@@ -243,6 +243,7 @@ constexpr int kTurnForcedProbeBatches = 200;    // ... or whatever the model say
 constexpr int kTurnFirstProbeBatches = 4;       // batches on one persistent form before the other, never measured, is given one
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
+constexpr int kWideMaxCand = 2;                // weight sets a fused pass of the weight-streamed path carries at most
 constexpr int kMinResidentWaves = 4;           // fewer waves than this beside the weight image: the network runs on the weight-streamed path
 constexpr int kWideStepPatchMax = 2048;      // widest proposal whose candidate image the step workgroup keeps by itself (weight-streamed path)
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)
@@ -274,14 +275,14 @@ struct LaunchPlan {
 bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16);
 int wide_build(npbnn_ctx* ctx, bool f16);
 void wide_free(npbnn_ctx* ctx);
-int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp);
+int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp, int want_cand = 1);
 void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, float* image, int* flags);
 // the forward pass + likelihood of the weights in `image` on the ctx stream; the launch's EvalParams must be in ctx->d_eparams.
 // chain_pass: a pass of a device chain (the kernels leave at once when the chain's batch is through; candidate slopes from the chain)
 // only_layer0: stop behind the first layer's product (timing hook); info: that product's geometry, or nullptr
-int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0 = false, int* info = nullptr);
+int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0 = false, int* info = nullptr, int n_cand = 1);
 int wide_cand_begin(npbnn_ctx* ctx);     // start of a chain batch: candidate image = committed image, nothing patched
-void wide_cand_sync(npbnn_ctx* ctx, int M);   // before a pass of a chain with wide proposals: candidate image = committed image + the pending proposal
+void wide_cand_sync(npbnn_ctx* ctx, int M, int n_cand);   // before a pass of a chain with wide proposals: candidate image = committed image + the pending proposal
 int ensure_conf(npbnn_ctx* ctx, int n_classes);
 // one evaluation launch of a plan on the ctx stream (resident: the plan's kernel; weight-streamed: wide_forward on the committed image)
 int launch_plain_eval(npbnn_ctx* ctx, const LaunchPlan& lp, int which);

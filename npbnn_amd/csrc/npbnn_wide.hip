@@ -15,19 +15,20 @@ namespace {
 // bytes a block reads per product fall with its size.
 struct GemmCfg {
     wide_gemm_fn_t f16, f32;
+    wide_gemm_fn_t f16_d2, f32_d2;   // the same tiling with two weight sets per pass (fused passes of a device chain), or nullptr
     int xt, wt;            // row tiles / output tiles of a workgroup
     int threads, ppw;      // LDS-DMA pieces a wave requests per K-unit
     int n_stage;           // stages of the ring
     int wc;                // waves along the outputs (1: every wave holds whole rows of the block - the fused end applies)
-    bool attr16 = false, attr32 = false;
+    bool attr16 = false, attr32 = false, attr16_d2 = false, attr32_d2 = false;
 };
 GemmCfg g_cfg[6] = {
-    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, 16, 16, 512, 8, 2, 4},    // 256 x 256: 64 KiB per stage
-    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
-    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
-    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
-    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
-    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
+    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, nullptr, nullptr, 16, 16, 512, 8, 2, 4},    // 256 x 256: 64 KiB per stage
+    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, nullptr, nullptr, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
+    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, wide_gemm_kernel<2, 4, 8, 1, true, 2>, wide_gemm_kernel<2, 4, 8, 1, false, 2>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
+    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, wide_gemm_kernel<2, 4, 4, 1, true, 2>, wide_gemm_kernel<2, 4, 4, 1, false, 2>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, wide_gemm_kernel<2, 2, 4, 1, true, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 2>, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
+    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, nullptr, nullptr, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
 };
 // the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)
 GemmCfg& cfg_for(int mt, int n_row_tiles, int n_cu) {
@@ -95,7 +96,8 @@ bool fused_pass(const npbnn_ctx* ctx, const Dataset& d, int* n_row_blocks, size_
     int tail_floats = 0;
     if (!tail_desc(ctx, 1, nullptr, false, 64 * 1024, &t, &tail_floats)) return false;
     const int ldz = ((m.n_out + 15) & ~15) + 1;
-    const size_t need = ((size_t)((tail_floats + 3) & ~3) + (size_t)(cf.threads / 64) * 16 * ldz) * 4;
+    const size_t need = ((size_t)kWideMaxCand * ((tail_floats + 3) & ~3) + (size_t)(cf.threads / 64) * 16 * ldz) * 4      // (room for two candidates' tails,
+                        + 16 + (size_t)(cf.threads / 64) * kPartialStride * 8;                                              //  the rows' scratch, the waves' sums)
     if (need > 150 * 1024) return false;
     *n_row_blocks = (d.n_tiles + cf.xt - 1) / cf.xt;
     *lds_need = need;
@@ -215,8 +217,8 @@ int wide_build(npbnn_ctx* ctx, bool f16) {
     wide_free(ctx);
     HIP_TRY(ctx, hipMalloc(&ctx->d_image, (size_t)m.image_floats * sizeof(float)));
     HIP_TRY(ctx, hipMemset(ctx->d_image, 0, (size_t)m.image_floats * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_wide_cand, (size_t)m.image_floats * sizeof(float)));
-    HIP_TRY(ctx, hipMemset(ctx->d_wide_cand, 0, (size_t)m.image_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_wide_cand, (size_t)kWideMaxCand * m.image_floats * sizeof(float)));      // (a candidate image per weight set of a pass)
+    HIP_TRY(ctx, hipMemset(ctx->d_wide_cand, 0, (size_t)kWideMaxCand * m.image_floats * sizeof(float)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_wide_cs, sizeof(WideCandState)));
     HIP_TRY(ctx, hipMemset(ctx->d_wide_cs, 0, sizeof(WideCandState)));
     std::vector<int> map((size_t)ctx->n_weights);
@@ -256,7 +258,7 @@ int wide_build(npbnn_ctx* ctx, bool f16) {
     return NPBNN_OK;
 }
 
-int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp) {
+int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp, int want_cand) {
     Dataset& d = ctx->ds[which];
     const WideMeta& m = ctx->wmeta;
     int max_ld = 16;
@@ -296,7 +298,7 @@ int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp) {
     }
     lp->fn = nullptr;
     lp->fn_spec = nullptr;
-    lp->n_cand = 1;
+    lp->n_cand = 1;            // (two for fused passes that asked for them: below)
     lp->wpb = 4;
     lp->lds = 0;
     lp->fast = false;
@@ -305,7 +307,13 @@ int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp) {
     if (grid < 1) grid = 1;
     int n_rb = 0;
     size_t fuse_lds = 0;
-    if (fused_pass(ctx, d, &n_rb, &fuse_lds)) grid = n_rb;        // (one partial record per row block of the first layer's product)
+    if (fused_pass(ctx, d, &n_rb, &fuse_lds)) {
+        grid = n_rb;        // (one partial record per row block of the first layer's product)
+        // two candidates per pass where the fused product has a build for them: its intake of X, not its arithmetic, bounds it
+        static const bool one = getenv("NPBNN_WIDE_ONE_CAND") != nullptr;
+        const GemmCfg& cf = cfg_for(m.L[0].mt, d.n_tiles, ctx->n_cu);
+        if (want_cand >= 2 && !one && cf.f16_d2 != nullptr && !ctx->slopes_option) lp->n_cand = 2;
+    }
     lp->grid = grid;             // workgroups that write a partial record each (wide_lik_kernel's, or the fused product's row blocks)
     lp->n_waves = grid;
     return NPBNN_OK;
@@ -317,7 +325,7 @@ void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, 
                        ctx->n_classw ? ctx->d_classw : nullptr, image, ctx->wmeta, ctx->wmeta.L[0].f16 ? ctx->d_wscale : nullptr, flags);
 }
 
-int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0, int* info) {
+int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0, int* info, int n_cand) {
     Dataset& d = ctx->ds[which];
     const WideMeta& m = ctx->wmeta;
     hipStream_t st = ctx->stream;
@@ -385,17 +393,24 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
             g.image = image;
             g.classw_off = m.classw_off;
             if (m.n_layers == 1) g.act_kind = -1;
+            g.cand_stride = m.image_floats;
+        } else if (n_cand > 1) {
+            return fail(ctx, NPBNN_E_STATE, "the weight-streamed path carries several candidates in fused passes only (internal error)");
         }
         int n_stage = stages_env() >= 2 ? stages_env() : cf.n_stage;
-        const int stage_bytes = (cf.xt + cf.wt) * 2048;
-        while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * cf.ppw > kWideMaxYounger)) --n_stage;
+        const int n_sets = (l == 0 && !only_layer0 && n_cand == 2) ? 2 : 1;
+        const int stage_bytes = (cf.xt + n_sets * cf.wt) * 2048;
+        const int ppw = 2 * (cf.xt + n_sets * cf.wt) / (cf.threads / 64);
+        while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * ppw > kWideMaxYounger)) --n_stage;
         if (n_stage > L.units + 1) n_stage = L.units + 1 < 2 ? 2 : L.units + 1;
         g.n_stage = n_stage;
         size_t lds = (size_t)n_stage * stage_bytes;
         if (fuse && fuse_lds > lds) lds = fuse_lds;
         const bool use16 = L.f16 != 0;
-        wide_gemm_fn_t fn = use16 ? cf.f16 : cf.f32;
-        bool& attr = use16 ? cf.attr16 : cf.attr32;
+        const bool two = fuse && n_cand == 2;
+        wide_gemm_fn_t fn = two ? (use16 ? cf.f16_d2 : cf.f32_d2) : (use16 ? cf.f16 : cf.f32);
+        bool& attr = two ? (use16 ? cf.attr16_d2 : cf.attr32_d2) : (use16 ? cf.attr16 : cf.attr32);
+        if (fn == nullptr) return fail(ctx, NPBNN_E_STATE, "no build of the weight-streamed product for this launch (internal error)");
         if (!attr) {         // (the largest ring any launch asks for: once per kernel)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_limit));
             attr = true;
@@ -434,17 +449,20 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
 }
 
 int wide_cand_begin(npbnn_ctx* ctx) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wide_cand, ctx->d_image, (size_t)ctx->wmeta.image_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int j = 0; j < kWideMaxCand; ++j)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wide_cand + (size_t)j * ctx->wmeta.image_floats, ctx->d_image, (size_t)ctx->wmeta.image_floats * sizeof(float),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_wide_cs, 0, sizeof(WideCandState), ctx->stream));
     return NPBNN_OK;
 }
 
 // before a chain pass whose proposals are too wide for the step to keep the candidate image itself (chain_prepare: ChainParams::cand_image unset)
-void wide_cand_sync(npbnn_ctx* ctx, int M) {
+void wide_cand_sync(npbnn_ctx* ctx, int M, int n_cand) {
     const unsigned grid = (unsigned)((M + 255) / 256);
-    hipLaunchKernelGGL(wide_cand_restore_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, (const WideCandState*)ctx->d_wide_cs,
-                       ctx->d_wide_cand, (const float*)ctx->d_image);
-    hipLaunchKernelGGL(wide_cand_apply_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand);
+    const long long stride = ctx->wmeta.image_floats;
+    hipLaunchKernelGGL(wide_cand_restore_kernel, dim3(grid, n_cand), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, (const WideCandState*)ctx->d_wide_cs,
+                       ctx->d_wide_cand, (const float*)ctx->d_image, stride);
+    hipLaunchKernelGGL(wide_cand_apply_kernel, dim3(grid, n_cand), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand, stride);
 }
 
 }  // namespace npbnn_api

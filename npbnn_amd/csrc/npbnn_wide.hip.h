@@ -160,12 +160,13 @@ struct WideTailDesc {
     const double* act_prm_dev;    // device chain with trainable slopes: the candidate's slopes of these layers, or nullptr
 };
 // the layers' fragments and biases into LDS (every thread of the workgroup; a barrier follows at the caller)
-__device__ __forceinline__ void wide_tail_stage(const WideTailDesc& t, float* lds, int tid, int n_threads) {
+__device__ __forceinline__ void wide_tail_stage(const WideTailDesc& t, float* lds, int tid, int n_threads, const float* image = nullptr) {
+    if (image == nullptr) image = t.image;
     for (int l = 0; l < t.n_layers; ++l) {
-        const f32x4* gf = reinterpret_cast<const f32x4*>(t.image + t.frag_off[l]);
+        const f32x4* gf = reinterpret_cast<const f32x4*>(image + t.frag_off[l]);
         f32x4* lf = reinterpret_cast<f32x4*>(lds + t.lds_frag[l]);
         for (int i = tid; i < t.frag_floats[l] / 4; i += n_threads) lf[i] = gf[i];
-        const f32x4* gb = reinterpret_cast<const f32x4*>(t.image + t.bias_off[l]);
+        const f32x4* gb = reinterpret_cast<const f32x4*>(image + t.bias_off[l]);
         f32x4* lb = reinterpret_cast<f32x4*>(lds + t.lds_bias[l]);
         for (int i = tid; i < 4 * t.mt[l]; i += n_threads) lb[i] = gb[i];
     }
@@ -387,7 +388,7 @@ __device__ __forceinline__ void wide_row_terms_lean(const EvalParams& p, const f
     }
 }
 template <typename ACC, int KT>
-__device__ __forceinline__ void wide_block_partials_t(const EvalParams& p, const ACC& A, double* red, int n_waves, int slot, int n_slots) {
+__device__ __forceinline__ void wide_block_partials_t(const EvalParams& p, const ACC& A, double* red, int n_waves, int slot, int n_slots, int cand = 0) {
     const int lik_kind = p.net.lik_kind, k = p.net.k_targets;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lik_kind == NPBNN_LIK_GAUSS) {
@@ -408,7 +409,7 @@ __device__ __forceinline__ void wide_block_partials_t(const EvalParams& p, const
         const int v = it <= k ? it : 1 + NPBNN_MAX_TARGETS + (it - k - 1);
         double s = 0.0;
         for (int w = 0; w < n_waves; ++w) s += red[w * kPartialStride + v];
-        p.partials[(size_t)v * n_slots + slot] = s;          // (candidate 0 of pass parity 0: [value][workgroup])
+        p.partials[((size_t)cand * kPartialStride + v) * n_slots + slot] = s;          // (pass parity 0: [candidate][value][workgroup])
     }
 }
 // one partial record per workgroup: lanes -> wave (fixed butterfly) -> workgroup (waves in order) -> partials[value][slot of n_slots]
@@ -450,6 +451,7 @@ struct WideGemmArgs {
     const EvalParams* p;
     const float* image;
     long long classw_off;
+    long long cand_stride;    // D > 1 (fused passes of a device chain): candidate j's weight image starts j * cand_stride floats behind W / bias / image
 };
 
 #define NPBNN_WVM_(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -469,15 +471,19 @@ constexpr int kWideMaxYounger = 48;
 constexpr int kWideMaxSlices = 8;    // K-slices a layer's contraction is cut into at most
 constexpr int kWideFlush = 8;        // K-units (256 columns) added up by the matrix cores before the sum joins the running total
 
-// RT x CT: 16 x 16 tiles a wave computes (rows x outputs); WR x WC: waves of the workgroup (rows x outputs); F16: fp16-split operands
-template <int RT, int CT, int WR, int WC, bool F16>
+// RT x CT: 16 x 16 tiles a wave computes (rows x outputs); WR x WC: waves of the workgroup (rows x outputs); F16: fp16-split operands;
+// D: weight sets multiplied against the SAME pieces of the rows (the candidates of a speculative chain pass - the resident path's
+// idea: narrow networks on many features are bound by the intake of X, so a second candidate's fragments cost a third more bytes and
+// no more time per row; fused passes only)
+template <int RT, int CT, int WR, int WC, bool F16, int D = 1>
 __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmArgs a) {
     constexpr int NW = WR * WC;
     constexpr int XT = WR * RT, WT = WC * CT;            // row tiles / output tiles of the workgroup
-    constexpr int PIECES = 2 * (XT + WT);                // 1-KiB LDS-DMA pieces per stage
+    constexpr int PIECES = 2 * (XT + D * WT);            // 1-KiB LDS-DMA pieces per stage
     static_assert(PIECES % NW == 0, "every wave requests the same number of pieces per unit");
+    static_assert(D == 1 || WC == 1, "several candidates: fused passes only (every wave holds whole rows)");
     constexpr int PPW = PIECES / NW;
-    constexpr int STAGE = (XT + WT) * 2048;
+    constexpr int STAGE = (XT + D * WT) * 2048;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (a.pass != nullptr) {
         const int n_cand = __builtin_amdgcn_readfirstlane(a.pass->n_cand);
@@ -524,17 +530,19 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
             half_x[i] = h;
         } else {
             const int q = p - 2 * XT;
-            const int c = q >> 1, h = q & 1;
+            const int jc = q / (2 * WT), qq = q % (2 * WT);       // candidate, piece of its fragments
+            const int c = qq >> 1, h = qq & 1;
             int mt = cb * WT + c;
             if (mt > a.mt_total - 1) mt = a.mt_total - 1;
+            const float* const Wj = a.W + (long long)jc * a.cand_stride;
             if constexpr (F16) {
-                src[i] = a.W + ((long long)mt * 2 + h) * 256 + lane * 4;
+                src[i] = Wj + ((long long)mt * 2 + h) * 256 + lane * 4;
                 ustride[i] = (long long)a.mt_total * 512;
             } else {
-                src[i] = a.W + ((long long)h * a.mt_total + mt) * 256 + lane * 4;
+                src[i] = Wj + ((long long)h * a.mt_total + mt) * 256 + lane * 4;
                 ustride[i] = (long long)a.mt_total * 512;
             }
-            lds_off[i] = XT * 2048 + c * 2048 + h * 1024;
+            lds_off[i] = XT * 2048 + (jc * WT + c) * 2048 + h * 1024;
             half_x[i] = 0;
         }
     }
@@ -554,21 +562,24 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
     // ---- two levels of float32 accumulation: the matrix cores add into `acc`, which is emptied into `tot` every kWideFlush units
     //      (a long contraction's rounding error grows with the length of ONE chain of additions: thousands of columns would
     //      otherwise cost the last layer's values a digit); `tot` starts from the bias ----
-    constexpr bool TWO = RT * CT <= 16 && NW <= 8;      // (the tilings of 32 tiles per wave have no registers for a second set: their long
+    constexpr bool TWO = D * RT * CT <= 16 && NW <= 8;      // (the tilings of 32 tiles per wave have no registers for a second set: their long
                                               // contractions are cut into K-slices, whose sums meet in wide_reduce_kernel)
-    f32x4 acc[RT][CT], tot[TWO ? RT : 1][TWO ? CT : 1];
+    f32x4 accs[D][RT][CT], tots[TWO ? D : 1][TWO ? RT : 1][TWO ? CT : 1];
+    auto& acc = accs[0];            // (the single weight set of the plain forms below)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        int mt = cb * WT + wc * CT + ct;
-        if (mt > a.mt_total - 1) mt = a.mt_total - 1;
-        f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + 16 * mt + 4 * kq);
-        if (slice > 0) b = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jc = 0; jc < D; ++jc)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if constexpr (TWO) { tot[rt][ct] = b; acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            else acc[rt][ct] = b;
+        for (int ct = 0; ct < CT; ++ct) {
+            int mt = cb * WT + wc * CT + ct;
+            if (mt > a.mt_total - 1) mt = a.mt_total - 1;
+            f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + (long long)jc * a.cand_stride + 16 * mt + 4 * kq);
+            if (slice > 0) b = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (TWO) { tots[jc][rt][ct] = b; accs[jc][rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                else accs[jc][rt][ct] = b;
+            }
         }
-    }
     int since_flush = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the bias loads: not counted with the pieces below)
 
@@ -591,17 +602,19 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
                 xl[rt] = *reinterpret_cast<const f16x8*>(px + 256);
             }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const char* pw = sb + XT * 2048 + (wc * CT + ct) * 2048 + lane * 16;
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(pw);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(pw + 1024);
+            for (int jc = 0; jc < D; ++jc)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[rt], acc[rt][ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const char* pw = sb + XT * 2048 + (jc * WT + wc * CT + ct) * 2048 + lane * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(pw);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(pw + 1024);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[rt], acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) accs[jc][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[rt], accs[jc][rt][ct], 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[rt], acc[rt][ct], 0, 0, 0);
-            }
+                    for (int rt = 0; rt < RT; ++rt) accs[jc][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[rt], accs[jc][rt][ct], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) accs[jc][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[rt], accs[jc][rt][ct], 0, 0, 0);
+                }
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -609,31 +622,37 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const f32x4*>(sb + (wr * RT + rt) * 2048 + h * 1024 + lane * 16);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sb + XT * 2048 + (wc * CT + ct) * 2048 + h * 1024 + lane * 16);
+                for (int jc = 0; jc < D; ++jc)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(sb + XT * 2048 + (jc * WT + wc * CT + ct) * 2048 + h * 1024 + lane * 16);
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], x[rt][s], acc[rt][ct], 0, 0, 0);
-                }
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) accs[jc][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], x[rt][s], accs[jc][rt][ct], 0, 0, 0);
+                    }
             }
         }
         if constexpr (TWO) {
             if (++since_flush == kWideFlush) {
                 since_flush = 0;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int jc = 0; jc < D; ++jc)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) { tot[rt][ct] += acc[rt][ct]; acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) { tots[jc][rt][ct] += accs[jc][rt][ct]; accs[jc][rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
         }
     }
 
     if constexpr (TWO) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int jc = 0; jc < D; ++jc)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += tot[rt][ct];
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) accs[jc][rt][ct] += tots[jc][rt][ct];
     }
     // ---- activation, store: lane (n, kq) holds the units 4 kq .. 4 kq + 3 of a tile for row n ----
     float prm = a.act_prm;
@@ -644,55 +663,68 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
             // free: every wave is through with the last unit after the barrier), the rows' values through a per-wave LDS scratch to one
             // lane per row for the likelihood terms
             const EvalParams& p = *a.p;
-            WideRowAux aux[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const long long row = ((long long)(rb * XT + wr * RT + rt)) * 16 + lane;
-                aux[rt] = wide_row_aux(p, row, lane < 16 && row < p.n_rows);
-            }
             __syncthreads();
             float* const lds = reinterpret_cast<float*>(smem);
-            wide_tail_stage(a.tail, lds, tid, NW * 64);
+            int tail_floats = 0;
+            if (a.tail.n_layers > 0) tail_floats = a.tail.lds_bias[a.tail.n_layers - 1] + 16 * a.tail.mt[a.tail.n_layers - 1];
+            const int tail_pad = (tail_floats + 3) & ~3;
+            for (int jc = 0; jc < D; ++jc) wide_tail_stage(a.tail, lds + jc * tail_pad, tid, NW * 64, a.tail.image + (long long)jc * a.cand_stride);
             __syncthreads();
             const int C = p.net.n_out;
             const int ldz = ((C + 15) & ~15) + 1;            // (odd: the 16 lanes that each read one row of the scratch hit 16 banks)
-            int tail_floats = 0;
-            if (a.tail.n_layers > 0) tail_floats = a.tail.lds_bias[a.tail.n_layers - 1] + 16 * a.tail.mt[a.tail.n_layers - 1];
-            float* const zs = lds + ((tail_floats + 3) & ~3) + wave * 16 * ldz;
-            WideRowAccLean A;
-            A.ll = 0.0;
-#pragma unroll
-            for (int j = 0; j < kFuseTargets; ++j) { A.s1[j] = 0.0; A.s2[j] = 0.0; }
+            float* const zs = lds + D * tail_pad + wave * 16 * ldz;
+            double* const red = reinterpret_cast<double*>(zs + (NW - wave) * 16 * ldz + 4);      // (behind every wave's scratch, 8-byte aligned below)
+            double* const red8 = reinterpret_cast<double*>((reinterpret_cast<size_t>(red) + 7) & ~(size_t)7);
             const float fprm = p.net.act_prm[p.net.n_layers - 1];
+            // ONE copy of the tail and the row terms in the code, run per (candidate, row tile): the tile's accumulators are picked by a
+            // switch with constant indices in every case (a run-time index into the register arrays would put them in scratch, and the
+            // body unrolled D x RT times is tens of thousands of instructions)
+#pragma unroll 1
+            for (int jc = 0; jc < D; ++jc) {
+                WideRowAccLean A;
+                A.ll = 0.0;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int T = rb * XT + wr * RT + rt;
-                if (T >= a.n_row_tiles) continue;
-                f32x4 h[kTailIn];
+                for (int j = 0; j < kFuseTargets; ++j) { A.s1[j] = 0.0; A.s2[j] = 0.0; }
+#pragma unroll 1
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int T = rb * XT + wr * RT + rt;
+                    if (T >= a.n_row_tiles) continue;
+                    const long long row = (long long)T * 16 + lane;
+                    const WideRowAux aux = wide_row_aux(p, row, lane < 16 && row < p.n_rows);      // (requested ahead of the tail's arithmetic)
+                    f32x4 h[kTailIn];
 #pragma unroll
-                for (int ct = 0; ct < kTailIn; ++ct) {
-                    h[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ct < CT && ct < a.mt_total) {
-                        h[ct] = acc[rt][ct < CT ? ct : 0];
-                        if (a.act_kind >= 0) {
+                    for (int ct = 0; ct < kTailIn; ++ct) h[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int item = jc * RT + rt;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) h[ct][i] = act_apply(h[ct][i], a.act_kind, prm);
+                    for (int q = 0; q < D * RT; ++q)
+                        if (item == q) {
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) h[ct] = accs[q / RT][q % RT][ct];
                         }
-                    }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        if (ct < a.mt_total) {
+                            if (a.act_kind >= 0) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) h[ct][i] = act_apply(h[ct][i], a.act_kind, prm);
+                            }
+                        } else {
+                            h[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    const int mt_last = wide_tail_layers(a.tail, lds + jc * tail_pad, h, a.mt_total, lane, kq);
+#pragma unroll
+                    for (int mt = 0; mt < kTailOut; ++mt)
+                        if (mt < mt_last) {                                  // (the odd row stride leaves no 16-byte alignment: dword stores)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) zs[n * ldz + 16 * mt + 4 * kq + i] = h[mt][i];
+                        }
+                    if (lane < 16 && row < p.n_rows)
+                        wide_row_terms_lean(p, zs + lane * ldz, row, a.image + (long long)jc * a.cand_stride, a.classw_off, fprm, aux, A);
                 }
-                const int mt_last = wide_tail_layers(a.tail, lds, h, a.mt_total, lane, kq);
-#pragma unroll
-                for (int mt = 0; mt < kTailOut; ++mt)
-                    if (mt < mt_last) {                                  // (the odd row stride leaves no 16-byte alignment: dword stores)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) zs[n * ldz + 16 * mt + 4 * kq + i] = h[mt][i];
-                    }
-                const long long row = (long long)T * 16 + lane;
-                if (lane < 16 && row < p.n_rows) wide_row_terms_lean(p, zs + lane * ldz, row, a.image, a.classw_off, fprm, aux[rt], A);
-            }
-            if (p.partials != nullptr) {
-                __syncthreads();                                  // (every wave is through with the tail weights' neighbours: the sums go where they sat)
-                wide_block_partials_t<WideRowAccLean, kFuseTargets>(p, A, reinterpret_cast<double*>(smem), NW, rb, a.n_row_blocks);
+                if (p.partials != nullptr) {
+                    __syncthreads();                              // (the sums' scratch: free of the candidate before)
+                    wide_block_partials_t<WideRowAccLean, kFuseTargets>(p, A, red8, NW, rb, a.n_row_blocks, jc);
+                }
             }
             return;
         }
@@ -716,7 +748,7 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
 }
 
 typedef void (*wide_gemm_fn_t)(const WideGemmArgs);
-struct WideCandState { int prev_t0, prev_cnt; };      // entries the candidate image's last patch covered (wide_cand_*_kernel)
+struct WideCandState { int prev_t0, prev_n, prev_cnt[kMaxCand]; };      // what the candidate images' last patches covered (wide_cand_*_kernel)
 
 #ifdef NPBNN_KERNELS_WIDE
 // the K-slices' sums of a layer, added in slice order (fixed: the same bits every run), then the activation
@@ -842,21 +874,31 @@ __global__ void __launch_bounds__(256) wide_lik_kernel(const WideLikArgs a) {
 // between the step and the pass: the entries the pass before had patched go back to the committed image's values (which hold the
 // accepted proposal, if it was accepted), then the pending proposal's entries are patched in.
 // ------------------------------------------------------------------------------------------------
+// grid.y = candidate image; the entries every candidate of the pass before had patched go back to the committed image's values in ALL
+// of them (an accepted candidate's entries changed the committed image: the others take them over here)
 __global__ void __launch_bounds__(256) wide_cand_restore_kernel(const ChainParams* __restrict__ cp, const WideCandState* __restrict__ st, float* __restrict__ cand,
-                                                                const float* __restrict__ image) {
+                                                                const float* __restrict__ image, long long cand_stride) {
     const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (e >= st->prev_cnt) return;
-    restore_image_entry(cand, image, cp->pos[(size_t)st->prev_t0 * cp->M + e]);
+    float* const mine = cand + (long long)blockIdx.y * cand_stride;
+    const int n_old = st->prev_n;
+    for (int j = 0; j < n_old; ++j)
+        if (e < st->prev_cnt[j]) restore_image_entry(mine, image, cp->pos[(size_t)(st->prev_t0 + j) * cp->M + e]);
 }
-__global__ void __launch_bounds__(256) wide_cand_apply_kernel(const ChainParams* __restrict__ cp, WideCandState* __restrict__ st, float* __restrict__ cand) {
+// grid.y = candidate j of the pending pass: its proposal's entries patched into its image
+__global__ void __launch_bounds__(256) wide_cand_apply_kernel(const ChainParams* __restrict__ cp, WideCandState* __restrict__ st, float* __restrict__ cand,
+                                                              long long cand_stride) {
     const ChainParams& c = *cp;
     const PassDesc d = c.pass[0];
-    const int cnt = d.n_cand > 0 ? d.cnt[0] : 0;
+    const int j = (int)blockIdx.y;
+    const int cnt = j < d.n_cand ? d.cnt[j] : 0;
     const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (e == 0) { st->prev_t0 = d.t0; st->prev_cnt = cnt; }      // (read by the NEXT restore launch only)
+    if (e == 0) {                                           // (read by the NEXT restore launch only)
+        if (j == 0) { st->prev_t0 = d.t0; st->prev_n = d.n_cand; }
+        st->prev_cnt[j] = cnt;
+    }
     if (e >= cnt) return;
-    const size_t k = (size_t)d.t0 * c.M + e;
-    patch_image(cand, c.pos[k], c.pscale ? c.pscale[k] : 1.0f, c.pv[e], 16);
+    const size_t k = (size_t)(d.t0 + j) * c.M + e;
+    patch_image(cand + (long long)j * cand_stride, c.pos[k], c.pscale ? c.pscale[k] : 1.0f, c.pv[(size_t)j * c.M + e], 16);
 }
 #endif  // NPBNN_KERNELS_WIDE
 

@@ -243,7 +243,7 @@ constexpr int kTurnForcedProbeBatches = 200;    // ... or whatever the model say
 constexpr int kTurnFirstProbeBatches = 4;       // batches on one persistent form before the other, never measured, is given one
 constexpr int kTurnReprobeBatches = 48;         // batches on one persistent form before the other's measured turn time is refreshed
 constexpr int kPersistSerialMaxWidth = 640;     // ... and the widest proposal (weights perturbed per iteration) it is picked for
-constexpr int kWideMaxCand = 2;                // weight sets a fused pass of the weight-streamed path carries at most
+constexpr int kWideMaxCand = 3;                // weight sets a fused pass of the weight-streamed path carries at most
 constexpr int kMinResidentWaves = 4;           // fewer waves than this beside the weight image: the network runs on the weight-streamed path
 constexpr int kWideStepPatchMax = 2048;      // widest proposal whose candidate image the step workgroup keeps by itself (weight-streamed path)
 constexpr size_t kChainMinCapacity = 2048;    // iterations the per-batch chain buffers are sized for at least (allocation is slow)

@@ -16,19 +16,20 @@ namespace {
 struct GemmCfg {
     wide_gemm_fn_t f16, f32;
     wide_gemm_fn_t f16_d2, f32_d2;   // the same tiling with two weight sets per pass (fused passes of a device chain), or nullptr
+    wide_gemm_fn_t f16_d3, f32_d3;   // ... with three
     int xt, wt;            // row tiles / output tiles of a workgroup
     int threads, ppw;      // LDS-DMA pieces a wave requests per K-unit
     int n_stage;           // stages of the ring
     int wc;                // waves along the outputs (1: every wave holds whole rows of the block - the fused end applies)
-    bool attr16 = false, attr32 = false, attr16_d2 = false, attr32_d2 = false;
+    bool attr16 = false, attr32 = false, attr16_d2 = false, attr32_d2 = false, attr16_d3 = false, attr32_d3 = false;
 };
 GemmCfg g_cfg[6] = {
-    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, nullptr, nullptr, 16, 16, 512, 8, 2, 4},    // 256 x 256: 64 KiB per stage
-    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, nullptr, nullptr, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
-    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, wide_gemm_kernel<2, 4, 8, 1, true, 2>, wide_gemm_kernel<2, 4, 8, 1, false, 2>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
-    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, wide_gemm_kernel<2, 4, 4, 1, true, 2>, wide_gemm_kernel<2, 4, 4, 1, false, 2>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
-    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, wide_gemm_kernel<2, 2, 4, 1, true, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 2>, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
-    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, nullptr, nullptr, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
+    {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, nullptr, nullptr, nullptr, nullptr, 16, 16, 512, 8, 2, 4},    // 256 x 256: 64 KiB per stage
+    {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, nullptr, nullptr, nullptr, nullptr, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
+    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, wide_gemm_kernel<2, 4, 8, 1, true, 2>, wide_gemm_kernel<2, 4, 8, 1, false, 2>, wide_gemm_kernel<2, 4, 8, 1, true, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 3>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
+    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, wide_gemm_kernel<2, 4, 4, 1, true, 2>, wide_gemm_kernel<2, 4, 4, 1, false, 2>, wide_gemm_kernel<2, 4, 4, 1, true, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 3>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, wide_gemm_kernel<2, 2, 4, 1, true, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 2>, nullptr, nullptr, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
+    {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, nullptr, nullptr, nullptr, nullptr, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
 };
 // the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)
 GemmCfg& cfg_for(int mt, int n_row_tiles, int n_cu) {
@@ -313,6 +314,8 @@ int wide_plan(npbnn_ctx* ctx, int which, LaunchPlan* lp, int want_cand) {
         static const bool one = getenv("NPBNN_WIDE_ONE_CAND") != nullptr;
         const GemmCfg& cf = cfg_for(m.L[0].mt, d.n_tiles, ctx->n_cu);
         if (want_cand >= 2 && !one && cf.f16_d2 != nullptr && !ctx->slopes_option) lp->n_cand = 2;
+        static const int cap = getenv("NPBNN_WIDE_MAX_CAND") ? atoi(getenv("NPBNN_WIDE_MAX_CAND")) : kWideMaxCand;
+        if (want_cand >= 3 && !one && cf.f16_d3 != nullptr && !ctx->slopes_option && cap >= 3) lp->n_cand = 3;
     }
     lp->grid = grid;             // workgroups that write a partial record each (wide_lik_kernel's, or the fused product's row blocks)
     lp->n_waves = grid;
@@ -398,7 +401,7 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
             return fail(ctx, NPBNN_E_STATE, "the weight-streamed path carries several candidates in fused passes only (internal error)");
         }
         int n_stage = stages_env() >= 2 ? stages_env() : cf.n_stage;
-        const int n_sets = (l == 0 && !only_layer0 && n_cand == 2) ? 2 : 1;
+        const int n_sets = (l == 0 && !only_layer0 && n_cand > 1) ? n_cand : 1;
         const int stage_bytes = (cf.xt + n_sets * cf.wt) * 2048;
         const int ppw = 2 * (cf.xt + n_sets * cf.wt) / (cf.threads / 64);
         while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * ppw > kWideMaxYounger)) --n_stage;
@@ -407,9 +410,9 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
         size_t lds = (size_t)n_stage * stage_bytes;
         if (fuse && fuse_lds > lds) lds = fuse_lds;
         const bool use16 = L.f16 != 0;
-        const bool two = fuse && n_cand == 2;
-        wide_gemm_fn_t fn = two ? (use16 ? cf.f16_d2 : cf.f32_d2) : (use16 ? cf.f16 : cf.f32);
-        bool& attr = two ? (use16 ? cf.attr16_d2 : cf.attr32_d2) : (use16 ? cf.attr16 : cf.attr32);
+        const int sets = fuse ? n_cand : 1;
+        wide_gemm_fn_t fn = sets == 3 ? (use16 ? cf.f16_d3 : cf.f32_d3) : sets == 2 ? (use16 ? cf.f16_d2 : cf.f32_d2) : (use16 ? cf.f16 : cf.f32);
+        bool& attr = sets == 3 ? (use16 ? cf.attr16_d3 : cf.attr32_d3) : sets == 2 ? (use16 ? cf.attr16_d2 : cf.attr32_d2) : (use16 ? cf.attr16 : cf.attr32);
         if (fn == nullptr) return fail(ctx, NPBNN_E_STATE, "no build of the weight-streamed product for this launch (internal error)");
         if (!attr) {         // (the largest ring any launch asks for: once per kernel)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_limit));

@@ -615,6 +615,46 @@ def wide_config(args):
     return out
 
 
+def wide_fused_config(args):
+    """The reference's default network on a thousand features: the weight-streamed path's fused passes (one launch per pass, up to three
+    candidates per read of X).  Bound by the intake of X: priced against the HBM peak like the resident kernels."""
+    from bench_support import workload
+    _drop_the_last_leg()
+    wl = workload(8)
+    bnn, mcmc = wl.build()
+    ctx = mcmc._backend.ctx
+    spin_up(mcmc, bnn)
+    for _ in range(args.warmup):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    book = dict(passes=mcmc._device_passes, its=mcmc._device_iterations, acc=mcmc._device_accepted)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mcmc.run_steps(bnn, ITERATIONS_PER_STEP)
+    el = time.perf_counter() - t0
+    done = mcmc._device_iterations - book["its"]
+    passes = max(1, mcmc._device_passes - book["passes"])
+    ms_pass, cand = ctx.time_pass(bnn._w_layers, n_candidates=mcmc.n_candidates, iters=200)
+    ms_one, _ = ctx.time_pass(bnn._w_layers, n_candidates=1, iters=200)
+    t0 = time.perf_counter()
+    mcmc.run_steps(bnn, 2000)
+    one_call = 2000 / (time.perf_counter() - t0)
+    out = {"workload": wl.description, "path": "weight-streamed" if ctx.is_wide() else "resident", "layer0": ctx.l0_mode(),
+           "value": args.steps * ITERATIONS_PER_STEP / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / args.steps, "one_call_of_2000": one_call,
+           "candidates_per_pass": cand, "iterations_per_pass": done / passes, "accept_rate": float(mcmc._device_accepted - book["acc"]) / max(1, done),
+           "schedule": int(mcmc._device_schedule_used),
+           "roofline": {"bound": "hbm", "kernel": "wide_gemm_kernel<2,4,8,1,%s,D=%d> (fused pass: product + narrow layers + likelihood)" % ("fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand),
+                        "kernel_ms": ms_pass, "achieved": wl.bytes_per_proposal / (ms_pass * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": wl.bytes_per_proposal / (ms_pass * 1e-3) / HBM_PEAK, "traffic": None,
+                        "single_candidate_kernel_ms": ms_one, "single_candidate_frac": wl.bytes_per_proposal / (ms_one * 1e-3) / HBM_PEAK,
+                        "note": "achieved = one read of X (algorithmic bytes of a proposal) / the pass's duration: %d candidates share that read" % cand,
+                        "roofline_it_per_s_one_read_per_proposal": HBM_PEAK / wl.bytes_per_proposal},
+           "parity": wl.parity(bnn, mcmc)}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, budget_s=5.0)
+    mcmc._backend.close()
+    return out
+
+
 def recorded_wide_counters():
     """What the rocprofv3 --pmc passes under profiles/ recorded for the first layer's product of the wide leg (a RECORDED measurement of
     the round the file name carries): HBM bytes per launch and the share of its cycles the matrix cores were busy."""
@@ -787,7 +827,8 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                     line["other_configs"][name] = other_config(args, cfg)
                 except Exception as e:        # noqa: BLE001 - the headline must not be lost to a side measurement
                     line["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
-            for name, leg in (("wide", lambda: wide_config(args)), ("group_pass", group_pass_leg)):
+            for name, leg in (("wide", lambda: wide_config(args)), ("default network on 1024 features", lambda: wide_fused_config(args)),
+                              ("group_pass", group_pass_leg)):
                 try:
                     line["other_configs"][name] = leg()
                 except Exception as e:        # noqa: BLE001

@@ -234,8 +234,44 @@ class WideNetwork(Workload):
                     tolerance="1e-4 relative (BASELINE.json)")
 
 
+class DefaultNetworkManyFeatures(Workload):
+    """The reference's DEFAULT model (npBNN(n_nodes=[50, 5]), ReLU, bias 1; np_bnn/BNN_env.py:20-23) on 100k x 1024 features: its
+    weight image (52 x 1024 x 4 B) no longer fits a compute unit's LDS - the weight-streamed path with its fused passes (the first
+    layer's product takes the narrow end of the network and the likelihood along, up to three candidates per read of X)."""
+    config = 8
+    n, f, c, hidden = 100_000, 1024, 10, [50, 5]
+    short = "default network on 1024 features (100k x 1024, [50,5])"
+    description = "weight-streamed path, fused passes: 100k x 1024 features, 10 classes, the reference's default network [50,5], ReLU, bias 1"
+
+    def __init__(self):
+        rs = np.random.default_rng(0)
+        self.x = rs.standard_normal((self.n, self.f)).astype(np.float32)
+        self.y = rs.integers(0, self.c, self.n)
+        self.bytes_per_proposal = 4.0 * self.n * self.f + 4.0 * self.n
+        self.flops_layer0 = 2.0 * self.n * self.f * self.hidden[0]
+
+    def build(self, mcmc_id=0, temperature=1.0, randomize_seed=False, **sampler_kw):
+        dat = dict(data=self.x, labels=self.y, test_data=np.zeros((0, self.f)), test_labels=np.zeros(0))
+        np.random.seed(1234)
+        bnn = _quiet(bn.npBNN, dat)
+        return bnn, bn.MCMC(bnn, temperature=temperature, mcmc_id=mcmc_id, randomize_seed=randomize_seed, **sampler_kw)
+
+    def oracle_chain(self, orc):
+        np.random.seed(1234)
+        return orc.make_chain(self.x.astype(np.float64), self.y, self.hidden, act=orc.Act("ReLU"), use_bias_node=1, prior_kind=1, p_scale=1)
+
+    def parity(self, bnn, mcmc):
+        import oracle as orc
+        w = [np.array(v, dtype=np.float64) for v in bnn._w_layers]
+        pred = orc.forward(self.x.astype(np.float64), w, orc.Act("ReLU"), orc.out_softmax)
+        ll = orc.lik_categorical(pred, self.y, np.arange(self.n))
+        dev = mcmc._backend.evaluate(bnn._w_layers, None)["loglik"]
+        return dict(loglik_oracle=float(ll), loglik_device=float(dev), loglik_rel_err=float(abs(dev - ll) / abs(ll)),
+                    chain_loglik_rel_err=float(abs(mcmc._logLik - ll) / abs(ll)), tolerance="1e-4 relative (BASELINE.json)")
+
+
 def workload(config):
-    return {2: Config2, 4: Config4, 5: Config5, 0: DefaultNetwork, 9: WideNetwork}[config]()
+    return {2: Config2, 4: Config4, 5: Config5, 0: DefaultNetwork, 9: WideNetwork, 8: DefaultNetworkManyFeatures}[config]()
 
 
 def build_config2(x, y, hidden, mcmc_id=0, temperature=1.0, randomize_seed=False):

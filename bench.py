@@ -558,6 +558,7 @@ def other_config(args, config):
            "ms_per_step": 1e3 * el / args.steps, "roofline_it_per_s_one_read_per_proposal": HBM_PEAK / wl.bytes_per_proposal,
            "accept_rate": acc_rate, "iterations_per_pass": done / passes,
            "schedule": int(mcmc._device_schedule_used), "candidates_per_pass": cand, "layer0": mcmc._backend.ctx.l0_mode(),
+           "fp16_columns_with_moved_scale": list(mcmc._backend.ctx.f16_moved_columns()),
            "roofline": roof, "parity": wl.parity(bnn, mcmc), "one_call_of_4000": one_call,
            "ms_per_step_median": 1e3 * sorted(per_step)[len(per_step) // 2], "ms_slowest_step": 1e3 * max(per_step),
            "slowest_step_index": per_step.index(max(per_step))}
@@ -827,6 +828,12 @@ def report(args, wl, bnn, mcmc, world, el, its, book, comm_kind, nranks_seen, de
                     line["other_configs"][name] = other_config(args, cfg)
                 except Exception as e:        # noqa: BLE001 - the headline must not be lost to a side measurement
                     line["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:       # heavy-tailed features stay on the fp16 pair
+                leg = other_config(args, 12)
+                leg.pop("moving_chain", None)
+                line["other_configs"]["config 2 on log-normal features"] = leg
+            except Exception as e:        # noqa: BLE001
+                line["other_configs"]["config 2 on log-normal features"] = {"error": "%s: %s" % (type(e).__name__, e)}
             for name, leg in (("wide", lambda: wide_config(args)), ("default network on 1024 features", lambda: wide_fused_config(args)),
                               ("group_pass", group_pass_leg)):
                 try:

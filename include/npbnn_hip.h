@@ -160,7 +160,11 @@ int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
  * weights would leave a compute unit's LDS fewer than 8 waves beside them (the reference's default n_nodes = [50, 5], np_bnn/BNN_env.py:20,
  * from ~550 features on; MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape): every layer is then a tiled matrix product
  * whose operands both stream through LDS, weights from a resident image in HBM, one weight set per pass.  1 = every network runs on it
- * (A/B timing, tests).  NPBNN_INFO_WIDE: 1 when the architecture set last runs on it. */
+ * (A/B timing, tests).  NPBNN_INFO_WIDE: 1 when the architecture set last runs on it.
+ * NPBNN_INFO_F16_MOVED_COLUMNS / _F16_MAX_MOVE: the fp16-split copy scales every column by a power of two taken from its largest entry;
+ * heavy-tailed columns (typical entries many powers of two below the largest) get that scale moved up so that the pair keeps their
+ * typical entries (the largest entry then lies below 2^move instead of below 1; the weights' scale moves the other way): how many
+ * columns of the training matrix were moved, and the largest move in powers of two (<= 12).  Valid once a launch has built the copy. */
 enum { NPBNN_OPT_L0_PRECISION = 1, NPBNN_OPT_FAST_TAILS = 2, NPBNN_OPT_PERSISTENT = 3, NPBNN_OPT_TRAINABLE_SLOPES = 4, NPBNN_OPT_WIDE = 5 };
 enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
 /* NPBNN_INFO_TURN_NS_OVERLAPPED / _BETWEEN: what NPBNN_SCHED_AUTO last measured for one launch turn (a pass, decided or void) of the
@@ -171,7 +175,8 @@ enum { NPBNN_L0_AUTO = 0, NPBNN_L0_F32 = 1, NPBNN_L0_F16 = 2 };
  * candidates of a speculative chain pass, the chains of a group pass (npbnn_chains_run_batched), the sets of npbnn_predict_sets. */
 enum { NPBNN_INFO_L0_F16 = 1, NPBNN_INFO_WAVES_PER_BLOCK = 2, NPBNN_INFO_N_CU = 3, NPBNN_INFO_FAST_TAILS = 4,
        NPBNN_INFO_TURN_NS_OVERLAPPED = 5, NPBNN_INFO_TURN_NS_BETWEEN = 6, NPBNN_INFO_MAX_CANDIDATES = 7,
-       NPBNN_INFO_IT_NS_OVERLAPPED = 8, NPBNN_INFO_IT_NS_BETWEEN = 9, NPBNN_INFO_WIDE = 10 };
+       NPBNN_INFO_IT_NS_OVERLAPPED = 8, NPBNN_INFO_IT_NS_BETWEEN = 9, NPBNN_INFO_WIDE = 10,
+       NPBNN_INFO_F16_MOVED_COLUMNS = 11, NPBNN_INFO_F16_MAX_MOVE = 12 };
 int npbnn_set_option(npbnn_ctx* ctx, int option, int value);
 int npbnn_get_info(npbnn_ctx* ctx, int what, int* out);
 

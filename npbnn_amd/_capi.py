@@ -29,6 +29,7 @@ L0_AUTO, L0_F32, L0_F16 = 0, 1, 2
 INFO_L0_F16, INFO_WAVES_PER_BLOCK, INFO_N_CU, INFO_FAST_TAILS, INFO_TURN_NS_OVERLAPPED, INFO_TURN_NS_BETWEEN, INFO_MAX_CANDIDATES = 1, 2, 3, 4, 5, 6, 7
 INFO_IT_NS_OVERLAPPED, INFO_IT_NS_BETWEEN = 8, 9
 INFO_WIDE = 10
+INFO_F16_MOVED_COLUMNS, INFO_F16_MAX_MOVE = 11, 12
 E_RANGE = -6
 E_SYNC = -7
 

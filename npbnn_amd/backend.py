@@ -139,6 +139,10 @@ class HipContext:
         """Does the architecture set last run on the weight-streamed path?"""
         return bool(self.info(capi.INFO_WIDE))
 
+    def f16_moved_columns(self):
+        """(columns of the training matrix whose fp16 scale was moved up because of heavy tails, largest move in powers of two)."""
+        return self.info(capi.INFO_F16_MOVED_COLUMNS), self.info(capi.INFO_F16_MAX_MOVE)
+
     def set_persistent(self, on):
         """May the library pick the persistent form of the overlapped chain schedule by itself (default on)?"""
         self._chk(self._lib.npbnn_set_option(self._ctx, capi.OPT_PERSISTENT, 1 if on else 0))

@@ -281,6 +281,40 @@ eval_fn_t pick_kernel(const NetMeta& net, int n_cand) {
     return npbnn_pick_eval_kernel(net.L[0].mt, max_inner_tiles(net) == 1 ? 1 : 8, net.l0_f16, n_cand, lik_class(net.lik_kind));
 }
 
+// Per column of a resident matrix under the context's scales (split_quality_kernel): how far the fp16 pair's largest counted entry
+// error is from its bounds - max(error / (2^-17 x mean |entry|), error / (2^-12 x typical |entry|)); <= 1 passes, 0 for an exact column.
+static int column_quality(npbnn_ctx* ctx, const Dataset& d, std::vector<double>* badness) {
+    const int Fq = d.Fp;
+    unsigned* d_err = nullptr;
+    unsigned long long* d_sum = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_err, (size_t)Fq * sizeof(unsigned)));
+    HIP_TRY(ctx, hipMalloc(&d_sum, (size_t)Fq * 3 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(d_err, 0, (size_t)Fq * sizeof(unsigned), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, (size_t)Fq * 3 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(split_quality_kernel, dim3((Fq + 255) / 256, (unsigned)((d.n_rows + 1023) / 1024)), dim3(256), 0, ctx->stream,
+                       (const float*)d.X, (long long)d.n_rows, d.Fp, (const float*)ctx->d_xscale, d_err, d_sum, d_sum + Fq, d_sum + 2 * (size_t)Fq);
+    std::vector<unsigned> h_err((size_t)Fq);
+    std::vector<unsigned long long> h_sum((size_t)Fq * 3);
+    HIP_TRY(ctx, hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_err);
+    (void)hipFree(d_sum);
+    badness->assign((size_t)d.F, 0.0);
+    for (int c = 0; c < d.F; ++c) {
+        float e;
+        memcpy(&e, &h_err[(size_t)c], 4);
+        const unsigned long long cnt = h_sum[2 * (size_t)Fq + c];
+        if (cnt == 0 || !(e > 0.f)) continue;                 // an all-zero column, or one the pair holds exactly
+        const double mean_abs = (double)h_sum[(size_t)c] / 268435456.0 / (double)d.n_rows;
+        const double typical = std::exp2((double)(long long)h_sum[(size_t)Fq + c] / 65536.0 / (double)cnt);
+        const double by_mean = mean_abs > 0.0 ? (double)e / mean_abs / (double)kF16QualityTol : 1e300;
+        const double by_typical = (double)e / typical / (double)kF16TypicalTol;
+        (*badness)[(size_t)c] = by_mean > by_typical ? by_mean : by_typical;
+    }
+    return NPBNN_OK;
+}
+
 // ---- fp16-split data: scales from the training matrix, split copies built on the device ----
 int ensure_scales(npbnn_ctx* ctx) {
     Dataset& tr = ctx->ds[0];
@@ -296,18 +330,47 @@ int ensure_scales(npbnn_ctx* ctx) {
     if (!ctx->d_xscale) HIP_TRY(ctx, hipMalloc(&ctx->d_xscale, (size_t)Fp16 * sizeof(float)));
     if (!ctx->d_wscale) HIP_TRY(ctx, hipMalloc(&ctx->d_wscale, (size_t)Fp16 * sizeof(float)));
     hipLaunchKernelGGL(col_scale_kernel, dim3((Fp16 + 255) / 256), dim3(256), 0, ctx->stream, d_max, Fp16, ctx->d_xscale,
-                       ctx->d_wscale);
+                       ctx->d_wscale, (const int*)nullptr);
     std::vector<unsigned> h((size_t)Fp16);
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_max, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_max);
     ctx->scale_F = tr.F;
+    ctx->f16_shifted_cols = 0;
+    ctx->f16_max_shift = 0;
     tr.f16_state = 0;
     for (unsigned bits : h) {
         float m;
         memcpy(&m, &bits, 4);
         if (!std::isfinite(m)) tr.f16_state = -1;     // inf / NaN in the data: stay on the exact float32 path
     }
+    // Heavy-tailed columns: with the largest entry just under 1 the typical entries sit where the pair's absolute error floor
+    // (2^-25) is a visible fraction of them.  Such a column's scale moves up by the power of two that brings its error / typical |value|
+    // under the bound with a factor 2 to spare (the fp16 range above 1 is otherwise unused); the weights' scale moves down with it.
+    // Columns inside the bound keep the scale they always had.
+    if (tr.f16_state == 0 && !getenv("NPBNN_F16_NO_SHIFT")) {
+        std::vector<double> ratio;
+        int rcq = column_quality(ctx, tr, &ratio);
+        if (rcq) { (void)hipFree(d_max); return rcq; }
+        std::vector<int> shift((size_t)Fp16, 0);
+        for (int c = 0; c < tr.F; ++c) {
+            if (!(ratio[(size_t)c] > 1.0)) continue;
+            int k = (int)std::ceil(std::log2(ratio[(size_t)c])) + 1;
+            if (k > kF16MaxShift) k = kF16MaxShift;
+            shift[(size_t)c] = k;
+            ++ctx->f16_shifted_cols;
+            if (k > ctx->f16_max_shift) ctx->f16_max_shift = k;
+        }
+        if (ctx->f16_shifted_cols > 0) {
+            int* d_shift = nullptr;
+            HIP_TRY(ctx, hipMalloc(&d_shift, (size_t)Fp16 * sizeof(int)));
+            HIP_TRY(ctx, hipMemcpy(d_shift, shift.data(), (size_t)Fp16 * sizeof(int), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(col_scale_kernel, dim3((Fp16 + 255) / 256), dim3(256), 0, ctx->stream, d_max, Fp16, ctx->d_xscale,
+                               ctx->d_wscale, (const int*)d_shift);
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(d_shift);
+        }
+    }
+    (void)hipFree(d_max);
     return NPBNN_OK;
 }
 
@@ -337,33 +400,14 @@ int ensure_x16(npbnn_ctx* ctx, int which, int* usable) {
         memcpy(&m, &bits, 4);
         d.f16_state = (std::isfinite(m) && m <= kF16Safe) ? 1 : -1;    // a test set far outside the training range
         if (d.f16_state > 0) {      // and is the pair of fp16 numbers a fair picture of every column? (split_quality_kernel)
-            const int Fq = d.Fp;
-            unsigned* d_err = nullptr;
-            unsigned long long* d_sum = nullptr;
-            HIP_TRY(ctx, hipMalloc(&d_err, (size_t)Fq * sizeof(unsigned)));
-            HIP_TRY(ctx, hipMalloc(&d_sum, (size_t)Fq * sizeof(unsigned long long)));
-            HIP_TRY(ctx, hipMemsetAsync(d_err, 0, (size_t)Fq * sizeof(unsigned), ctx->stream));
-            HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, (size_t)Fq * sizeof(unsigned long long), ctx->stream));
-            hipLaunchKernelGGL(split_quality_kernel, dim3((Fq + 255) / 256, (unsigned)((d.n_rows + 1023) / 1024)), dim3(256), 0, ctx->stream,
-                               (const float*)d.X, (long long)d.n_rows, d.Fp, (const float*)ctx->d_xscale, d_err, d_sum);
-            std::vector<unsigned> h_err((size_t)Fq);
-            std::vector<unsigned long long> h_sum((size_t)Fq);
-            HIP_TRY(ctx, hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(d_err);
-            (void)hipFree(d_sum);
+            std::vector<double> ratio;
+            int rcq = column_quality(ctx, d, &ratio);
+            if (rcq) return rcq;
             d.f16_worst_col = -1;
             d.f16_worst_ratio = 0.0;
-            for (int c = 0; c < d.F; ++c) {
-                float e;
-                memcpy(&e, &h_err[(size_t)c], 4);
-                const double mean_abs = (double)h_sum[(size_t)c] / 4294967296.0 / (double)d.n_rows;
-                if (!(mean_abs > 0.0)) continue;                 // an all-zero column is exact
-                const double ratio = (double)e / mean_abs;
-                if (ratio > d.f16_worst_ratio) { d.f16_worst_ratio = ratio; d.f16_worst_col = c; }
-            }
-            if (d.f16_worst_ratio > (double)kF16QualityTol && !getenv("NPBNN_F16_NO_QUALITY_CHECK")) d.f16_state = -2;   // heavy-tailed column(s)
+            for (int c = 0; c < d.F; ++c)
+                if (ratio[(size_t)c] > d.f16_worst_ratio) { d.f16_worst_ratio = ratio[(size_t)c]; d.f16_worst_col = c; }
+            if (d.f16_worst_ratio > 1.0 && !getenv("NPBNN_F16_NO_QUALITY_CHECK")) d.f16_state = -2;   // heavy-tailed column(s) past what a moved scale holds
         }
         if (d.f16_state < 0 && d.X16) { (void)hipFree(d.X16); d.X16 = nullptr; }      // (nobody will read it)
     }
@@ -402,8 +446,8 @@ int plan_launch(npbnn_ctx* ctx, int which, LaunchPlan* lp, int force_f32, int wa
         if (!usable && ctx->l0_option == NPBNN_L0_F16) {
             if (d.f16_state == -2)
                 return fail(ctx, NPBNN_E_RANGE, "fp16-split layer 0 was requested but column %d spans too many powers of two for a pair of fp16 "
-                                                "numbers (largest entry error %.2e of its mean |value|; bound %.2e)", d.f16_worst_col,
-                            d.f16_worst_ratio, (double)kF16QualityTol);
+                                                "numbers, even with its scale moved as far as fp16 allows (largest entry error %.1f x the bound: 2^-17 of the column's mean, "
+                                                "2^-12 of its typical |value|)", d.f16_worst_col, d.f16_worst_ratio);
             return fail(ctx, NPBNN_E_RANGE, "fp16-split layer 0 was requested but the data cannot be represented in it");
         }
         want_f16 = usable != 0;
@@ -891,6 +935,8 @@ int npbnn_share_data(npbnn_ctx* ctx, npbnn_ctx* owner) {
         d.borrowed = true;
     }
     ctx->d_xscale = owner->d_xscale;
+    ctx->f16_shifted_cols = owner->f16_shifted_cols;
+    ctx->f16_max_shift = owner->f16_max_shift;
     ctx->d_wscale = owner->d_wscale;
     ctx->scale_F = owner->scale_F;
     ctx->data_owner = owner;
@@ -1060,6 +1106,8 @@ int npbnn_get_info(npbnn_ctx* ctx, int what, int* out) {
     if (!ctx || !out) return fail(ctx, NPBNN_E_ARG, "get_info: bad arguments");
     if (what == NPBNN_INFO_L0_F16) { *out = ctx->net.l0_f16; return NPBNN_OK; }
     if (what == NPBNN_INFO_WIDE) { *out = (ctx->arch_set && ctx->wide) ? 1 : 0; return NPBNN_OK; }
+    if (what == NPBNN_INFO_F16_MOVED_COLUMNS) { *out = ctx->f16_shifted_cols; return NPBNN_OK; }
+    if (what == NPBNN_INFO_F16_MAX_MOVE) { *out = ctx->f16_max_shift; return NPBNN_OK; }
     if (ctx->arch_set && ctx->wide && (what == NPBNN_INFO_WAVES_PER_BLOCK || what == NPBNN_INFO_MAX_CANDIDATES || what == NPBNN_INFO_FAST_TAILS)) {
         *out = what == NPBNN_INFO_WAVES_PER_BLOCK ? 4 : what == NPBNN_INFO_MAX_CANDIDATES ? 1 : 0;      // (group passes and prediction sets: one weight set per pass)
         return NPBNN_OK;

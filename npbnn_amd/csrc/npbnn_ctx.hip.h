@@ -118,6 +118,8 @@ struct npbnn_ctx {
     std::vector<unsigned char> l0_blocks;      // [mt][ceil(in_dim / 16)]
     float* d_xscale = nullptr;     // per-feature power-of-two scales of the fp16-split path (from the training matrix)
     float* d_wscale = nullptr;
+    int f16_shifted_cols = 0;      // columns whose scale was moved up (heavy tails: ensure_scales) and the largest such move (powers of two)
+    int f16_max_shift = 0;
     int scale_F = 0;
     int* d_overflow = nullptr;
     // parameter blocks of the kernels: device copies (kernels take a pointer) + pinned host staging

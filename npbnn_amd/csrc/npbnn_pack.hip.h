@@ -191,12 +191,13 @@ __global__ void __launch_bounds__(256) col_absmax_kernel(const float* __restrict
 
 #ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) col_scale_kernel(const unsigned* __restrict__ absmax, int Fp, float* __restrict__ x_scale,
-                                                        float* __restrict__ w_scale) {
+                                                        float* __restrict__ w_scale, const int* __restrict__ shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Fp) return;
     const float m = __uint_as_float(absmax[c]);
     int e = 0;
     if (m > 0.f && isfinite(m)) (void)frexpf(m, &e);
+    if (shift) e -= shift[c];           // (a heavy-tailed column: its largest entry lands below 2^shift instead of below 1)
     x_scale[c] = ldexpf(1.f, -e);
     w_scale[c] = ldexpf(1.f, e);
 }
@@ -230,16 +231,30 @@ __global__ void __launch_bounds__(256) split_x_kernel(const float* __restrict__ 
 }
 #endif  // NPBNN_KERNELS_MAIN
 
-// How well does the fp16 pair represent column c?  An entry's absolute error |x' - (hi + lo)| is bounded by half the fp16 subnormal
-// spacing, 2^-25 of the column's scale - fine while the column's typical entry is within a few powers of two of its largest, but a
-// heavy-tailed column (one 1e4 outlier over values of 1e-2, log-normal features, ...) puts its typical entries where that error is
-// per cent of the value.  Per column: the largest error of any entry and the sum of |x'| (as a 2^-32 fixed-point integer, so that
-// the sum does not depend on the order of the atomics); the host compares the two (kF16QualityTol).
-constexpr float kF16QualityTol = 7.62939453125e-06f;        // 2^-17: largest entry error <= this x the column's mean |value| (normal data: 6e-7,
-                                                            // log-normal sigma 1: 5e-6, Student t3: 1.4e-5, log-normal sigma 3: 2e-4, an outlier 1e6 x the rest: 5e-3)
+// How well does the fp16 pair represent column c?  Inside fp16's normal range the pair keeps 22 bits of an entry - a RELATIVE error
+// like float32's own (two bits short of it) and not counted here (kF16PairRel).  Below it, an entry's absolute error |x' - (hi + lo)|
+// is bounded by half the fp16 subnormal spacing, 2^-25 in scaled units - fine while the column's typical entry is within a few powers
+// of two of its largest, but with the column's largest entry scaled to just under 1 a heavy-tailed column (one 1e4 outlier over values
+// of 1e-2, log-normal features, ...) puts its typical entries where that error is per cent of the value.  Per column the kernel
+// returns the largest counted error of any entry and two yardsticks: the mean |x'| (what the column contributes with: sum of |x'|
+// clamped at 2^12, as a 2^-28 fixed-point integer) and the TYPICAL |x'| - the geometric mean of the non-zero entries (zeros are
+// exact), from the sum of log2 |x'| as a 2^-16 fixed-point integer; integers, so that the sums do not depend on the order of the
+// atomics.  The host (column_quality) asks for error <= 2^-17 of the mean (kF16QualityTol, the bound of rounds 3-4) AND <= 2^-12 of
+// the typical entry (kF16TypicalTol: a mean carried by a few outliers must not hide that every other entry is down to a few bits).
+// A column past either bound gets its scale MOVED UP by a power of two (ensure_scales: the largest entry stays below
+// 2^kF16MaxShift - fp16 has 15 powers of two above 1 that the max-scaled copy leaves unused; the weights' scale moves down by the
+// same factor, products unchanged) and is measured again; the cap keeps what a weight's own 2^-25 floor turns into on the row of the
+// largest entry at 2^-13.
+constexpr float kF16QualityTol = 7.62939453125e-06f;        // 2^-17 of the column's mean |value| (normal data: 2^-21.4; log-normal sigma 1: 2^-18.7;
+                                                            // Student t3: 2^-18.1; before any move: log-normal sigma 3: 2^-11.7, one 1e4 outlier
+                                                            // over N(0, 1e-2): 2^-10)
+constexpr float kF16TypicalTol = 2.44140625e-04f;           // 2^-12 of the column's typical |value|
+constexpr float kF16PairRel = 4.76837158203125e-07f;        // 2^-21: an error within this x |entry| is the pair's own 22-bit rounding
+constexpr int kF16MaxShift = 12;                            // scaled entries stay below 2^12 (fp16: 65504)
 #ifdef NPBNN_KERNELS_MAIN
 __global__ void __launch_bounds__(256) split_quality_kernel(const float* __restrict__ X, long long n_rows, int Fp, const float* __restrict__ x_scale,
-                                                            unsigned* __restrict__ max_err, unsigned long long* __restrict__ sum_abs) {
+                                                            unsigned* __restrict__ max_err, unsigned long long* __restrict__ sum_abs,
+                                                            unsigned long long* __restrict__ sum_log2, unsigned long long* __restrict__ n_nonzero) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Fp) return;
     const long long r0 = (long long)blockIdx.y * 1024;
@@ -247,18 +262,25 @@ __global__ void __launch_bounds__(256) split_quality_kernel(const float* __restr
     if (r1 > n_rows) r1 = n_rows;
     const float sc = x_scale[c];
     float worst = 0.f;
-    unsigned long long sum = 0;
+    unsigned long long sum = 0, cnt = 0;
+    long long lsum = 0;
     for (long long r = r0; r < r1; ++r) {
         const float v = X[r * Fp + c] * sc;
         _Float16 h, l;
         split_f16(v, h, l);
         const float e = fabsf(v - ((float)h + (float)l));      // (hi + lo spans at most 23 bits: the sum is exact in float32)
-        worst = e > worst ? e : worst;
         const float a = fabsf(v);
-        sum += (unsigned long long)((double)(a < 2.f ? a : 2.f) * 4294967296.0);
+        worst = (e > worst && e > kF16PairRel * a) ? e : worst;
+        sum += (unsigned long long)((double)(a < 4096.f ? a : 4096.f) * 268435456.0);
+        if (a > 0.f && a < INFINITY) {
+            lsum += (long long)(log2f(a) * 65536.0f);
+            ++cnt;
+        }
     }
     atomicMax(max_err + c, __float_as_uint(worst));
     atomicAdd(sum_abs + c, sum);
+    atomicAdd(sum_log2 + c, (unsigned long long)lsum);         // (two's complement: the signed sum, whatever the order)
+    atomicAdd(n_nonzero + c, cnt);
 }
 #endif  // NPBNN_KERNELS_MAIN
 

@@ -835,3 +835,45 @@ def test_automatic_schedule_goes_by_the_cost_it_measured():
     assert (ma._logLik, ma._logPrior) == (mb._logLik, mb._logPrior)
     for wa, wb in zip(ba._w_layers, bb._w_layers):
         np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("kind", ["lognormal3", "outlier"])
+def test_chain_on_heavy_tailed_features_runs_on_the_fp16_pair_and_is_the_float32_chain(kind):
+    """Heavy-tailed features (log-normal columns with sigma 3; one 1e4 outlier per column over N(0, 1e-2) data) used to send `auto`
+    to the float32 layer 0 at half the speed; their columns' scales are moved up instead (ensure_scales) and the
+    device chain stays on the fp16 pair: same decisions and weights as the chain on the exact float32 path and as the host loop."""
+    rs = np.random.default_rng(3)
+    n, f, c = 30000, 40, 4
+    if kind == "lognormal3":
+        x = np.exp(3.0 * rs.standard_normal((n, f)))
+    else:
+        x = rs.normal(0, 1e-2, (n, f))
+        x[rs.integers(0, n, f), np.arange(f)] = 1e4
+    score = np.tanh(np.log1p(np.abs(x[:, :6])) - np.log1p(np.abs(x[:, :6])).mean(axis=0)).sum(axis=1) + rs.normal(0, 0.5, n)
+    lab = np.digitize(score, np.quantile(score, [0.25, 0.5, 0.75]))
+    dat = dict(data=x, labels=lab, test_data=np.zeros((0, f)), test_labels=np.zeros(0))
+    runs = []
+    for mode in ("auto", "f32", "loop"):
+        np.random.seed(77)
+        bnn = quiet(bn.npBNN, dat, n_nodes=[12, 6], actFun=bn.ActFun(fun="tanh"), use_bias_node=1, prior_f=1, p_scale=1, init_std=0.1)
+        # (weights in units of the columns: a proposal moves a typical row's pre-activation by O(0.01))
+        bnn._w_layers[0][:, 1:] /= np.abs(x).mean(axis=0)
+        m = bn.MCMC(bnn, update_f=[0.05, 0.1, 0.2], update_ws=[0.01, 0.05, 0.05])
+        runs.append((bnn, m, mode))
+    for bnn, m, mode in runs:
+        if mode == "f32":
+            m._backend.ctx.set_l0_precision("f32")
+        if mode == "loop":
+            for _ in range(150):
+                m.mh_step(bnn)
+        else:
+            m.run_steps(bnn, 150)
+        assert m._backend.ctx.l0_mode() == ("f32" if mode == "f32" else "f16-split")
+    (ba, ma, _), (bb, mb, _), (bc, mc, _) = runs
+    assert ma._backend.ctx.f16_moved_columns()[0] > 0
+    assert ma._last_accepted_mem == mb._last_accepted_mem == mc._last_accepted_mem
+    assert 5 < sum(ma._last_accepted_mem) < 150
+    np.testing.assert_allclose(ma._logLik, mb._logLik, rtol=2e-6)
+    for wa, wb, wc in zip(ba._w_layers, bb._w_layers, bc._w_layers):
+        np.testing.assert_array_equal(wa, wb)
+        np.testing.assert_array_equal(wa, wc)

@@ -157,9 +157,12 @@ int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
 /* NPBNN_OPT_TRAINABLE_SLOPES (default 0): 1 reserves a slot per hidden layer in the weight image for the activation slope, so that the
  * candidates of a chain pass can each carry their own (npbnn_chain_cfg.slope_idx ...); such a network runs on the general builds. */
 /* NPBNN_OPT_WIDE (default 0): the weight-streamed path.  A network runs on it BY ITSELF when a layer has more than 128 nodes or when its
- * weights would leave a compute unit's LDS fewer than 8 waves beside them (the reference's default n_nodes = [50, 5], np_bnn/BNN_env.py:20,
- * from ~550 features on; MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape): every layer is then a tiled matrix product
- * whose operands both stream through LDS, weights from a resident image in HBM, one weight set per pass.  1 = every network runs on it
+ * weights would leave a compute unit's LDS fewer than 4 waves beside them (the reference's default n_nodes = [50, 5], np_bnn/BNN_env.py:20,
+ * from ~700 features on, [32, 8] from ~1200; MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape): every layer is then a
+ * tiled matrix product whose operands both stream through LDS, weights from images resident in HBM (widths up to NPBNN_MAX_WIDTH, images
+ * up to 2 GiB); a chain pass carries up to three candidates where the pass is one fused launch (narrow networks on many rows), else
+ * one.  Same results as the resident path to rounding (not bit for bit: another order of float32 additions); the envelope and the
+ * rates either side of the switch are in DESIGN.md 4.4.  1 = every network runs on it
  * (A/B timing, tests).  NPBNN_INFO_WIDE: 1 when the architecture set last runs on it.
  * NPBNN_INFO_F16_MOVED_COLUMNS / _F16_MAX_MOVE: the fp16-split copy scales every column by a power of two taken from its largest entry;
  * heavy-tailed columns (typical entries many powers of two below the largest) get that scale moved up so that the pair keeps their

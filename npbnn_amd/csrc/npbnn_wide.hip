@@ -26,9 +26,9 @@ struct GemmCfg {
 GemmCfg g_cfg[6] = {
     {wide_gemm_kernel<8, 4, 2, 4, true>, wide_gemm_kernel<8, 4, 2, 4, false>, nullptr, nullptr, nullptr, nullptr, 16, 16, 512, 8, 2, 4},    // 256 x 256: 64 KiB per stage
     {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, nullptr, nullptr, nullptr, nullptr, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
-    {wide_gemm_kernel<2, 4, 8, 1, true>, wide_gemm_kernel<2, 4, 8, 1, false>, wide_gemm_kernel<2, 4, 8, 1, true, 2>, wide_gemm_kernel<2, 4, 8, 1, false, 2>, wide_gemm_kernel<2, 4, 8, 1, true, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 3>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
-    {wide_gemm_kernel<2, 4, 4, 1, true>, wide_gemm_kernel<2, 4, 4, 1, false>, wide_gemm_kernel<2, 4, 4, 1, true, 2>, wide_gemm_kernel<2, 4, 4, 1, false, 2>, wide_gemm_kernel<2, 4, 4, 1, true, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 3>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
-    {wide_gemm_kernel<2, 2, 4, 1, true>, wide_gemm_kernel<2, 2, 4, 1, false>, wide_gemm_kernel<2, 2, 4, 1, true, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 2>, nullptr, nullptr, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
+    {wide_gemm_kernel<2, 4, 8, 1, true, 1, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 1, 3>, wide_gemm_kernel<2, 4, 8, 1, true, 2, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 2, 3>, wide_gemm_kernel<2, 4, 8, 1, true, 3, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 3, 3>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
+    {wide_gemm_kernel<2, 4, 4, 1, true, 1, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 1, 3>, wide_gemm_kernel<2, 4, 4, 1, true, 2, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 2, 3>, wide_gemm_kernel<2, 4, 4, 1, true, 3, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 3, 3>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true, 1, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 1, 2>, wide_gemm_kernel<2, 2, 4, 1, true, 2, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 2, 2>, nullptr, nullptr, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
     {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, nullptr, nullptr, nullptr, nullptr, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
 };
 // the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)

@@ -475,7 +475,7 @@ constexpr int kWideFlush = 8;        // K-units (256 columns) added up by the ma
 // D: weight sets multiplied against the SAME pieces of the rows (the candidates of a speculative chain pass - the resident path's
 // idea: narrow networks on many features are bound by the intake of X, so a second candidate's fragments cost a third more bytes and
 // no more time per row; fused passes only)
-template <int RT, int CT, int WR, int WC, bool F16, int D = 1>
+template <int RT, int CT, int WR, int WC, bool F16, int D = 1, int DMAX = D>
 __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmArgs a) {
     constexpr int NW = WR * WC;
     constexpr int XT = WR * RT, WT = WC * CT;            // row tiles / output tiles of the workgroup
@@ -562,7 +562,9 @@ __global__ void __launch_bounds__(WR * WC * 64) wide_gemm_kernel(const WideGemmA
     // ---- two levels of float32 accumulation: the matrix cores add into `acc`, which is emptied into `tot` every kWideFlush units
     //      (a long contraction's rounding error grows with the length of ONE chain of additions: thousands of columns would
     //      otherwise cost the last layer's values a digit); `tot` starts from the bias ----
-    constexpr bool TWO = D * RT * CT <= 16 && NW <= 8;      // (the tilings of 32 tiles per wave have no registers for a second set: their long
+    // DMAX = the most candidates this tiling is built for: ALL its builds accumulate alike, so that a chain's sums do not depend on how many
+    // candidates share a pass (and mh_step's single evaluations are those of run_steps' passes, bit for bit)
+    constexpr bool TWO = DMAX * RT * CT <= 16 && NW <= 8;   // (the tilings of 32 tiles per wave have no registers for a second set: their long
                                               // contractions are cut into K-slices, whose sums meet in wide_reduce_kernel)
     f32x4 accs[D][RT][CT], tots[TWO ? D : 1][TWO ? RT : 1][TWO ? CT : 1];
     auto& acc = accs[0];            // (the single weight set of the plain forms below)

@@ -270,6 +270,35 @@ def test_run_steps_is_the_mh_step_loop_on_streamed_networks(name):
     assert abs(mcmc_b._logLik - want) / abs(want) < LL_RTOL
 
 
+@pytest.mark.parametrize("shape", [(40000, 800, [50, 5], 10, "ReLU", 1), (40000, 1300, [32, 8], 6, "tanh", 2), (36000, 1800, [20], 4, "tanh", 2)])
+def test_streamed_candidates_do_not_change_the_chain(shape):
+    """The fused pass of the weight-streamed path evaluates up to three candidates per read of X (wide_gemm_kernel<..., D>): the chain
+    is the same one - decisions, weights, log-likelihood bit for bit - with one, two or three candidates per pass (a tiling's builds
+    all accumulate alike: DMAX in wide_gemm_kernel), and fewer passes are spent on it."""
+    from test_hip_sampler import quiet
+    n, f, hidden, c, fun, bias = shape
+    dat = cases.classification_data(5, n, f, c, n_test=0)
+    runs = []
+    for d in (1, 2, 3):
+        np.random.seed(31)
+        bnn = quiet(bn.npBNN, dat, n_nodes=hidden, actFun=bn.ActFun(fun=fun), use_bias_node=bias, prior_f=1, p_scale=1)
+        m = bn.MCMC(bnn, update_f=[0.01] * (len(hidden) + 1), update_ws=[0.04] * (len(hidden) + 1), n_iteration=100000)
+        m.n_candidates = d
+        for _ in range(3):
+            m.run_steps(bnn, 50)
+        assert m._backend.ctx.is_wide()
+        runs.append((bnn, m))
+    (b1, m1), (b2, m2), (b3, m3) = runs
+    assert m1._device_passes == 150
+    assert m3._device_passes <= m2._device_passes < 150
+    assert 0 < sum(m1._last_accepted_mem) < 100
+    for b, m in ((b2, m2), (b3, m3)):
+        assert m._last_accepted_mem == m1._last_accepted_mem
+        assert m._logLik == m1._logLik and m._logPrior == m1._logPrior
+        for wa, wb in zip(b1._w_layers, b._w_layers):
+            np.testing.assert_array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("name", list(cases.TRACES))
 def test_forced_chain_follows_the_reference_trace(name, golden_dir, monkeypatch):
     """The reference's golden Metropolis-Hastings traces with the networks forced onto the streamed path: mh_step free-running

@@ -645,7 +645,8 @@ def wide_fused_config(args):
            "schedule": int(mcmc._device_schedule_used),
            "roofline": {"bound": "hbm", "kernel": "wide_gemm_kernel<2,4,8,1,%s,D=%d> (fused pass: product + narrow layers + likelihood)" % ("fp16-split" if ctx.l0_mode() == "f16-split" else "f32", cand),
                         "kernel_ms": ms_pass, "achieved": wl.bytes_per_proposal / (ms_pass * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": wl.bytes_per_proposal / (ms_pass * 1e-3) / HBM_PEAK, "traffic": None,
+                        "frac": wl.bytes_per_proposal / (ms_pass * 1e-3) / HBM_PEAK, "traffic": recorded_fused_counters(cand).get("traffic"),
+                        "recorded": recorded_fused_counters(cand),
                         "single_candidate_kernel_ms": ms_one, "single_candidate_frac": wl.bytes_per_proposal / (ms_one * 1e-3) / HBM_PEAK,
                         "note": "achieved = one read of X (algorithmic bytes of a proposal) / the pass's duration: %d candidates share that read" % cand,
                         "roofline_it_per_s_one_read_per_proposal": HBM_PEAK / wl.bytes_per_proposal},
@@ -654,6 +655,18 @@ def wide_fused_config(args):
         out["cpu_baseline"] = cpu_baseline(wl, budget_s=5.0)
     mcmc._backend.close()
     return out
+
+
+def recorded_fused_counters(cand):
+    """Traffic and matrix-core occupancy of the fused pass with ``cand`` candidates from the newest profiles/r*_widefused_pass<cand>_counters.json
+    (tools/collect_wide_profiles.sh; a recorded measurement, not re-measured by this run)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_widefused_pass%d_counters.json" % cand)), reverse=True)
+    if not files:
+        return {}
+    with open(files[0]) as fh:
+        rec = json.load(fh)
+    return {"traffic": rec.get("traffic"), "mfma_busy": rec.get("mfma_busy"), "l2_hit_rate": rec.get("l2_hit_rate"),
+            "kernel_ms_profiles": (rec.get("kernel_ns_rocprof") or 0.0) * 1e-6 or None, "source": os.path.relpath(files[0], ROOT)}
 
 
 def recorded_wide_counters():

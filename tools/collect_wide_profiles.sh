@@ -13,5 +13,16 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$n -o p -- python3 tools/profile_wide.py --iters 3 > $out/pmc_$n.log 2>&1 < /dev/null || echo "pmc $n failed"
   f=$(find $out/pmc_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $out/keep/${tag}_wide_pmc_$n.csv
 done
+# the fused pass of the default network on 1024 features (bench leg "default network on 1024 features"), three candidates and one
+for cand in 3 1; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/fused_stats_d$cand -o k -- python3 tools/profile_wide.py --config 8 --cand $cand --iters 300 > $out/fused_stats_d$cand.log 2>&1 < /dev/null || echo "fused kernel stats failed"
+  f=$(find $out/fused_stats_d$cand -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/keep/${tag}_widefused_pass${cand}_kernel_stats.csv
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+    n=$(echo $c | tr ' ' '_')
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/fused_pmc_d${cand}_$n -o p -- python3 tools/profile_wide.py --config 8 --cand $cand --iters 3 > $out/fused_pmc_d${cand}_$n.log 2>&1 < /dev/null || echo "fused pmc $n failed"
+    f=$(find $out/fused_pmc_d${cand}_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $out/keep/${tag}_widefused_pass${cand}_pmc_$n.csv
+  done
+done
 python3 tools/read_wide_pmc.py $out/keep $tag > $out/keep/${tag}_wide_layer0_counters.json 2> $out/read.err
-cat $out/keep/${tag}_wide_layer0_counters.json; cat $out/read.err | tail -5; ls $out/keep
+for cand in 3 1; do python3 tools/read_wide_pmc.py $out/keep $tag $cand > $out/keep/${tag}_widefused_pass${cand}_counters.json 2>> $out/read.err; done
+cat $out/keep/${tag}_wide_layer0_counters.json $out/keep/${tag}_widefused_pass3_counters.json; cat $out/read.err | tail -5; ls $out/keep

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The counters tools/collect_wide_profiles.sh recorded for the first layer's product of the weight-streamed leg, per launch, as the JSON
-bench.py quotes (profiles/rNN_wide_layer0_counters.json).   python tools/read_wide_pmc.py <dir with the csv files> <tag>"""
+bench.py quotes (profiles/rNN_wide_layer0_counters.json).   python tools/read_wide_pmc.py <dir with the csv files> <tag>
+With a third argument D (3 or 1): the fused pass of the default network on 1024 features with D candidates instead
+(rNN_widefused_pass<D>_*.csv -> rNN_widefused_pass<D>_counters.json)."""
 import csv
 import glob
 import json
@@ -9,6 +11,12 @@ import sys
 
 d, tag = sys.argv[1], sys.argv[2]
 KERNEL = "wide_gemm_kernel<8, 4, 2, 4"
+GROUP = "wide"
+LABEL = "wide_gemm_kernel<8,4,2,4,fp16-split>, 20k x 4096 x 256, 3 K-slices"
+if len(sys.argv) > 3:
+    KERNEL = "wide_gemm_kernel<2, 4, 8, 1, true, %s," % sys.argv[3]
+    GROUP = "widefused_pass%s" % sys.argv[3]
+    LABEL = "wide_gemm_kernel<2,4,8,1,fp16-split,D=%s> (fused pass), 100k x 1024, [50,5]" % sys.argv[3]
 
 
 def mean_counter(path, name):
@@ -21,21 +29,21 @@ def mean_counter(path, name):
 
 
 out = {}
-for path in sorted(glob.glob(os.path.join(d, "%s_wide_pmc_*.csv" % tag))):
+for path in sorted(glob.glob(os.path.join(d, "%s_%s_pmc_*.csv" % (tag, GROUP)))):
     with open(path, newline="") as fh:
         names = sorted({row.get("Counter_Name") for row in csv.DictReader(fh)} - {None})
     for name in names:
         v = mean_counter(path, name)
         if v is not None:
             out[name] = v
-stats = os.path.join(d, "%s_wide_kernel_stats.csv" % tag)
+stats = os.path.join(d, "%s_%s_kernel_stats.csv" % (tag, GROUP))
 dur_ns = None
 if os.path.exists(stats):
     with open(stats, newline="") as fh:
         for row in csv.DictReader(fh):
             if KERNEL in row.get("Name", ""):
                 dur_ns = float(row["AverageNs"])
-res = {"kernel": "wide_gemm_kernel<8,4,2,4,fp16-split>, 20k x 4096 x 256, 3 K-slices", "kernel_ns_rocprof": dur_ns, "counters_per_launch": out,
+res = {"kernel": LABEL, "kernel_ns_rocprof": dur_ns, "counters_per_launch": out,
        "units": "FETCH_SIZE / WRITE_SIZE in KiB; SQ counters cover 1/32 of the chip (8 CUs = 32 SIMDs) per dispatch: SQ_VALU_MFMA_BUSY_CYCLES in clock "
                 "cycles, SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_BUSY_CYCLES in quad-cycles (chip-wide sums in this collection: see mfma_busy)"}
 if "FETCH_SIZE" in out:

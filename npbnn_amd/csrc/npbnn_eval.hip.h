@@ -1331,7 +1331,6 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
     int* const look_words = reinterpret_cast<int*>(smem + D * IB + (size_t)wpb * uni(p.lay.wave_lds));       // (the flag word's 64 bytes)
     // ---------------- per-workgroup partials (float64, fixed order): waves -> LDS -> global [candidate][value][workgroup] ----
     if (g_partials || GN) {
-        constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if constexpr (LK == kLikGauss) {
@@ -1381,8 +1380,11 @@ __global__ void __launch_bounds__(max_waves_for(MT0, MTI, F16, D, LK, FAST) * 64
         __syncthreads();
         // (the LAST wave adds them up and writes them: in a flag-ordered launch it is also the one that reports the workgroup done,
         // after waiting for these very stores)
+        constexpr int nvals = (LK == kLikGauss) ? kPartialStride : 1;
         for (int item = tid - ((int)blockDim.x - 64); item >= 0 && item < D * nvals; item += 64) {
             const int j = item / nvals, v = item % nvals;
+            // (only the values in use leave the workgroup - 1 + 2k of the Gaussian record's 33, the ones every reader asks for: partial_value_index)
+            if constexpr (LK == kLikGauss) { if (v != 0 && ((v - 1) & (NPBNN_MAX_TARGETS - 1)) >= p_generic.net.k_targets) continue; }
             double s = 0.0;
             for (int w = 0; w < wpb; ++w) s += wsum[((size_t)j * wpb + w) * kPartialStride + v];
             // (group pass: candidate j is slot 0 of chain j's own partial block)

@@ -182,6 +182,78 @@ def test_shapes_the_lds_cannot_hold_against_the_oracle(name, precision):
     ctx.close()
 
 
+def _drawn_shape(seed):
+    """A network np.dot would take without a thought (BNN_lib.py:154-162): ragged row counts (down to a single row), feature counts that
+    are no multiple of anything, one to five weight matrices of 1-400 nodes, with and without bias nodes."""
+    rs = np.random.default_rng(1000 + seed)
+    n = int(rs.choice([1, 2, 15, 16, 17, 255, 257, 1000, 2999, int(rs.integers(1, 3000))]))
+    f = int(rs.choice([1, 3, 31, 32, 33, 100, 255, 700, int(rs.integers(1, 700))]))
+    n_hidden = int(rs.integers(0, 5))
+    hidden = [int(rs.choice([1, 2, 15, 17, 50, 128, 129, 400, int(rs.integers(1, 400))])) for _ in range(n_hidden)]
+    c = int(rs.choice([2, 3, 10, 129, 300]))
+    bias = [int(rs.integers(0, 2)) for _ in range(n_hidden + 1)]       # (per weight matrix: a bias column or none)
+    fun = ["tanh", "ReLU", "swish"][int(rs.integers(0, 3))]
+    return n, f, hidden, c, bias, fun
+
+
+@pytest.mark.parametrize("forced", [True, False], ids=["forced", "library's choice"])
+@pytest.mark.parametrize("seed", range(30))
+def test_drawn_shapes_against_the_oracle(seed, forced):
+    """Thirty drawn shapes (see _drawn_shape) forced onto the weight-streamed path and on the path the library picks by itself, fp16-split
+    and float32 layer 0: last layer's values, class probabilities, log-likelihood and confusion counts against the float64 oracle."""
+    n, f, hidden, c, bias, fun = _drawn_shape(seed)
+    rs = np.random.default_rng(seed)
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    lab = rs.integers(0, c, n)
+    dims = [f] + hidden + [c]
+    w = []
+    for l in range(len(dims) - 1):
+        w.append(rs.normal(0, 1.0 / np.sqrt(dims[l] + 1), (dims[l + 1], dims[l] + bias[l])))
+    act = orc.Act(fun)
+    x64 = x.astype(np.float64)
+    y64 = orc.forward(x64, w, act, orc.out_softmax)
+    z64 = orc.forward_logits(x64, w, act)
+    want = orc.lik_categorical(y64, lab, np.arange(n))
+    for precision in ("auto", "f32"):
+        ctx = make_ctx(x, w, act, 0, 0, labels=lab, precision=precision, wide=forced)
+        assert ctx.is_wide() or not forced
+        assert ctx.is_wide() or max(hidden + [c]) <= 128
+        r = ctx.eval(w, want_confusion=True)
+        assert abs(r["loglik"] - want) <= LL_RTOL * abs(want) + 1e-9, (n, f, hidden, c, bias, fun, precision)
+        check_confusion(r["confusion"], y64, lab)
+        assert_close(ctx.predict(w, apply_out_fn=False), z64)
+        assert_close(ctx.predict(w), y64)
+        ctx.close()
+
+
+def test_the_widest_and_the_deepest_network_the_header_allows():
+    """NPBNN_MAX_WIDTH = 4096 nodes in a layer, NPBNN_MAX_LAYERS = 8 weight matrices: both ends of the header's envelope, against the
+    oracle (the reference itself has no limit: np.dot)."""
+    rs = np.random.default_rng(9)
+    for n, f, hidden, c in ((300, 64, [capi.MAX_WIDTH, 7], 3), (500, 40, [24, 130, 16, 9, 200, 5, 33], 4)):
+        x = rs.standard_normal((n, f)).astype(np.float32)
+        lab = rs.integers(0, c, n)
+        dims = [f] + hidden + [c]
+        w = [rs.normal(0, 1.0 / np.sqrt(dims[l] + 1), (dims[l + 1], dims[l] + (1 if l < len(dims) - 2 else 0))) for l in range(len(dims) - 1)]
+        assert len(w) <= 8
+        act = orc.Act("tanh")
+        ctx = make_ctx(x, w, act, 0, 0, labels=lab, wide=False)
+        assert ctx.is_wide()
+        x64 = x.astype(np.float64)
+        y64 = orc.forward(x64, w, act, orc.out_softmax)
+        want = orc.lik_categorical(y64, lab, np.arange(n))
+        assert abs(ctx.eval(w)["loglik"] - want) / abs(want) < LL_RTOL
+        assert_close(ctx.predict(w, apply_out_fn=False), orc.forward_logits(x64, w, act), Z_TOL * 2)
+        ctx.close()
+    from npbnn_amd import NpbnnError
+    w = [rs.normal(0, 0.1, (capi.MAX_WIDTH + 1, 9)), rs.normal(0, 0.1, (3, capi.MAX_WIDTH + 1))]
+    ctx = bn.HipContext(0)
+    ctx.set_data(rs.standard_normal((64, 8)).astype(np.float32))
+    with pytest.raises(NpbnnError):
+        ctx.set_arch_from_weights(w, 8, 3, 0, 0, 0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("f", [608, 672, 704, 736, 800])
 def test_either_side_of_the_switch_between_the_paths(f):
     """The reference's default [50, 5] on 600-800 features: the weight image takes 127-166 KB of a compute unit's 160 KB of LDS.  While

@@ -226,6 +226,37 @@ def test_drawn_shapes_against_the_oracle(seed, forced):
         ctx.close()
 
 
+@pytest.mark.parametrize("forced", [True, False], ids=["forced", "library's choice"])
+@pytest.mark.parametrize("seed", range(20))
+def test_drawn_regression_shapes_against_the_oracle(seed, forced):
+    """The same drawn networks with 1-16 Gaussian targets (calc_likelihood_regression, BNN_lib.py:123-131): predictions, the
+    log-likelihood with a given sigma per column and with the empirical one (BNN_env.py:475-476), the residual moments."""
+    n, f, hidden, _, bias, fun = _drawn_shape(100 + seed)
+    rs = np.random.default_rng(100 + seed)
+    n = max(n, 17)
+    k = int(rs.choice([1, 2, 3, 4, 5, 9, 16]))
+    x = rs.standard_normal((n, f)).astype(np.float32)
+    dims = [f] + hidden + [k]
+    w = [rs.normal(0, 1.0 / np.sqrt(dims[l] + 1), (dims[l + 1], dims[l] + bias[l])) for l in range(len(dims) - 1)]
+    act = orc.Act(fun)
+    x64 = x.astype(np.float64)
+    y64 = orc.forward(x64, w, act, orc.out_identity)
+    t = y64 + rs.normal(0, 0.7, y64.shape) + 0.1
+    sig = rs.uniform(0.5, 2.0, k)
+    want_emp, sig_emp = orc.closed_gaussian_empirical(y64, t)
+    want_sig = orc.lik_gaussian(y64, t, sig2=sig)
+    ctx = make_ctx(x, w, act, 1, 1, targets=t, n_targets=k, wide=forced)
+    assert ctx.is_wide() or not forced
+    r = ctx.eval(w)
+    np.testing.assert_allclose(r["loglik"], want_emp, rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sigma"][:k], sig_emp, rtol=1e-5)
+    np.testing.assert_allclose(ctx.eval(w, sigma=sig)["loglik"], want_sig, rtol=LL_RTOL)
+    np.testing.assert_allclose(ctx.eval(w, sigma=sig, lik_temp=0.6)["loglik"], 0.6 * want_sig, rtol=LL_RTOL)
+    np.testing.assert_allclose(r["sum_r2"][:k], np.sum((t - y64) ** 2, axis=0), rtol=1e-5)
+    assert_close(ctx.predict(w), y64)
+    ctx.close()
+
+
 def test_the_widest_and_the_deepest_network_the_header_allows():
     """NPBNN_MAX_WIDTH = 4096 nodes in a layer, NPBNN_MAX_LAYERS = 8 weight matrices: both ends of the header's envelope, against the
     oracle (the reference itself has no limit: np.dot)."""

@@ -373,19 +373,29 @@ def test_run_steps_is_the_mh_step_loop_on_streamed_networks(name):
     assert abs(mcmc_b._logLik - want) / abs(want) < LL_RTOL
 
 
-@pytest.mark.parametrize("shape", [(40000, 800, [50, 5], 10, "ReLU", 1), (40000, 1300, [32, 8], 6, "tanh", 2), (36000, 1800, [20], 4, "tanh", 2)])
+@pytest.mark.parametrize("shape", [(40000, 800, [50, 5], 10, "ReLU", 1, 0.01), (40000, 1300, [32, 8], 6, "tanh", 2, 0.01), (36000, 1800, [20], 4, "tanh", 2, 0.01),
+                                   (40000, 800, [50, 5], 10, "ReLU", 1, 0.06), (40000, 900, [40, 6], 0, "tanh", 2, 0.01)],
+                         ids=["default-net-800", "32-8-on-1300", "one-hidden-layer", "proposals-of-2.5k-entries", "regression-2-targets"])
 def test_streamed_candidates_do_not_change_the_chain(shape):
     """The fused pass of the weight-streamed path evaluates up to three candidates per read of X (wide_gemm_kernel<..., D>): the chain
     is the same one - decisions, weights, log-likelihood bit for bit - with one, two or three candidates per pass (a tiling's builds
-    all accumulate alike: DMAX in wide_gemm_kernel), and fewer passes are spent on it."""
+    all accumulate alike: DMAX in wide_gemm_kernel), and fewer passes are spent on it.  Proposals of more than 2048 entries have their
+    candidate images kept by the launches over all compute units (wide_cand_*_kernel), narrower ones with one candidate per pass by the
+    chain step itself; the regression case runs the Gaussian epilogue (two targets, empirical error)."""
     from test_hip_sampler import quiet
-    n, f, hidden, c, fun, bias = shape
-    dat = cases.classification_data(5, n, f, c, n_test=0)
+    n, f, hidden, c, fun, bias, uf = shape
+    if c:
+        dat = cases.classification_data(5, n, f, c, n_test=0)
+        extra = {}
+    else:
+        dat = cases.regression_data(5, n, f, 2, 0)
+        extra = dict(estimation_mode="regression", empirical_error=True)
     runs = []
     for d in (1, 2, 3):
         np.random.seed(31)
-        bnn = quiet(bn.npBNN, dat, n_nodes=hidden, actFun=bn.ActFun(fun=fun), use_bias_node=bias, prior_f=1, p_scale=1)
-        m = bn.MCMC(bnn, update_f=[0.01] * (len(hidden) + 1), update_ws=[0.04] * (len(hidden) + 1), n_iteration=100000)
+        bnn = quiet(bn.npBNN, dat, n_nodes=hidden, actFun=bn.ActFun(fun=fun), use_bias_node=bias, prior_f=1, p_scale=1, **extra)
+        kw = dict(estimate_error=False) if not c else {}
+        m = bn.MCMC(bnn, update_f=[uf] * (len(hidden) + 1), update_ws=[0.04 if uf < 0.05 else 0.01] * (len(hidden) + 1), n_iteration=100000, **kw)
         m.n_candidates = d
         for _ in range(3):
             m.run_steps(bnn, 50)

@@ -143,6 +143,10 @@ struct ChainParams {
     float* cand_image;         // weight-streamed path (npbnn_wide.hip.h; serial schedule, one candidate per pass): the image its kernels read -
                                // the committed image with the pending proposal's entries patched in by the step itself (prepare), and put
                                // back when the proposal is rejected; nullptr on the resident path, whose kernels patch their LDS copies
+    double* prep_terms;        // weight-streamed path, candidates kept by launches over all compute units: [kMaxCand][M] - the step leaves the
+                               // making of the candidates (values, prior terms, image entries) to wide_cand_prepare_kernel, which runs on the
+                               // whole chip between the step and the pass, and adds up the prior terms of a pass - one per entry, in the order
+                               // it would have added them itself - when it decides that pass; nullptr: the step makes them (every other case)
     const int* pos;            // [K][M] image position of every pre-drawn entry; bit 31 set: fp16-split layer-0 entry (the
                                // low bits are the half index of the high part, low part 512 halfs later); kSkipPos: none
     const float* pscale;       // [K][M] fp16-split column scale of every pre-drawn entry, or nullptr
@@ -400,7 +404,9 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
         if (pl.fly >= 0 && st->void_launch == pl.launch - 1) n_pend = 0;     // that pass saw a state that an accept replaced
     }
     double prefetch_sink = 0.0;
-    if (pl.fly < 0) {   // serial schedule: whichever candidate wins, the next pass starts at t0+1 .. t0+n_pend: pull those rows of
+    bool deferred = false;
+    if constexpr (WIDE) deferred = c.prep_terms != nullptr;
+    if (pl.fly < 0 && !deferred) {   // serial schedule: whichever candidate wins, the next pass starts at t0+1 .. t0+n_pend: pull those rows of
         // the pre-drawn arrays towards the L2 now, while the partial sums are being reduced (the values are not used here)
         const int r_lo = t0 + (pl.first ? 0 : 1), r_hi = min(c.K, t0 + n_pend + c.D);
         double sink = 0.0;
@@ -412,6 +418,35 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
     double d_cand[kMaxCand], d_logu[kMaxCand], d_h[kMaxCand], d_ll = 0.0, d_lp = 0.0, d_temp = 1.0;
 #pragma unroll
     for (int j = 0; j < kMaxCand; ++j) { d_cand[j] = 0.0; d_logu[j] = 0.0; d_h[j] = 0.0; }
+    if constexpr (WIDE) {
+        if (deferred && n_pend > 0) {      // the prior terms wide_cand_prepare_kernel left, one per entry: thread, wave and workgroup add them in
+                                           // the order the step's own preparation does (entry tid, tid + 1024, ...: the same bits)
+            constexpr int TS = 3;                  // (a thread's first three terms of every candidate are requested together)
+            int n_terms[kMaxCand];
+            double x[kMaxCand][TS];
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                n_terms[j] = j < n_pend ? c.pass[pl.dec].cnt[j] : 0;
+#pragma unroll
+                for (int u = 0; u < TS; ++u) {
+                    const int e = tid + u * (int)blockDim.x;
+                    x[j][u] = e < n_terms[j] ? c.prep_terms[(size_t)j * c.M + e] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                const double* tj = c.prep_terms + (size_t)j * c.M;
+                double sum = 0.0;
+#pragma unroll
+                for (int u = 0; u < TS; ++u)
+                    if (tid + u * (int)blockDim.x < n_terms[j]) sum += x[j][u];
+                for (int e = tid + TS * (int)blockDim.x; e < n_terms[j]; e += (int)blockDim.x) sum += tj[e];
+                sum = butterfly_sum_f64(sum);
+                if ((tid & 63) == 0) sh.red3[j][tid >> 6] = sum;
+            }
+            __syncthreads();
+        }
+    }
     if (tid == 0 && n_pend > 0) {
         d_ll = st->logLik;
         d_lp = st->logPrior;
@@ -420,6 +455,13 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
         for (int j = 0; j < kMaxCand; ++j)
             if (j < n_pend) {
                 d_cand[j] = st->cand_logPrior[pl.dec][j];
+                if constexpr (WIDE) {
+                    if (deferred) {         // (held the log prior of the state the candidates start from: base + sum, as the step forms it)
+                        double sj = 0.0;
+                        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sj += sh.red3[j][w];
+                        d_cand[j] = d_cand[j] + sj;
+                    }
+                }
                 d_logu[j] = c.log_u[t0 + j];
                 d_h[j] = c.hastings ? c.hastings[t0 + j] : 0.0;
             }
@@ -600,7 +642,11 @@ __device__ __forceinline__ void chain_step(const ChainParams& c_generic, const S
         return;
     }
     double dlp[kMaxCand];
-    {
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j) dlp[j] = 0.0;
+    }
+    if (!deferred) {
         // staged so that the loads of all candidates are in flight together: (1) the pre-drawn entry, (2) the weight it
         // touches, (3) arithmetic and stores.  One entry per thread and candidate; wider proposals loop.
         const double* __restrict__ wcur = c.w_cur;

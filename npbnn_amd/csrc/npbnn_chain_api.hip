@@ -35,6 +35,7 @@ struct ChainBatch {
     bool persist = false;                      // persistent form: one launch loops over the passes (device flags order them)
     bool sync = false;                         // overlapped schedule with the launches alternating between two streams (device flags)
     bool forked = false;                       // sync: the two streams have been made to wait for ctx->stream
+    bool make_cands = false;                   // weight-streamed path: the candidates are made between step and pass (ChainParams::prep_terms)
     size_t wb = 0;
     int launch = 0;                            // launches enqueued so far (overlapped schedule: the pass parity follows it)
     unsigned long long* d_stamps = nullptr;    // diagnostics
@@ -395,6 +396,22 @@ int chain_prepare(npbnn_ctx* ctx, const npbnn_chain_cfg* cfg, const double* W_in
     // (weight-streamed path: the step keeps the candidate image itself while a proposal fits its staged entries; wider ones get two
     // launches over all compute units between step and pass - wide_cand_sync)
     c.cand_image = (lp.wide && M <= kWideStepPatchMax && D == 1) ? ctx->d_wide_cand : nullptr;
+    // ... and where those launches run anyway they also MAKE the candidates (values, prior terms: wide_cand_prepare_kernel) - one
+    // workgroup's walk over 3 x 2.6 k entries is 24 us of a 37-us step.  Plain batches without slopes of their own only (an exchange
+    // run stops a chain at the proposal that leaves the fp16 range: the step must see that flag when it prepares).
+    c.prep_terms = nullptr;
+    B->make_cands = false;
+    if (lp.wide && !c.cand_image && seg_len == 0 && !cfg->slope_idx && !getenv("NPBNN_WIDE_STEP_MAKES")) {
+        const size_t need_terms = (size_t)kMaxCand * M;
+        if (need_terms > ctx->prep_cap) {
+            if (ctx->d_prep_terms) (void)hipFree(ctx->d_prep_terms);
+            ctx->d_prep_terms = nullptr; ctx->prep_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_prep_terms, need_terms * sizeof(double)));
+            ctx->prep_cap = need_terms;
+        }
+        c.prep_terms = ctx->d_prep_terms;
+        B->make_cands = true;
+    }
     c.pos = ctx->d_pos;
     c.pscale = f16 ? ctx->d_pscale : nullptr;
     c.pv = spec ? ctx->d_spec_pv : ctx->d_pv;      // (spec: the first step writes pass 0 into slot (parity 0, outcome 0))
@@ -619,7 +636,7 @@ int chain_enqueue(npbnn_ctx* ctx, ChainBatch& B, int n) {
     } else {
         for (int i = 0; i < n; ++i, ++B.launch) {
             if (lp.wide) {      // the layers' products and the likelihood of the candidate image (kept by the step, or by wide_cand_sync)
-                if (B.M > kWideStepPatchMax || B.D > 1) wide_cand_sync(ctx, B.M, B.D);
+                if (B.M > kWideStepPatchMax || B.D > 1) wide_cand_sync(ctx, B.M, B.D, B.make_cands);
                 const int rcw = wide_forward(ctx, 0, ctx->d_wide_cand, true, false, nullptr, B.D);
                 if (rcw) return rcw;
             } else {

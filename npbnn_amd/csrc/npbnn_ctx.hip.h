@@ -220,6 +220,8 @@ struct npbnn_ctx {
     float* d_wide_cand = nullptr;  // candidate image of a device chain (the committed image with the pending proposal patched in)
     float* d_wide_act[3] = {nullptr, nullptr, nullptr};   // hidden activations [rows][16 * tiles], ping-pong between layers; [2]: the K-slices' sums
     size_t wide_act_cap = 0;       // floats each
+    double* d_prep_terms = nullptr;       // [kMaxCand][M] prior terms of the pending candidates' entries (ChainParams::prep_terms)
+    size_t prep_cap = 0;
     WideCandState* d_wide_cs = nullptr;   // what the candidate image's last patch covered (wide proposals: wide_cand_sync)
     unsigned conf_cap = 0;         // classes d_conf / h_conf are sized for
 };
@@ -284,7 +286,7 @@ void wide_pack(npbnn_ctx* ctx, const double* d_w, const double* d_col_override, 
 // only_layer0: stop behind the first layer's product (timing hook); info: that product's geometry, or nullptr
 int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass, bool only_layer0 = false, int* info = nullptr, int n_cand = 1);
 int wide_cand_begin(npbnn_ctx* ctx);     // start of a chain batch: candidate image = committed image, nothing patched
-void wide_cand_sync(npbnn_ctx* ctx, int M, int n_cand);   // before a pass of a chain with wide proposals: candidate image = committed image + the pending proposal
+void wide_cand_sync(npbnn_ctx* ctx, int M, int n_cand, bool make_them);   // before a pass of a chain with wide proposals: candidate image = committed image + the pending proposal
 int ensure_conf(npbnn_ctx* ctx, int n_classes);
 // one evaluation launch of a plan on the ctx stream (resident: the plan's kernel; weight-streamed: wide_forward on the committed image)
 int launch_plain_eval(npbnn_ctx* ctx, const LaunchPlan& lp, int which);

@@ -177,6 +177,7 @@ void wide_free(npbnn_ctx* ctx) {
         if (ctx->d_wide_act[i]) { (void)hipFree(ctx->d_wide_act[i]); ctx->d_wide_act[i] = nullptr; }
     ctx->wide_act_cap = 0;
     if (ctx->d_wide_cs) { (void)hipFree(ctx->d_wide_cs); ctx->d_wide_cs = nullptr; }
+    if (ctx->d_prep_terms) { (void)hipFree(ctx->d_prep_terms); ctx->d_prep_terms = nullptr; ctx->prep_cap = 0; }
 }
 
 // image layout, device images, packed weight -> image position map (called by rebuild_net after build_net has filled ctx->net)
@@ -460,12 +461,16 @@ int wide_cand_begin(npbnn_ctx* ctx) {
 }
 
 // before a chain pass whose proposals are too wide for the step to keep the candidate image itself (chain_prepare: ChainParams::cand_image unset)
-void wide_cand_sync(npbnn_ctx* ctx, int M, int n_cand) {
+// make_them: the step left the making of the candidates to this launch (ChainParams::prep_terms, wide_cand_prepare_kernel)
+void wide_cand_sync(npbnn_ctx* ctx, int M, int n_cand, bool make_them) {
     const unsigned grid = (unsigned)((M + 255) / 256);
     const long long stride = ctx->wmeta.image_floats;
     hipLaunchKernelGGL(wide_cand_restore_kernel, dim3(grid, n_cand), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, (const WideCandState*)ctx->d_wide_cs,
                        ctx->d_wide_cand, (const float*)ctx->d_image, stride);
-    hipLaunchKernelGGL(wide_cand_apply_kernel, dim3(grid, n_cand), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand, stride);
+    if (make_them)
+        hipLaunchKernelGGL(wide_cand_prepare_kernel, dim3(grid, n_cand), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand, stride);
+    else
+        hipLaunchKernelGGL(wide_cand_apply_kernel, dim3(grid, n_cand), dim3(256), 0, ctx->stream, (const ChainParams*)ctx->d_cparams, ctx->d_wide_cs, ctx->d_wide_cand, stride);
 }
 
 }  // namespace npbnn_api

@@ -902,6 +902,47 @@ __global__ void __launch_bounds__(256) wide_cand_apply_kernel(const ChainParams*
     const size_t k = (size_t)(d.t0 + j) * c.M + e;
     patch_image(cand + (long long)j * cand_stride, c.pos[k], c.pscale ? c.pscale[k] : 1.0f, c.pv[(size_t)j * c.M + e], 16);
 }
+// The same launch when the step leaves the making of the candidates to it (ChainParams::prep_terms): grid.y = candidate j of the pending
+// pass, one thread per entry of its proposal - the value (W_cur + delta, reflected at the bounds, masked: spec_entry, the step's own
+// arithmetic), its place in the patch list the commit reads, the fp16-range flag, the candidate image's entry, and the entry's prior term
+// for the step to add up when it decides the pass (in the order its own preparation adds them: the same log prior to the bit).  The
+// step is ONE workgroup: 2.6 k entries x 3 candidates (the default network on 1024 features) cost it 24 us of dependent round trips.
+__global__ void __launch_bounds__(256) wide_cand_prepare_kernel(const ChainParams* __restrict__ cp, WideCandState* __restrict__ st, float* __restrict__ cand,
+                                                                long long cand_stride) {
+    const ChainParams& c = *cp;
+    const PassDesc d = c.pass[0];
+    const int j = (int)blockIdx.y;
+    const int cnt = j < d.n_cand ? d.cnt[j] : 0;
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e == 0) {                                           // (read by the NEXT restore launch only)
+        if (j == 0) { st->prev_t0 = d.t0; st->prev_n = d.n_cand; }
+        st->prev_cnt[j] = cnt;
+    }
+    if (e >= cnt) return;
+    const size_t k = (size_t)(d.t0 + j) * c.M + e;
+    const int i = c.idx[k];
+    double term = 0.0;
+    if (i >= 0) {
+        const double dl = c.delta[k];
+        const int pos = c.pos[k];
+        const float sc = c.pscale ? c.pscale[k] : 1.0f;
+        const double base = c.w_cur[i];
+        const double m = c.mask ? c.mask[i] : 1.0;
+        const double scale_w = c.prior_scale_w ? c.prior_scale_w[i] : 1.0;
+        double his = c.half_inv_s2[0], lsc = c.prior_scale[0];
+#pragma unroll
+        for (int q = 1; q < kMaxLayers; ++q) {
+            const bool past = q < c.net.n_layers && i >= c.net.L[q].w_off;
+            his = past ? c.half_inv_s2[q] : his;
+            lsc = past ? c.prior_scale[q] : lsc;
+        }
+        const double v = spec_entry<false>(c.w_bound, c.prior_kind, c.prior_scale_w != nullptr, base, dl, m, scale_w, his, lsc, term);
+        c.pv[(size_t)j * c.M + e] = v;
+        if (pos < 0 && !(fabs(v * (double)sc) <= (double)kF16Safe)) atomicOr(c.overflow, kFlagF16Range);
+        patch_image(cand + (long long)j * cand_stride, pos, sc, v, 16);
+    }
+    c.prep_terms[(size_t)j * c.M + e] = term;
+}
 #endif  // NPBNN_KERNELS_WIDE
 
 }  // namespace npbnn

@@ -158,7 +158,7 @@ int npbnn_set_layer_mask(npbnn_ctx* ctx, const double* mask_packed);
  * candidates of a chain pass can each carry their own (npbnn_chain_cfg.slope_idx ...); such a network runs on the general builds. */
 /* NPBNN_OPT_WIDE (default 0): the weight-streamed path.  A network runs on it BY ITSELF when a layer has more than 128 nodes or when its
  * weights would leave a compute unit's LDS fewer than 4 waves beside them (the reference's default n_nodes = [50, 5], np_bnn/BNN_env.py:20,
- * from ~700 features on, [32, 8] from ~1200; MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape): every layer is then a
+ * from ~700 features on, [32, 8] from ~980 (first layers of one or two output tiles leave it below eight waves); MatrixMultiplicationD, np_bnn/BNN_lib.py:154-162, takes any shape): every layer is then a
  * tiled matrix product whose operands both stream through LDS, weights from images resident in HBM (widths up to NPBNN_MAX_WIDTH, images
  * up to 2 GiB); a chain pass carries up to three candidates where the pass is one fused launch (narrow networks on many rows), else
  * one.  Same results as the resident path to rounding (not bit for bit: another order of float32 additions); the envelope and the

@@ -28,7 +28,7 @@ GemmCfg g_cfg[6] = {
     {wide_gemm_kernel<4, 4, 4, 2, true>, wide_gemm_kernel<4, 4, 4, 2, false>, nullptr, nullptr, nullptr, nullptr, 16, 8, 512, 6, 3, 2},     // 256 x 128: 48 KiB
     {wide_gemm_kernel<2, 4, 8, 1, true, 1, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 1, 3>, wide_gemm_kernel<2, 4, 8, 1, true, 2, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 2, 3>, wide_gemm_kernel<2, 4, 8, 1, true, 3, 3>, wide_gemm_kernel<2, 4, 8, 1, false, 3, 3>, 16, 4, 512, 5, 3, 1},     // 256 x 64 : 40 KiB
     {wide_gemm_kernel<2, 4, 4, 1, true, 1, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 1, 3>, wide_gemm_kernel<2, 4, 4, 1, true, 2, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 2, 3>, wide_gemm_kernel<2, 4, 4, 1, true, 3, 3>, wide_gemm_kernel<2, 4, 4, 1, false, 3, 3>, 8, 4, 256, 6, 3, 1},      // 128 x 64 : 24 KiB
-    {wide_gemm_kernel<2, 2, 4, 1, true, 1, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 1, 2>, wide_gemm_kernel<2, 2, 4, 1, true, 2, 2>, wide_gemm_kernel<2, 2, 4, 1, false, 2, 2>, nullptr, nullptr, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
+    {wide_gemm_kernel<2, 2, 4, 1, true, 1, 3>, wide_gemm_kernel<2, 2, 4, 1, false, 1, 3>, wide_gemm_kernel<2, 2, 4, 1, true, 2, 3>, wide_gemm_kernel<2, 2, 4, 1, false, 2, 3>, wide_gemm_kernel<2, 2, 4, 1, true, 3, 3>, wide_gemm_kernel<2, 2, 4, 1, false, 3, 3>, 8, 2, 256, 5, 3, 1},      // 128 x 32 : 20 KiB
     {wide_gemm_kernel<4, 4, 4, 4, true>, wide_gemm_kernel<4, 4, 4, 4, false>, nullptr, nullptr, nullptr, nullptr, 16, 16, 1024, 4, 2, 4},   // 256 x 256 on 16 waves (experiment: NPBNN_WIDE_CFG=5)
 };
 // the tiling of a layer: by its width; tables of few rows take the 128-row blocks (more workgroups)
@@ -167,7 +167,14 @@ bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     // (never fewer than four: the resident kernel deals a workgroup's tiles to the four SIMDs of its compute unit and, there, to the
     // waves of that SIMD - with fewer than four waves the tiles of the SIMDs without one are never computed.  Until this round such
     // launches were planned whenever the image left room for 1-3 waves: sums over 1/4 to 3/4 of the rows, silently)
-    const int w = min_waves < 4 ? 4 : min_waves;
+    int w = min_waves < 4 ? 4 : min_waves;
+    // First layers of one or two output tiles on many rows leave the resident kernel EARLIER: with fewer than eight waves beside the
+    // image it carries one candidate per pass at 4 TB/s and less, while the streamed path's 128 x 32 tiling (two workgroups per compute
+    // unit, three candidates per fused pass) is at its best there - 100k rows, freshly initialised chains (tools/switch_sweep.py):
+    // [32, 8] on 992 / 1024 features 10.5 / 10.3 k it/s resident (7 / 6 waves) against 14.8 / 13.6 k streamed; [16, 4] on 2048 features
+    // 5.7 against 10.6 k; level at eight to ten waves.  (Chains that accept a third of their proposals or more keep about half of that
+    // advantage.)  Few rows stay as they were: their passes are not fused, one candidate each.
+    if (!getenv("NPBNN_WIDE_MIN_WAVES") && a->n_layers >= 2 && a->out_dim[0] <= 32 && ctx->ds[0].X != nullptr && ctx->ds[0].n_rows >= 65536 && w < 8) w = 8;
     return resident_lds_bytes(ctx, a, f16, w) > ctx->lds_limit;
 }
 
@@ -407,6 +414,13 @@ int wide_forward(npbnn_ctx* ctx, int which, const float* image, bool chain_pass,
         const int ppw = 2 * (cf.xt + n_sets * cf.wt) / (cf.threads / 64);
         while (n_stage > 2 && ((size_t)n_stage * stage_bytes > ctx->lds_limit || (n_stage - 2) * ppw > kWideMaxYounger)) --n_stage;
         if (n_stage > L.units + 1) n_stage = L.units + 1 < 2 ? 2 : L.units + 1;
+        // The four-wave tilings live on TWO workgroups per compute unit (four waves alone take in 7 B per clock, eight 12:
+        // tools/microbench_ingest.hip): a third stage that costs the second workgroup its place costs more than it hides (128 x 32,
+        // three candidates, 100k x 1280: 282 us with three stages and one workgroup per compute unit, 171 us with two and two).
+        if (cf.threads == 256 && n_stage == 3 && stages_env() < 2) {
+            const size_t lds3 = std::max((size_t)3 * stage_bytes, fuse ? fuse_lds : (size_t)0), lds2 = std::max((size_t)2 * stage_bytes, fuse ? fuse_lds : (size_t)0);
+            if (ctx->lds_limit / lds3 < 2 && ctx->lds_limit / lds2 >= 2) n_stage = 2;
+        }
         g.n_stage = n_stage;
         size_t lds = (size_t)n_stage * stage_bytes;
         if (fuse && fuse_lds > lds) lds = fuse_lds;

@@ -229,6 +229,99 @@ static inline double fast_standard_normal(pcg64_t* r, bitgen_t* own_bg) {
     return random_standard_normal(own_bg);
 }
 
+/* ---- raw outputs made a block ahead of their use ----
+ * One PCG64 output hangs on the one before it through a 128-bit multiply-add and, with the state behind a pointer, a store and a load:
+ * ~10 cycles per output, and every draw of a wide proposal (53 k perturbed weights per iteration of a million-weight network: two
+ * bounded integers and a normal each) waits on that chain - 10.6 ns per entry on the GPU box's EPYC 9575F, 6.6 of them the normal.
+ * state[i + 4] = A^4 state[i] + c (A^3 + A^2 + A + 1): four chains side by side fill a block of outputs with no dependence between
+ * neighbours; the draws then read the block.  The SEQUENCE of outputs is the generator's own, and so is the order the draws take
+ * them in (rejections of Lemire's method and the ziggurat's rare branches simply take the next ones); blk_sync puts the generator's
+ * state where the last output USED leaves it (before numpy's own routines take over, and at the end of every iteration). */
+#define PCG_BLK 32
+typedef struct {
+    uint64_t out[PCG_BLK];
+    int pos, n;            /* next output to hand out; outputs in the block (0: none made) */
+    u128 start;            /* the state the block was made from */
+} pcg_block_t;
+
+static inline uint64_t pcg_output(u128 st) {
+    const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(st >> 122);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+static void blk_refill(pcg64_t* r, pcg_block_t* b) {
+    const u128 A = PCG_MULT, A2 = A * A, A4 = A2 * A2, c = r->inc, c4 = c * (A2 * A + A2 + A + 1);
+    b->start = r->state;
+    u128 s0 = r->state * A + c, s1 = s0 * A + c, s2 = s1 * A + c, s3 = s2 * A + c;
+    for (int k = 0; k < PCG_BLK; k += 4) {
+        b->out[k] = pcg_output(s0); b->out[k + 1] = pcg_output(s1); b->out[k + 2] = pcg_output(s2); b->out[k + 3] = pcg_output(s3);
+        if (k + 4 == PCG_BLK) r->state = s3;           /* the state after the block's last output */
+        s0 = s0 * A4 + c4; s1 = s1 * A4 + c4; s2 = s2 * A4 + c4; s3 = s3 * A4 + c4;
+    }
+    b->pos = 0;
+    b->n = PCG_BLK;
+}
+
+static void blk_sync(pcg64_t* r, pcg_block_t* b) {
+    if (b->n == 0) return;
+    u128 st = b->start;
+    for (int i = 0; i < b->pos; ++i) st = st * PCG_MULT + r->inc;
+    r->state = st;
+    b->pos = b->n = 0;
+}
+
+static inline uint64_t blk_next64(pcg64_t* r, pcg_block_t* b) {
+    if (b->pos == b->n) blk_refill(r, b);
+    return b->out[b->pos++];
+}
+
+static inline uint32_t blk_next32(pcg64_t* r, pcg_block_t* b) {
+    if (r->has_uint32) { r->has_uint32 = 0; return r->uinteger; }
+    const uint64_t next = blk_next64(r, b);
+    r->has_uint32 = 1;
+    r->uinteger = (uint32_t)(next >> 32);
+    return (uint32_t)(next & 0xffffffffu);
+}
+
+static inline double blk_double(pcg64_t* r, pcg_block_t* b) { return (blk_next64(r, b) >> 11) * (1.0 / 9007199254740992.0); }
+
+static inline uint32_t blk_bounded32(pcg64_t* r, pcg_block_t* b, uint32_t rng) {
+    const uint32_t rng_excl = rng + 1u;
+    uint64_t m = (uint64_t)blk_next32(r, b) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        const uint32_t threshold = (0xffffffffu - rng) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)blk_next32(r, b) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+
+static inline double blk_standard_normal(pcg64_t* r, pcg_block_t* b, bitgen_t* own_bg) {
+    const uint64_t u = blk_next64(r, b);
+    const int layer = (int)(u & 0xff);
+    const uint64_t v = u >> 8;
+    const uint64_t rabs = (v >> 1) & 0x000fffffffffffffULL;
+    if (rabs < zig_ki[layer]) {
+        /* (the sign as a bit, not as a choice: a random branch is mispredicted every other time - half of what a normal cost;
+         *  x >= 0, so setting the sign bit is the negation, -0.0 included) */
+        const double x = (double)(int64_t)rabs * zig_wi[layer];
+        uint64_t bits;
+        memcpy(&bits, &x, sizeof bits);
+        bits |= (v & 1) << 63;
+        double y;
+        memcpy(&y, &bits, sizeof y);
+        return y;
+    }
+    b->pos -= 1;                                         /* the rare branches: numpy's own routine, from the same output on */
+    blk_sync(r, b);
+    return random_standard_normal(own_bg);
+}
+
 static int fast_build_and_verify(void);
 /* Runs ONCE per process (pthread_once: ctypes releases the interpreter lock, so the helper thread's pre-draw and a pre-draw on the
  * main thread - or two samplers - can arrive together); fast_state says "verified" only after the last comparison has passed, so
@@ -279,6 +372,27 @@ static int fast_build_and_verify(void) {
         if (a.state != b.state || a.has_uint32 != b.has_uint32 || a.uinteger != b.uinteger) return 0;
         const double x = fast_double(&a), y = random_standard_uniform(&bgb);
         if (x != y) return 0;
+    }
+    /* ... and the same draws read from blocks of outputs made ahead (blk_*), interleaved with numpy's own routines on the shared state */
+    {
+        pcg_block_t blk;
+        blk.pos = blk.n = 0;
+        for (int round = 0; round < 64; ++round) {
+            for (int i = 0; i < 1000 + 37 * round; ++i) {
+                const double x = blk_standard_normal(&a, &blk, &bga), y = random_standard_normal(&bgb);
+                if (memcmp(&x, &y, sizeof x) != 0) return 0;
+            }
+            const uint32_t rng = ranges[round % (sizeof ranges / sizeof ranges[0])];
+            uint64_t want[129];
+            random_bounded_uint64_fill(&bgb, 0, rng, 129, 0, want);
+            for (int i = 0; i < 129; ++i)
+                if ((uint64_t)blk_bounded32(&a, &blk, rng) != want[i]) return 0;
+            if (blk_double(&a, &blk) != random_standard_uniform(&bgb)) return 0;
+            blk_sync(&a, &blk);
+            if (a.state != b.state || a.has_uint32 != b.has_uint32 || a.uinteger != b.uinteger) return 0;
+            const double x = random_standard_normal(&bga), y = random_standard_normal(&bgb);     /* (numpy's routine on the synchronised state) */
+            if (memcmp(&x, &y, sizeof x) != 0 || a.state != b.state) return 0;
+        }
     }
     return 1;
 }
@@ -398,6 +512,8 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
     for (int i = 0; i < n_weights; ++i) last[i] = -1;
     pcg64_t local;
     bitgen_t local_bg;
+    pcg_block_t blk;            /* outputs made ahead for the inlined draws (empty between two iterations) */
+    blk.pos = blk.n = 0;
     if (own_state) pcg64_bitgen(own_state, &local_bg);
     for (int t = 0; t < K; ++t) {
         bitgen_t* bg = own_state ? &local_bg : (bitgen_t*)bitgen;
@@ -421,7 +537,7 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
             random_standard_uniform_fill(bg, sigma_k, sigma_u + (size_t)t * sigma_k);
         }
         double rr[NPBNN_HOST_MAX_LAYERS];
-        if (fr) { for (int i = 0; i < spec->n_layers; ++i) rr[i] = fast_double(fr); }
+        if (fr) { for (int i = 0; i < spec->n_layers; ++i) rr[i] = blk_double(fr, &blk); }
         else random_standard_uniform_fill(bg, spec->n_layers, rr);
         int amin = 0;
         for (int i = 1; i < spec->n_layers; ++i)
@@ -436,8 +552,8 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
             const int n = spec->update_n[i];
             if (fr) {      /* (a range of one value draws nothing, as in numpy's fill) */
                 const uint32_t rmax = (uint32_t)(spec->rows[i] - 1), cmax = (uint32_t)(spec->cols[i] - 1);
-                if (rmax == 0) { for (int j = 0; j < n; ++j) ix[j] = 0; } else { for (int j = 0; j < n; ++j) ix[j] = fast_bounded32(fr, rmax); }
-                if (cmax == 0) { for (int j = 0; j < n; ++j) iy[j] = 0; } else { for (int j = 0; j < n; ++j) iy[j] = fast_bounded32(fr, cmax); }
+                if (rmax == 0) { for (int j = 0; j < n; ++j) ix[j] = 0; } else { for (int j = 0; j < n; ++j) ix[j] = blk_bounded32(fr, &blk, rmax); }
+                if (cmax == 0) { for (int j = 0; j < n; ++j) iy[j] = 0; } else { for (int j = 0; j < n; ++j) iy[j] = blk_bounded32(fr, &blk, cmax); }
             } else {
                 random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->rows[i] - 1), n, 0, ix);
                 random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->cols[i] - 1), n, 0, iy);
@@ -456,7 +572,7 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
                 const double scale = uniform ? scale0 : spec->update_ws[i][local_pos];
                 const int flat = spec->w_off[i] + local_pos;
                 /* random_normal(loc, scale) = loc + scale * standard normal */
-                row_delta[base + j] = fr ? 0.0 + scale * fast_standard_normal(fr, bg) : random_normal(bg, 0.0, scale);
+                row_delta[base + j] = fr ? 0.0 + scale * blk_standard_normal(fr, &blk, bg) : random_normal(bg, 0.0, scale);
                 if (last[flat] >= base) row_idx[last[flat]] = -1;   /* superseded within this layer */
                 row_idx[base + j] = flat;
                 last[flat] = base + j;
@@ -468,7 +584,8 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
         for (int j = used; j < max_per_iter; ++j) { row_idx[j] = -1; row_delta[j] = 0.0; }      /* (the caller's arrays come uninitialised) */
         cnt[t] = used;
         layer_mask[t] = mask;
-        log_u[t] = fr ? fast_double(fr) : random_standard_uniform(bg);
+        log_u[t] = fr ? blk_double(fr, &blk) : random_standard_uniform(bg);
+        if (fr) blk_sync(fr, &blk);      /* (the next iteration may start with numpy's own routines, or with a generator of its own) */
     }
     free(last);
     free(ix);

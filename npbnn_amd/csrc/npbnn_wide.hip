@@ -174,7 +174,12 @@ bool wide_needed(const npbnn_ctx* ctx, const npbnn_arch* a, bool f16) {
     // [32, 8] on 992 / 1024 features 10.5 / 10.3 k it/s resident (7 / 6 waves) against 14.8 / 13.6 k streamed; [16, 4] on 2048 features
     // 5.7 against 10.6 k; level at eight to ten waves.  (Chains that accept a third of their proposals or more keep about half of that
     // advantage.)  Few rows stay as they were: their passes are not fused, one candidate each.
-    if (!getenv("NPBNN_WIDE_MIN_WAVES") && a->n_layers >= 2 && a->out_dim[0] <= 32 && ctx->ds[0].X != nullptr && ctx->ds[0].n_rows >= 65536 && w < 8) w = 8;
+    // (only where the streamed pass is the fused one that carries them: later layers of at most 128 nodes, categorical likelihood or
+    // a Gaussian one of at most kFuseTargets columns, no class weights' / row-wise float64 terms - fused_pass)
+    bool fusable = a->n_layers >= 2 && a->out_dim[a->n_layers - 1] <= 128 && !lik_needs_row_scratch(a->lik_kind) &&
+                   (a->lik_kind == NPBNN_LIK_CATEGORICAL || (a->lik_kind == NPBNN_LIK_GAUSS && a->n_targets <= kFuseTargets));
+    for (int l = 1; l < a->n_layers; ++l) fusable = fusable && a->out_dim[l] <= 128;
+    if (!getenv("NPBNN_WIDE_MIN_WAVES") && fusable && a->out_dim[0] <= 32 && ctx->ds[0].X != nullptr && ctx->ds[0].n_rows >= 65536 && w < 8) w = 8;
     return resident_lds_bytes(ctx, a, f16, w) > ctx->lds_limit;
 }
 

@@ -301,6 +301,32 @@ static inline uint32_t blk_bounded32(pcg64_t* r, pcg_block_t* b, uint32_t rng) {
     return (uint32_t)(m >> 32);
 }
 
+/* n bounded integers (numpy: random_bounded_uint64_fill -> buffered_bounded_lemire_uint32 for ranges below 2^32): two per 64-bit output,
+ * low half first - what the buffered 32-bit draws amount to - with the rare rejection (a product's low word below the range) redone by
+ * the one-at-a-time routine from the same output on */
+static inline void blk_bounded32_fill(pcg64_t* r, pcg_block_t* b, uint32_t rng, int n, uint64_t* out) {
+    const uint32_t rng_excl = rng + 1u;
+    int j = 0;
+    if (n > 0 && r->has_uint32) out[j++] = blk_bounded32(r, b, rng);       /* (the half a previous draw left behind goes first) */
+    for (; j + 1 < n; j += 2) {
+        const uint64_t raw = blk_next64(r, b);
+        const uint64_t m0 = (uint64_t)(uint32_t)raw * rng_excl, m1 = (raw >> 32) * rng_excl;
+        if ((uint32_t)m0 < rng_excl || (uint32_t)m1 < rng_excl) {          /* possibly a rejection: one at a time, from this output on */
+            b->pos -= 1;
+            out[j] = blk_bounded32(r, b, rng);
+            out[j + 1] = blk_bounded32(r, b, rng);
+            if (r->has_uint32) {                                            /* (a rejection shifted the halves: realign on the next draw) */
+                if (j + 2 < n) { out[j + 2] = blk_bounded32(r, b, rng); j += 1; }
+            }
+            continue;
+        }
+        out[j] = m0 >> 32;
+        out[j + 1] = m1 >> 32;
+        r->uinteger = (uint32_t)(raw >> 32);                                /* (what the buffered draws leave in the generator's state: the half last held) */
+    }
+    for (; j < n; ++j) out[j] = blk_bounded32(r, b, rng);
+}
+
 static inline double blk_standard_normal(pcg64_t* r, pcg_block_t* b, bitgen_t* own_bg) {
     const uint64_t u = blk_next64(r, b);
     const int layer = (int)(u & 0xff);
@@ -388,6 +414,15 @@ static int fast_build_and_verify(void) {
             for (int i = 0; i < 129; ++i)
                 if ((uint64_t)blk_bounded32(&a, &blk, rng) != want[i]) return 0;
             if (blk_double(&a, &blk) != random_standard_uniform(&bgb)) return 0;
+            {
+                uint64_t got[131], want2[131];
+                const int nf = 128 + (round % 3);                       /* (even and odd counts, with and without a half left behind) */
+                random_bounded_uint64_fill(&bgb, 0, rng, nf, 0, want2);
+                blk_bounded32_fill(&a, &blk, rng, nf, got);
+                for (int i = 0; i < nf; ++i)
+                    if (got[i] != want2[i]) return 0;
+                if (round & 1) { if ((uint64_t)blk_bounded32(&a, &blk, 6) != (random_bounded_uint64_fill(&bgb, 0, 6, 1, 0, want2), want2[0])) return 0; }
+            }
             blk_sync(&a, &blk);
             if (a.state != b.state || a.has_uint32 != b.has_uint32 || a.uinteger != b.uinteger) return 0;
             const double x = random_standard_normal(&bga), y = random_standard_normal(&bgb);     /* (numpy's routine on the synchronised state) */
@@ -552,8 +587,8 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
             const int n = spec->update_n[i];
             if (fr) {      /* (a range of one value draws nothing, as in numpy's fill) */
                 const uint32_t rmax = (uint32_t)(spec->rows[i] - 1), cmax = (uint32_t)(spec->cols[i] - 1);
-                if (rmax == 0) { for (int j = 0; j < n; ++j) ix[j] = 0; } else { for (int j = 0; j < n; ++j) ix[j] = blk_bounded32(fr, &blk, rmax); }
-                if (cmax == 0) { for (int j = 0; j < n; ++j) iy[j] = 0; } else { for (int j = 0; j < n; ++j) iy[j] = blk_bounded32(fr, &blk, cmax); }
+                if (rmax == 0) { for (int j = 0; j < n; ++j) ix[j] = 0; } else blk_bounded32_fill(fr, &blk, rmax, n, ix);
+                if (cmax == 0) { for (int j = 0; j < n; ++j) iy[j] = 0; } else blk_bounded32_fill(fr, &blk, cmax, n, iy);
             } else {
                 random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->rows[i] - 1), n, 0, ix);
                 random_bounded_uint64_fill(bg, 0, (uint64_t)(spec->cols[i] - 1), n, 0, iy);
@@ -562,6 +597,20 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
             const int uniform = spec->ws_uniform[i];
             const double scale0 = spec->update_ws[i][0];
             const int cols_i = spec->cols[i], off_i = spec->w_off[i];
+            if (fr && uniform) {
+                /* the sampler's default (one step size per layer) with the inlined draws: the deviates in a loop of their own - nothing in it
+                 * waits for the last-writer table - then the table's loop with its slots requested well ahead */
+                for (int j = 0; j < n; ++j) {
+                    row_idx[base + j] = off_i + (int)ix[j] * cols_i + (int)iy[j];
+                    row_delta[base + j] = 0.0 + scale0 * blk_standard_normal(fr, &blk, bg);
+                }
+                for (int j = 0; j < n; ++j) {
+                    if (j + 16 < n) __builtin_prefetch(&last[row_idx[base + j + 16]], 1, 1);
+                    const int flat = row_idx[base + j];
+                    if (last[flat] >= base) row_idx[last[flat]] = -1;   /* superseded within this layer */
+                    last[flat] = base + j;
+                }
+            } else
             for (int j = 0; j < n; ++j) {
                 if (j + 8 < n) {      /* (the entry's slot of the last-writer table, requested ahead: 4 bytes per weight, out of cache on wide layers) */
                     const int ahead = off_i + (int)ix[j + 8] * cols_i + (int)iy[j + 8];

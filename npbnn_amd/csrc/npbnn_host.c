@@ -545,6 +545,8 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
     }
     uint64_t* iy = ix + (max_n > 0 ? max_n : 1);
     for (int i = 0; i < n_weights; ++i) last[i] = -1;
+    int64_t stamp = 0;          /* entries get running numbers in the last-writer table: a slot at or above a layer's first number was
+                                   written by that layer in this iteration - nothing to wipe between layers (wrapped: the table starts over) */
     pcg64_t local;
     bitgen_t local_bg;
     pcg_block_t blk;            /* outputs made ahead for the inlined draws (empty between two iterations) */
@@ -597,6 +599,12 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
             const int uniform = spec->ws_uniform[i];
             const double scale0 = spec->update_ws[i][0];
             const int cols_i = spec->cols[i], off_i = spec->w_off[i];
+            if (stamp + n >= 0x7fffffff) {                      /* (never in practice: 2^31 entries in one call) */
+                for (int q = 0; q < n_weights; ++q) last[q] = -1;
+                stamp = 0;
+            }
+            const int s0 = (int)stamp;
+            stamp += n;
             if (fr && uniform) {
                 /* the sampler's default (one step size per layer) with the inlined draws: the deviates in a loop of their own - nothing in it
                  * waits for the last-writer table - then the table's loop with its slots requested well ahead */
@@ -607,8 +615,8 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
                 for (int j = 0; j < n; ++j) {
                     if (j + 16 < n) __builtin_prefetch(&last[row_idx[base + j + 16]], 1, 1);
                     const int flat = row_idx[base + j];
-                    if (last[flat] >= base) row_idx[last[flat]] = -1;   /* superseded within this layer */
-                    last[flat] = base + j;
+                    if (last[flat] >= s0) row_idx[base + (last[flat] - s0)] = -1;   /* superseded within this layer */
+                    last[flat] = s0 + j;
                 }
             } else
             for (int j = 0; j < n; ++j) {
@@ -622,12 +630,10 @@ static int predraw_core(void* bitgen, pcg64_t* own_state, int randomize_seed, in
                 const int flat = spec->w_off[i] + local_pos;
                 /* random_normal(loc, scale) = loc + scale * standard normal */
                 row_delta[base + j] = fr ? 0.0 + scale * blk_standard_normal(fr, &blk, bg) : random_normal(bg, 0.0, scale);
-                if (last[flat] >= base) row_idx[last[flat]] = -1;   /* superseded within this layer */
+                if (last[flat] >= s0) row_idx[base + (last[flat] - s0)] = -1;   /* superseded within this layer */
                 row_idx[base + j] = flat;
-                last[flat] = base + j;
+                last[flat] = s0 + j;
             }
-            for (int j = 0; j < n; ++j)
-                if (row_idx[base + j] >= 0) last[row_idx[base + j]] = -1;
             used += n;
         }
         for (int j = used; j < max_per_iter; ++j) { row_idx[j] = -1; row_delta[j] = 0.0; }      /* (the caller's arrays come uninitialised) */
